@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the `kmdiff diff` hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the
+256-partition synthetic count matrix, 20 controls v 20 cases, k = 31, 4-byte counts,
+39 062 500 rows per partition (10^10 rows / 256).  One STEP = one partition through stage 1
+(merge observer + Poisson LRT + threshold + survivor compaction, kmd_poisson_filter) with the
+partition already resident in HBM (SoA: counts[sample][row] + kmer[row]).  After the K timed
+steps the job's single exchange (counter all-reduce, and for BH/Holm the survivor p-value
+all-gather) and the significance correction (stage 3) run inside the timed region too.
+
+Sharding: partition p belongs to rank p % N (weak scaling: every rank does K steps).
+
+The JSON line also carries
+  roofline     : algorithmic bytes (168 B/row) / average kernel duration, measured with HIP
+                 events around each launch, against the 8 TB/s HBM3E peak;
+  cpu_baseline : the reference's own arithmetic (oracle/_ref, kind "reference") or the C
+                 restatement (kind "port") on the host cores, on a bounded sample of the same
+                 workload, tail function evaluated for every row as the reference does.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x6B6D64696666
+NC, NK, K_SIZE, COUNT_BYTES = 20, 20, 31, 4
+N_PARTITIONS = 256
+ROWS_PER_PARTITION = 39_062_500          # 10^10 / 256
+THRESHOLD, CUTOFF, LOG_FACTORIAL = 0.05, 100000, 10000      # -s, -u, --log-factorial defaults
+BYTES_PER_ROW = 8 * ((K_SIZE + 31) // 32) + (NC + NK) * COUNT_BYTES       # 168
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(rows_per_part, tc, tk):
+    """Host-core baseline on a bounded sample (one partition per thread)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as OL
+    o = OL.load()
+    cores = os.cpu_count() or 1
+    thr = THRESHOLD / CUTOFF
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libkmdiff_ref.so")
+    if os.path.exists(ref_path):
+        # the reference's LogFactorialTable + alglib::chisquarecdistribution around the
+        # 20-line process() glue (oracle/ref_shim.cpp); one partition per thread
+        R = C.CDLL(ref_path)
+        R.kmdref_model_new.restype = C.c_void_p
+        R.kmdref_model_new.argtypes = [C.c_size_t] * 3 + [C.c_uint64] * 2
+        R.kmdref_model_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
+        model = R.kmdref_model_new(LOG_FACTORIAL, NC, NK, tc, tk)
+        n = 1_000_000
+        secs = [0.0] * cores
+        nsig = [0] * cores
+
+        def work(t):
+            host, _, _ = o.synth_rows(SEED, t % N_PARTITIONS, 0, n, NC, NK, COUNT_BYTES)
+            p = np.zeros(n); s = np.zeros(n, dtype=np.int32); mc = np.zeros(n); mk = np.zeros(n)
+            t0 = time.perf_counter()
+            R.kmdref_model_process(C.c_void_p(model), host.ctypes.data, n, p.ctypes.data, s.ctypes.data,
+                                   mc.ctypes.data, mk.ctypes.data)
+            nsig[t] = int((p <= thr).sum())
+            secs[t] = time.perf_counter() - t0
+        th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return {"value": cores * n / max(secs), "unit": "k-mers/s", "cores": cores, "kind": "reference",
+                "sample": "%d partitions x %d rows (20v20, u32), one per thread, row-major, reference "
+                          "LogFactorialTable + alglib chisquarecdistribution for every row; %d survivors"
+                          % (cores, n, sum(nsig))}
+    n = 2_000_000
+    c = OL.Counters()
+    s = o.L.kmdo_bench_partitions(SEED, cores, n, NC, NK, COUNT_BYTES, tc, tk, LOG_FACTORIAL, thr, cores,
+                                  C.byref(c))
+    return {"value": cores * n / s, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": "%d partitions x %d rows (20v20, u32), one per thread, row-major, C restatement "
+                      "with the tail function for every row; %d survivors" % (cores, n, c.n_sig)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_PARTITION, help="rows per partition")
+    ap.add_argument("--resident", type=int, default=8, help="distinct partitions kept in HBM per rank")
+    ap.add_argument("--correction", default="bonferroni")
+    ap.add_argument("--layout", default="soa", choices=["soa", "rows"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+
+    import kmdiff_amd as K
+    from kmdiff_amd import dist as D
+    lib = K._native.lib()
+    K._native.check(lib.kmd_set_device(local_rank))
+    layout = K.LAYOUT_SOA if args.layout == "soa" else K.LAYOUT_ROWS
+    thr = THRESHOLD / CUTOFF
+
+    # ---- setup (untimed): resident partitions, totals, model, survivor sink ------------------
+    n_res = max(1, min(args.resident, args.steps))
+    parts = [(rank + i * world) % N_PARTITIONS for i in range(n_res)]
+    mats = [K.synth_matrix(SEED, p, args.rows, NC, NK, COUNT_BYTES, layout) for p in parts]
+    tot_buf = K.DeviceBuffer((NC + NK) * 8).zero()
+    for m in mats:
+        K.column_sums(m, tot_buf)
+    K._native.check(lib.kmd_stream_sync(None))
+    totals = D.allreduce_totals(tot_buf.to_host(np.uint64, NC + NK))
+    model = K.PoissonLikelihood(NC, NK, totals[:NC], totals[NC:], LOG_FACTORIAL)
+    cap = max(1 << 20, int(args.rows * (args.steps + args.warmup) * 4e-4))
+    acc = K.SurvivorAccumulator(cap)
+    obs = K.diff_observer(model, acc, thr, NC, NK)
+
+    for i in range(args.warmup):
+        obs.process(mats[i % n_res])
+    K._native.check(lib.kmd_stream_sync(None))
+    acc.counters.zero()
+    K._native.check(lib.kmd_stream_sync(None))
+
+    ev = [(K.Event(), K.Event()) for _ in range(args.steps)]
+
+    # ---- timed region: exactly K steps + the job's exchange and correction -------------------
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        obs.process(mats[i % n_res])
+        ev[i][1].record()
+    n_surv = acc.finish(sort=True)
+    keep, g_counters, (n_ctrl, n_case) = D.correct_sharded(K, args.correction, THRESHOLD, acc.read_counters(),
+                                                          acc.bufs["pvalue"], acc.bufs["sign"], n_surv)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed)
+
+    kernel_ms = [a.elapsed_ms(b) for a, b in ev]
+    avg_kernel_ms = D.max_over_ranks(sum(kernel_ms) / len(kernel_ms))
+    kept = D.allreduce_counters([int(keep.sum()), n_ctrl, n_case])
+
+    if rank == 0:
+        total_rows = float(args.rows) * args.steps * world
+        value = total_rows / elapsed
+        achieved = args.rows * BYTES_PER_ROW / (avg_kernel_ms * 1e-3) / 1e9
+        copy_gbs = None
+        try:
+            nb = 1 << 30
+            a, b = K.DeviceBuffer(nb), K.DeviceBuffer(nb)
+            e0, e1 = K.Event(), K.Event()
+            for _ in range(2):
+                K._native.check(lib.kmd_copy_probe(b.ptr, a.ptr, nb, None))
+            e0.record()
+            for _ in range(5):
+                K._native.check(lib.kmd_copy_probe(b.ptr, a.ptr, nb, None))
+            e1.record()
+            copy_gbs = 5 * 2 * nb / (e0.elapsed_ms(e1) * 1e-3) / 1e9
+            a.free(); b.free()
+        except Exception:
+            pass
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "k-mers tested/sec + HBM GB/s (% roofline), k=31, 20v20 samples",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: 256-partition synthetic matrix, 20v20, k=31, u32 counts; "
+                                   "step = one partition of %d rows resident in HBM (%s layout); partition p on "
+                                   "rank p %% N" % (args.rows, args.layout),
+                       "rows_per_step_per_gpu": args.rows, "bytes_per_row_algorithmic": BYTES_PER_ROW,
+                       "threshold": thr, "correction": args.correction, "log_factorial": LOG_FACTORIAL,
+                       "resident_partitions": n_res, "device": K.device_name(),
+                       "counters": {"total": int(g_counters[0]), "n_sig": int(g_counters[1]),
+                                    "n_sig_control": int(g_counters[2]), "n_sig_case": int(g_counters[3]),
+                                    "kept_after_correction": int(kept[0])},
+                       "copy_probe_GBs": copy_gbs},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_filter_%s<u32>" % args.layout, "avg_kernel_ms": avg_kernel_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.rows, int(totals[:NC].sum()), int(totals[NC:].sum()))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/* kmdiff_hip.h -- C-ABI of libkmdiff_hip.so: the MI355X (gfx950) implementation of the
+ * `kmdiff diff` hot path of tlemane/kmdiff v1.1.0.
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only, status codes instead of
+ * exceptions.  Every entry point names the reference interface it replaces (paths are
+ * relative to the reference tree).  INTEGRATION.md shows the binding a kmdiff maintainer
+ * would add on the reference side.
+ *
+ * Conventions
+ *   - "d_" arguments are DEVICE pointers (HBM); all others are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Functions that take a stream are asynchronous unless stated otherwise.
+ *   - Every function returns KMD_OK (0) or a negative kmd_status; kmd_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - Significance values are the reference's enum (include/kmdiff/kmer.hpp:33-38).
+ */
+#ifndef KMDIFF_HIP_H
+#define KMDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMD_ABI_VERSION 1
+
+typedef enum {
+  KMD_OK = 0,
+  KMD_E_INVALID = -1,      /* bad argument (NULL, unsupported count width, misaligned ...) */
+  KMD_E_HIP = -2,          /* a HIP runtime call failed; see kmd_last_error() */
+  KMD_E_NO_DEVICE = -3,    /* no gfx950 device visible */
+  KMD_E_OVERFLOW = -4,     /* survivor capacity exceeded: counters are exact, records truncated */
+  KMD_E_NOMEM = -5
+} kmd_status;
+
+/* Significance, include/kmdiff/kmer.hpp:33-38 */
+enum { KMD_SIGN_CONTROL = 0, KMD_SIGN_CASE = 1, KMD_SIGN_NO = 2 };
+
+/* CorrectionType, include/kmdiff/correction.hpp:7-14 */
+enum { KMD_CORR_NOTHING = 0, KMD_CORR_BONFERRONI = 1, KMD_CORR_BENJAMINI = 2,
+       KMD_CORR_SIDAK = 3, KMD_CORR_HOLM = 4 };
+
+/* Count-matrix layouts accepted by the kernels.
+ *   KMD_LAYOUT_SOA : counts[sample][row]   (column stride ld >= n_rows, in elements);
+ *                    the device-native layout: one lane per row, fully coalesced.
+ *   KMD_LAYOUT_ROWS: counts[row][sample]   (row stride ld >= nc+nk, in elements);
+ *                    what km::MatrixReader / KmerMerger hand the observer
+ *                    (include/kmdiff/merge.hpp:68,194-203); staged through LDS. */
+enum { KMD_LAYOUT_SOA = 1, KMD_LAYOUT_ROWS = 0 };
+
+const char* kmd_status_string(int status);
+const char* kmd_last_error(void);
+int kmd_abi_version(void);
+
+/* ---- device plumbing (so that a C/C++ host needs nothing but this library) ----------- */
+int kmd_device_count(int* n);
+int kmd_set_device(int device);
+int kmd_device_name(char* buf, size_t len);
+int kmd_malloc(void** d_ptr, size_t bytes);
+int kmd_free(void* d_ptr);
+int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream);
+int kmd_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream);
+int kmd_memset(void* d_dst, int value, size_t bytes, void* stream);
+int kmd_stream_sync(void* stream);
+/* elapsed milliseconds of `fn`-independent timing helpers: HIP events on `stream` */
+int kmd_event_create(void** ev);
+int kmd_event_destroy(void* ev);
+int kmd_event_record(void* ev, void* stream);
+int kmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* syncs on ev_stop */
+
+/* ---- the model ------------------------------------------------------------------------
+ * Replaces PoissonLikelihood<MAX_C>'s constructor (include/kmdiff/model.hpp:106-118,
+ * 185-191) and LogFactorialTable (include/kmdiff/log_factorial_table.hpp:9-26,
+ * src/log_factorial_table.cpp:5-22): per-sample totals are summed into Tc, Tk; the
+ * log-factorial table of `log_factorial_size` entries (CLI --log-factorial, default
+ * 10000, src/cli.cpp:354-357) is built once with the reference's descending summation
+ * and uploaded to HBM.  Sums >= log_factorial_size are evaluated on the device by the
+ * reference's O(k) descending loop (wave-cooperative). */
+typedef struct kmd_model kmd_model;
+
+int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
+                     const uint64_t* total_controls, const uint64_t* total_cases,
+                     size_t log_factorial_size);
+int kmd_model_destroy(kmd_model* m);
+/* introspection used by tests: host copy of the table, Tc/Tk */
+int kmd_model_info(const kmd_model* m, int* nc, int* nk, uint64_t* tc, uint64_t* tk,
+                   size_t* lf_n);
+int kmd_model_lf_table(const kmd_model* m, double* out, size_t n);
+
+/* ---- stage 1: merge observer + Poisson LRT + threshold + compaction ---------------------
+ * Replaces diff_observer<KSIZE,CMAX>::process (include/kmdiff/merge.hpp:68-103) applied to
+ * every row of one partition tile, i.e. the body of the per-partition task of
+ * global_merge::merge (merge.hpp:259-307) after the k-way merge: for each row
+ *   (p, sign, mean_control, mean_case) = PoissonLikelihood::process(controls, cases)
+ *                                               (include/kmdiff/model.hpp:142-176)
+ *   total++ ; if (p <= threshold) push KmerSign, ++n_sig, ++n_sig_control | ++n_sig_case.
+ */
+
+/* Device-resident survivor sink: replaces IAccumulator<KmerSign<KSIZE>>::push
+ * (include/kmdiff/accumulator.hpp:36-54) with SoA device arrays of `capacity` records.
+ * Any array pointer may be NULL (field not recorded).  Survivors are appended in
+ * unspecified order; `row` (row_base + row index in the tile) restores the reference's
+ * ascending-k-mer order (kmd_survivors_sort_by_row). */
+typedef struct {
+  uint64_t* d_row;
+  uint64_t* d_kmer_lo;      /* 2-bit packed k-mer, low 64 bits (k <= 32: the whole k-mer)  */
+  uint64_t* d_kmer_hi;      /* high 64 bits for 32 < k <= 64, else NULL                     */
+  double*   d_pvalue;
+  int32_t*  d_sign;
+  double*   d_mean_control; /* KmerSign::m_mean_control = sum_ctrl * Tk / Tc (model.hpp:165) */
+  double*   d_mean_case;    /* KmerSign::m_mean_case    = raw case sum                        */
+  size_t    capacity;
+} kmd_survivors;
+
+/* Device counters (uint64_t[KMD_NCOUNTERS], caller zeroes them once per partition/run;
+ * calls accumulate).  [0..3] are diff_observer's m_total, m_sign_kmer_per_part,
+ * m_sign_controls, m_sign_cases (merge.hpp:104-131). */
+enum { KMD_CNT_TOTAL = 0, KMD_CNT_SIG = 1, KMD_CNT_SIG_CONTROL = 2, KMD_CNT_SIG_CASE = 3,
+       KMD_CNT_CANDIDATES = 4,   /* rows whose tail function was evaluated                 */
+       KMD_CNT_DEFERRED = 5,     /* rows with a count sum >= log_factorial_size            */
+       KMD_CNT_RESERVED6 = 6, KMD_CNT_RESERVED7 = 7, KMD_NCOUNTERS = 8 };
+
+typedef struct {
+  const void*     d_counts;   /* count matrix tile                                         */
+  int             count_bytes;/* 1, 2 or 4: km::selectC<MAX_C>::type (imodel.hpp:27)       */
+  int             layout;     /* KMD_LAYOUT_SOA | KMD_LAYOUT_ROWS                          */
+  size_t          ld;         /* leading dimension in elements                             */
+  const uint64_t* d_kmer_lo;  /* per-row k-mers (may be NULL: survivors carry only `row`)  */
+  const uint64_t* d_kmer_hi;
+  size_t          n_rows;
+  uint64_t        row_base;   /* global index of row 0 within its partition                */
+} kmd_tile;
+
+int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, double threshold,
+                       const kmd_survivors* out, uint64_t* d_counters, void* stream);
+
+/* Every row's result (no threshold): IModel<MAX_C>::process (imodel.hpp:36) over a tile.
+ * Output arrays are device pointers of n_rows elements; any may be NULL. */
+int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, double* d_pvalue,
+                        int32_t* d_sign, double* d_mean_control, double* d_mean_case,
+                        void* stream);
+
+/* Sort the first n survivor records by `row` ascending (the order the reference pushes
+ * them in, merge.hpp:100).  Synchronous. */
+int kmd_survivors_sort_by_row(const kmd_survivors* s, size_t n, void* stream);
+
+/* Gather the count vectors of survivors as doubles, KmerSign::m_counts_ratio
+ * (merge.hpp:91-92): d_out[i*S + s] = (double) counts[row_i - row_base][s]. */
+int kmd_survivors_gather_counts(const kmd_tile* tile, int n_samples, const uint64_t* d_rows,
+                                size_t n, double* d_out, void* stream);
+
+/* ---- stage 3: significance correction ---------------------------------------------------
+ * Replaces make_corrector + aggregator::worker / sorted_aggregator::run
+ * (src/corrector.cpp:6-116, include/kmdiff/aggregator.hpp:137-171,240-322): d_keep[i] = 1
+ * when survivor i passes `correction` at level `threshold` with N = total_kmers.  BH and
+ * Holm walk the survivors in ascending p and stop at the first rejection.  n_kept,
+ * n_control, n_case are host outputs (control = sign CONTROL, case = everything else,
+ * aggregator.hpp:155-162).  Synchronous. */
+int kmd_correct(int correction, double threshold, uint64_t total_kmers,
+                const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
+                uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream);
+
+/* ---- synthetic count matrices (benchmark / test support) ------------------
+ * Counter-based generator, every cell a pure function of (seed, partition, row, sample);
+ * the CPU oracle replays it.  d_kmer_lo / d_kmer_hi may be NULL. */
+int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc,
+                   int nk, int count_bytes, int layout, size_t ld, void* d_counts,
+                   uint64_t* d_kmer_lo, uint64_t* d_kmer_hi, void* stream);
+/* d_totals[s] += sum over rows of counts[.][s]  (uint64_t[nc+nk], caller zeroes);
+ * the role of get_total_kmer (src/kmtricks_utils.cpp:78-139) for synthetic data. */
+int kmd_column_sums(const void* d_counts, int count_bytes, int layout, size_t ld,
+                    size_t n_rows, int n_samples, uint64_t* d_totals, void* stream);
+/* Streaming-copy bandwidth probe (float4 copy of `bytes`), for the measured roofline. */
+int kmd_copy_probe(void* d_dst, const void* d_src, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMDIFF_HIP_H */

@@ -1,0 +1,19 @@
+"""kmdiff_amd -- MI355X-native hot path of `kmdiff diff` (tlemane/kmdiff).
+
+Host-side mirror of the reference's operator interface for the path (names follow the
+reference: PoissonLikelihood, diff_observer, make_corrector / aggregator) over the C-ABI of
+libkmdiff_hip.so.  All arithmetic runs in the HIP library; nothing here computes results on
+the CPU.
+"""
+from ._native import (KmdError, LIB_PATH, SIGN_CONTROL, SIGN_CASE, SIGN_NO, CORR_NOTHING,
+                      CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM, LAYOUT_ROWS,
+                      LAYOUT_SOA)
+from .hip import (DeviceBuffer, PoissonLikelihood, CountMatrix, SurvivorAccumulator,
+                  diff_observer, aggregate, synth_matrix, column_sums, device_count,
+                  device_name, Event, CORRECTION_BY_NAME)
+
+__all__ = ["KmdError", "LIB_PATH", "DeviceBuffer", "PoissonLikelihood", "CountMatrix",
+           "SurvivorAccumulator", "diff_observer", "aggregate", "synth_matrix", "column_sums",
+           "device_count", "device_name", "Event", "CORRECTION_BY_NAME",
+           "SIGN_CONTROL", "SIGN_CASE", "SIGN_NO", "CORR_NOTHING", "CORR_BONFERRONI",
+           "CORR_BENJAMINI", "CORR_SIDAK", "CORR_HOLM", "LAYOUT_ROWS", "LAYOUT_SOA"]

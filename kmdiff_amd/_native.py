@@ -1,0 +1,101 @@
+"""ctypes binding of libkmdiff_hip.so (include/kmdiff_hip.h).
+
+There is no CPU fallback: importing the package works without a GPU (so that the symbol
+table can be checked), but every compute call goes through the HIP library and raises
+KmdError when the library or a device is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkmdiff_hip.so")
+
+KMD_OK = 0
+KMD_E_OVERFLOW = -4
+SIGN_CONTROL, SIGN_CASE, SIGN_NO = 0, 1, 2
+CORR_NOTHING, CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM = 0, 1, 2, 3, 4
+LAYOUT_ROWS, LAYOUT_SOA = 0, 1
+NCOUNTERS = 8
+(CNT_TOTAL, CNT_SIG, CNT_SIG_CONTROL, CNT_SIG_CASE, CNT_CANDIDATES, CNT_DEFERRED) = range(6)
+
+
+class KmdError(RuntimeError):
+    pass
+
+
+class Survivors(C.Structure):
+    _fields_ = [("d_row", C.c_void_p), ("d_kmer_lo", C.c_void_p), ("d_kmer_hi", C.c_void_p),
+                ("d_pvalue", C.c_void_p), ("d_sign", C.c_void_p), ("d_mean_control", C.c_void_p),
+                ("d_mean_case", C.c_void_p), ("capacity", C.c_size_t)]
+
+
+class Tile(C.Structure):
+    _fields_ = [("d_counts", C.c_void_p), ("count_bytes", C.c_int), ("layout", C.c_int),
+                ("ld", C.c_size_t), ("d_kmer_lo", C.c_void_p), ("d_kmer_hi", C.c_void_p),
+                ("n_rows", C.c_size_t), ("row_base", C.c_uint64)]
+
+
+# name -> (restype, argtypes); the list mirrors include/kmdiff_hip.h and is what
+# tests/test_abi.py checks against the header and the built library.
+_vp, _sz, _u64, _i, _d = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_double
+SIGNATURES = {
+    "kmd_status_string": (C.c_char_p, [_i]),
+    "kmd_last_error": (C.c_char_p, []),
+    "kmd_abi_version": (_i, []),
+    "kmd_device_count": (_i, [C.POINTER(_i)]),
+    "kmd_set_device": (_i, [_i]),
+    "kmd_device_name": (_i, [C.c_char_p, _sz]),
+    "kmd_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "kmd_free": (_i, [_vp]),
+    "kmd_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "kmd_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "kmd_memset": (_i, [_vp, _i, _sz, _vp]),
+    "kmd_stream_sync": (_i, [_vp]),
+    "kmd_event_create": (_i, [C.POINTER(_vp)]),
+    "kmd_event_destroy": (_i, [_vp]),
+    "kmd_event_record": (_i, [_vp, _vp]),
+    "kmd_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "kmd_model_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _sz]),
+    "kmd_model_destroy": (_i, [_vp]),
+    "kmd_model_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u64), C.POINTER(_u64),
+                            C.POINTER(_sz)]),
+    "kmd_model_lf_table": (_i, [_vp, _vp, _sz]),
+    "kmd_poisson_filter": (_i, [_vp, C.POINTER(Tile), _d, C.POINTER(Survivors), _vp, _vp]),
+    "kmd_poisson_process": (_i, [_vp, C.POINTER(Tile), _vp, _vp, _vp, _vp, _vp]),
+    "kmd_survivors_sort_by_row": (_i, [C.POINTER(Survivors), _sz, _vp]),
+    "kmd_survivors_gather_counts": (_i, [C.POINTER(Tile), _i, _vp, _sz, _vp, _vp]),
+    "kmd_correct": (_i, [_i, _d, _u64, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
+                         C.POINTER(_u64), _vp]),
+    "kmd_synth_fill": (_i, [_u64, C.c_uint32, _u64, _sz, _i, _i, _i, _i, _sz, _vp, _vp, _vp, _vp]),
+    "kmd_column_sums": (_i, [_vp, _i, _i, _sz, _sz, _i, _vp, _vp]),
+    "kmd_copy_probe": (_i, [_vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libkmdiff_hip.so (once).  Raises KmdError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KmdError("libkmdiff_hip.so is not built (%s); run `python -c 'import "
+                           "__graft_entry__ as g; g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise KmdError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != KMD_OK:
+        L = lib()
+        msg = L.kmd_last_error().decode() or L.kmd_status_string(status).decode()
+        raise KmdError("%s: %s (status %d)" % (what or "kmd", msg, status))
+    return status

@@ -1,0 +1,418 @@
+// kmd_api.hip -- C-ABI plumbing of libkmdiff_hip.so: error reporting, device memory and
+// event helpers, the model object, the synthetic-matrix generator and the small support
+// kernels (column sums, copy probe).
+#include "kmd_internal.h"
+#include "kmd_math.h"
+#include "kmd_synth_tables.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void kmd::set_error(const std::string& msg) { g_last_error = msg; }
+
+int kmd::hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+  char buf[512];
+  std::snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_last_error = buf;
+  return e == hipErrorOutOfMemory ? KMD_E_NOMEM : KMD_E_HIP;
+}
+
+extern "C" {
+
+const char* kmd_status_string(int status)
+{
+  switch (status)
+  {
+    case KMD_OK: return "ok";
+    case KMD_E_INVALID: return "invalid argument";
+    case KMD_E_HIP: return "HIP runtime error";
+    case KMD_E_NO_DEVICE: return "no HIP device";
+    case KMD_E_OVERFLOW: return "survivor capacity exceeded";
+    case KMD_E_NOMEM: return "out of device memory";
+    default: return "unknown status";
+  }
+}
+
+const char* kmd_last_error(void) { return g_last_error.c_str(); }
+int kmd_abi_version(void) { return KMD_ABI_VERSION; }
+
+int kmd_device_count(int* n)
+{
+  KMD_REQUIRE(n, "kmd_device_count: NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *n = 0; (void)hipGetLastError(); kmd::set_error("no HIP device"); return KMD_E_NO_DEVICE; }
+  *n = c;
+  return c > 0 ? KMD_OK : KMD_E_NO_DEVICE;
+}
+
+int kmd_set_device(int device) { KMD_HIP(hipSetDevice(device)); return KMD_OK; }
+
+int kmd_device_name(char* buf, size_t len)
+{
+  KMD_REQUIRE(buf && len, "kmd_device_name: NULL");
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  KMD_HIP(hipGetDeviceProperties(&prop, dev));
+  std::snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return KMD_OK;
+}
+
+int kmd_malloc(void** d_ptr, size_t bytes)
+{
+  KMD_REQUIRE(d_ptr, "kmd_malloc: NULL");
+  KMD_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return KMD_OK;
+}
+int kmd_free(void* d_ptr) { if (d_ptr) KMD_HIP(hipFree(d_ptr)); return KMD_OK; }
+int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream)
+{
+  if (!bytes) return KMD_OK;
+  KMD_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return KMD_OK;
+}
+int kmd_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream)
+{
+  if (!bytes) return KMD_OK;
+  KMD_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return KMD_OK;
+}
+int kmd_memset(void* d_dst, int value, size_t bytes, void* stream)
+{
+  if (!bytes) return KMD_OK;
+  KMD_HIP(hipMemsetAsync(d_dst, value, bytes, static_cast<hipStream_t>(stream)));
+  return KMD_OK;
+}
+int kmd_stream_sync(void* stream) { KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return KMD_OK; }
+
+int kmd_event_create(void** ev)
+{
+  KMD_REQUIRE(ev, "kmd_event_create: NULL");
+  hipEvent_t e;
+  KMD_HIP(hipEventCreate(&e));
+  *ev = e;
+  return KMD_OK;
+}
+int kmd_event_destroy(void* ev) { if (ev) KMD_HIP(hipEventDestroy(static_cast<hipEvent_t>(ev))); return KMD_OK; }
+int kmd_event_record(void* ev, void* stream)
+{
+  KMD_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)));
+  return KMD_OK;
+}
+int kmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms)
+{
+  KMD_REQUIRE(ms, "kmd_event_elapsed_ms: NULL");
+  KMD_HIP(hipEventSynchronize(static_cast<hipEvent_t>(ev_stop)));
+  KMD_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)));
+  return KMD_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------
+
+int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
+                     const uint64_t* total_controls, const uint64_t* total_cases,
+                     size_t log_factorial_size)
+{
+  KMD_REQUIRE(out, "kmd_model_create: NULL out");
+  KMD_REQUIRE(nb_controls > 0 && nb_cases > 0, "kmd_model_create: need >= 1 control and >= 1 case");
+  KMD_REQUIRE(total_controls && total_cases, "kmd_model_create: NULL totals");
+  KMD_REQUIRE(log_factorial_size < 0x80000000ull, "kmd_model_create: log-factorial table too large");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); kmd::set_error("no HIP device"); return KMD_E_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  KMD_HIP(hipGetDeviceProperties(&prop, dev));
+
+  kmd_model* m = new (std::nothrow) kmd_model();
+  if (!m) return KMD_E_NOMEM;
+  m->device = dev;
+  m->nc = nb_controls; m->nk = nb_cases;
+  // model.hpp:185-188: std::accumulate over the per-sample totals
+  m->tc = 0; m->tk = 0;
+  for (int i = 0; i < nb_controls; ++i) m->tc += total_controls[i];
+  for (int i = 0; i < nb_cases; ++i) m->tk += total_cases[i];
+  m->dT = static_cast<double>(m->tc + m->tk);
+  m->dTc = static_cast<double>(m->tc);
+  m->dTk = static_cast<double>(m->tk);
+  m->lg_half = kmd::lngamma_half_host();
+  m->lf_n = log_factorial_size;
+  m->n_cu = prop.multiProcessorCount;
+  size_t lds = prop.sharedMemPerBlock;
+  int optin = 0;
+  if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess &&
+      (size_t)optin > lds)
+    lds = (size_t)optin;
+  (void)hipGetLastError();
+  m->lds_per_block_max = lds;
+
+  // LogFactorialTable::LogFactorialTable (src/log_factorial_table.cpp:5-22): entry i is the
+  // descending sum log(i) + log(i-1) + ... + log(2), each entry summed from scratch.
+  const size_t n = log_factorial_size ? log_factorial_size : 1;
+  m->h_lf = static_cast<double*>(std::malloc(n * sizeof(double)));
+  if (!m->h_lf) { delete m; return KMD_E_NOMEM; }
+  m->h_lf[0] = 0;
+  for (size_t i = 0; i < log_factorial_size; ++i)
+  {
+    double res = 0;
+    for (size_t k = i; k > 1; --k) res += std::log(static_cast<double>(k));
+    m->h_lf[i] = res;
+  }
+  m->d_lf = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_lf), n * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(m->d_lf, m->h_lf, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess)
+  {
+    if (m->d_lf) (void)hipFree(m->d_lf);
+    std::free(m->h_lf); delete m;
+    return kmd::hip_fail(e, "upload log-factorial table", __FILE__, __LINE__);
+  }
+  *out = m;
+  return KMD_OK;
+}
+
+int kmd_model_destroy(kmd_model* m)
+{
+  if (!m) return KMD_OK;
+  if (m->d_lf) (void)hipFree(m->d_lf);
+  std::free(m->h_lf);
+  delete m;
+  return KMD_OK;
+}
+
+int kmd_model_info(const kmd_model* m, int* nc, int* nk, uint64_t* tc, uint64_t* tk, size_t* lf_n)
+{
+  KMD_REQUIRE(m, "kmd_model_info: NULL");
+  if (nc) *nc = m->nc;
+  if (nk) *nk = m->nk;
+  if (tc) *tc = m->tc;
+  if (tk) *tk = m->tk;
+  if (lf_n) *lf_n = m->lf_n;
+  return KMD_OK;
+}
+
+int kmd_model_lf_table(const kmd_model* m, double* out, size_t n)
+{
+  KMD_REQUIRE(m && out, "kmd_model_lf_table: NULL");
+  KMD_REQUIRE(n <= m->lf_n, "kmd_model_lf_table: n > table size");
+  KMD_HIP(hipMemcpy(out, m->d_lf, n * sizeof(double), hipMemcpyDeviceToHost));
+  return KMD_OK;
+}
+
+} // extern "C"
+
+// ---- synthetic matrices ----------------------------------------------------------------------
+// Definition (also restated, independently, by the CPU oracle):
+//   h_row   = mix(mix(seed ^ C_PART*(part+1)) ^ C_ROW*(row+1))
+//   class   = rate class from h_row[0,16) with weights .40 .30 .15 .10 .04 .01 -> lambda index
+//             base {1,3,5,7,11,17}  (lambda_j = 0.5 * 2^(j/2), tables in kmd_synth_tables.h)
+//   big     = (h_row >> 16) % 1e6 == 1   -> base index 24 (count sums beyond the lf table)
+//   planted = (h_row >> 36) % 1e4 == 0   -> +6 steps (x8) on cases, on controls if h_row bit 63
+//   depth_s = mix(seed ^ C_DEPTH*(s+1)) % 3 -> +0/+1/+2 steps per sample
+//   cell    = hc = mix(h_row ^ C_CELL*(s+1)); classes 0,1 zero-inflated (p = 0.3) on
+//             hc[32,48); else inverse-CDF Poisson draw of the low 32 bits of hc
+//   all-zero rows get count 1 in sample h_row % S
+//   kmer    = part*2^54 + row*2^21 + 1 + (mix(h_row ^ C_KMER) & 0xFFFFF); for k > 32 that is
+//             the high limb and the low limb is mix(h_row ^ C_KMER2)
+namespace {
+
+constexpr uint64_t C_PART = 0xA0761D6478BD642Full, C_ROW = 0xE7037ED1A0B428DBull,
+                   C_DEPTH = 0x8EBC6AF09C88C6E3ull, C_CELL = 0x589965CC75374CC3ull,
+                   C_KMER = 0x1D8E4E27C47D124Full, C_KMER2 = 0xEB44ACCAB455D165ull;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+struct synth_tables { const uint32_t* off; const uint32_t* c0; const uint32_t* len; const uint32_t* thr; };
+synth_tables g_tables[16] = {};          // per device
+bool g_tables_ready[16] = {};
+
+int ensure_tables(synth_tables& t)
+{
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
+  KMD_REQUIRE(dev < 16, "kmd_synth: device index >= 16");
+  if (!g_tables_ready[dev])
+  {
+    uint32_t* d = nullptr;
+    const size_t n = 3 * KMD_SYNTH_NJ + KMD_SYNTH_NTHR;
+    KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(uint32_t)));
+    KMD_HIP(hipMemcpy(d, KMD_SYNTH_OFF, KMD_SYNTH_NJ * 4, hipMemcpyHostToDevice));
+    KMD_HIP(hipMemcpy(d + KMD_SYNTH_NJ, KMD_SYNTH_C0, KMD_SYNTH_NJ * 4, hipMemcpyHostToDevice));
+    KMD_HIP(hipMemcpy(d + 2 * KMD_SYNTH_NJ, KMD_SYNTH_LEN, KMD_SYNTH_NJ * 4, hipMemcpyHostToDevice));
+    KMD_HIP(hipMemcpy(d + 3 * KMD_SYNTH_NJ, KMD_SYNTH_THR, KMD_SYNTH_NTHR * 4, hipMemcpyHostToDevice));
+    g_tables[dev] = synth_tables{ d, d + KMD_SYNTH_NJ, d + 2 * KMD_SYNTH_NJ, d + 3 * KMD_SYNTH_NJ };
+    g_tables_ready[dev] = true;
+  }
+  t = g_tables[dev];
+  return KMD_OK;
+}
+
+template <typename CT>
+__global__ void __launch_bounds__(256) k_synth(uint64_t seed, uint32_t part, uint64_t row0, size_t n_rows,
+                                               int nc, int nk, int layout, size_t ld, CT* __restrict__ counts,
+                                               uint64_t* __restrict__ kmer_lo, uint64_t* __restrict__ kmer_hi,
+                                               synth_tables T)
+{
+  const int S = nc + nk;
+  constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
+  {
+    const uint64_t row = row0 + r;
+    const uint64_t h = mix64(mix64(seed ^ (C_PART * ((uint64_t)part + 1))) ^ (C_ROW * (row + 1)));
+    const uint32_t u16 = (uint32_t)(h & 0xFFFF);
+    int cls = u16 < 26214 ? 0 : u16 < 45875 ? 1 : u16 < 55705 ? 2 : u16 < 62259 ? 3 : u16 < 64880 ? 4 : 5;
+    int jbase = cls == 0 ? 1 : cls == 1 ? 3 : cls == 2 ? 5 : cls == 3 ? 7 : cls == 4 ? 11 : 17;
+    if ((h >> 16) % 1000000ull == 1) { jbase = 24; cls = 6; }
+    const bool planted = (h >> 36) % 10000ull == 0;
+    const int boost_controls = (int)(h >> 63);
+    bool any = false;
+    for (int s = 0; s < S; ++s)
+    {
+      const uint64_t hc = mix64(h ^ (C_CELL * ((uint64_t)s + 1)));
+      uint32_t v = 0;
+      if (!(cls <= 1 && ((hc >> 32) & 0xFFFF) < 19661))
+      {
+        int j = jbase + (int)(mix64(seed ^ (C_DEPTH * ((uint64_t)s + 1))) % 3);
+        const int is_case = s >= nc;
+        if (planted && boost_controls != is_case) j += 6;
+        if (j > KMD_SYNTH_NJ - 1) j = KMD_SYNTH_NJ - 1;
+        const uint32_t* thr = T.thr + T.off[j];
+        const uint32_t u = (uint32_t)hc;
+        uint32_t lo = 0, hi = T.len[j];
+        while (lo < hi)
+        {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (thr[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        v = T.c0[j] + lo;
+      }
+      any |= (v != 0);
+      if (v > cmax) v = cmax;
+      const size_t idx = (layout == KMD_LAYOUT_ROWS) ? r * ld + s : (size_t)s * ld + r;
+      counts[idx] = (CT)v;
+    }
+    if (!any)
+    {
+      const int s = (int)(h % (uint64_t)S);
+      const size_t idx = (layout == KMD_LAYOUT_ROWS) ? r * ld + s : (size_t)s * ld + r;
+      counts[idx] = (CT)1;
+    }
+    if (kmer_lo)
+    {
+      const uint64_t v = ((uint64_t)part << 54) + (row << 21) + 1 + (mix64(h ^ C_KMER) & 0xFFFFF);
+      if (kmer_hi) { kmer_hi[r] = v; kmer_lo[r] = mix64(h ^ C_KMER2); }
+      else kmer_lo[r] = v;
+    }
+  }
+}
+
+// per-sample totals: d_totals[s] += sum_rows counts[.][s]
+template <typename CT>
+__global__ void __launch_bounds__(256) k_column_sums(const CT* __restrict__ counts, int layout, size_t ld,
+                                                     size_t n_rows, int n_samples,
+                                                     unsigned long long* __restrict__ totals)
+{
+  __shared__ unsigned long long s_part[4];
+  // blockIdx.y = sample; blockIdx.x strides rows
+  const int s = blockIdx.y;
+  unsigned long long acc = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
+    acc += (layout == KMD_LAYOUT_ROWS) ? counts[r * ld + s] : counts[(size_t)s * ld + r];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(&totals[s], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  (void)n_samples;
+}
+
+__global__ void __launch_bounds__(256) k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+} // namespace
+
+extern "C" {
+
+int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc,
+                   int nk, int count_bytes, int layout, size_t ld, void* d_counts,
+                   uint64_t* d_kmer_lo, uint64_t* d_kmer_hi, void* stream)
+{
+  KMD_REQUIRE(d_counts || n_rows == 0, "kmd_synth_fill: NULL counts");
+  KMD_REQUIRE(nc > 0 && nk > 0, "kmd_synth_fill: nc, nk must be positive");
+  KMD_REQUIRE(count_bytes == 1 || count_bytes == 2 || count_bytes == 4, "kmd_synth_fill: count_bytes");
+  KMD_REQUIRE(layout == KMD_LAYOUT_SOA || layout == KMD_LAYOUT_ROWS, "kmd_synth_fill: layout");
+  KMD_REQUIRE(partition < 256, "kmd_synth_fill: partition >= 256");
+  if (n_rows == 0) return KMD_OK;
+  synth_tables T;
+  int rc = ensure_tables(T);
+  if (rc != KMD_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  size_t grid = (n_rows + 255) / 256;
+  if (grid > 65535 * 4) grid = 65535 * 4;
+  switch (count_bytes)
+  {
+    case 1: hipLaunchKernelGGL((k_synth<uint8_t>), dim3((unsigned)grid), dim3(256), 0, st, seed, partition, row0, n_rows, nc, nk, layout, ld, static_cast<uint8_t*>(d_counts), d_kmer_lo, d_kmer_hi, T); break;
+    case 2: hipLaunchKernelGGL((k_synth<uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, seed, partition, row0, n_rows, nc, nk, layout, ld, static_cast<uint16_t*>(d_counts), d_kmer_lo, d_kmer_hi, T); break;
+    default: hipLaunchKernelGGL((k_synth<uint32_t>), dim3((unsigned)grid), dim3(256), 0, st, seed, partition, row0, n_rows, nc, nk, layout, ld, static_cast<uint32_t*>(d_counts), d_kmer_lo, d_kmer_hi, T); break;
+  }
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+int kmd_column_sums(const void* d_counts, int count_bytes, int layout, size_t ld,
+                    size_t n_rows, int n_samples, uint64_t* d_totals, void* stream)
+{
+  KMD_REQUIRE(d_totals && (d_counts || n_rows == 0), "kmd_column_sums: NULL");
+  KMD_REQUIRE(count_bytes == 1 || count_bytes == 2 || count_bytes == 4, "kmd_column_sums: count_bytes");
+  KMD_REQUIRE(n_samples > 0 && n_samples <= 65535, "kmd_column_sums: n_samples");
+  if (n_rows == 0) return KMD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  size_t gx = (n_rows + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, (unsigned)n_samples);
+  unsigned long long* tot = reinterpret_cast<unsigned long long*>(d_totals);
+  switch (count_bytes)
+  {
+    case 1: hipLaunchKernelGGL((k_column_sums<uint8_t>), grid, dim3(256), 0, st, static_cast<const uint8_t*>(d_counts), layout, ld, n_rows, n_samples, tot); break;
+    case 2: hipLaunchKernelGGL((k_column_sums<uint16_t>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(d_counts), layout, ld, n_rows, n_samples, tot); break;
+    default: hipLaunchKernelGGL((k_column_sums<uint32_t>), grid, dim3(256), 0, st, static_cast<const uint32_t*>(d_counts), layout, ld, n_rows, n_samples, tot); break;
+  }
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+int kmd_copy_probe(void* d_dst, const void* d_src, size_t bytes, void* stream)
+{
+  KMD_REQUIRE(d_dst && d_src, "kmd_copy_probe: NULL");
+  KMD_REQUIRE(bytes % 16 == 0, "kmd_copy_probe: bytes % 16");
+  const size_t n = bytes / 16;
+  if (!n) return KMD_OK;
+  size_t grid = (n + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(k_copy_probe, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float4*>(d_src), static_cast<float4*>(d_dst), n);
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,632 @@
+// kmd_filter.hip -- K1: merge observer + Poisson likelihood-ratio test + threshold +
+// survivor compaction for one partition tile, hand-written for gfx950 (CDNA4, wave64).
+//
+// Replaces, per row, diff_observer::process (include/kmdiff/merge.hpp:68-103) calling
+// PoissonLikelihood::process (include/kmdiff/model.hpp:142-176).
+//
+// Shape of the work (HBM-bound, no MFMA: nothing here is a contraction):
+//   * one wavefront lane per k-mer row; with the SoA layout each lane owns RPL consecutive
+//     rows so every column read is one 16-byte load per lane (1 KiB per wave instruction);
+//   * persistent workgroups (grid = CUs x blocks/CU) stage the head of the log-factorial
+//     table in LDS once and then grid-stride over row tiles;
+//   * the four log() of the likelihood ratio run for every row, the chi-square tail
+//     function only for rows whose LR can reach the threshold (igamc is monotone in LR; the
+//     reference never exposes p for rows with p > threshold, merge.hpp:78);
+//   * survivors are compacted with a wave ballot + one atomic per wave;
+//   * count sums beyond the table (LogFactorialTable::operator[] fallback,
+//     log_factorial_table.hpp:14-18) are evaluated by the whole wave in the reference's
+//     descending order: 64 log() in parallel, one ordered accumulation.
+#include "kmd_internal.h"
+#include "kmd_math.h"
+
+namespace {
+
+constexpr int kBlock = 512;
+
+struct filter_params
+{
+  const void* counts;
+  size_t ld;
+  size_t n_rows;
+  uint64_t row_base;
+  const uint64_t* kmer_lo;
+  const uint64_t* kmer_hi;
+  int nc, nk;
+  double dT, dTc, dTk, lg_half, lr_cut, threshold;
+  const double* lf;
+  uint32_t lf_n;
+  uint32_t lds_n;
+  kmd_survivors out;
+  unsigned long long* counters;
+};
+
+template <typename T, int N> struct vec_of;
+template <> struct vec_of<uint32_t, 1> { using type = uint32_t; };
+template <> struct vec_of<uint32_t, 2> { using type = uint2; };
+template <> struct vec_of<uint32_t, 4> { using type = uint4; };
+template <> struct vec_of<uint16_t, 1> { using type = uint16_t; };
+template <> struct vec_of<uint16_t, 8> { using type = uint4; };
+template <> struct vec_of<uint8_t, 1> { using type = uint8_t; };
+template <> struct vec_of<uint8_t, 16> { using type = uint4; };
+
+// accumulator wide enough for nc+nk <= 65535 samples
+template <typename CT> struct acc_of { using type = uint32_t; };
+template <> struct acc_of<uint32_t> { using type = uint64_t; };
+
+template <typename CT, int RPL, typename ACC>
+__device__ __forceinline__ void accumulate(const CT* __restrict__ p, ACC (&acc)[RPL])
+{
+  using V = typename vec_of<CT, RPL>::type;
+  if constexpr (RPL == 1)
+  {
+    acc[0] += (ACC)(*p);
+  }
+  else
+  {
+    const V v = *reinterpret_cast<const V*>(p);
+    if constexpr (sizeof(CT) == 4)
+    {
+      if constexpr (RPL == 2) { acc[0] += v.x; acc[1] += v.y; }
+      else { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
+    }
+    else
+    {
+      const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+      constexpr int per = 4 / sizeof(CT);            // elements per dword
+      constexpr uint32_t mask = sizeof(CT) == 1 ? 0xFFu : 0xFFFFu;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < per; ++e)
+          acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
+    }
+  }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// LogFactorialTable::log_factorial (src/log_factorial_table.cpp:13-22) for a wave-uniform
+// k: res = log(k) + log(k-1) + ... + log(2), accumulated in exactly that order.  The 64
+// lanes evaluate 64 consecutive terms at once; the additions stay sequential.
+__device__ double wave_lf_descending(uint64_t k)
+{
+  const int lane = __lane_id();
+  double res = 0;
+  while (k > 1)
+  {
+    const uint64_t n_terms = k - 1 < 64 ? k - 1 : 64;      // terms k, k-1, ..., k-n_terms+1
+    const double t = ((uint64_t)lane < n_terms) ? ::log((double)(k - (uint64_t)lane)) : 0.0;
+    if (n_terms == 64)
+    {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) res += readlane_f64(t, i);
+    }
+    else
+    {
+      for (int i = 0; i < (int)n_terms; ++i) res += readlane_f64(t, i);
+    }
+    k -= n_terms;
+  }
+  return res;
+}
+
+struct row_state
+{
+  uint64_t sum_c, sum_k;
+  uint64_t row;        // local row index in the tile
+  bool valid;
+};
+
+// One row from its two count sums to the survivor sink.  Must be called by all 64 lanes of
+// the wave together (ballots / cooperative fallback inside).
+__device__ __forceinline__ void finish_row(const filter_params& P, const double* s_lf,
+                                           const row_state& st)
+{
+  const uint32_t kc = kmd::table_index(st.sum_c);
+  const uint32_t kk = kmd::table_index(st.sum_k);
+  double lf_c = 0, lf_k = 0;
+  if (kc < P.lds_n) lf_c = s_lf[kc]; else if (kc < P.lf_n) lf_c = P.lf[kc];
+  if (kk < P.lds_n) lf_k = s_lf[kk]; else if (kk < P.lf_n) lf_k = P.lf[kk];
+
+  // table misses: the whole wave serves one (lane, k) at a time
+  bool miss_c = st.valid && kc >= P.lf_n;
+  bool miss_k = st.valid && kk >= P.lf_n;
+  unsigned long long need = __ballot(miss_c | miss_k);
+  if (need)
+  {
+    const int lane = __lane_id();
+    unsigned long long n_def = __popcll(need);
+    if (lane == (int)(__ffsll((long long)need) - 1))
+      atomicAdd(&P.counters[KMD_CNT_DEFERRED], n_def);
+    while (need)
+    {
+      const int src = __ffsll((long long)need) - 1;
+      const uint32_t skc = (uint32_t)__builtin_amdgcn_readlane((int)kc, src);
+      const uint32_t skk = (uint32_t)__builtin_amdgcn_readlane((int)kk, src);
+      double v_c = 0, v_k = 0;
+      if (skc >= P.lf_n) v_c = wave_lf_descending(skc);
+      if (skk >= P.lf_n) v_k = (skk == skc && skc >= P.lf_n) ? v_c : wave_lf_descending(skk);
+      if (lane == src)
+      {
+        if (miss_c) lf_c = v_c;
+        if (miss_k) lf_k = v_k;
+      }
+      need &= need - 1;
+    }
+  }
+
+  const kmd::lrt_result r = kmd::lrt_from_sums(st.sum_c, st.sum_k, lf_c, lf_k, P.dT, P.dTc, P.dTk);
+  const bool cand = st.valid && (r.lr >= P.lr_cut);
+  bool surv = false;
+  double p = 1.0;
+  const unsigned long long cand_mask = __ballot(cand);
+  if (cand_mask)
+  {
+    if (cand)
+    {
+      p = kmd::igamc_half(r.lr, P.lg_half);                 // model.hpp:161
+      surv = (p <= P.threshold);                            // merge.hpp:78
+    }
+    const unsigned long long surv_mask = __ballot(surv);
+    const unsigned long long ctrl_mask = __ballot(surv && r.sign == KMD_SIGN_CONTROL);
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)cand_mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader)
+    {
+      atomicAdd(&P.counters[KMD_CNT_CANDIDATES], (unsigned long long)__popcll(cand_mask));
+      if (surv_mask)
+      {
+        const unsigned long long ns = __popcll(surv_mask), nctl = __popcll(ctrl_mask);
+        base = atomicAdd(&P.counters[KMD_CNT_SIG], ns);                    // merge.hpp:101
+        if (nctl) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], nctl);       // merge.hpp:95-96
+        if (ns - nctl) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], ns - nctl);// merge.hpp:97-98
+      }
+    }
+    if (surv_mask)
+    {
+      base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+             (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+      if (surv)
+      {
+        const unsigned long long slot =
+            base + __popcll(surv_mask & ((1ull << lane) - 1ull));
+        if (slot < P.out.capacity)
+        {
+          if (P.out.d_row) P.out.d_row[slot] = P.row_base + st.row;
+          if (P.out.d_kmer_lo && P.kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[st.row];
+          if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[st.row];
+          if (P.out.d_pvalue) P.out.d_pvalue[slot] = p;
+          if (P.out.d_sign) P.out.d_sign[slot] = r.sign;
+          if (P.out.d_mean_control) P.out.d_mean_control[slot] = r.mean_control;
+          if (P.out.d_mean_case) P.out.d_mean_case[slot] = (double)st.sum_k;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_table(const filter_params& P, double* s_lf)
+{
+  for (uint32_t i = threadIdx.x; i < P.lds_n; i += blockDim.x) s_lf[i] = P.lf[i];
+  __syncthreads();
+}
+
+// ---- SoA layout: counts[sample][row] ------------------------------------------------------
+template <typename CT, int RPL>
+__global__ void __launch_bounds__(kBlock) k_filter_soa(const filter_params P)
+{
+  extern __shared__ double s_lf[];
+  stage_table(P, s_lf);
+
+  using ACC = typename acc_of<CT>::type;
+  const CT* __restrict__ base = static_cast<const CT*>(P.counts);
+  const size_t tile_rows = (size_t)blockDim.x * RPL;
+  const size_t n_tiles = (P.n_rows + tile_rows - 1) / tile_rows;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);    // merge.hpp:76
+
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+  {
+    const size_t r0 = tile * tile_rows + (size_t)threadIdx.x * RPL;
+    ACC sc[RPL], sk[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) { sc[j] = 0; sk[j] = 0; }
+
+    if (r0 + RPL <= P.n_rows)
+    {
+      const CT* __restrict__ col = base + r0;
+#pragma unroll 8
+      for (int s = 0; s < P.nc; ++s, col += P.ld) accumulate<CT, RPL>(col, sc);
+#pragma unroll 8
+      for (int s = 0; s < P.nk; ++s, col += P.ld) accumulate<CT, RPL>(col, sk);
+    }
+    else if (r0 < P.n_rows)
+    {
+      // ragged last tile: scalar loads with a bound check per row
+      for (int j = 0; j < RPL; ++j)
+      {
+        if (r0 + j >= P.n_rows) break;
+        const CT* __restrict__ col = base + r0 + j;
+        for (int s = 0; s < P.nc; ++s, col += P.ld) sc[j] += (ACC)(*col);
+        for (int s = 0; s < P.nk; ++s, col += P.ld) sk[j] += (ACC)(*col);
+      }
+    }
+
+#pragma unroll
+    for (int j = 0; j < RPL; ++j)
+    {
+      row_state st;
+      st.sum_c = sc[j]; st.sum_k = sk[j];
+      st.row = r0 + j;
+      st.valid = (r0 + j) < P.n_rows;
+      finish_row(P, s_lf, st);
+    }
+  }
+}
+
+// ---- row-major layout: counts[row][sample] -------------------------------------------------
+// What km::MatrixReader / KmerMerger hand the observer (merge.hpp:68,194-203).  A workgroup
+// copies a tile of kRowsBlock rows x one column chunk into LDS with coalesced loads (16 bytes
+// per lane when the pitch allows), re-pitched to an odd dword stride so that the per-lane
+// row walk is bank-conflict free; each lane then sums its own row out of LDS.
+constexpr int kRowsBlock = 256;
+
+template <typename CT, int VEC>
+__global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params P, const uint32_t pitch_dw,
+                                                            const uint32_t chunk_dw)
+{
+  extern __shared__ double s_all[];
+  double* s_lf = s_all;
+  uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_all + P.lds_n);
+  stage_table(P, s_lf);
+
+  const uint32_t S = (uint32_t)(P.nc + P.nk);
+  constexpr uint32_t per = 4 / sizeof(CT);                      // counts per dword
+  constexpr uint32_t emask = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  const uint32_t row_dw = (S + per - 1) / per;                  // dwords spanned by one row
+  const size_t ld_dw = P.ld / per;                              // row pitch in dwords (exact)
+  const uint32_t* __restrict__ base = static_cast<const uint32_t*>(P.counts);
+  const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
+
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+  {
+    const size_t row0 = tile * kRowsBlock;
+    const uint32_t rows_here = (uint32_t)((P.n_rows - row0) < (size_t)kRowsBlock ? (P.n_rows - row0) : kRowsBlock);
+    uint64_t sc = 0, sk = 0;
+    for (uint32_t c0 = 0; c0 < row_dw; c0 += chunk_dw)
+    {
+      const uint32_t cw = (row_dw - c0) < chunk_dw ? (row_dw - c0) : chunk_dw;
+      __syncthreads();                                          // previous chunk consumed
+      if constexpr (VEC == 4)
+      {
+        const uint32_t cw4 = cw >> 2;                           // cw % 4 == 0 by construction
+        const uint32_t n = rows_here * cw4;
+        for (uint32_t i = threadIdx.x; i < n; i += kRowsBlock)
+        {
+          const uint32_t r = i / cw4, c = (i - r * cw4) << 2;
+          const uint4 v = *reinterpret_cast<const uint4*>(base + (row0 + r) * ld_dw + c0 + c);
+          uint32_t* d = s_tile + r * pitch_dw + c;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+      }
+      else
+      {
+        const uint32_t n = rows_here * cw;
+        for (uint32_t i = threadIdx.x; i < n; i += kRowsBlock)
+        {
+          const uint32_t r = i / cw, c = i - r * cw;
+          s_tile[r * pitch_dw + c] = base[(row0 + r) * ld_dw + c0 + c];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < rows_here)
+      {
+        const uint32_t* __restrict__ mine = s_tile + threadIdx.x * pitch_dw;
+        uint32_t el = c0 * per;
+        for (uint32_t d = 0; d < cw; ++d)
+        {
+          const uint32_t w = mine[d];
+#pragma unroll
+          for (uint32_t e = 0; e < per; ++e, ++el)
+          {
+            const uint32_t v = (per == 1) ? w : ((w >> (8 * sizeof(CT) * e)) & emask);
+            if (el < (uint32_t)P.nc) sc += v; else if (el < S) sk += v;
+          }
+        }
+      }
+    }
+    row_state st;
+    st.row = row0 + threadIdx.x;
+    st.valid = threadIdx.x < rows_here;
+    st.sum_c = sc; st.sum_k = sk;
+    finish_row(P, s_lf, st);
+  }
+}
+
+// Row-major rows whose pitch is not a whole number of dwords: each lane walks its own row
+// straight from global memory (correct for any pitch/alignment; not a tuned path).
+template <typename CT>
+__global__ void __launch_bounds__(kRowsBlock) k_filter_rows_direct(const filter_params P)
+{
+  extern __shared__ double s_lf[];
+  stage_table(P, s_lf);
+  const CT* __restrict__ base = static_cast<const CT*>(P.counts);
+  const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+  {
+    row_state st;
+    st.row = tile * kRowsBlock + threadIdx.x;
+    st.valid = st.row < P.n_rows;
+    uint64_t sc = 0, sk = 0;
+    if (st.valid)
+    {
+      const CT* __restrict__ r = base + st.row * P.ld;
+      for (int s = 0; s < P.nc; ++s) sc += r[s];
+      for (int s = 0; s < P.nk; ++s) sk += r[P.nc + s];
+    }
+    st.sum_c = sc; st.sum_k = sk;
+    finish_row(P, s_lf, st);
+  }
+}
+
+// ---- every row's result, no threshold: IModel::process over a tile -----------------------
+template <typename CT>
+__global__ void __launch_bounds__(256) k_process_all(const filter_params P, int layout,
+                                                     double* __restrict__ o_p, int32_t* __restrict__ o_sign,
+                                                     double* __restrict__ o_mc, double* __restrict__ o_mk)
+{
+  const CT* __restrict__ base = static_cast<const CT*>(P.counts);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // whole waves stay in the loop together (the table fallback is wave-cooperative)
+  const size_t n_round = (P.n_rows + 63) / 64 * 64;
+  for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_round; row += stride)
+  {
+    const bool valid = row < P.n_rows;
+    uint64_t sc = 0, sk = 0;
+    if (valid)
+    {
+      if (layout == KMD_LAYOUT_SOA)
+      {
+        const CT* col = base + row;
+        for (int s = 0; s < P.nc; ++s, col += P.ld) sc += *col;
+        for (int s = 0; s < P.nk; ++s, col += P.ld) sk += *col;
+      }
+      else
+      {
+        const CT* r = base + row * P.ld;
+        for (int s = 0; s < P.nc; ++s) sc += r[s];
+        for (int s = 0; s < P.nk; ++s) sk += r[P.nc + s];
+      }
+    }
+    const uint32_t kc = kmd::table_index(sc), kk = kmd::table_index(sk);
+    double lf_c = 0, lf_k = 0;
+    if (kc < P.lf_n) lf_c = P.lf[kc];
+    if (kk < P.lf_n) lf_k = P.lf[kk];
+    const bool miss_c = valid && kc >= P.lf_n, miss_k = valid && kk >= P.lf_n;
+    unsigned long long need = __ballot(miss_c | miss_k);
+    while (need)
+    {
+      const int src = __ffsll((long long)need) - 1;
+      const uint32_t skc = (uint32_t)__builtin_amdgcn_readlane((int)kc, src);
+      const uint32_t skk = (uint32_t)__builtin_amdgcn_readlane((int)kk, src);
+      double v_c = 0, v_k = 0;
+      if (skc >= P.lf_n) v_c = wave_lf_descending(skc);
+      if (skk >= P.lf_n) v_k = (skk == skc && skc >= P.lf_n) ? v_c : wave_lf_descending(skk);
+      if ((int)__lane_id() == src) { if (miss_c) lf_c = v_c; if (miss_k) lf_k = v_k; }
+      need &= need - 1;
+    }
+    if (valid)
+    {
+      const kmd::lrt_result r = kmd::lrt_from_sums(sc, sk, lf_c, lf_k, P.dT, P.dTc, P.dTk);
+      if (o_p) o_p[row] = kmd::igamc_half(r.lr, P.lg_half);
+      if (o_sign) o_sign[row] = r.sign;
+      if (o_mc) o_mc[row] = r.mean_control;
+      if (o_mk) o_mk[row] = (double)sk;
+    }
+  }
+}
+
+int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double threshold)
+{
+  KMD_REQUIRE(m && t, "kmd: NULL model or tile");
+  KMD_REQUIRE(t->count_bytes == 1 || t->count_bytes == 2 || t->count_bytes == 4,
+              "kmd: count_bytes must be 1, 2 or 4");
+  KMD_REQUIRE(t->layout == KMD_LAYOUT_SOA || t->layout == KMD_LAYOUT_ROWS, "kmd: bad layout");
+  KMD_REQUIRE(t->n_rows == 0 || t->d_counts, "kmd: NULL count matrix");
+  KMD_REQUIRE(m->nc + m->nk <= 65535, "kmd: more than 65535 samples");
+  if (t->layout == KMD_LAYOUT_SOA) KMD_REQUIRE(t->ld >= t->n_rows, "kmd: SoA ld < n_rows");
+  else KMD_REQUIRE(t->ld >= (size_t)(m->nc + m->nk), "kmd: row-major ld < nc+nk");
+  P.counts = t->d_counts; P.ld = t->ld; P.n_rows = t->n_rows; P.row_base = t->row_base;
+  P.kmer_lo = t->d_kmer_lo; P.kmer_hi = t->d_kmer_hi;
+  P.nc = m->nc; P.nk = m->nk;
+  P.dT = m->dT; P.dTc = m->dTc; P.dTk = m->dTk; P.lg_half = m->lg_half;
+  P.threshold = threshold;
+  P.lr_cut = kmd::lr_cut_for_threshold(threshold, m->lg_half);
+  P.lf = m->d_lf; P.lf_n = (uint32_t)m->lf_n;
+  P.lds_n = 0;
+  P.counters = nullptr;
+  P.out = kmd_survivors{};
+  return KMD_OK;
+}
+
+template <typename K> int allow_big_lds(K kernel, size_t lds_bytes);
+
+template <typename CT>
+int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int blocks_per_cu,
+               hipStream_t stream)
+{
+  constexpr int vec = 16 / sizeof(CT);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
+                       ((P.ld * sizeof(CT)) % 16 == 0);
+  const size_t rpl = aligned ? vec : 1;
+  const size_t tile_rows = (size_t)kBlock * rpl;
+  size_t n_tiles = (P.n_rows + tile_rows - 1) / tile_rows;
+  size_t grid = (size_t)m->n_cu * blocks_per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  if (grid == 0) grid = 1;
+  if (aligned)
+  {
+    int rc = allow_big_lds(k_filter_soa<CT, vec>, lds_bytes);
+    if (rc != KMD_OK) return rc;
+    hipLaunchKernelGGL((k_filter_soa<CT, vec>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, P);
+  }
+  else
+  {
+    int rc = allow_big_lds(k_filter_soa<CT, 1>, lds_bytes);
+    if (rc != KMD_OK) return rc;
+    hipLaunchKernelGGL((k_filter_soa<CT, 1>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, P);
+  }
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+template <typename K>
+int allow_big_lds(K kernel, size_t lds_bytes)
+{
+  if (lds_bytes > 64 * 1024)
+    KMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  return KMD_OK;
+}
+
+template <typename CT>
+int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
+{
+  constexpr uint32_t per = 4 / sizeof(CT);
+  const uint32_t S = (uint32_t)(P.nc + P.nk);
+  const size_t half = m->lds_per_block_max / 2 - 256;
+  const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
+  const bool dword_rows = (P.ld % per == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 3u) == 0);
+  if (!dword_rows)
+  {
+    size_t want = (size_t)P.lf_n * sizeof(double);
+    if (want > half) want = half / sizeof(double) * sizeof(double);
+    P.lds_n = (uint32_t)(want / sizeof(double));
+    size_t grid = (size_t)m->n_cu * 4;
+    if (grid > n_tiles) grid = n_tiles;
+    int rc = allow_big_lds(k_filter_rows_direct<CT>, want);
+    if (rc != KMD_OK) return rc;
+    hipLaunchKernelGGL((k_filter_rows_direct<CT>), dim3((unsigned)grid), dim3(kRowsBlock), want, stream, P);
+    KMD_HIP(hipGetLastError());
+    return KMD_OK;
+  }
+  const uint32_t row_dw = (S + per - 1) / per;
+  const size_t ld_dw = P.ld / per;
+  const bool vec4 = (row_dw % 4 == 0) && (ld_dw % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);
+  // column chunk: whole rows when they fit in ~48 KiB of LDS, else 44-dword chunks
+  uint32_t chunk_dw = row_dw <= 47 ? row_dw : 44;
+  const uint32_t pitch = chunk_dw | 1u;                 // odd dword pitch: conflict-free walk
+  const size_t tile_bytes = (size_t)kRowsBlock * pitch * 4;
+  size_t want = (size_t)P.lf_n * sizeof(double);
+  const size_t avail = half - tile_bytes;
+  if (want > avail) want = avail / sizeof(double) * sizeof(double);
+  P.lds_n = (uint32_t)(want / sizeof(double));
+  const size_t lds = want + tile_bytes;
+  size_t grid = (size_t)m->n_cu * 2;
+  if (grid > n_tiles) grid = n_tiles;
+  if (vec4)
+  {
+    int rc = allow_big_lds(k_filter_rows<CT, 4>, lds);
+    if (rc != KMD_OK) return rc;
+    hipLaunchKernelGGL((k_filter_rows<CT, 4>), dim3((unsigned)grid), dim3(kRowsBlock), lds, stream, P, pitch, chunk_dw);
+  }
+  else
+  {
+    int rc = allow_big_lds(k_filter_rows<CT, 1>, lds);
+    if (rc != KMD_OK) return rc;
+    hipLaunchKernelGGL((k_filter_rows<CT, 1>), dim3((unsigned)grid), dim3(kRowsBlock), lds, stream, P, pitch, chunk_dw);
+  }
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+} // namespace
+
+// smallest LR with igamc(1/2, LR) <= threshold (bisection on the host with the same
+// Cephes restatement), lowered by a margin that is ~1e6 x the device/host libm difference.
+double kmd::lr_cut_for_threshold(double threshold, double lg_half)
+{
+  if (!(threshold >= 0)) return INFINITY;               // negative or NaN: nothing passes
+  if (threshold >= 1) return -INFINITY;                 // p <= 1 always
+  double lo = 0, hi = 800;                              // igamc(1/2, 800) == 0
+  for (int i = 0; i < 200; ++i)
+  {
+    const double mid = 0.5 * (lo + hi);
+    if (kmd::igamc_half(mid, lg_half) <= threshold) hi = mid; else lo = mid;
+  }
+  const double margin = hi * 1e-9 > 1e-6 ? hi * 1e-9 : 1e-6;
+  return lo - margin;
+}
+
+extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, double threshold,
+                                  const kmd_survivors* out, uint64_t* d_counters, void* stream)
+{
+  filter_params P;
+  int rc = fill_params(P, m, tile, threshold);
+  if (rc != KMD_OK) return rc;
+  KMD_REQUIRE(d_counters, "kmd_poisson_filter: NULL counters");
+  P.counters = reinterpret_cast<unsigned long long*>(d_counters);
+  if (out) P.out = *out;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tile->n_rows == 0) return KMD_OK;
+
+  // LDS budget: the table head; two workgroups per CU when it fits in half of the LDS
+  const size_t lds_cap = m->lds_per_block_max;          // 160 KiB on gfx950
+  if (tile->layout == KMD_LAYOUT_SOA)
+  {
+    size_t want = m->lf_n * sizeof(double);
+    int blocks_per_cu = 2;
+    size_t budget = lds_cap / 2 - 256;
+    if (want > budget) want = budget / sizeof(double) * sizeof(double);
+    P.lds_n = (uint32_t)(want / sizeof(double));
+    switch (tile->count_bytes)
+    {
+      case 1: return launch_soa<uint8_t>(P, m, want, blocks_per_cu, st);
+      case 2: return launch_soa<uint16_t>(P, m, want, blocks_per_cu, st);
+      default: return launch_soa<uint32_t>(P, m, want, blocks_per_cu, st);
+    }
+  }
+  else
+  {
+    switch (tile->count_bytes)
+    {
+      case 1: return launch_rows<uint8_t>(P, m, st);
+      case 2: return launch_rows<uint16_t>(P, m, st);
+      default: return launch_rows<uint32_t>(P, m, st);
+    }
+  }
+}
+
+extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, double* d_pvalue,
+                                   int32_t* d_sign, double* d_mean_control, double* d_mean_case,
+                                   void* stream)
+{
+  filter_params P;
+  int rc = fill_params(P, m, tile, 1.0);
+  if (rc != KMD_OK) return rc;
+  if (tile->n_rows == 0) return KMD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  size_t grid = (tile->n_rows + 255) / 256;
+  if (grid > (size_t)m->n_cu * 8) grid = (size_t)m->n_cu * 8;
+  switch (tile->count_bytes)
+  {
+    case 1: hipLaunchKernelGGL((k_process_all<uint8_t>), dim3((unsigned)grid), dim3(256), 0, st, P, tile->layout, d_pvalue, d_sign, d_mean_control, d_mean_case); break;
+    case 2: hipLaunchKernelGGL((k_process_all<uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, P, tile->layout, d_pvalue, d_sign, d_mean_control, d_mean_case); break;
+    default: hipLaunchKernelGGL((k_process_all<uint32_t>), dim3((unsigned)grid), dim3(256), 0, st, P, tile->layout, d_pvalue, d_sign, d_mean_control, d_mean_case); break;
+  }
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}

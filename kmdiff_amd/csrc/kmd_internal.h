@@ -1,0 +1,43 @@
+// kmd_internal.h -- shared between the translation units of libkmdiff_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/kmdiff_hip.h"
+
+// The model: device-resident state of PoissonLikelihood + LogFactorialTable.
+struct kmd_model
+{
+  int device;
+  int nc, nk;
+  uint64_t tc, tk;          // sums of the per-sample totals (model.hpp:185-188)
+  double dT, dTc, dTk;      // double(Tc+Tk), double(Tc), double(Tk)
+  double lg_half;           // Cephes lgam(1/2)
+  size_t lf_n;              // --log-factorial
+  double* h_lf;             // host copy of the table
+  double* d_lf;             // device copy
+  int n_cu;                 // multiProcessorCount
+  size_t lds_per_block_max; // sharedMemPerBlock
+};
+
+namespace kmd {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define KMD_HIP(call)                                                       \
+  do {                                                                      \
+    hipError_t e__ = (call);                                                \
+    if (e__ != hipSuccess) return kmd::hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define KMD_REQUIRE(cond, msg)                                              \
+  do { if (!(cond)) { kmd::set_error(msg); return KMD_E_INVALID; } } while (0)
+
+// smallest LR at which igamc(1/2, LR) <= threshold, minus a safety margin; rows with a
+// likelihood ratio below it cannot pass `p <= threshold` (kmd_filter.hip).
+double lr_cut_for_threshold(double threshold, double lg_half);
+
+} // namespace kmd

@@ -1,0 +1,356 @@
+"""Host-side mirror of the reference's operator interface for the `diff` hot path, over the
+C-ABI (include/kmdiff_hip.h).  Names and argument meaning follow the reference:
+
+  PoissonLikelihood(nb_controls, nb_cases, total_controls, total_cases, preload)
+                                              include/kmdiff/model.hpp:106-118
+  diff_observer(model, acc, threshold, ...).process(matrix)
+                                              include/kmdiff/merge.hpp:44-131 (whole tile at once)
+  SurvivorAccumulator                         include/kmdiff/accumulator.hpp:36-54 (IAccumulator)
+  aggregate(correction, threshold, total_kmers, acc)
+                                              src/corrector.cpp:101-116 + include/kmdiff/aggregator.hpp:343-365
+
+Everything numeric happens inside libkmdiff_hip.so; this module only owns buffers and
+copies results out.  numpy is used for host arrays only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from ._native import KmdError, check, lib
+
+CORRECTION_BY_NAME = {"nothing": N.CORR_NOTHING, "disabled": N.CORR_NOTHING,
+                      "bonferroni": N.CORR_BONFERRONI, "benjamini": N.CORR_BENJAMINI,
+                      "sidak": N.CORR_SIDAK, "holm": N.CORR_HOLM}
+
+_COUNT_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32}
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().kmd_device_count(C.byref(n))
+    return n.value
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    check(lib().kmd_device_name(buf, 256), "kmd_device_name")
+    return buf.value.decode()
+
+
+def _require_device():
+    if device_count() < 1:
+        raise KmdError("no HIP device visible: the kmdiff hot path has no CPU fallback")
+
+
+class DeviceBuffer:
+    """A block of HBM owned through kmd_malloc/kmd_free."""
+
+    def __init__(self, nbytes):
+        _require_device()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().kmd_malloc(C.byref(p), self.nbytes), "kmd_malloc(%d)" % self.nbytes)
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        if arr.nbytes:
+            check(lib().kmd_memcpy_h2d(b.ptr, arr.ctypes.data, arr.nbytes, None), "h2d")
+        return b
+
+    def zero(self):
+        check(lib().kmd_memset(self.ptr, 0, self.nbytes, None), "memset")
+        return self
+
+    def to_host(self, dtype, count=None, offset_bytes=0):
+        dtype = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset_bytes) // dtype.itemsize
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            check(lib().kmd_memcpy_d2h(out.ctypes.data, self.ptr + offset_bytes, out.nbytes, None), "d2h")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().kmd_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    """HIP event on a stream of the library (for timing kernels inside bench.py)."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().kmd_event_create(C.byref(p)), "event_create")
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        check(lib().kmd_event_record(self.ptr, stream), "event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        check(lib().kmd_event_elapsed_ms(self.ptr, stop.ptr, C.byref(ms)), "event_elapsed")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().kmd_event_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class CountMatrix:
+    """One partition tile of the merged count matrix, resident in HBM.
+
+    layout LAYOUT_SOA: counts[sample][row] (device-native); LAYOUT_ROWS: counts[row][sample]
+    (what km::MatrixReader / KmerMerger emit, merge.hpp:194-203)."""
+
+    def __init__(self, n_rows, n_samples, count_bytes=4, layout=N.LAYOUT_SOA, ld=None,
+                 with_kmers=True, kmer_limbs=1, row_base=0):
+        self.n_rows, self.n_samples = int(n_rows), int(n_samples)
+        self.count_bytes, self.layout = int(count_bytes), int(layout)
+        if ld is None:
+            if layout == N.LAYOUT_SOA:
+                per16 = 16 // self.count_bytes       # keep columns 16-byte aligned
+                ld = (self.n_rows + per16 - 1) // per16 * per16
+            else:
+                ld = self.n_samples
+        self.ld = int(ld)
+        n_el = self.ld * (self.n_samples if layout == N.LAYOUT_SOA else self.n_rows)
+        self.counts = DeviceBuffer(max(n_el, 1) * self.count_bytes)
+        self.kmer_lo = DeviceBuffer(max(self.n_rows, 1) * 8) if with_kmers else None
+        self.kmer_hi = DeviceBuffer(max(self.n_rows, 1) * 8) if (with_kmers and kmer_limbs == 2) else None
+        self.row_base = int(row_base)
+
+    @classmethod
+    def from_host(cls, counts, layout=N.LAYOUT_ROWS, kmer_lo=None, kmer_hi=None, row_base=0):
+        """counts: 2-D numpy array; [row][sample] for LAYOUT_ROWS, [sample][row] for SOA."""
+        counts = np.ascontiguousarray(counts)
+        cb = counts.dtype.itemsize
+        if layout == N.LAYOUT_ROWS:
+            n_rows, n_samples = counts.shape
+            m = cls(n_rows, n_samples, cb, layout, ld=n_samples, with_kmers=kmer_lo is not None,
+                    kmer_limbs=2 if kmer_hi is not None else 1, row_base=row_base)
+            if counts.nbytes:
+                check(lib().kmd_memcpy_h2d(m.counts.ptr, counts.ctypes.data, counts.nbytes, None), "h2d")
+        else:
+            n_samples, n_rows = counts.shape
+            m = cls(n_rows, n_samples, cb, layout, with_kmers=kmer_lo is not None,
+                    kmer_limbs=2 if kmer_hi is not None else 1, row_base=row_base)
+            padded = np.zeros((n_samples, m.ld), dtype=counts.dtype)
+            padded[:, :n_rows] = counts
+            if padded.nbytes:
+                check(lib().kmd_memcpy_h2d(m.counts.ptr, padded.ctypes.data, padded.nbytes, None), "h2d")
+        if kmer_lo is not None and n_rows:
+            a = np.ascontiguousarray(kmer_lo, dtype=np.uint64)
+            check(lib().kmd_memcpy_h2d(m.kmer_lo.ptr, a.ctypes.data, a.nbytes, None), "h2d")
+        if kmer_hi is not None and n_rows:
+            a = np.ascontiguousarray(kmer_hi, dtype=np.uint64)
+            check(lib().kmd_memcpy_h2d(m.kmer_hi.ptr, a.ctypes.data, a.nbytes, None), "h2d")
+        return m
+
+    def tile(self):
+        return N.Tile(self.counts.ptr, self.count_bytes, self.layout, self.ld,
+                      self.kmer_lo.ptr if self.kmer_lo else None,
+                      self.kmer_hi.ptr if self.kmer_hi else None, self.n_rows, self.row_base)
+
+    def to_host(self):
+        """counts back as a [row][sample] numpy array (test helper)."""
+        dt = _COUNT_DTYPES[self.count_bytes]
+        if self.layout == N.LAYOUT_ROWS:
+            a = self.counts.to_host(dt, self.n_rows * self.ld).reshape(self.n_rows, self.ld)
+            return a[:, :self.n_samples].copy()
+        a = self.counts.to_host(dt, self.n_samples * self.ld).reshape(self.n_samples, self.ld)
+        return a[:, :self.n_rows].T.copy()
+
+    def kmers_to_host(self):
+        lo = self.kmer_lo.to_host(np.uint64, self.n_rows) if self.kmer_lo else None
+        hi = self.kmer_hi.to_host(np.uint64, self.n_rows) if self.kmer_hi else None
+        return lo, hi
+
+
+class PoissonLikelihood:
+    """include/kmdiff/model.hpp:94-192 -- constructor arguments as in the reference."""
+
+    def __init__(self, nb_controls, nb_cases, total_controls, total_cases, preload=10000):
+        _require_device()
+        tc = np.ascontiguousarray(total_controls, dtype=np.uint64)
+        tk = np.ascontiguousarray(total_cases, dtype=np.uint64)
+        if len(tc) != nb_controls or len(tk) != nb_cases:
+            raise ValueError("total_controls/total_cases must have nb_controls/nb_cases entries")
+        self.nb_controls, self.nb_cases, self.preload = int(nb_controls), int(nb_cases), int(preload)
+        h = C.c_void_p()
+        check(lib().kmd_model_create(C.byref(h), self.nb_controls, self.nb_cases, tc.ctypes.data,
+                                     tk.ctypes.data, self.preload), "kmd_model_create")
+        self.handle = h.value
+        self.sum_controls, self.sum_cases = int(tc.sum(dtype=np.uint64)), int(tk.sum(dtype=np.uint64))
+
+    def lf_table(self):
+        out = np.empty(self.preload, dtype=np.float64)
+        if self.preload:
+            check(lib().kmd_model_lf_table(self.handle, out.ctypes.data, self.preload), "lf_table")
+        return out
+
+    def process(self, matrix):
+        """IModel::process (imodel.hpp:36) for every row of `matrix`:
+        returns (p_value, sign, mean_control, mean_case) arrays."""
+        n = matrix.n_rows
+        bp, bs, bc, bk = (DeviceBuffer(max(n, 1) * 8), DeviceBuffer(max(n, 1) * 4),
+                          DeviceBuffer(max(n, 1) * 8), DeviceBuffer(max(n, 1) * 8))
+        t = matrix.tile()
+        check(lib().kmd_poisson_process(self.handle, C.byref(t), bp.ptr, bs.ptr, bc.ptr, bk.ptr, None),
+              "kmd_poisson_process")
+        check(lib().kmd_stream_sync(None), "sync")
+        return (bp.to_host(np.float64, n), bs.to_host(np.int32, n), bc.to_host(np.float64, n),
+                bk.to_host(np.float64, n))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().kmd_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SurvivorAccumulator:
+    """IAccumulator<KmerSign<KSIZE>> (accumulator.hpp:36-54) as device SoA arrays."""
+
+    FIELDS = (("row", np.uint64), ("kmer_lo", np.uint64), ("kmer_hi", np.uint64),
+              ("pvalue", np.float64), ("sign", np.int32), ("mean_control", np.float64),
+              ("mean_case", np.float64))
+
+    def __init__(self, capacity, kmer_limbs=1):
+        self.capacity = int(capacity)
+        cap = max(self.capacity, 1)
+        self.bufs = {}
+        for name, dt in self.FIELDS:
+            if name == "kmer_hi" and kmer_limbs < 2:
+                self.bufs[name] = None
+                continue
+            self.bufs[name] = DeviceBuffer(cap * np.dtype(dt).itemsize)
+        self.counters = DeviceBuffer(N.NCOUNTERS * 8).zero()
+        self._size = None
+
+    def struct(self):
+        g = lambda k: self.bufs[k].ptr if self.bufs[k] else None
+        return N.Survivors(g("row"), g("kmer_lo"), g("kmer_hi"), g("pvalue"), g("sign"),
+                           g("mean_control"), g("mean_case"), self.capacity)
+
+    def read_counters(self):
+        check(lib().kmd_stream_sync(None), "sync")
+        return self.counters.to_host(np.uint64, N.NCOUNTERS)
+
+    def finish(self, sort=True):
+        """IAccumulator::finish: returns the number of survivors stored (sorted by row, the
+        reference's push order).  Raises KmdError(KMD_E_OVERFLOW) if records were dropped."""
+        c = self.read_counters()
+        n = int(c[N.CNT_SIG])
+        if n > self.capacity:
+            raise KmdError("survivor capacity exceeded: %d > %d (status %d)" % (n, self.capacity, N.KMD_E_OVERFLOW))
+        if sort and n > 1:
+            s = self.struct()
+            check(lib().kmd_survivors_sort_by_row(C.byref(s), n, None), "sort_by_row")
+        self._size = n
+        return n
+
+    def size(self):
+        if self._size is None:
+            self.finish()
+        return self._size
+
+    def get(self):
+        """All stored survivors as a dict of numpy arrays."""
+        n = self.size()
+        out = {}
+        for name, dt in self.FIELDS:
+            out[name] = self.bufs[name].to_host(dt, n) if self.bufs[name] else None
+        return out
+
+
+class diff_observer:
+    """include/kmdiff/merge.hpp:44-131, applied to a whole tile per call instead of a row."""
+
+    def __init__(self, model, acc, threshold, nb_controls=None, nb_cases=None, partition=0):
+        self.model, self.acc, self.threshold, self.partition = model, acc, float(threshold), partition
+        if nb_controls is not None and nb_controls != model.nb_controls:
+            raise ValueError("nb_controls differs from the model's")
+        if nb_cases is not None and nb_cases != model.nb_cases:
+            raise ValueError("nb_cases differs from the model's")
+
+    def process(self, matrix, stream=None):
+        if matrix.n_samples != self.model.nb_controls + self.model.nb_cases:
+            raise ValueError("matrix has %d samples, model expects %d" %
+                             (matrix.n_samples, self.model.nb_controls + self.model.nb_cases))
+        t = matrix.tile()
+        s = self.acc.struct()
+        check(lib().kmd_poisson_filter(self.model.handle, C.byref(t), self.threshold, C.byref(s),
+                                       self.acc.counters.ptr, stream), "kmd_poisson_filter")
+        self.acc._size = None
+
+    def _c(self, i):
+        return int(self.acc.read_counters()[i])
+
+    def total(self):
+        return self._c(N.CNT_TOTAL)
+
+    def nb_sign(self):
+        return self._c(N.CNT_SIG)
+
+    def nb_signs(self):
+        c = self.acc.read_counters()
+        return int(c[N.CNT_SIG_CONTROL]), int(c[N.CNT_SIG_CASE])
+
+
+def aggregate(correction, threshold, total_kmers, pvalue_buf, sign_buf, n):
+    """make_corrector + make_aggregator()->run() decisions (corrector.cpp:101-116,
+    aggregator.hpp:343-365) over n device-resident survivors.
+    Returns (keep mask as numpy uint8, n_control, n_case)."""
+    if isinstance(correction, str):
+        correction = CORRECTION_BY_NAME[correction.lower()]
+    keep = DeviceBuffer(max(n, 1))
+    nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    check(lib().kmd_correct(int(correction), float(threshold), int(total_kmers),
+                            pvalue_buf.ptr if n else None, sign_buf.ptr if (n and sign_buf) else None,
+                            n, keep.ptr, C.byref(nk), C.byref(nc), C.byref(nca), None), "kmd_correct")
+    return keep.to_host(np.uint8, n), int(nc.value), int(nca.value)
+
+
+def synth_matrix(seed, partition, n_rows, nb_controls, nb_cases, count_bytes=4,
+                 layout=N.LAYOUT_SOA, kmer_limbs=1, row0=0, with_kmers=True, stream=None):
+    """Synthetic partition generated on the device."""
+    m = CountMatrix(n_rows, nb_controls + nb_cases, count_bytes, layout, with_kmers=with_kmers,
+                    kmer_limbs=kmer_limbs, row_base=row0)
+    check(lib().kmd_synth_fill(int(seed), int(partition), int(row0), m.n_rows, nb_controls, nb_cases,
+                               count_bytes, layout, m.ld, m.counts.ptr,
+                               m.kmer_lo.ptr if m.kmer_lo else None,
+                               m.kmer_hi.ptr if m.kmer_hi else None, stream), "kmd_synth_fill")
+    return m
+
+
+def column_sums(matrix, totals_buf=None, stream=None):
+    """Per-sample totals of a device matrix (the role of get_total_kmer for synthetic data)."""
+    own = totals_buf is None
+    if own:
+        totals_buf = DeviceBuffer(matrix.n_samples * 8).zero()
+    check(lib().kmd_column_sums(matrix.counts.ptr, matrix.count_bytes, matrix.layout, matrix.ld,
+                                matrix.n_rows, matrix.n_samples, totals_buf.ptr, stream), "column_sums")
+    if own:
+        check(lib().kmd_stream_sync(None), "sync")
+        return totals_buf.to_host(np.uint64, matrix.n_samples)
+    return None

@@ -1,0 +1,373 @@
+"""Parity of the HIP path (through the C-ABI of libkmdiff_hip.so) with the CPU oracle and the
+committed golden vectors.  Run on the MI355X box:  python -m pytest tests -m gpu
+
+Bars (BASELINE.json north_star):
+  * k-mer identity, row index, sign, counters, mean_control, mean_case: bit-exact;
+  * p-values: |p_hip - p_ref| <= 1e-10 absolute (P_ABS_TOL); the tests additionally hold the
+    device to a relative 1e-9 (P_REL_TOL) because survivors have p << 1e-10/1e-3.
+The device uses ROCm's ocml log/exp, the oracle glibc's: they differ by <= 1 ulp, which is the
+only source of p differences (the operation order is the reference's on both sides).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as OL
+
+pytestmark = pytest.mark.gpu
+
+P_ABS_TOL = 1e-10
+P_REL_TOL = 1e-9
+SEED = 0x6B6D64696666
+THR = 0.05 / 100000          # -s 0.05 / -u 100000 (cmd/diff.hpp:147)
+fh = float.fromhex
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kmdiff_amd as K
+    assert K.device_count() >= 1, "no GPU: the HIP path has no CPU fallback"
+    return K
+
+
+def assert_p_close(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max(initial=0.0) <= P_ABS_TOL
+    nz = want > 0
+    assert (got[~nz] == 0).all() or np.abs(got[~nz]).max(initial=0.0) < 1e-300
+    rel = np.abs(got[nz] - want[nz]) / want[nz]
+    assert rel.max(initial=0.0) <= P_REL_TOL, rel.max()
+
+
+def totals_of(counts_rows, nc):
+    t = counts_rows.sum(axis=0, dtype=np.uint64)
+    return t[:nc], t[nc:]
+
+
+# ---------------------------------------------------------------------------------------------
+def test_log_factorial_table_is_the_reference_table(K, oracle):
+    m = K.PoissonLikelihood(2, 2, [1, 1], [1, 1], 2000)
+    assert m.lf_table().tolist() == oracle.lf_table(2000).tolist()
+    t = m.lf_table()
+    assert t[10] == 15.104412573075514            # tests/factorial_test.cpp:12
+
+
+@pytest.mark.parametrize("layout_name", ["rows", "soa"])
+@pytest.mark.parametrize("dtype", [np.uint32, np.uint16, np.uint8])
+def test_process_golden_rows(K, golden_dir, layout_name, dtype):
+    """IModel::process over the golden rows made by the reference's own sources."""
+    with open(os.path.join(golden_dir, "poisson_rows.json")) as f:
+        g = json.load(f)
+    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    for case in g["cases"]:
+        rows = np.array(case["rows"], dtype=np.uint32)
+        if rows.max() > np.iinfo(dtype).max:
+            continue
+        rows = rows.astype(dtype)
+        model = K.PoissonLikelihood(case["nc"], case["nk"], case["total_controls"], case["total_cases"],
+                                    case["preload"])
+        mat = K.CountMatrix.from_host(rows if layout == K.LAYOUT_ROWS else rows.T, layout)
+        p, s, mc, mk = model.process(mat)
+        assert s.tolist() == case["sign"]
+        assert [float(x).hex() for x in mc] == case["mean_control"]
+        assert [float(x).hex() for x in mk] == case["mean_case"]
+        assert_p_close(p, [fh(x) for x in case["p"]])
+
+
+def test_reference_model_test_signs(K):
+    """tests/model_test.cpp:45-81 through the HIP model."""
+    model = K.PoissonLikelihood(30, 30, [1] * 30, [1] * 30, 10)
+    v = np.array([[200] * 30 + [100] * 30, [100] * 30 + [200] * 30, [100] * 60], dtype=np.uint32)
+    p, s, mc, mk = model.process(K.CountMatrix.from_host(v, K.LAYOUT_ROWS))
+    assert s.tolist() == [K.SIGN_CONTROL, K.SIGN_CASE, K.SIGN_NO]
+    assert abs(p[0] - 1.0932047323640264e-223) <= 1e-9 * 1.0932047323640264e-223
+    assert (mc[0], mk[0]) == (6000.0, 3000.0)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout_name", ["soa", "rows"])
+@pytest.mark.parametrize("count_bytes", [4, 2, 1])
+def test_synth_device_equals_oracle_replay(K, oracle, layout_name, count_bytes):
+    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    n = 20011
+    m = K.synth_matrix(SEED, 5, n, 3, 4, count_bytes, layout, row0=1234)
+    want, lo, _ = oracle.synth_rows(SEED, 5, 1234, n, 3, 4, count_bytes)
+    assert (m.to_host() == want).all()
+    assert (m.kmers_to_host()[0] == lo).all()
+    m2 = K.synth_matrix(SEED, 5, 100, 3, 4, 4, layout, kmer_limbs=2)
+    _, lo2, hi2 = oracle.synth_rows(SEED, 5, 0, 100, 3, 4, 4, kmer_limbs=2)
+    glo, ghi = m2.kmers_to_host()
+    assert (glo == lo2).all() and (ghi == hi2).all()
+    assert (K.column_sums(m) == want.sum(axis=0, dtype=np.uint64)).all()
+
+
+def run_filter(K, mat, nc, nk, tcs, tks, preload, thr, cap=None, limbs=1):
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, preload)
+    acc = K.SurvivorAccumulator(mat.n_rows if cap is None else cap, kmer_limbs=limbs)
+    obs = K.diff_observer(model, acc, thr, nc, nk)
+    obs.process(mat)
+    n = acc.finish()
+    return obs, acc, n
+
+
+def check_against_oracle(K, oracle, mat, host_rows, kmers, nc, nk, preload, thr):
+    tcs, tks = totals_of(host_rows, nc)
+    obs, acc, n = run_filter(K, mat, nc, nk, tcs, tks, preload, thr, limbs=2 if kmers[1] is not None else 1)
+    want = oracle.diff_partition(host_rows, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()),
+                                 oracle.lf_table(preload), thr)
+    got = acc.get()
+    c = acc.read_counters()
+    assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == want["counters"]
+    assert obs.total() == host_rows.shape[0] and obs.nb_sign() == n
+    assert obs.nb_signs() == (want["counters"][2], want["counters"][3])
+    assert (got["row"] - mat.row_base).tolist() == want["row"].tolist()      # identity + order
+    assert got["sign"].tolist() == want["sign"].tolist()
+    assert got["mean_control"].tolist() == want["mean_control"].tolist()
+    assert got["mean_case"].tolist() == want["mean_case"].tolist()
+    assert_p_close(got["pvalue"], want["pvalue"])
+    idx = want["row"].astype(np.int64)
+    if kmers[0] is not None:
+        assert got["kmer_lo"].tolist() == kmers[0][idx].tolist()
+    if kmers[1] is not None:
+        assert got["kmer_hi"].tolist() == kmers[1][idx].tolist()
+    return want["counters"]
+
+
+@pytest.mark.parametrize("layout_name", ["soa", "rows"])
+@pytest.mark.parametrize("count_bytes,nc,nk", [(4, 4, 4), (4, 20, 20), (2, 5, 3), (1, 7, 9), (4, 50, 50)])
+def test_filter_matches_oracle_on_synthetic_partition(K, oracle, layout_name, count_bytes, nc, nk):
+    """diff_observer over one synthetic partition == the oracle's row loop."""
+    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    n = 150_003 if nc + nk <= 40 else 40_001
+    limbs = 2 if nc == 50 else 1
+    mat = K.synth_matrix(SEED, 2, n, nc, nk, count_bytes, layout, kmer_limbs=limbs)
+    host, lo, hi = oracle.synth_rows(SEED, 2, 0, n, nc, nk, count_bytes, kmer_limbs=limbs)
+    counters = check_against_oracle(K, oracle, mat, host, (lo, hi), nc, nk, 10000, THR)
+    assert counters[1] > 0            # the planted signal produces survivors
+
+
+@pytest.mark.parametrize("layout_name", ["soa", "rows"])
+def test_table_fallback_small_preload(K, oracle, layout_name):
+    """Count sums >= --log-factorial take LogFactorialTable's O(k) fallback
+    (log_factorial_table.hpp:14-18): wave-cooperative on the device."""
+    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    n = 30_000
+    mat = K.synth_matrix(SEED, 9, n, 6, 6, 4, layout)
+    host, lo, _ = oracle.synth_rows(SEED, 9, 0, n, 6, 6, 4)
+    for preload in (64, 1, 0):
+        check_against_oracle(K, oracle, mat, host, (lo, None), 6, 6, preload, THR)
+    tcs, tks = totals_of(host, 6)
+    obs, acc, _ = run_filter(K, mat, 6, 6, tcs, tks, 64, THR)
+    assert int(acc.read_counters()[5]) > 0          # rows that went through the fallback
+
+
+@pytest.mark.parametrize("thr", [1.0, 0.5, 1e-3, 1e-30, 0.0])
+def test_thresholds_from_everything_to_nothing(K, oracle, thr):
+    n = 8_191
+    mat = K.synth_matrix(SEED, 1, n, 4, 4, 4, K.LAYOUT_SOA)
+    host, lo, _ = oracle.synth_rows(SEED, 1, 0, n, 4, 4, 4)
+    c = check_against_oracle(K, oracle, mat, host, (lo, None), 4, 4, 10000, thr)
+    if thr >= 1.0:
+        assert c[1] == n
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 4099])
+def test_empty_and_ragged_tiles(K, oracle, n):
+    for layout in (K.LAYOUT_SOA, K.LAYOUT_ROWS):
+        mat = K.synth_matrix(SEED, 0, n, 4, 4, 4, layout)
+        host, lo, _ = oracle.synth_rows(SEED, 0, 0, n, 4, 4, 4)
+        if n == 0:
+            model = K.PoissonLikelihood(4, 4, [1] * 4, [1] * 4, 100)
+            acc = K.SurvivorAccumulator(4)
+            K.diff_observer(model, acc, 1.0).process(mat)
+            assert acc.finish() == 0 and int(acc.read_counters()[0]) == 0
+            continue
+        check_against_oracle(K, oracle, mat, host, (lo, None), 4, 4, 10000, 0.01)
+
+
+def test_unaligned_soa_pitch_and_padded_rows(K, oracle):
+    """SoA with a column pitch that is not a multiple of 16 bytes (scalar-load kernel) and
+    row-major with ld > nc+nk give the same survivors."""
+    n, nc, nk = 10_007, 4, 4
+    host, lo, _ = oracle.synth_rows(SEED, 6, 0, n, nc, nk, 4)
+    tcs, tks = totals_of(host, nc)
+    want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()),
+                                 oracle.lf_table(10000), 0.01)
+    # SoA, ld = n (odd): columns are only 4-byte aligned
+    m = K.CountMatrix(n, nc + nk, 4, K.LAYOUT_SOA, ld=n, with_kmers=False)
+    K._native.check(K._native.lib().kmd_memcpy_h2d(m.counts.ptr, np.ascontiguousarray(host.T).ctypes.data,
+                                                   host.nbytes, None))
+    _, acc, _ = run_filter(K, m, nc, nk, tcs, tks, 10000, 0.01)
+    assert (acc.get()["row"]).tolist() == want["row"].tolist()
+    # row-major, ld = 11 (padding column garbage must be ignored)
+    padded = np.full((n, 11), 77, dtype=np.uint32)
+    padded[:, :8] = host
+    m = K.CountMatrix(n, nc + nk, 4, K.LAYOUT_ROWS, ld=11, with_kmers=False)
+    K._native.check(K._native.lib().kmd_memcpy_h2d(m.counts.ptr, padded.ctypes.data, padded.nbytes, None))
+    _, acc, _ = run_filter(K, m, nc, nk, tcs, tks, 10000, 0.01)
+    assert (acc.get()["row"]).tolist() == want["row"].tolist()
+    # u8 rows with an odd number of samples: rows are not dword aligned (direct kernel)
+    host8, _, _ = oracle.synth_rows(SEED, 6, 0, n, 4, 3, 1)
+    t8c, t8k = totals_of(host8, 4)
+    want8 = oracle.diff_partition(host8, OL.LAYOUT_ROWS, 4, 3, int(t8c.sum()), int(t8k.sum()),
+                                  oracle.lf_table(10000), 0.01)
+    m = K.CountMatrix.from_host(host8, K.LAYOUT_ROWS)
+    _, acc, _ = run_filter(K, m, 4, 3, t8c, t8k, 10000, 0.01)
+    assert (acc.get()["row"]).tolist() == want8["row"].tolist()
+
+
+def test_survivor_capacity_overflow_is_reported(K, oracle):
+    n = 5000
+    mat = K.synth_matrix(SEED, 1, n, 4, 4, 4, K.LAYOUT_SOA)
+    host, _, _ = oracle.synth_rows(SEED, 1, 0, n, 4, 4, 4)
+    tcs, tks = totals_of(host, 4)
+    model = K.PoissonLikelihood(4, 4, tcs, tks, 10000)
+    acc = K.SurvivorAccumulator(10)
+    K.diff_observer(model, acc, 1.0).process(mat)
+    with pytest.raises(K.KmdError):
+        acc.finish()
+    c = acc.read_counters()
+    assert int(c[1]) == n and int(c[2]) + int(c[3]) == n      # counters stay exact
+
+
+def test_bad_arguments_fail_loudly(K):
+    model = K.PoissonLikelihood(2, 2, [1, 1], [1, 1], 10)
+    acc = K.SurvivorAccumulator(4)
+    mat = K.CountMatrix(10, 5, 4, K.LAYOUT_SOA)             # 5 samples, model has 4
+    with pytest.raises(ValueError):
+        K.diff_observer(model, acc, 0.5).process(mat)
+    with pytest.raises(K.KmdError):
+        K.PoissonLikelihood(0, 2, [], [1, 1], 10)
+    t = mat.tile()
+    t.count_bytes = 3
+    import ctypes as C
+    s = acc.struct()
+    rc = K._native.lib().kmd_poisson_filter(model.handle, C.byref(t), 0.5, C.byref(s), acc.counters.ptr, None)
+    assert rc == -1 and b"count_bytes" in K._native.lib().kmd_last_error()
+
+
+def test_two_tiles_equal_one_partition(K, oracle):
+    """A partition streamed as two tiles (row_base) accumulates to the same survivors."""
+    n, nc, nk = 100_000, 4, 4
+    host, lo, _ = oracle.synth_rows(SEED, 3, 0, n, nc, nk, 4)
+    tcs, tks = totals_of(host, nc)
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, 10000)
+    acc = K.SurvivorAccumulator(n)
+    obs = K.diff_observer(model, acc, THR)
+    a = K.synth_matrix(SEED, 3, 60_000, nc, nk, 4, K.LAYOUT_SOA, row0=0)
+    b = K.synth_matrix(SEED, 3, 40_000, nc, nk, 4, K.LAYOUT_ROWS, row0=60_000)
+    obs.process(a)
+    obs.process(b)
+    acc.finish()
+    want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()),
+                                 oracle.lf_table(10000), THR)
+    got = acc.get()
+    assert got["row"].tolist() == want["row"].tolist()
+    assert got["kmer_lo"].tolist() == lo[want["row"].astype(np.int64)].tolist()
+    assert obs.total() == n
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["nothing", "bonferroni", "sidak", "benjamini", "holm"])
+def test_correction_matches_oracle(K, oracle, name):
+    n, nc, nk = 200_000, 4, 4
+    mat = K.synth_matrix(SEED, 4, n, nc, nk, 4, K.LAYOUT_SOA)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(n)
+    K.diff_observer(model, acc, 1e-3).process(mat)
+    ns = acc.finish()
+    assert ns > 50
+    got = acc.get()
+    ctype = K.CORRECTION_BY_NAME[name]
+    for total in (n, 50 * n):
+        keep, n_ctrl, n_case = K.aggregate(name, 0.05, total, acc.bufs["pvalue"], acc.bufs["sign"], ns)
+        want = oracle.aggregate(ctype, 0.05, total, got["pvalue"])
+        assert keep.tolist() == want.tolist()
+        assert n_ctrl == int(((got["sign"] == 0) & (want == 1)).sum())
+        assert n_case == int(((got["sign"] != 0) & (want == 1)).sum())
+    keep, _, _ = K.aggregate(name, 0.05, n, acc.bufs["pvalue"], acc.bufs["sign"], 0)
+    assert len(keep) == 0
+
+
+def test_correction_golden_streams(K, golden_dir):
+    """The reference's own corrector decisions (golden) on ascending streams: for BH/Holm the
+    kept set is the prefix before the first rejection; for the stateless ones apply()."""
+    with open(os.path.join(golden_dir, "correctors.json")) as f:
+        g = json.load(f)
+    for case in g["cases"]:
+        p = np.array([fh(x) for x in case["p"]])
+        buf = K.DeviceBuffer.from_host(p)
+        keep, _, _ = K.aggregate(case["type"], fh(case["threshold"]), case["total"], buf, None, len(p))
+        dec = np.array(case["apply"], dtype=np.uint8)
+        if case["name"] in ("benjamini", "holm"):
+            first = int(np.argmin(dec)) if (dec == 0).any() else len(dec)
+            want = np.zeros(len(dec), dtype=np.uint8)
+            want[:first] = 1
+        else:
+            want = dec
+        assert keep.tolist() == want.tolist(), case["name"]
+
+
+def test_gather_counts_of_survivors(K, oracle):
+    import ctypes as C
+    n, nc, nk = 50_000, 5, 5
+    for layout in (K.LAYOUT_SOA, K.LAYOUT_ROWS):
+        mat = K.synth_matrix(SEED, 8, n, nc, nk, 2, layout, row0=777)
+        host, _, _ = oracle.synth_rows(SEED, 8, 777, n, nc, nk, 2)
+        tcs, tks = totals_of(host, nc)
+        _, acc, ns = run_filter(K, mat, nc, nk, tcs, tks, 10000, 1e-4)
+        assert ns > 0
+        out = K.DeviceBuffer(ns * 10 * 8)
+        t = mat.tile()
+        K._native.check(K._native.lib().kmd_survivors_gather_counts(C.byref(t), 10, acc.bufs["row"].ptr, ns,
+                                                                     out.ptr, None))
+        K._native.check(K._native.lib().kmd_stream_sync(None))
+        rows = acc.get()["row"].astype(np.int64) - 777
+        assert (out.to_host(np.float64, ns * 10).reshape(ns, 10) == host[rows].astype(np.float64)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+def test_full_size_config2_properties(K, oracle):
+    """BASELINE.json configs[1]: 10^8 rows, 4v4, k=31, one partition resident in HBM.
+    Size-independent properties + exact oracle replay of sampled windows."""
+    n, nc, nk = 100_000_000, 4, 4
+    mat = K.synth_matrix(SEED, 0, n, nc, nk, 4, K.LAYOUT_SOA)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    cap = n // 500
+    acc = K.SurvivorAccumulator(cap)
+    obs = K.diff_observer(model, acc, THR)
+    obs.process(mat)
+    ns = acc.finish()
+    c = acc.read_counters()
+    assert int(c[0]) == n and int(c[1]) == ns and int(c[2]) + int(c[3]) == ns
+    got = acc.get()
+    assert (np.diff(got["row"].astype(np.int64)) > 0).all()               # ascending, no duplicates
+    assert (np.diff(got["kmer_lo"].astype(np.int64)) > 0).all()           # ascending k-mers
+    assert (got["pvalue"] <= THR).all()
+    assert 1e-5 < ns / n < 1e-3
+    # idempotence: a second pass reproduces the same survivors bit for bit
+    acc2 = K.SurvivorAccumulator(cap)
+    K.diff_observer(model, acc2, THR).process(mat)
+    acc2.finish()
+    g2 = acc2.get()
+    for k in ("row", "kmer_lo", "pvalue", "sign", "mean_control", "mean_case"):
+        assert (got[k] == g2[k]).all(), k
+    # exact replay of sampled windows with the oracle
+    rng = np.random.default_rng(7)
+    lf = oracle.lf_table(10000)
+    tc, tk = int(tot[:nc].sum()), int(tot[nc:].sum())
+    starts = np.concatenate([[0, n - 4096], rng.integers(0, n - 4096, 30)])
+    srows = got["row"].astype(np.int64)
+    for s in starts:
+        host, lo, _ = oracle.synth_rows(SEED, 0, int(s), 4096, nc, nk, 4)
+        want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, tc, tk, lf, THR)
+        sel = (srows >= s) & (srows < s + 4096)
+        assert (srows[sel] - s).tolist() == want["row"].tolist()
+        assert got["sign"][sel].tolist() == want["sign"].tolist()
+        assert got["kmer_lo"][sel].tolist() == lo[want["row"].astype(np.int64)].tolist()
+        assert_p_close(got["pvalue"][sel], want["pvalue"])
