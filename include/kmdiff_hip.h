@@ -76,8 +76,9 @@ int kmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* syncs on 
  * src/log_factorial_table.cpp:5-22): per-sample totals are summed into Tc, Tk; the
  * log-factorial table of `log_factorial_size` entries (CLI --log-factorial, default
  * 10000, src/cli.cpp:354-357) is built once with the reference's descending summation
- * and uploaded to HBM.  Sums >= log_factorial_size are evaluated on the device by the
- * reference's O(k) descending loop (wave-cooperative). */
+ * and uploaded to HBM.  Sums >= log_factorial_size (LogFactorialTable::operator[]'s O(k)
+ * fallback) are evaluated on the device: the same descending loop below 256, the Stirling
+ * series of ln k! above (kmd_filter.hip, lf_beyond_table). */
 typedef struct kmd_model kmd_model;
 
 int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
@@ -174,6 +175,9 @@ int kmd_column_sums(const void* d_counts, int count_bytes, int layout, size_t ld
                     size_t n_rows, int n_samples, uint64_t* d_totals, void* stream);
 /* Streaming-copy bandwidth probe (float4 copy of `bytes`), for the measured roofline. */
 int kmd_copy_probe(void* d_dst, const void* d_src, size_t bytes, void* stream);
+/* Streaming read of `bytes` with 4-, 8- or 16-byte loads per lane: a known byte count that
+ * calibrates the FETCH_SIZE counter for the filter kernel's access width. */
+int kmd_read_probe(const void* d_src, size_t bytes, int width_bytes, uint64_t* d_sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkmdiff_hip.so")
+LIB_PATH = os.environ.get("KMD_LIB") or os.path.join(_HERE, "lib", "libkmdiff_hip.so")
 
 KMD_OK = 0
 KMD_E_OVERFLOW = -4
@@ -69,6 +69,7 @@ SIGNATURES = {
     "kmd_synth_fill": (_i, [_u64, C.c_uint32, _u64, _sz, _i, _i, _i, _i, _sz, _vp, _vp, _vp, _vp]),
     "kmd_column_sums": (_i, [_vp, _i, _i, _sz, _sz, _i, _vp, _vp]),
     "kmd_copy_probe": (_i, [_vp, _vp, _sz, _vp]),
+    "kmd_read_probe": (_i, [_vp, _sz, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -154,6 +154,7 @@ int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
     lds = (size_t)optin;
   (void)hipGetLastError();
   m->lds_per_block_max = lds;
+  m->cut_valid = false; m->cut_threshold_bits = 0; m->cut_value = 0;
 
   // LogFactorialTable::LogFactorialTable (src/log_factorial_table.cpp:5-22): entry i is the
   // descending sum log(i) + log(i-1) + ... + log(2), each entry summed from scratch.
@@ -349,9 +350,44 @@ __global__ void __launch_bounds__(256) k_copy_probe(const float4* __restrict__ s
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// streaming-read probes of a known byte count, one per load width: calibrates the FETCH_SIZE
+// PMC counter for the access pattern of the filter kernel (MI355X_MICROARCH.md, HBM section)
+template <typename V>
+__global__ void __launch_bounds__(256) k_read_probe(const V* __restrict__ src, size_t n,
+                                                    unsigned long long* __restrict__ sink)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned int acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  {
+    const V v = src[i];
+    if constexpr (sizeof(V) == 4) acc += v;
+    else if constexpr (sizeof(V) == 8) acc += v.x ^ v.y;
+    else acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9E3779B9u) atomicAdd(sink, 1ull);     // keeps the loads alive
+}
+
 } // namespace
 
 extern "C" {
+
+int kmd_read_probe(const void* d_src, size_t bytes, int width_bytes, uint64_t* d_sink, void* stream)
+{
+  KMD_REQUIRE(d_src && d_sink, "kmd_read_probe: NULL");
+  KMD_REQUIRE(width_bytes == 4 || width_bytes == 8 || width_bytes == 16, "kmd_read_probe: width");
+  KMD_REQUIRE(bytes % 16 == 0, "kmd_read_probe: bytes % 16");
+  const size_t n = bytes / (size_t)width_bytes;
+  if (!n) return KMD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned long long* sink = reinterpret_cast<unsigned long long*>(d_sink);
+  const dim3 grid(256 * 8), block(256);
+  if (width_bytes == 4) hipLaunchKernelGGL((k_read_probe<uint32_t>), grid, block, 0, st, static_cast<const uint32_t*>(d_src), n, sink);
+  else if (width_bytes == 8) hipLaunchKernelGGL((k_read_probe<uint2>), grid, block, 0, st, static_cast<const uint2*>(d_src), n, sink);
+  else hipLaunchKernelGGL((k_read_probe<uint4>), grid, block, 0, st, static_cast<const uint4*>(d_src), n, sink);
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
 
 int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc,
                    int nk, int count_bytes, int layout, size_t ld, void* d_counts,

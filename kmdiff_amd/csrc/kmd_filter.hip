@@ -14,14 +14,32 @@
 //     reference never exposes p for rows with p > threshold, merge.hpp:78);
 //   * survivors are compacted with a wave ballot + one atomic per wave;
 //   * count sums beyond the table (LogFactorialTable::operator[] fallback,
-//     log_factorial_table.hpp:14-18) are evaluated by the whole wave in the reference's
-//     descending order: 64 log() in parallel, one ordered accumulation.
+//     log_factorial_table.hpp:14-18) are evaluated in O(1) by the Stirling series (the
+//     reference's O(k) loop would stall a wave for milliseconds on one high-count row).
 #include "kmd_internal.h"
 #include "kmd_math.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace {
 
-constexpr int kBlock = 512;
+#ifndef KMD_BLOCK
+#define KMD_BLOCK 512
+#endif
+#ifndef KMD_MINWAVES
+#define KMD_MINWAVES 4
+#endif
+#ifndef KMD_BATCH
+#define KMD_BATCH 4
+#endif
+#ifndef KMD_RPL_U32
+#define KMD_RPL_U32 2
+#endif
+#ifndef KMD_XPREFETCH
+#define KMD_XPREFETCH 1
+#endif
+constexpr int kBlock = KMD_BLOCK;
 
 struct filter_params
 {
@@ -83,36 +101,30 @@ __device__ __forceinline__ void accumulate(const CT* __restrict__ p, ACC (&acc)[
   }
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
+// LogFactorialTable::operator[] for k >= table size (log_factorial_table.hpp:14-18 falls back
+// to the O(k) loop log(k) + log(k-1) + ... + log(2), src/log_factorial_table.cpp:13-22).
+//   k <  kStirlingMin : the same descending loop, per lane (bounded, reference order);
+//   k >= kStirlingMin : ln k! by the Stirling series, O(1):
+//        (k + 1/2) ln k - k + ln(2 pi)/2 + 1/(12k) - 1/(360k^3) + 1/(1260k^5)
+//     truncation error < 1e-20 for k >= 256; the result is within ~1 ulp of ln k!, whereas
+//     the reference's k-term running sum carries its own rounding error of order
+//     sqrt(k) ulp.  The table value enters alt and null hypotheses identically
+//     (model.hpp:152-156), so this difference cancels in the likelihood ratio down to the
+//     rounding of the individual terms (tests/test_gpu_parity.py::test_table_fallback*).
+constexpr uint32_t kStirlingMin = 256;
 
-// LogFactorialTable::log_factorial (src/log_factorial_table.cpp:13-22) for a wave-uniform
-// k: res = log(k) + log(k-1) + ... + log(2), accumulated in exactly that order.  The 64
-// lanes evaluate 64 consecutive terms at once; the additions stay sequential.
-__device__ double wave_lf_descending(uint64_t k)
+__device__ __forceinline__ double lf_beyond_table(uint32_t k)
 {
-  const int lane = __lane_id();
-  double res = 0;
-  while (k > 1)
+  if (k < kStirlingMin)
   {
-    const uint64_t n_terms = k - 1 < 64 ? k - 1 : 64;      // terms k, k-1, ..., k-n_terms+1
-    const double t = ((uint64_t)lane < n_terms) ? ::log((double)(k - (uint64_t)lane)) : 0.0;
-    if (n_terms == 64)
-    {
-#pragma unroll
-      for (int i = 0; i < 64; ++i) res += readlane_f64(t, i);
-    }
-    else
-    {
-      for (int i = 0; i < (int)n_terms; ++i) res += readlane_f64(t, i);
-    }
-    k -= n_terms;
+    double res = 0;
+    for (uint32_t j = k; j > 1; --j) res += ::log((double)j);
+    return res;
   }
-  return res;
+  const double x = (double)k;
+  const double r = 1.0 / x, r2 = r * r;
+  const double corr = r * (8.3333333333333333e-02 - r2 * (2.7777777777777778e-03 - r2 * 7.9365079365079365e-04));
+  return ((x + 0.5) * ::log(x) - x) + (0.91893853320467274178 + corr);
 }
 
 struct row_state
@@ -127,37 +139,26 @@ struct row_state
 __device__ __forceinline__ void finish_row(const filter_params& P, const double* s_lf,
                                            const row_state& st)
 {
+#ifdef KMD_ABLATE_MATH   // dev only: memory-side ceiling of the load loop (results are wrong)
+  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
+  return;
+#endif
   const uint32_t kc = kmd::table_index(st.sum_c);
   const uint32_t kk = kmd::table_index(st.sum_k);
   double lf_c = 0, lf_k = 0;
   if (kc < P.lds_n) lf_c = s_lf[kc]; else if (kc < P.lf_n) lf_c = P.lf[kc];
   if (kk < P.lds_n) lf_k = s_lf[kk]; else if (kk < P.lf_n) lf_k = P.lf[kk];
 
-  // table misses: the whole wave serves one (lane, k) at a time
-  bool miss_c = st.valid && kc >= P.lf_n;
-  bool miss_k = st.valid && kk >= P.lf_n;
-  unsigned long long need = __ballot(miss_c | miss_k);
+  // table misses (rare with the default 10000-entry table)
+  const bool miss_c = st.valid && kc >= P.lf_n;
+  const bool miss_k = st.valid && kk >= P.lf_n;
+  const unsigned long long need = __ballot(miss_c | miss_k);
   if (need)
   {
-    const int lane = __lane_id();
-    unsigned long long n_def = __popcll(need);
-    if (lane == (int)(__ffsll((long long)need) - 1))
-      atomicAdd(&P.counters[KMD_CNT_DEFERRED], n_def);
-    while (need)
-    {
-      const int src = __ffsll((long long)need) - 1;
-      const uint32_t skc = (uint32_t)__builtin_amdgcn_readlane((int)kc, src);
-      const uint32_t skk = (uint32_t)__builtin_amdgcn_readlane((int)kk, src);
-      double v_c = 0, v_k = 0;
-      if (skc >= P.lf_n) v_c = wave_lf_descending(skc);
-      if (skk >= P.lf_n) v_k = (skk == skc && skc >= P.lf_n) ? v_c : wave_lf_descending(skk);
-      if (lane == src)
-      {
-        if (miss_c) lf_c = v_c;
-        if (miss_k) lf_k = v_k;
-      }
-      need &= need - 1;
-    }
+    if (miss_c) lf_c = lf_beyond_table(kc);
+    if (miss_k) lf_k = (kk == kc && miss_c) ? lf_c : lf_beyond_table(kk);
+    if (__lane_id() == (int)(__ffsll((long long)need) - 1))
+      atomicAdd(&P.counters[KMD_CNT_DEFERRED], (unsigned long long)__popcll(need));
   }
 
   const kmd::lrt_result r = kmd::lrt_from_sums(st.sum_c, st.sum_k, lf_c, lf_k, P.dT, P.dTc, P.dTk);
@@ -218,8 +219,119 @@ __device__ __forceinline__ void stage_table(const filter_params& P, double* s_lf
 }
 
 // ---- SoA layout: counts[sample][row] ------------------------------------------------------
+// Column loads are issued in batches of kBatch (one 16-byte load per lane per column when
+// RPL > 1) into two register sets: while one batch is being added up the next one is already
+// in flight, and the first batch of the NEXT tile is issued before the FP64 phase of the
+// current one, so a wave always has kBatch..2*kBatch KiB-sized loads outstanding.
+constexpr int kBatch = KMD_BATCH;
+
 template <typename CT, int RPL>
-__global__ void __launch_bounds__(kBlock) k_filter_soa(const filter_params P)
+struct soa_batch
+{
+  using V = typename vec_of<CT, RPL>::type;
+  V v[kBatch];
+
+  // columns s0 .. s0+kBatch-1 of the lane's RPL rows; indices past the last column re-read
+  // column S-1 (served by L1/TA, never added)
+  __device__ __forceinline__ void load(const CT* __restrict__ rows0, size_t ld, int s0, int S)
+  {
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j)
+    {
+      const int s = (s0 + j < S) ? (s0 + j) : (S - 1);
+      v[j] = *reinterpret_cast<const V*>(rows0 + (size_t)s * ld);
+    }
+  }
+
+  template <typename ACC>
+  __device__ __forceinline__ void add_one(int j, ACC (&acc)[RPL]) const
+  {
+    if constexpr (RPL == 1)
+    {
+      acc[0] += (ACC)v[j];
+    }
+    else if constexpr (sizeof(CT) == 4 && RPL == 2)
+    {
+      acc[0] += v[j].x; acc[1] += v[j].y;
+    }
+    else if constexpr (sizeof(CT) == 4)
+    {
+      acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w;
+    }
+    else
+    {
+      const uint32_t w[4] = { v[j].x, v[j].y, v[j].z, v[j].w };
+      constexpr int per = 4 / sizeof(CT);
+      constexpr uint32_t mask = sizeof(CT) == 1 ? 0xFFu : 0xFFFFu;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < per; ++e)
+          acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
+    }
+  }
+
+  template <typename ACC>
+  __device__ __forceinline__ void add_masked(int j, uint32_t m, ACC (&acc)[RPL]) const
+  {
+    if constexpr (RPL == 1)
+    {
+      acc[0] += (ACC)((uint32_t)v[j] & m);
+    }
+    else if constexpr (sizeof(CT) == 4 && RPL == 2)
+    {
+      acc[0] += v[j].x & m; acc[1] += v[j].y & m;
+    }
+    else if constexpr (sizeof(CT) == 4)
+    {
+      acc[0] += v[j].x & m; acc[1] += v[j].y & m; acc[2] += v[j].z & m; acc[3] += v[j].w & m;
+    }
+    else
+    {
+      const uint32_t w[4] = { v[j].x & m, v[j].y & m, v[j].z & m, v[j].w & m };
+      constexpr int per = 4 / sizeof(CT);
+      constexpr uint32_t mask = sizeof(CT) == 1 ? 0xFFu : 0xFFFFu;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < per; ++e)
+          acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
+    }
+  }
+
+  // all conditions are wave-uniform (scalar branches)
+  template <typename ACC>
+  __device__ __forceinline__ void consume(int s0, int nc, int S, ACC (&sc)[RPL], ACC (&sk)[RPL]) const
+  {
+    if (s0 + kBatch <= nc)
+    {
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) add_one(j, sc);
+    }
+    else if (s0 >= nc && s0 + kBatch <= S)
+    {
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) add_one(j, sk);
+    }
+    else
+    {
+      // straddling / tail batch: branch-free select with wave-uniform masks (a branchy
+      // form makes the compiler address sc/sk through scratch memory)
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j)
+      {
+        const int s = s0 + j;
+        const uint32_t mc = (s < nc) ? 0xFFFFFFFFu : 0u;
+        const uint32_t mk = (s >= nc && s < S) ? 0xFFFFFFFFu : 0u;
+        add_masked(j, mc, sc);
+        add_masked(j, mk, sk);
+      }
+    }
+  }
+};
+
+template <typename CT, int RPL>
+__global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filter_params P)
 {
   extern __shared__ double s_lf[];
   stage_table(P, s_lf);
@@ -228,47 +340,98 @@ __global__ void __launch_bounds__(kBlock) k_filter_soa(const filter_params P)
   const CT* __restrict__ base = static_cast<const CT*>(P.counts);
   const size_t tile_rows = (size_t)blockDim.x * RPL;
   const size_t n_tiles = (P.n_rows + tile_rows - 1) / tile_rows;
+  const size_t n_full_tiles = P.n_rows / tile_rows;            // tiles with every row in range
+  const int S = P.nc + P.nk;
+  const int n_batches = (S + kBatch - 1) / kBatch;
 
   if (blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);    // merge.hpp:76
 
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+#ifdef KMD_TIMING
+  unsigned long long t_load = 0, t_math = 0, n_tiles_done = 0;
+  const unsigned long long t_begin = __builtin_readcyclecounter(), w_begin = wall_clock64();
+#endif
+  soa_batch<CT, RPL> A, B;
+  size_t tile = blockIdx.x;
+#if KMD_XPREFETCH
+  if (tile < n_full_tiles)
+    A.load(base + tile * tile_rows + (size_t)threadIdx.x * RPL, P.ld, 0, S);
+#endif
+
+  for (; tile < n_tiles; tile += gridDim.x)
   {
     const size_t r0 = tile * tile_rows + (size_t)threadIdx.x * RPL;
     ACC sc[RPL], sk[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) { sc[j] = 0; sk[j] = 0; }
 
-    if (r0 + RPL <= P.n_rows)
+#ifdef KMD_TIMING
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+    if (tile < n_full_tiles)
     {
-      const CT* __restrict__ col = base + r0;
-#pragma unroll 8
-      for (int s = 0; s < P.nc; ++s, col += P.ld) accumulate<CT, RPL>(col, sc);
-#pragma unroll 8
-      for (int s = 0; s < P.nk; ++s, col += P.ld) accumulate<CT, RPL>(col, sk);
+      const CT* __restrict__ rows0 = base + r0;
+#if !KMD_XPREFETCH
+      A.load(rows0, P.ld, 0, S);
+#endif
+      for (int b = 0; b < n_batches; b += 2)
+      {
+        if (b + 1 < n_batches) B.load(rows0, P.ld, (b + 1) * kBatch, S);
+        A.consume(b * kBatch, P.nc, S, sc, sk);
+        if (b + 2 < n_batches) A.load(rows0, P.ld, (b + 2) * kBatch, S);
+        if (b + 1 < n_batches) B.consume((b + 1) * kBatch, P.nc, S, sc, sk);
+      }
+#if KMD_XPREFETCH
+      const size_t next = tile + gridDim.x;
+      if (next < n_full_tiles)
+        A.load(base + next * tile_rows + (size_t)threadIdx.x * RPL, P.ld, 0, S);
+#endif
     }
-    else if (r0 < P.n_rows)
+    else
     {
-      // ragged last tile: scalar loads with a bound check per row
+      // the ragged last tile: scalar loads with a bound check per row
+#pragma unroll
       for (int j = 0; j < RPL; ++j)
       {
-        if (r0 + j >= P.n_rows) break;
-        const CT* __restrict__ col = base + r0 + j;
-        for (int s = 0; s < P.nc; ++s, col += P.ld) sc[j] += (ACC)(*col);
-        for (int s = 0; s < P.nk; ++s, col += P.ld) sk[j] += (ACC)(*col);
+        if (r0 + j < P.n_rows)       // (no break: keeps sc/sk in registers)
+        {
+          const CT* __restrict__ col = base + r0 + j;
+          ACC a = 0, b = 0;
+          for (int s = 0; s < P.nc; ++s, col += P.ld) a += (ACC)(*col);
+          for (int s = 0; s < P.nk; ++s, col += P.ld) b += (ACC)(*col);
+          sc[j] = a; sk[j] = b;
+        }
       }
     }
 
-#pragma unroll
+#ifdef KMD_TIMING
+    const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
+    // FP64 phase, one row at a time: a rolled loop that rotates the sums through slot 0
+    // keeps one copy of finish_row's code and registers instead of RPL of them
+#pragma unroll 1
     for (int j = 0; j < RPL; ++j)
     {
       row_state st;
-      st.sum_c = sc[j]; st.sum_k = sk[j];
+      st.sum_c = sc[0]; st.sum_k = sk[0];
       st.row = r0 + j;
       st.valid = (r0 + j) < P.n_rows;
       finish_row(P, s_lf, st);
+#pragma unroll
+      for (int i = 0; i + 1 < RPL; ++i) { sc[i] = sc[i + 1]; sk[i] = sk[i + 1]; }
     }
+#ifdef KMD_TIMING
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    t_load += t1 - t0; t_math += t2 - t1; ++n_tiles_done;
+#endif
   }
+#ifdef KMD_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    P.counters[8] = t_load; P.counters[9] = t_math; P.counters[10] = n_tiles_done;
+    P.counters[11] = __builtin_readcyclecounter() - t_begin; P.counters[12] = wall_clock64() - w_begin;
+  }
+#endif
 }
 
 // ---- row-major layout: counts[row][sample] -------------------------------------------------
@@ -414,19 +577,8 @@ __global__ void __launch_bounds__(256) k_process_all(const filter_params P, int 
     double lf_c = 0, lf_k = 0;
     if (kc < P.lf_n) lf_c = P.lf[kc];
     if (kk < P.lf_n) lf_k = P.lf[kk];
-    const bool miss_c = valid && kc >= P.lf_n, miss_k = valid && kk >= P.lf_n;
-    unsigned long long need = __ballot(miss_c | miss_k);
-    while (need)
-    {
-      const int src = __ffsll((long long)need) - 1;
-      const uint32_t skc = (uint32_t)__builtin_amdgcn_readlane((int)kc, src);
-      const uint32_t skk = (uint32_t)__builtin_amdgcn_readlane((int)kk, src);
-      double v_c = 0, v_k = 0;
-      if (skc >= P.lf_n) v_c = wave_lf_descending(skc);
-      if (skk >= P.lf_n) v_k = (skk == skc && skc >= P.lf_n) ? v_c : wave_lf_descending(skk);
-      if ((int)__lane_id() == src) { if (miss_c) lf_c = v_c; if (miss_k) lf_k = v_k; }
-      need &= need - 1;
-    }
+    if (valid && kc >= P.lf_n) lf_c = lf_beyond_table(kc);
+    if (valid && kk >= P.lf_n) lf_k = lf_beyond_table(kk);
     if (valid)
     {
       const kmd::lrt_result r = kmd::lrt_from_sums(sc, sk, lf_c, lf_k, P.dT, P.dTc, P.dTk);
@@ -453,7 +605,14 @@ int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double 
   P.nc = m->nc; P.nk = m->nk;
   P.dT = m->dT; P.dTc = m->dTc; P.dTk = m->dTk; P.lg_half = m->lg_half;
   P.threshold = threshold;
-  P.lr_cut = kmd::lr_cut_for_threshold(threshold, m->lg_half);
+  // the cut only depends on the threshold: cache the last one (hot loop calls reuse it)
+  if (!(m->cut_valid && m->cut_threshold_bits == kmd::bits_of(threshold)))
+  {
+    m->cut_value = kmd::lr_cut_for_threshold(threshold, m->lg_half);
+    m->cut_threshold_bits = kmd::bits_of(threshold);
+    m->cut_valid = true;
+  }
+  P.lr_cut = m->cut_value;
   P.lf = m->d_lf; P.lf_n = (uint32_t)m->lf_n;
   P.lds_n = 0;
   P.counters = nullptr;
@@ -467,7 +626,7 @@ template <typename CT>
 int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int blocks_per_cu,
                hipStream_t stream)
 {
-  constexpr int vec = 16 / sizeof(CT);
+  constexpr int vec = sizeof(CT) == 4 ? KMD_RPL_U32 : 16 / sizeof(CT);
   const bool aligned = ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
                        ((P.ld * sizeof(CT)) % 16 == 0);
   const size_t rpl = aligned ? vec : 1;
@@ -495,9 +654,19 @@ int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int
 template <typename K>
 int allow_big_lds(K kernel, size_t lds_bytes)
 {
-  if (lds_bytes > 64 * 1024)
-    KMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // one hipFuncSetAttribute per kernel and size class, not per launch (kernels of different
+  // instantiations share the function TYPE, so the cache is keyed by address)
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> allowed;
+  if (lds_bytes <= 64 * 1024) return KMD_OK;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = allowed[fn];
+  if (lds_bytes > have)
+  {
+    KMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    have = lds_bytes;
+  }
   return KMD_OK;
 }
 

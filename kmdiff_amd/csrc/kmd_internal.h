@@ -20,6 +20,10 @@ struct kmd_model
   double* d_lf;             // device copy
   int n_cu;                 // multiProcessorCount
   size_t lds_per_block_max; // sharedMemPerBlock
+  // cache of lr_cut_for_threshold (host-side constant of the last threshold used)
+  mutable bool cut_valid;
+  mutable uint64_t cut_threshold_bits;
+  mutable double cut_value;
 };
 
 namespace kmd {
@@ -39,5 +43,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // smallest LR at which igamc(1/2, LR) <= threshold, minus a safety margin; rows with a
 // likelihood ratio below it cannot pass `p <= threshold` (kmd_filter.hip).
 double lr_cut_for_threshold(double threshold, double lg_half);
+
+inline uint64_t bits_of(double x) { uint64_t b; __builtin_memcpy(&b, &x, 8); return b; }
 
 } // namespace kmd

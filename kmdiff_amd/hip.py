@@ -123,8 +123,12 @@ class CountMatrix:
         self.count_bytes, self.layout = int(count_bytes), int(layout)
         if ld is None:
             if layout == N.LAYOUT_SOA:
-                per16 = 16 // self.count_bytes       # keep columns 16-byte aligned
-                ld = (self.n_rows + per16 - 1) // per16 * per16
+                # column pitch: whole 256-byte lines, so that every column starts on an L2
+                # line and no wave access straddles one (16 bytes is the kernel's minimum
+                # for its vector loads; KMD_LD_ALIGN overrides for experiments)
+                import os
+                per = max(int(os.environ.get("KMD_LD_ALIGN", "256")), 16) // self.count_bytes
+                ld = (self.n_rows + per - 1) // per * per
             else:
                 ld = self.n_samples
         self.ld = int(ld)
@@ -244,7 +248,7 @@ class SurvivorAccumulator:
                 self.bufs[name] = None
                 continue
             self.bufs[name] = DeviceBuffer(cap * np.dtype(dt).itemsize)
-        self.counters = DeviceBuffer(N.NCOUNTERS * 8).zero()
+        self.counters = DeviceBuffer(2 * N.NCOUNTERS * 8).zero()   # [NCOUNTERS..] dev-only timing slots
         self._size = None
 
     def struct(self):

@@ -198,8 +198,8 @@ def test_unaligned_soa_pitch_and_padded_rows(K, oracle):
                                  oracle.lf_table(10000), 0.01)
     # SoA, ld = n (odd): columns are only 4-byte aligned
     m = K.CountMatrix(n, nc + nk, 4, K.LAYOUT_SOA, ld=n, with_kmers=False)
-    K._native.check(K._native.lib().kmd_memcpy_h2d(m.counts.ptr, np.ascontiguousarray(host.T).ctypes.data,
-                                                   host.nbytes, None))
+    host_t = np.ascontiguousarray(host.T)          # keep alive across the ctypes call
+    K._native.check(K._native.lib().kmd_memcpy_h2d(m.counts.ptr, host_t.ctypes.data, host_t.nbytes, None))
     _, acc, _ = run_filter(K, m, nc, nk, tcs, tks, 10000, 0.01)
     assert (acc.get()["row"]).tolist() == want["row"].tolist()
     # row-major, ld = 11 (padding column garbage must be ignored)
