@@ -47,8 +47,13 @@ enum { KMD_CORR_NOTHING = 0, KMD_CORR_BONFERRONI = 1, KMD_CORR_BENJAMINI = 2,
  *                    the device-native layout: one lane per row, fully coalesced.
  *   KMD_LAYOUT_ROWS: counts[row][sample]   (row stride ld >= nc+nk, in elements);
  *                    what km::MatrixReader / KmerMerger hand the observer
- *                    (include/kmdiff/merge.hpp:68,194-203); staged through LDS. */
-enum { KMD_LAYOUT_SOA = 1, KMD_LAYOUT_ROWS = 0 };
+ *                    (include/kmdiff/merge.hpp:68,194-203); staged through LDS.
+ *   KMD_LAYOUT_TILED: counts[row / T][sample][row % T] with T = ld rows per block
+ *                    (T a multiple of 4096; the buffer holds ceil(n_rows / T) whole blocks).
+ *                    SoA inside a block, so lanes stay coalesced, but one block of rows is
+ *                    one contiguous span of S*T counts: better DRAM page locality than S
+ *                    far-apart columns (measured +3..10 % over plain SoA). */
+enum { KMD_LAYOUT_ROWS = 0, KMD_LAYOUT_SOA = 1, KMD_LAYOUT_TILED = 2 };
 
 const char* kmd_status_string(int status);
 const char* kmd_last_error(void);
@@ -126,7 +131,7 @@ enum { KMD_CNT_TOTAL = 0, KMD_CNT_SIG = 1, KMD_CNT_SIG_CONTROL = 2, KMD_CNT_SIG_
 typedef struct {
   const void*     d_counts;   /* count matrix tile                                         */
   int             count_bytes;/* 1, 2 or 4: km::selectC<MAX_C>::type (imodel.hpp:27)       */
-  int             layout;     /* KMD_LAYOUT_SOA | KMD_LAYOUT_ROWS                          */
+  int             layout;     /* KMD_LAYOUT_SOA | KMD_LAYOUT_ROWS | KMD_LAYOUT_TILED       */
   size_t          ld;         /* leading dimension in elements                             */
   const uint64_t* d_kmer_lo;  /* per-row k-mers (may be NULL: survivors carry only `row`)  */
   const uint64_t* d_kmer_hi;

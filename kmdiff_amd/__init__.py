@@ -7,7 +7,7 @@ the CPU.
 """
 from ._native import (KmdError, LIB_PATH, SIGN_CONTROL, SIGN_CASE, SIGN_NO, CORR_NOTHING,
                       CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM, LAYOUT_ROWS,
-                      LAYOUT_SOA)
+                      LAYOUT_SOA, LAYOUT_TILED)
 from .hip import (DeviceBuffer, PoissonLikelihood, CountMatrix, SurvivorAccumulator,
                   diff_observer, aggregate, synth_matrix, column_sums, device_count,
                   device_name, Event, CORRECTION_BY_NAME)
@@ -16,4 +16,4 @@ __all__ = ["KmdError", "LIB_PATH", "DeviceBuffer", "PoissonLikelihood", "CountMa
            "SurvivorAccumulator", "diff_observer", "aggregate", "synth_matrix", "column_sums",
            "device_count", "device_name", "Event", "CORRECTION_BY_NAME",
            "SIGN_CONTROL", "SIGN_CASE", "SIGN_NO", "CORR_NOTHING", "CORR_BONFERRONI",
-           "CORR_BENJAMINI", "CORR_SIDAK", "CORR_HOLM", "LAYOUT_ROWS", "LAYOUT_SOA"]
+           "CORR_BENJAMINI", "CORR_SIDAK", "CORR_HOLM", "LAYOUT_ROWS", "LAYOUT_SOA", "LAYOUT_TILED"]

@@ -305,13 +305,13 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, uint32_t part, uin
       }
       any |= (v != 0);
       if (v > cmax) v = cmax;
-      const size_t idx = (layout == KMD_LAYOUT_ROWS) ? r * ld + s : (size_t)s * ld + r;
+      const size_t idx = kmd::count_index(layout, ld, S, r, s);
       counts[idx] = (CT)v;
     }
     if (!any)
     {
       const int s = (int)(h % (uint64_t)S);
-      const size_t idx = (layout == KMD_LAYOUT_ROWS) ? r * ld + s : (size_t)s * ld + r;
+      const size_t idx = kmd::count_index(layout, ld, S, r, s);
       counts[idx] = (CT)1;
     }
     if (kmer_lo)
@@ -335,13 +335,12 @@ __global__ void __launch_bounds__(256) k_column_sums(const CT* __restrict__ coun
   unsigned long long acc = 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
-    acc += (layout == KMD_LAYOUT_ROWS) ? counts[r * ld + s] : counts[(size_t)s * ld + r];
+    acc += counts[kmd::count_index(layout, ld, n_samples, r, s)];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0)
     atomicAdd(&totals[s], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
-  (void)n_samples;
 }
 
 __global__ void __launch_bounds__(256) k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
@@ -396,7 +395,8 @@ int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_ro
   KMD_REQUIRE(d_counts || n_rows == 0, "kmd_synth_fill: NULL counts");
   KMD_REQUIRE(nc > 0 && nk > 0, "kmd_synth_fill: nc, nk must be positive");
   KMD_REQUIRE(count_bytes == 1 || count_bytes == 2 || count_bytes == 4, "kmd_synth_fill: count_bytes");
-  KMD_REQUIRE(layout == KMD_LAYOUT_SOA || layout == KMD_LAYOUT_ROWS, "kmd_synth_fill: layout");
+  KMD_REQUIRE(kmd::layout_ok(layout), "kmd_synth_fill: layout");
+  KMD_REQUIRE(layout != KMD_LAYOUT_TILED || (ld > 0 && ld % 4096 == 0), "kmd_synth_fill: tiled ld % 4096");
   KMD_REQUIRE(partition < 256, "kmd_synth_fill: partition >= 256");
   if (n_rows == 0) return KMD_OK;
   synth_tables T;

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_gather_counts(const CT* __restrict__ co
   const size_t i = t / (size_t)S;
   const int s = (int)(t - i * (size_t)S);
   const size_t r = (size_t)(rows[i] - row_base);
-  const CT v = (layout == KMD_LAYOUT_ROWS) ? counts[r * ld + s] : counts[(size_t)s * ld + r];
+  const CT v = counts[kmd::count_index(layout, ld, S, r, s)];
   out[t] = (double)v;                                          // merge.hpp:91
 }
 

@@ -36,6 +36,12 @@ namespace {
 #ifndef KMD_RPL_U32
 #define KMD_RPL_U32 2
 #endif
+#ifndef KMD_RPL_U16
+#define KMD_RPL_U16 4
+#endif
+#ifndef KMD_RPL_U8
+#define KMD_RPL_U8 8
+#endif
 #ifndef KMD_XPREFETCH
 #define KMD_XPREFETCH 1
 #endif
@@ -44,7 +50,9 @@ constexpr int kBlock = KMD_BLOCK;
 struct filter_params
 {
   const void* counts;
-  size_t ld;
+  size_t ld;            // SoA: column stride; rows: row stride; tiled: T (= column stride)
+  size_t tiles_per_blk; // tiled: kernel tiles per T-row block (T / tile_rows); else 0
+  size_t blk_stride;    // tiled: S * T elements between blocks
   size_t n_rows;
   uint64_t row_base;
   const uint64_t* kmer_lo;
@@ -63,43 +71,17 @@ template <> struct vec_of<uint32_t, 1> { using type = uint32_t; };
 template <> struct vec_of<uint32_t, 2> { using type = uint2; };
 template <> struct vec_of<uint32_t, 4> { using type = uint4; };
 template <> struct vec_of<uint16_t, 1> { using type = uint16_t; };
+template <> struct vec_of<uint16_t, 2> { using type = uint32_t; };
+template <> struct vec_of<uint16_t, 4> { using type = uint2; };
 template <> struct vec_of<uint16_t, 8> { using type = uint4; };
 template <> struct vec_of<uint8_t, 1> { using type = uint8_t; };
+template <> struct vec_of<uint8_t, 4> { using type = uint32_t; };
+template <> struct vec_of<uint8_t, 8> { using type = uint2; };
 template <> struct vec_of<uint8_t, 16> { using type = uint4; };
 
 // accumulator wide enough for nc+nk <= 65535 samples
 template <typename CT> struct acc_of { using type = uint32_t; };
 template <> struct acc_of<uint32_t> { using type = uint64_t; };
-
-template <typename CT, int RPL, typename ACC>
-__device__ __forceinline__ void accumulate(const CT* __restrict__ p, ACC (&acc)[RPL])
-{
-  using V = typename vec_of<CT, RPL>::type;
-  if constexpr (RPL == 1)
-  {
-    acc[0] += (ACC)(*p);
-  }
-  else
-  {
-    const V v = *reinterpret_cast<const V*>(p);
-    if constexpr (sizeof(CT) == 4)
-    {
-      if constexpr (RPL == 2) { acc[0] += v.x; acc[1] += v.y; }
-      else { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
-    }
-    else
-    {
-      const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-      constexpr int per = 4 / sizeof(CT);            // elements per dword
-      constexpr uint32_t mask = sizeof(CT) == 1 ? 0xFFu : 0xFFFFu;
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < per; ++e)
-          acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
-    }
-  }
-}
 
 // LogFactorialTable::operator[] for k >= table size (log_factorial_table.hpp:14-18 falls back
 // to the O(k) loop log(k) + log(k-1) + ... + log(2), src/log_factorial_table.cpp:13-22).
@@ -137,7 +119,7 @@ struct row_state
 // One row from its two count sums to the survivor sink.  Must be called by all 64 lanes of
 // the wave together (ballots / cooperative fallback inside).
 __device__ __forceinline__ void finish_row(const filter_params& P, const double* s_lf,
-                                           const row_state& st)
+                                           const row_state& st, uint32_t& n_beyond)
 {
 #ifdef KMD_ABLATE_MATH   // dev only: memory-side ceiling of the load loop (results are wrong)
   if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
@@ -152,13 +134,12 @@ __device__ __forceinline__ void finish_row(const filter_params& P, const double*
   // table misses (rare with the default 10000-entry table)
   const bool miss_c = st.valid && kc >= P.lf_n;
   const bool miss_k = st.valid && kk >= P.lf_n;
-  const unsigned long long need = __ballot(miss_c | miss_k);
-  if (need)
+  if (miss_c | miss_k)
   {
     if (miss_c) lf_c = lf_beyond_table(kc);
     if (miss_k) lf_k = (kk == kc && miss_c) ? lf_c : lf_beyond_table(kk);
-    if (__lane_id() == (int)(__ffsll((long long)need) - 1))
-      atomicAdd(&P.counters[KMD_CNT_DEFERRED], (unsigned long long)__popcll(need));
+    ++n_beyond;        // flushed once per wave at kernel end: with many samples most waves
+                       // see such rows, and a global atomic per wave serialises the chip
   }
 
   const kmd::lrt_result r = kmd::lrt_from_sums(st.sum_c, st.sum_k, lf_c, lf_k, P.dT, P.dTc, P.dTk);
@@ -212,6 +193,14 @@ __device__ __forceinline__ void finish_row(const filter_params& P, const double*
   }
 }
 
+// one atomic per wave per launch for the beyond-table row count
+__device__ __forceinline__ void flush_beyond(const filter_params& P, uint32_t n_beyond)
+{
+  for (int o = 32; o > 0; o >>= 1) n_beyond += __shfl_down(n_beyond, o, 64);
+  if (__lane_id() == 0 && n_beyond)
+    atomicAdd(&P.counters[KMD_CNT_DEFERRED], (unsigned long long)n_beyond);
+}
+
 __device__ __forceinline__ void stage_table(const filter_params& P, double* s_lf)
 {
   for (uint32_t i = threadIdx.x; i < P.lds_n; i += blockDim.x) s_lf[i] = P.lf[i];
@@ -260,16 +249,23 @@ struct soa_batch
     }
     else
     {
-      const uint32_t w[4] = { v[j].x, v[j].y, v[j].z, v[j].w };
       constexpr int per = 4 / sizeof(CT);
+      constexpr int ndw = RPL / per;                     // dwords in the vector
       constexpr uint32_t mask = sizeof(CT) == 1 ? 0xFFu : 0xFFFFu;
+      uint32_t w[ndw];
+      unpack_dwords(v[j], w);
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < ndw; ++d)
 #pragma unroll
         for (int e = 0; e < per; ++e)
           acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
     }
   }
+
+  static __device__ __forceinline__ void unpack_dwords(const uint32_t& x, uint32_t (&w)[1]) { w[0] = x; }
+  static __device__ __forceinline__ void unpack_dwords(const uint2& x, uint32_t (&w)[2]) { w[0] = x.x; w[1] = x.y; }
+  static __device__ __forceinline__ void unpack_dwords(const uint4& x, uint32_t (&w)[4])
+  { w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; }
 
   template <typename ACC>
   __device__ __forceinline__ void add_masked(int j, uint32_t m, ACC (&acc)[RPL]) const
@@ -288,14 +284,16 @@ struct soa_batch
     }
     else
     {
-      const uint32_t w[4] = { v[j].x & m, v[j].y & m, v[j].z & m, v[j].w & m };
       constexpr int per = 4 / sizeof(CT);
+      constexpr int ndw = RPL / per;
       constexpr uint32_t mask = sizeof(CT) == 1 ? 0xFFu : 0xFFFFu;
+      uint32_t w[ndw];
+      unpack_dwords(v[j], w);
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < ndw; ++d)
 #pragma unroll
         for (int e = 0; e < per; ++e)
-          acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
+          acc[d * per + e] += ((w[d] & m) >> (8 * sizeof(CT) * e)) & mask;
     }
   }
 
@@ -330,17 +328,31 @@ struct soa_batch
   }
 };
 
+// first element (sample 0) of a kernel tile: plain SoA tiles are tile_rows apart in every
+// column; tiled-layout tiles live inside blocks of T rows that are S*T elements apart
+template <typename CT>
+__device__ __forceinline__ const CT* tile_base(const filter_params& P, const CT* base, size_t tile,
+                                               size_t tile_rows)
+{
+  if (P.tiles_per_blk == 0) return base + tile * tile_rows;
+  const size_t blk = tile / P.tiles_per_blk, sub = tile - blk * P.tiles_per_blk;
+  return base + blk * P.blk_stride + sub * tile_rows;
+}
+
 template <typename CT, int RPL>
 __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filter_params P)
 {
   extern __shared__ double s_lf[];
   stage_table(P, s_lf);
+  uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
 
   using ACC = typename acc_of<CT>::type;
   const CT* __restrict__ base = static_cast<const CT*>(P.counts);
   const size_t tile_rows = (size_t)blockDim.x * RPL;
   const size_t n_tiles = (P.n_rows + tile_rows - 1) / tile_rows;
-  const size_t n_full_tiles = P.n_rows / tile_rows;            // tiles with every row in range
+  // tiles whose vector loads are in bounds: all of them for the tiled layout (the buffer is
+  // whole blocks), else the ones with every row in range
+  const size_t n_full_tiles = P.tiles_per_blk ? n_tiles : P.n_rows / tile_rows;
   const int S = P.nc + P.nk;
   const int n_batches = (S + kBatch - 1) / kBatch;
 
@@ -355,7 +367,7 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
   size_t tile = blockIdx.x;
 #if KMD_XPREFETCH
   if (tile < n_full_tiles)
-    A.load(base + tile * tile_rows + (size_t)threadIdx.x * RPL, P.ld, 0, S);
+    A.load(tile_base(P, base, tile, tile_rows) + (size_t)threadIdx.x * RPL, P.ld, 0, S);
 #endif
 
   for (; tile < n_tiles; tile += gridDim.x)
@@ -370,7 +382,7 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
 #endif
     if (tile < n_full_tiles)
     {
-      const CT* __restrict__ rows0 = base + r0;
+      const CT* __restrict__ rows0 = tile_base(P, base, tile, tile_rows) + (size_t)threadIdx.x * RPL;
 #if !KMD_XPREFETCH
       A.load(rows0, P.ld, 0, S);
 #endif
@@ -384,7 +396,7 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
 #if KMD_XPREFETCH
       const size_t next = tile + gridDim.x;
       if (next < n_full_tiles)
-        A.load(base + next * tile_rows + (size_t)threadIdx.x * RPL, P.ld, 0, S);
+        A.load(tile_base(P, base, next, tile_rows) + (size_t)threadIdx.x * RPL, P.ld, 0, S);
 #endif
     }
     else
@@ -416,7 +428,7 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
       st.sum_c = sc[0]; st.sum_k = sk[0];
       st.row = r0 + j;
       st.valid = (r0 + j) < P.n_rows;
-      finish_row(P, s_lf, st);
+      finish_row(P, s_lf, st, n_beyond);
 #pragma unroll
       for (int i = 0; i + 1 < RPL; ++i) { sc[i] = sc[i + 1]; sk[i] = sk[i + 1]; }
     }
@@ -425,6 +437,7 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
     t_load += t1 - t0; t_math += t2 - t1; ++n_tiles_done;
 #endif
   }
+  flush_beyond(P, n_beyond);
 #ifdef KMD_TIMING
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
@@ -449,6 +462,7 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params 
   double* s_lf = s_all;
   uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_all + P.lds_n);
   stage_table(P, s_lf);
+  uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
 
   const uint32_t S = (uint32_t)(P.nc + P.nk);
   constexpr uint32_t per = 4 / sizeof(CT);                      // counts per dword
@@ -512,8 +526,9 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params 
     st.row = row0 + threadIdx.x;
     st.valid = threadIdx.x < rows_here;
     st.sum_c = sc; st.sum_k = sk;
-    finish_row(P, s_lf, st);
+    finish_row(P, s_lf, st, n_beyond);
   }
+  flush_beyond(P, n_beyond);
 }
 
 // Row-major rows whose pitch is not a whole number of dwords: each lane walks its own row
@@ -523,6 +538,7 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows_direct(const filter_
 {
   extern __shared__ double s_lf[];
   stage_table(P, s_lf);
+  uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
   const CT* __restrict__ base = static_cast<const CT*>(P.counts);
   const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -540,8 +556,9 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows_direct(const filter_
       for (int s = 0; s < P.nk; ++s) sk += r[P.nc + s];
     }
     st.sum_c = sc; st.sum_k = sk;
-    finish_row(P, s_lf, st);
+    finish_row(P, s_lf, st, n_beyond);
   }
+  flush_beyond(P, n_beyond);
 }
 
 // ---- every row's result, no threshold: IModel::process over a tile -----------------------
@@ -560,18 +577,9 @@ __global__ void __launch_bounds__(256) k_process_all(const filter_params P, int 
     uint64_t sc = 0, sk = 0;
     if (valid)
     {
-      if (layout == KMD_LAYOUT_SOA)
-      {
-        const CT* col = base + row;
-        for (int s = 0; s < P.nc; ++s, col += P.ld) sc += *col;
-        for (int s = 0; s < P.nk; ++s, col += P.ld) sk += *col;
-      }
-      else
-      {
-        const CT* r = base + row * P.ld;
-        for (int s = 0; s < P.nc; ++s) sc += r[s];
-        for (int s = 0; s < P.nk; ++s) sk += r[P.nc + s];
-      }
+      const int S = P.nc + P.nk;
+      for (int s = 0; s < P.nc; ++s) sc += base[kmd::count_index(layout, P.ld, S, row, s)];
+      for (int s = P.nc; s < S; ++s) sk += base[kmd::count_index(layout, P.ld, S, row, s)];
     }
     const uint32_t kc = kmd::table_index(sc), kk = kmd::table_index(sk);
     double lf_c = 0, lf_k = 0;
@@ -595,11 +603,13 @@ int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double 
   KMD_REQUIRE(m && t, "kmd: NULL model or tile");
   KMD_REQUIRE(t->count_bytes == 1 || t->count_bytes == 2 || t->count_bytes == 4,
               "kmd: count_bytes must be 1, 2 or 4");
-  KMD_REQUIRE(t->layout == KMD_LAYOUT_SOA || t->layout == KMD_LAYOUT_ROWS, "kmd: bad layout");
+  KMD_REQUIRE(kmd::layout_ok(t->layout), "kmd: bad layout");
   KMD_REQUIRE(t->n_rows == 0 || t->d_counts, "kmd: NULL count matrix");
   KMD_REQUIRE(m->nc + m->nk <= 65535, "kmd: more than 65535 samples");
   if (t->layout == KMD_LAYOUT_SOA) KMD_REQUIRE(t->ld >= t->n_rows, "kmd: SoA ld < n_rows");
-  else KMD_REQUIRE(t->ld >= (size_t)(m->nc + m->nk), "kmd: row-major ld < nc+nk");
+  else if (t->layout == KMD_LAYOUT_ROWS) KMD_REQUIRE(t->ld >= (size_t)(m->nc + m->nk), "kmd: row-major ld < nc+nk");
+  else KMD_REQUIRE(t->ld > 0 && t->ld % 4096 == 0, "kmd: tiled layout needs ld (rows per block) % 4096 == 0");
+  P.tiles_per_blk = 0; P.blk_stride = 0;
   P.counts = t->d_counts; P.ld = t->ld; P.n_rows = t->n_rows; P.row_base = t->row_base;
   P.kmer_lo = t->d_kmer_lo; P.kmer_hi = t->d_kmer_hi;
   P.nc = m->nc; P.nk = m->nk;
@@ -624,13 +634,20 @@ template <typename K> int allow_big_lds(K kernel, size_t lds_bytes);
 
 template <typename CT>
 int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int blocks_per_cu,
-               hipStream_t stream)
+               bool tiled, hipStream_t stream)
 {
-  constexpr int vec = sizeof(CT) == 4 ? KMD_RPL_U32 : 16 / sizeof(CT);
-  const bool aligned = ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
-                       ((P.ld * sizeof(CT)) % 16 == 0);
+  constexpr int vec = sizeof(CT) == 4 ? KMD_RPL_U32 : sizeof(CT) == 2 ? KMD_RPL_U16 : KMD_RPL_U8;
+  constexpr size_t vbytes = vec * sizeof(CT);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(P.counts) % vbytes) == 0) &&
+                       ((P.ld * sizeof(CT)) % vbytes == 0);
   const size_t rpl = aligned ? vec : 1;
   const size_t tile_rows = (size_t)kBlock * rpl;
+  filter_params Q = P;
+  if (tiled)
+  {
+    Q.tiles_per_blk = P.ld / tile_rows;               // ld = T, a multiple of 4096 >= tile_rows
+    Q.blk_stride = (size_t)(P.nc + P.nk) * P.ld;
+  }
   size_t n_tiles = (P.n_rows + tile_rows - 1) / tile_rows;
   size_t grid = (size_t)m->n_cu * blocks_per_cu;
   if (grid > n_tiles) grid = n_tiles;
@@ -639,13 +656,13 @@ int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int
   {
     int rc = allow_big_lds(k_filter_soa<CT, vec>, lds_bytes);
     if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_soa<CT, vec>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((k_filter_soa<CT, vec>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, Q);
   }
   else
   {
     int rc = allow_big_lds(k_filter_soa<CT, 1>, lds_bytes);
     if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_soa<CT, 1>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((k_filter_soa<CT, 1>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, Q);
   }
   KMD_HIP(hipGetLastError());
   return KMD_OK;
@@ -754,8 +771,9 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
 
   // LDS budget: the table head; two workgroups per CU when it fits in half of the LDS
   const size_t lds_cap = m->lds_per_block_max;          // 160 KiB on gfx950
-  if (tile->layout == KMD_LAYOUT_SOA)
+  if (tile->layout == KMD_LAYOUT_SOA || tile->layout == KMD_LAYOUT_TILED)
   {
+    const bool tiled = tile->layout == KMD_LAYOUT_TILED;
     size_t want = m->lf_n * sizeof(double);
     int blocks_per_cu = 2;
     size_t budget = lds_cap / 2 - 256;
@@ -763,9 +781,9 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
     P.lds_n = (uint32_t)(want / sizeof(double));
     switch (tile->count_bytes)
     {
-      case 1: return launch_soa<uint8_t>(P, m, want, blocks_per_cu, st);
-      case 2: return launch_soa<uint16_t>(P, m, want, blocks_per_cu, st);
-      default: return launch_soa<uint32_t>(P, m, want, blocks_per_cu, st);
+      case 1: return launch_soa<uint8_t>(P, m, want, blocks_per_cu, tiled, st);
+      case 2: return launch_soa<uint16_t>(P, m, want, blocks_per_cu, tiled, st);
+      default: return launch_soa<uint32_t>(P, m, want, blocks_per_cu, tiled, st);
     }
   }
   else

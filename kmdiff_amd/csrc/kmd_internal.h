@@ -28,6 +28,19 @@ struct kmd_model
 
 namespace kmd {
 
+// element index of (row, sample) in a count matrix of S samples
+__host__ __device__ inline size_t count_index(int layout, size_t ld, int S, size_t row, int s)
+{
+  if (layout == KMD_LAYOUT_ROWS) return row * ld + (size_t)s;
+  if (layout == KMD_LAYOUT_SOA) return (size_t)s * ld + row;
+  return (row / ld) * ((size_t)S * ld) + (size_t)s * ld + (row % ld);   // KMD_LAYOUT_TILED
+}
+
+inline bool layout_ok(int layout)
+{
+  return layout == KMD_LAYOUT_ROWS || layout == KMD_LAYOUT_SOA || layout == KMD_LAYOUT_TILED;
+}
+
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 

@@ -24,6 +24,7 @@ CORRECTION_BY_NAME = {"nothing": N.CORR_NOTHING, "disabled": N.CORR_NOTHING,
                       "sidak": N.CORR_SIDAK, "holm": N.CORR_HOLM}
 
 _COUNT_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32}
+TILED_BLOCK_ROWS = 4096     # T of LAYOUT_TILED: rows per block (multiple of 4096)
 
 
 def device_count():
@@ -129,10 +130,18 @@ class CountMatrix:
                 import os
                 per = max(int(os.environ.get("KMD_LD_ALIGN", "256")), 16) // self.count_bytes
                 ld = (self.n_rows + per - 1) // per * per
+                ld += int(os.environ.get("KMD_LD_PAD", "0")) // self.count_bytes
+            elif layout == N.LAYOUT_TILED:
+                ld = TILED_BLOCK_ROWS
             else:
                 ld = self.n_samples
         self.ld = int(ld)
-        n_el = self.ld * (self.n_samples if layout == N.LAYOUT_SOA else self.n_rows)
+        if layout == N.LAYOUT_SOA:
+            n_el = self.ld * self.n_samples
+        elif layout == N.LAYOUT_TILED:
+            n_el = (self.n_rows + self.ld - 1) // self.ld * self.ld * self.n_samples
+        else:
+            n_el = self.ld * self.n_rows
         self.counts = DeviceBuffer(max(n_el, 1) * self.count_bytes)
         self.kmer_lo = DeviceBuffer(max(self.n_rows, 1) * 8) if with_kmers else None
         self.kmer_hi = DeviceBuffer(max(self.n_rows, 1) * 8) if (with_kmers and kmer_limbs == 2) else None
@@ -153,8 +162,14 @@ class CountMatrix:
             n_samples, n_rows = counts.shape
             m = cls(n_rows, n_samples, cb, layout, with_kmers=kmer_lo is not None,
                     kmer_limbs=2 if kmer_hi is not None else 1, row_base=row_base)
-            padded = np.zeros((n_samples, m.ld), dtype=counts.dtype)
-            padded[:, :n_rows] = counts
+            if layout == N.LAYOUT_SOA:
+                padded = np.zeros((n_samples, m.ld), dtype=counts.dtype)
+                padded[:, :n_rows] = counts
+            else:   # tiled: [block][sample][row in block]
+                nb = (n_rows + m.ld - 1) // m.ld
+                padded = np.zeros((n_samples, nb * m.ld), dtype=counts.dtype)
+                padded[:, :n_rows] = counts
+                padded = np.ascontiguousarray(padded.reshape(n_samples, nb, m.ld).transpose(1, 0, 2))
             if padded.nbytes:
                 check(lib().kmd_memcpy_h2d(m.counts.ptr, padded.ctypes.data, padded.nbytes, None), "h2d")
         if kmer_lo is not None and n_rows:
@@ -176,6 +191,11 @@ class CountMatrix:
         if self.layout == N.LAYOUT_ROWS:
             a = self.counts.to_host(dt, self.n_rows * self.ld).reshape(self.n_rows, self.ld)
             return a[:, :self.n_samples].copy()
+        if self.layout == N.LAYOUT_TILED:
+            nb = (self.n_rows + self.ld - 1) // self.ld
+            a = self.counts.to_host(dt, nb * self.n_samples * self.ld).reshape(nb, self.n_samples, self.ld)
+            a = a.transpose(1, 0, 2).reshape(self.n_samples, nb * self.ld)
+            return a[:, :self.n_rows].T.copy()
         a = self.counts.to_host(dt, self.n_samples * self.ld).reshape(self.n_samples, self.ld)
         return a[:, :self.n_rows].T.copy()
 

@@ -55,13 +55,17 @@ def test_log_factorial_table_is_the_reference_table(K, oracle):
     assert t[10] == 15.104412573075514            # tests/factorial_test.cpp:12
 
 
-@pytest.mark.parametrize("layout_name", ["rows", "soa"])
+def layout_of(K, name):
+    return {"rows": K.LAYOUT_ROWS, "soa": K.LAYOUT_SOA, "tiled": K.LAYOUT_TILED}[name]
+
+
+@pytest.mark.parametrize("layout_name", ["rows", "soa", "tiled"])
 @pytest.mark.parametrize("dtype", [np.uint32, np.uint16, np.uint8])
 def test_process_golden_rows(K, golden_dir, layout_name, dtype):
     """IModel::process over the golden rows made by the reference's own sources."""
     with open(os.path.join(golden_dir, "poisson_rows.json")) as f:
         g = json.load(f)
-    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    layout = layout_of(K, layout_name)
     for case in g["cases"]:
         rows = np.array(case["rows"], dtype=np.uint32)
         if rows.max() > np.iinfo(dtype).max:
@@ -88,10 +92,10 @@ def test_reference_model_test_signs(K):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("layout_name", ["soa", "rows"])
+@pytest.mark.parametrize("layout_name", ["soa", "rows", "tiled"])
 @pytest.mark.parametrize("count_bytes", [4, 2, 1])
 def test_synth_device_equals_oracle_replay(K, oracle, layout_name, count_bytes):
-    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    layout = layout_of(K, layout_name)
     n = 20011
     m = K.synth_matrix(SEED, 5, n, 3, 4, count_bytes, layout, row0=1234)
     want, lo, _ = oracle.synth_rows(SEED, 5, 1234, n, 3, 4, count_bytes)
@@ -136,11 +140,11 @@ def check_against_oracle(K, oracle, mat, host_rows, kmers, nc, nk, preload, thr)
     return want["counters"]
 
 
-@pytest.mark.parametrize("layout_name", ["soa", "rows"])
+@pytest.mark.parametrize("layout_name", ["soa", "rows", "tiled"])
 @pytest.mark.parametrize("count_bytes,nc,nk", [(4, 4, 4), (4, 20, 20), (2, 5, 3), (1, 7, 9), (4, 50, 50)])
 def test_filter_matches_oracle_on_synthetic_partition(K, oracle, layout_name, count_bytes, nc, nk):
     """diff_observer over one synthetic partition == the oracle's row loop."""
-    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    layout = layout_of(K, layout_name)
     n = 150_003 if nc + nk <= 40 else 40_001
     limbs = 2 if nc == 50 else 1
     mat = K.synth_matrix(SEED, 2, n, nc, nk, count_bytes, layout, kmer_limbs=limbs)
@@ -149,11 +153,11 @@ def test_filter_matches_oracle_on_synthetic_partition(K, oracle, layout_name, co
     assert counters[1] > 0            # the planted signal produces survivors
 
 
-@pytest.mark.parametrize("layout_name", ["soa", "rows"])
+@pytest.mark.parametrize("layout_name", ["soa", "rows", "tiled"])
 def test_table_fallback_small_preload(K, oracle, layout_name):
     """Count sums >= --log-factorial take LogFactorialTable's O(k) fallback
     (log_factorial_table.hpp:14-18): wave-cooperative on the device."""
-    layout = K.LAYOUT_ROWS if layout_name == "rows" else K.LAYOUT_SOA
+    layout = layout_of(K, layout_name)
     n = 30_000
     mat = K.synth_matrix(SEED, 9, n, 6, 6, 4, layout)
     host, lo, _ = oracle.synth_rows(SEED, 9, 0, n, 6, 6, 4)
@@ -176,7 +180,7 @@ def test_thresholds_from_everything_to_nothing(K, oracle, thr):
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 4099])
 def test_empty_and_ragged_tiles(K, oracle, n):
-    for layout in (K.LAYOUT_SOA, K.LAYOUT_ROWS):
+    for layout in (K.LAYOUT_SOA, K.LAYOUT_ROWS, K.LAYOUT_TILED):
         mat = K.synth_matrix(SEED, 0, n, 4, 4, 4, layout)
         host, lo, _ = oracle.synth_rows(SEED, 0, 0, n, 4, 4, 4)
         if n == 0:
@@ -315,7 +319,7 @@ def test_correction_golden_streams(K, golden_dir):
 def test_gather_counts_of_survivors(K, oracle):
     import ctypes as C
     n, nc, nk = 50_000, 5, 5
-    for layout in (K.LAYOUT_SOA, K.LAYOUT_ROWS):
+    for layout in (K.LAYOUT_SOA, K.LAYOUT_ROWS, K.LAYOUT_TILED):
         mat = K.synth_matrix(SEED, 8, n, nc, nk, 2, layout, row0=777)
         host, _, _ = oracle.synth_rows(SEED, 8, 777, n, nc, nk, 2)
         tcs, tks = totals_of(host, nc)

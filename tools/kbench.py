@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--thr", type=float, default=5e-7)
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
-    layout = K.LAYOUT_SOA if a.layout == "soa" else K.LAYOUT_ROWS
+    layout = {"soa": K.LAYOUT_SOA, "rows": K.LAYOUT_ROWS, "tiled": K.LAYOUT_TILED}[a.layout]
     mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, a.nc, a.nk, a.count_bytes, layout)
     tot = K.column_sums(mat)
     model = K.PoissonLikelihood(a.nc, a.nk, tot[:a.nc], tot[a.nc:], 10000)
