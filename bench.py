@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 256-partition synthetic count matrix, 20 controls v 20 cases, k = 31, 4-byte counts,
 39 062 500 rows per partition (10^10 rows / 256).  One STEP = one partition through stage 1
 (merge observer + Poisson LRT + threshold + survivor compaction, kmd_poisson_filter) with the
-partition already resident in HBM (SoA: counts[sample][row] + kmer[row]).  After the K timed
+partition already resident in HBM (tiled SoA: counts[row/4096][sample][row%4096] + kmer[row];
+--layout soa|rows select the plain column-major and the reference's row-major layouts).  After the K timed
 steps the job's single exchange (counter all-reduce, and for BH/Holm the survivor p-value
 all-gather) and the significance correction (stage 3) run inside the timed region too.
 
@@ -87,12 +88,12 @@ def cpu_baseline(rows_per_part, tc, tk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=ROWS_PER_PARTITION, help="rows per partition")
     ap.add_argument("--resident", type=int, default=8, help="distinct partitions kept in HBM per rank")
     ap.add_argument("--correction", default="bonferroni")
-    ap.add_argument("--layout", default="soa", choices=["soa", "rows"])
+    ap.add_argument("--layout", default="tiled", choices=["tiled", "soa", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
     from kmdiff_amd import dist as D
     lib = K._native.lib()
     K._native.check(lib.kmd_set_device(local_rank))
-    layout = K.LAYOUT_SOA if args.layout == "soa" else K.LAYOUT_ROWS
+    layout = {"tiled": K.LAYOUT_TILED, "soa": K.LAYOUT_SOA, "rows": K.LAYOUT_ROWS}[args.layout]
     thr = THRESHOLD / CUTOFF
 
     # ---- setup (untimed): resident partitions, totals, model, survivor sink ------------------
@@ -200,7 +201,7 @@ def main():
                        "copy_probe_GBs": copy_gbs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_filter_%s<u32>" % args.layout, "avg_kernel_ms": avg_kernel_ms},
+                         "kernel": "k_filter_%s<u32>" % ("rows" if args.layout == "rows" else "soa"), "avg_kernel_ms": avg_kernel_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.rows, int(totals[:NC].sum()), int(totals[NC:].sum()))

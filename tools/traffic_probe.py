@@ -22,7 +22,8 @@ for w in (4, 8, 16):
         K._native.check(lib.kmd_read_probe(buf.ptr, nbytes, w, sink.ptr, None))
 lib.kmd_stream_sync(None)
 buf.free()
-mat = K.synth_matrix(0x6B6D64696666, 0, ROWS, 20, 20, 4, K.LAYOUT_SOA)
+LAYOUT = {"tiled": K.LAYOUT_TILED, "soa": K.LAYOUT_SOA, "rows": K.LAYOUT_ROWS}[os.environ.get("KMD_LAYOUT", "tiled")]
+mat = K.synth_matrix(0x6B6D64696666, 0, ROWS, 20, 20, 4, LAYOUT)
 tot = K.column_sums(mat)
 model = K.PoissonLikelihood(20, 20, tot[:20], tot[20:], 10000)
 acc = K.SurvivorAccumulator(1 << 20)
