@@ -168,6 +168,35 @@ int kmd_correct(int correction, double threshold, uint64_t total_kmers,
                 const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
                 uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream);
 
+/* ---- stage 2 (optional): population-stratification re-test ---------------------------------
+ * Replaces pop_strat_corrector (include/kmdiff/popstrat.hpp:148-367): constructor
+ * (src/popstrat.cpp:136-151), load_Z / load_Y (:153-171), init_global_features +
+ * standardize (:270-370, quirks preserved) and the once-fitted null model
+ * glm_irls(null features, Y) (:316-324, src/linear_model.cpp:297-410).
+ *   Z : n x z_cols row-major principal components as read from pcs.evec (z_cols = 10,
+ *       popstrat.hpp:152); the first `npc` columns are used (--n-pc, default 2)
+ *   Y : n phenotypes, Case -> 0.0, Control -> 1.0 (popstrat.cpp:168)
+ *   max_iter <= 0 selects the reference default 100 (popstrat.hpp:151)
+ * Covariates and sex are not representable in the reference either (load_C never terminates
+ * with a file, load_ginfo never finds a sex column: SURVEY.md 8a R9), so the design is
+ * [1, PC_1..PC_npc, total, kmer_count/total]. */
+typedef struct kmd_popstrat kmd_popstrat;
+int kmd_popstrat_create(kmd_popstrat** out, int nb_controls, int nb_cases,
+                        const uint64_t* total_controls, const uint64_t* total_cases,
+                        const double* Z, int z_cols, int npc, const double* Y,
+                        int standardize, int max_iter);
+int kmd_popstrat_destroy(kmd_popstrat* ps);
+/* introspection for tests: any output may be NULL.  alt_global is n x n_features_alt. */
+int kmd_popstrat_info(const kmd_popstrat* ps, int* n_samples, int* n_features_alt, double* alt_global,
+                      double* null_model, double* null_likelihood);
+/* pop_strat_corrector::apply(KmerSign&) (popstrat.hpp:249-333) for n survivors:
+ * d_pvalue[i] = chi2(1) tail of the logistic-regression likelihood ratio of survivor i.
+ * d_counts: the survivors' count vectors as doubles (KmerSign::m_counts_ratio), either
+ * survivor-major [n][S] as kmd_survivors_gather_counts writes them (sample_major = 0, ld
+ * ignored) or sample-major [S][ld] (sample_major = 1, ld >= n). */
+int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sample_major, size_t ld,
+                       size_t n, double* d_pvalue, void* stream);
+
 /* ---- synthetic count matrices (benchmark / test support) ------------------
  * Counter-based generator, every cell a pure function of (seed, partition, row, sample);
  * the CPU oracle replays it.  d_kmer_lo / d_kmer_hi may be NULL. */

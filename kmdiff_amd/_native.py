@@ -66,6 +66,10 @@ SIGNATURES = {
     "kmd_survivors_gather_counts": (_i, [C.POINTER(Tile), _i, _vp, _sz, _vp, _vp]),
     "kmd_correct": (_i, [_i, _d, _u64, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
                          C.POINTER(_u64), _vp]),
+    "kmd_popstrat_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i]),
+    "kmd_popstrat_destroy": (_i, [_vp]),
+    "kmd_popstrat_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), _vp, _vp, C.POINTER(_d)]),
+    "kmd_popstrat_apply": (_i, [_vp, _vp, _i, _sz, _sz, _vp, _vp]),
     "kmd_synth_fill": (_i, [_u64, C.c_uint32, _u64, _sz, _i, _i, _i, _i, _sz, _vp, _vp, _vp, _vp]),
     "kmd_column_sums": (_i, [_vp, _i, _i, _sz, _sz, _i, _vp, _vp]),
     "kmd_copy_probe": (_i, [_vp, _vp, _sz, _vp]),

@@ -341,6 +341,71 @@ class diff_observer:
         return int(c[N.CNT_SIG_CONTROL]), int(c[N.CNT_SIG_CASE])
 
 
+class pop_strat_corrector:
+    """include/kmdiff/popstrat.hpp:148-367 -- constructor arguments as in the reference plus the
+    data its load_Z / load_Y read from files (Z: n x z_cols principal components, Y: 1.0 for
+    controls / 0.0 for cases)."""
+
+    def __init__(self, nb_controls, nb_cases, control_totals, case_totals, npc, Z, Y=None,
+                 stand=True, max_iter=0):
+        _require_device()
+        n = nb_controls + nb_cases
+        tc = np.ascontiguousarray(control_totals, dtype=np.uint64)
+        tk = np.ascontiguousarray(case_totals, dtype=np.uint64)
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        if Z.shape[0] != n:
+            raise ValueError("Z must have one row per sample")
+        if Y is None:
+            Y = np.concatenate([np.ones(nb_controls), np.zeros(nb_cases)])       # popstrat.cpp:168
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().kmd_popstrat_create(C.byref(h), nb_controls, nb_cases, tc.ctypes.data, tk.ctypes.data,
+                                        Z.ctypes.data, Z.shape[1], int(npc), Y.ctypes.data, int(bool(stand)),
+                                        int(max_iter)), "kmd_popstrat_create")
+        self.handle, self.n = h.value, n
+        nf = C.c_int(0)
+        check(lib().kmd_popstrat_info(self.handle, None, C.byref(nf), None, None, None), "popstrat_info")
+        self.n_features = nf.value
+
+    def info(self):
+        alt = np.zeros((self.n, self.n_features))
+        nm = np.zeros(self.n_features - 1)
+        nl = C.c_double(0)
+        check(lib().kmd_popstrat_info(self.handle, None, None, alt.ctypes.data, nm.ctypes.data, C.byref(nl)),
+              "popstrat_info")
+        return alt, nm, nl.value
+
+    def apply(self, counts_buf, n, sample_major=False, ld=0):
+        """apply(KmerSign&) over n survivors; counts_buf holds their count vectors as doubles
+        (kmd_survivors_gather_counts order).  Returns the corrected p-values (numpy)."""
+        out = DeviceBuffer(max(n, 1) * 8)
+        check(lib().kmd_popstrat_apply(self.handle, counts_buf.ptr if n else None, int(sample_major), int(ld),
+                                       int(n), out.ptr, None), "kmd_popstrat_apply")
+        check(lib().kmd_stream_sync(None), "sync")
+        self.last_pvalues = out
+        return out.to_host(np.float64, n)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().kmd_popstrat_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_counts(matrix, rows_buf, n):
+    """KmerSign::m_counts_ratio of n survivors (merge.hpp:91-92): [n][S] doubles on the device."""
+    out = DeviceBuffer(max(n * matrix.n_samples, 1) * 8)
+    t = matrix.tile()
+    check(lib().kmd_survivors_gather_counts(C.byref(t), matrix.n_samples, rows_buf.ptr, n, out.ptr, None),
+          "gather_counts")
+    return out
+
+
 def aggregate(correction, threshold, total_kmers, pvalue_buf, sign_buf, n):
     """make_corrector + make_aggregator()->run() decisions (corrector.cpp:101-116,
     aggregator.hpp:343-365) over n device-resident survivors.

@@ -736,3 +736,44 @@ double kmdo_popstrat_pvalue(const double* alt_global, int n, int f, const double
   free(local); free(model);
   return kmdo_chisqc(1, llr);                                                    /* :328 */
 }
+
+/* src/popstrat.cpp:136-151 (ctor), 270-311 (init_global_features without covariates / sex:
+ * load_C never terminates with a file and load_ginfo never finds a sex column, SURVEY.md
+ * 8a R9) and 327-370 (standardize, quirks and all).  null_out: n x (2+npc), alt_out:
+ * n x (3+npc) with the last (k-mer) column left 0. */
+void kmdo_popstrat_features(int nc, int nk, const uint64_t* totals_c, const uint64_t* totals_k,
+                            const double* Z, int z_cols, int npc, int standardize,
+                            double* null_out, double* alt_out, double* totals_out)
+{
+  const int n = nc + nk, fn = 1 + npc + 0 + 1, fa = fn + 1;
+  for (int i = 0; i < nc; i++) totals_out[i] = (double)totals_c[i];
+  for (int i = 0; i < nk; i++) totals_out[nc + i] = (double)totals_k[i];
+  memset(null_out, 0, sizeof(double) * (size_t)n * (size_t)fn);
+  memset(alt_out, 0, sizeof(double) * (size_t)n * (size_t)fa);
+  for (int i = 0; i < n; i++)
+  {
+    null_out[i * fn] = 1; alt_out[i * fa] = 1;                                   /* :282-283 */
+    for (int z = 0; z < npc; z++)                                                /* :285-289 */
+    {
+      null_out[i * fn + z + 1] = Z[i * z_cols + z];
+      alt_out[i * fa + z + 1] = Z[i * z_cols + z];
+    }
+    null_out[i * fn + 1 + npc] = totals_out[i];                                  /* :305-308 (m_unkg != 0) */
+    alt_out[i * fa + 1 + npc] = totals_out[i];
+  }
+  if (!standardize) return;
+  double* means = calloc((size_t)fn, sizeof(double));
+  double* stddev = calloc((size_t)n, sizeof(double));                            /* :330 sized by ROWS */
+  for (int i = 0; i < n; i++) for (int j = 0; j < fn; j++) means[j] += null_out[i * fn + j];
+  for (int j = 1; j < fn; j++) means[j] /= fn;                                   /* :342 divides by ncols */
+  for (int i = 0; i < n; i++) for (int j = 1; j < fn; j++)
+    stddev[j] += pow(null_out[i * fn + j] - means[j], 2);                        /* :349 indexed by column */
+  for (int j = 1; j < fn; j++) { stddev[j] /= n; stddev[j] = sqrt(stddev[j]); }  /* :353-357 */
+  for (int i = 0; i < n; i++) for (int j = 1; j < fn; j++)
+    if (fabs(stddev[i]) > 1e-305)                                                /* :363 indexed by ROW */
+    {
+      null_out[i * fn + j] = (null_out[i * fn + j] - means[j]) / stddev[i];
+      alt_out[i * fa + j] = (alt_out[i * fa + j] - means[j]) / stddev[i];
+    }
+  free(means); free(stddev);
+}

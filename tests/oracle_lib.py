@@ -47,6 +47,8 @@ class Oracle:
         L.kmdo_popstrat_pvalue.restype = d
         L.kmdo_popstrat_pvalue.argtypes = [vp, i, i, vp, vp, vp, vp, i]
 
+        L.kmdo_popstrat_features.argtypes = [i, i, vp, vp, vp, i, i, i, vp, vp, vp]
+
         class Corr(C.Structure):
             _fields_ = [("type", i), ("threshold", d), ("total", u64), ("rank", u64)]
         self.Corr = Corr
@@ -121,6 +123,31 @@ class Oracle:
         keep = np.zeros(max(len(p), 1), dtype=np.uint8)
         self.L.kmdo_aggregate(ctype, float(threshold), int(total), p.ctypes.data, len(p), keep.ctypes.data)
         return keep[:len(p)]
+
+    # ---- R9
+    def popstrat_setup(self, nc, nk, totals_c, totals_k, Z, npc, standardize=True, max_iter=100):
+        """init_global_features + standardize + null-model fit.  Returns (alt, null_model, totals)."""
+        n, fn = nc + nk, 2 + npc
+        tc = np.ascontiguousarray(totals_c, dtype=np.uint64)
+        tk = np.ascontiguousarray(totals_k, dtype=np.uint64)
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        nul = np.zeros((n, fn))
+        alt = np.zeros((n, fn + 1))
+        tot = np.zeros(n)
+        self.L.kmdo_popstrat_features(nc, nk, tc.ctypes.data, tk.ctypes.data, Z.ctypes.data, Z.shape[1], npc,
+                                      int(standardize), nul.ctypes.data, alt.ctypes.data, tot.ctypes.data)
+        y = np.concatenate([np.ones(nc), np.zeros(nk)])
+        w = np.zeros(fn)
+        self.L.kmdo_glm_irls(nul.ctypes.data, y.ctypes.data, n, fn, max_iter, w.ctypes.data, None, None)
+        return alt, w, tot, y
+
+    def popstrat_pvalues(self, alt, null_model, totals, y, counts_rows, max_iter=100):
+        n, f = alt.shape
+        out = np.zeros(len(counts_rows))
+        for k, c in enumerate(np.ascontiguousarray(counts_rows, dtype=np.float64)):
+            out[k] = self.L.kmdo_popstrat_pvalue(alt.ctypes.data, n, f, y.ctypes.data, totals.ctypes.data,
+                                                 c.ctypes.data, null_model.ctypes.data, max_iter)
+        return out
 
     # ---- synthetic
     def synth_rows(self, seed, part, row0, n, nc, nk, count_bytes=4, kmer_limbs=1):

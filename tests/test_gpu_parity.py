@@ -335,6 +335,43 @@ def test_gather_counts_of_survivors(K, oracle):
 
 
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nc,nk,npc,stand", [(20, 20, 2, True), (12, 9, 2, False), (30, 34, 4, True), (100, 100, 2, True)])
+def test_popstrat_retest_matches_oracle(K, oracle, nc, nk, npc, stand):
+    """pop_strat_corrector::apply (popstrat.hpp:249-333) over the survivors of one partition:
+    features bit-exact (host arithmetic), p-values to the same bar as stage 1."""
+    S = nc + nk
+    n = 120_000 if S <= 64 else 30_000
+    rng = np.random.default_rng(11)
+    Z = rng.normal(0, 0.1, size=(S, 10))
+    Z[:nc, 0] += 0.05                          # a little structure correlated with phenotype
+    mat = K.synth_matrix(SEED, 12, n, nc, nk, 4, K.LAYOUT_TILED)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(n)
+    K.diff_observer(model, acc, 1e-4).process(mat)
+    ns = acc.finish()
+    assert ns > 20
+    pop = K.pop_strat_corrector(nc, nk, tot[:nc], tot[nc:], npc, Z, stand=stand)
+    alt_d, null_d, null_like = pop.info()
+    alt_o, null_o, totals_o, y = oracle.popstrat_setup(nc, nk, tot[:nc], tot[nc:], Z, npc, stand)
+    assert alt_d.tolist() == alt_o.tolist()
+    assert np.abs(null_d - null_o).max() <= 1e-9 * max(1.0, np.abs(null_o).max())
+    counts = K.gather_counts(mat, acc.bufs["row"], ns)
+    p_dev = pop.apply(counts, ns)
+    host, _, _ = oracle.synth_rows(SEED, 12, 0, n, nc, nk, 4)
+    rows = acc.get()["row"].astype(np.int64)
+    p_ref = oracle.popstrat_pvalues(alt_o, null_o, totals_o, y, host[rows])
+    assert np.abs(p_dev - p_ref).max() <= P_ABS_TOL
+    nz = p_ref > 1e-300
+    rel = np.abs(p_dev[nz] - p_ref[nz]) / p_ref[nz]
+    assert rel.max(initial=0.0) <= 1e-7, rel.max()
+    # sample-major input gives the same numbers
+    cm = counts.to_host(np.float64, ns * S).reshape(ns, S).T.copy()
+    p2 = pop.apply(K.DeviceBuffer.from_host(cm), ns, sample_major=True, ld=ns)
+    assert (p2 == p_dev).all()
+
+
+# ---------------------------------------------------------------------------------------------
 def test_full_size_config2_properties(K, oracle):
     """BASELINE.json configs[1]: 10^8 rows, 4v4, k=31, one partition resident in HBM.
     Size-independent properties + exact oracle replay of sampled windows."""
