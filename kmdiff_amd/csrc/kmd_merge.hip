@@ -1,0 +1,139 @@
+// kmd_merge.hip -- K2: the k-way merge of one partition's per-sample k-mer streams into the
+// merged count matrix, on the device.
+//
+// Replaces km::KmerMerger<KSIZE,CMAX>::merge as kmdiff drives it (include/kmdiff/merge.hpp:
+// 265-289: paths of one partition, abundance minima all 1, recurrence minimum 1, save_if 0 =>
+// every distinct k-mer is emitted, ascending, with the count of each sample or 0).  kmtricks
+// itself is not part of the reference tree (empty submodule); the contract restated here is
+// the one SURVEY.md 8a R1 derives from the call site and the fixture bytes.
+//
+// Round-1 form: correct and device-resident, NOT yet a tuned kernel.  The S sorted streams are
+// tagged with their sample id, radix-sorted together (rocPRIM), run heads are flagged and
+// scanned into row numbers, and a scatter kernel writes the matrix in the layout K1 wants.
+// The sort ignores that the inputs are already sorted; the bucketed LDS merge that uses it
+// (sampled splitters -> one workgroup merges one key range in LDS) is the planned
+// replacement and keeps this interface.
+#include <cstring>
+#include <string.h>
+
+#include "kmd_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// vals[i] = sample << 32 | count for the records of one sample
+__global__ void __launch_bounds__(256) k_tag(const uint32_t* __restrict__ counts, size_t begin, size_t end,
+                                             uint32_t sample, uint64_t* __restrict__ vals)
+{
+  const size_t i = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < end) vals[i] = ((uint64_t)sample << 32) | counts[i];
+}
+
+__global__ void __launch_bounds__(256) k_heads(const uint64_t* __restrict__ keys, size_t n, uint32_t* __restrict__ flag)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+template <typename CT>
+__global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals,
+                                                 const uint32_t* __restrict__ rank, size_t n, int layout, size_t ld,
+                                                 int S, CT* __restrict__ matrix, uint64_t* __restrict__ kmer_out)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t row = rank[i] - 1;                       // inclusive scan of head flags
+  const uint64_t v = vals[i];
+  const int s = (int)(v >> 32);
+  uint32_t c = (uint32_t)v;
+  constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  if (c > cmax) c = cmax;
+  matrix[kmd::count_index(layout, ld, S, row, s)] = (CT)c;
+  if (kmer_out && (i == 0 || keys[i] != keys[i - 1])) kmer_out[row] = keys[i];
+}
+
+struct scratch
+{
+  void* p[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  ~scratch() { for (void* q : p) if (q) (void)hipFree(q); }
+};
+
+} // namespace
+
+extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
+                                   const uint64_t* offsets, int count_bytes, int layout, size_t ld,
+                                   size_t row_capacity, void* d_matrix, uint64_t* d_kmer_out,
+                                   uint64_t* n_rows_out, void* stream)
+{
+  KMD_REQUIRE(n_samples > 0 && n_samples <= 65535 && offsets && n_rows_out, "kmd_merge_partition: arguments");
+  KMD_REQUIRE(count_bytes == 1 || count_bytes == 2 || count_bytes == 4, "kmd_merge_partition: count_bytes");
+  KMD_REQUIRE(kmd::layout_ok(layout), "kmd_merge_partition: layout");
+  KMD_REQUIRE(layout != KMD_LAYOUT_TILED || (ld > 0 && ld % 4096 == 0), "kmd_merge_partition: tiled ld % 4096");
+  const size_t n = (size_t)offsets[n_samples];
+  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_merge_partition: more than 2^32-1 records in one partition");
+  for (int s = 0; s < n_samples; ++s)
+    KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_partition: offsets must be ascending");
+  *n_rows_out = 0;
+  if (n == 0) return KMD_OK;
+  KMD_REQUIRE(d_kmers && d_counts && d_matrix, "kmd_merge_partition: NULL device buffers");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  scratch sc;   // [0] vals, [1] keys sorted, [2] vals sorted, [3] flags, [4] ranks, [5] rocprim temp
+  KMD_HIP(hipMalloc(&sc.p[0], n * 8));
+  KMD_HIP(hipMalloc(&sc.p[1], n * 8));
+  KMD_HIP(hipMalloc(&sc.p[2], n * 8));
+  KMD_HIP(hipMalloc(&sc.p[3], n * 4));
+  KMD_HIP(hipMalloc(&sc.p[4], n * 4));
+  uint64_t* vals = static_cast<uint64_t*>(sc.p[0]);
+  uint64_t* keys_s = static_cast<uint64_t*>(sc.p[1]);
+  uint64_t* vals_s = static_cast<uint64_t*>(sc.p[2]);
+  uint32_t* flag = static_cast<uint32_t*>(sc.p[3]);
+  uint32_t* rank = static_cast<uint32_t*>(sc.p[4]);
+
+  for (int s = 0; s < n_samples; ++s)
+  {
+    const size_t b = offsets[s], e = offsets[s + 1];
+    if (e > b)
+      hipLaunchKernelGGL(k_tag, dim3(blocks_for(e - b)), dim3(256), 0, st, d_counts, b, e, (uint32_t)s, vals);
+  }
+  KMD_HIP(hipGetLastError());
+
+  size_t tmp_sort = 0, tmp_scan = 0;
+  KMD_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort, d_kmers, keys_s, vals, vals_s, n, 0, 64, st));
+  KMD_HIP(rocprim::inclusive_scan(nullptr, tmp_scan, flag, rank, n, rocprim::plus<uint32_t>(), st));
+  const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+  KMD_HIP(hipMalloc(&sc.p[5], tmp ? tmp : 1));
+  KMD_HIP(rocprim::radix_sort_pairs(sc.p[5], tmp_sort, d_kmers, keys_s, vals, vals_s, n, 0, 64, st));
+  hipLaunchKernelGGL(k_heads, dim3(blocks_for(n)), dim3(256), 0, st, keys_s, n, flag);
+  KMD_HIP(hipGetLastError());
+  KMD_HIP(rocprim::inclusive_scan(sc.p[5], tmp_scan, flag, rank, n, rocprim::plus<uint32_t>(), st));
+  uint32_t n_rows32 = 0;
+  KMD_HIP(hipMemcpyAsync(&n_rows32, rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  KMD_HIP(hipStreamSynchronize(st));
+  const size_t n_rows = n_rows32;
+  if (n_rows > row_capacity)
+  {
+    *n_rows_out = n_rows;
+    kmd::set_error("kmd_merge_partition: row capacity exceeded");
+    return KMD_E_OVERFLOW;
+  }
+  // zero the part of the matrix the rows occupy, then scatter the counts
+  size_t n_el;
+  if (layout == KMD_LAYOUT_SOA) { KMD_REQUIRE(ld >= n_rows, "kmd_merge_partition: SoA ld < rows"); n_el = ld * (size_t)n_samples; }
+  else if (layout == KMD_LAYOUT_ROWS) { KMD_REQUIRE(ld >= (size_t)n_samples, "kmd_merge_partition: ld < samples"); n_el = ld * n_rows; }
+  else n_el = (n_rows + ld - 1) / ld * ld * (size_t)n_samples;
+  KMD_HIP(hipMemsetAsync(d_matrix, 0, n_el * (size_t)count_bytes, st));
+  switch (count_bytes)
+  {
+    case 1: hipLaunchKernelGGL((k_scatter<uint8_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint8_t*>(d_matrix), d_kmer_out); break;
+    case 2: hipLaunchKernelGGL((k_scatter<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint16_t*>(d_matrix), d_kmer_out); break;
+    default: hipLaunchKernelGGL((k_scatter<uint32_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint32_t*>(d_matrix), d_kmer_out); break;
+  }
+  KMD_HIP(hipGetLastError());
+  KMD_HIP(hipStreamSynchronize(st));
+  *n_rows_out = n_rows;
+  return KMD_OK;
+}

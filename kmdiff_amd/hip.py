@@ -341,6 +341,28 @@ class diff_observer:
         return int(c[N.CNT_SIG_CONTROL]), int(c[N.CNT_SIG_CASE])
 
 
+def merge_partition(streams, n_samples=None, count_bytes=4, layout=N.LAYOUT_TILED, row_capacity=None):
+    """km::KmerMerger over one partition (merge.hpp:265-289): `streams` is a list, one entry per
+    sample in fof order, of (kmers uint64[], counts uint32[]) sorted by k-mer.  Returns a
+    CountMatrix (with its k-mer column) resident on the device."""
+    n_samples = len(streams) if n_samples is None else n_samples
+    offs = np.zeros(n_samples + 1, dtype=np.uint64)
+    for s, (k, c) in enumerate(streams):
+        offs[s + 1] = offs[s] + len(k)
+    total = int(offs[-1])
+    kmers = np.concatenate([np.asarray(k, dtype=np.uint64) for k, _ in streams]) if total else np.zeros(0, np.uint64)
+    counts = np.concatenate([np.asarray(c, dtype=np.uint32) for _, c in streams]) if total else np.zeros(0, np.uint32)
+    cap = total if row_capacity is None else int(row_capacity)
+    m = CountMatrix(max(cap, 1), n_samples, count_bytes, layout, with_kmers=True)
+    dk, dc = DeviceBuffer.from_host(kmers), DeviceBuffer.from_host(counts)
+    n_rows = C.c_uint64(0)
+    check(lib().kmd_merge_partition(n_samples, dk.ptr if total else None, dc.ptr if total else None,
+                                    offs.ctypes.data, count_bytes, layout, m.ld, cap, m.counts.ptr, m.kmer_lo.ptr,
+                                    C.byref(n_rows), None), "kmd_merge_partition")
+    m.n_rows = int(n_rows.value)
+    return m
+
+
 class pop_strat_corrector:
     """include/kmdiff/popstrat.hpp:148-367 -- constructor arguments as in the reference plus the
     data its load_Z / load_Y read from files (Z: n x z_cols principal components, Y: 1.0 for

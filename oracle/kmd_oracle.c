@@ -777,3 +777,38 @@ void kmdo_popstrat_features(int nc, int nk, const uint64_t* totals_c, const uint
     }
   free(means); free(stddev);
 }
+
+
+/* R1  km::KmerMerger::merge as kmdiff drives it (include/kmdiff/merge.hpp:265-289; kmtricks
+ * un-vendored: contract per SURVEY.md 8a R1): S streams sorted by ascending k-mer -> one
+ * row per distinct k-mer, ascending, counts row-major [row][S] (0 when absent).  Returns
+ * the number of rows (at most cap rows are written). */
+size_t kmdo_merge_partition(int S, const uint64_t* kmers, const uint32_t* counts, const uint64_t* offsets,
+                            uint32_t* matrix_rows, uint64_t* kmer_out, size_t cap)
+{
+  uint64_t* pos = malloc(sizeof(uint64_t) * (size_t)S);
+  for (int s = 0; s < S; s++) pos[s] = offsets[s];
+  size_t row = 0;
+  for (;;)
+  {
+    int any = 0;
+    uint64_t best = 0;
+    for (int s = 0; s < S; s++)
+      if (pos[s] < offsets[s + 1] && (!any || kmers[pos[s]] < best)) { best = kmers[pos[s]]; any = 1; }
+    if (!any) break;
+    if (row < cap)
+    {
+      if (kmer_out) kmer_out[row] = best;
+      for (int s = 0; s < S; s++) matrix_rows[row * (size_t)S + (size_t)s] = 0;
+    }
+    for (int s = 0; s < S; s++)
+      if (pos[s] < offsets[s + 1] && kmers[pos[s]] == best)
+      {
+        if (row < cap) matrix_rows[row * (size_t)S + (size_t)s] = counts[pos[s]];
+        pos[s]++;
+      }
+    row++;
+  }
+  free(pos);
+  return row;
+}

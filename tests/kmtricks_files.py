@@ -1,0 +1,162 @@
+"""kmtricks on-disk formats (test infrastructure): the byte layouts SURVEY.md 8f derives from the
+reference's fixture tests/data_test/km_out_dir (written by kmtricks v1.1.1).  Read AND write, so
+that tests can fabricate run directories from synthetic matrices.
+
+  <id>.kmer.lz4 : 41-byte header  "kmtricks" u32 0  u8 compressed  "kmer\\0\\0\\0\\0"  u32 k
+                  u32 kmer_slots  u32 count_bytes  u32 sample_id  u32 partition ; then one LZ4
+                  frame of records [u64 kmer LE x slots][count LE], ascending by k-mer
+  <id>.hist     : "kmtricks" u32 0 u8 0 "khist\\0\\0\\0" u32 k u32 id  u64 lower u64 upper
+                  u64 uniq u64 total  4 x u64 out-of-bounds  u64 hist_u[upper-lower+1]
+                  u64 hist_n[upper-lower+1]
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+_L = None
+
+
+def _lz4():
+    global _L
+    if _L is None:
+        L = C.CDLL("liblz4.so.1")
+        L.LZ4F_createDecompressionContext.restype = C.c_size_t
+        L.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        L.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
+        L.LZ4F_decompress.restype = C.c_size_t
+        L.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p,
+                                      C.POINTER(C.c_size_t), C.c_void_p]
+        L.LZ4F_isError.argtypes = [C.c_size_t]
+        L.LZ4F_compressFrameBound.restype = C.c_size_t
+        L.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+        L.LZ4F_compressFrame.restype = C.c_size_t
+        L.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        _L = L
+    return _L
+
+
+def lz4_frame_decode(src):
+    L = _lz4()
+    ctx = C.c_void_p()
+    assert L.LZ4F_createDecompressionContext(C.byref(ctx), 100) == 0
+    out = bytearray()
+    buf = C.create_string_buffer(1 << 20)
+    pos = 0
+    src = bytes(src)
+    while pos < len(src):
+        dn = C.c_size_t(len(buf))
+        sn = C.c_size_t(len(src) - pos)
+        r = L.LZ4F_decompress(ctx, buf, C.byref(dn), src[pos:], C.byref(sn), None)
+        assert not L.LZ4F_isError(r), "LZ4F_decompress failed"
+        out += buf.raw[:dn.value]
+        pos += sn.value
+        if r == 0 and sn.value == 0:
+            break
+    L.LZ4F_freeDecompressionContext(ctx)
+    return bytes(out)
+
+
+def lz4_frame_encode(raw):
+    L = _lz4()
+    cap = L.LZ4F_compressFrameBound(len(raw), None)
+    buf = C.create_string_buffer(cap)
+    n = L.LZ4F_compressFrame(buf, cap, raw, len(raw), None)
+    assert not L.LZ4F_isError(n)
+    return buf.raw[:n]
+
+
+def read_kmer_file(path):
+    """Returns (header dict, kmers uint64[n] (low limb), counts uint32[n])."""
+    d = open(path, "rb").read()
+    magic, _, comp, kind, k, slots, cbytes, sid, part = struct.unpack("<8sIB8sIIIII", d[:41])
+    assert magic == b"kmtricks" and kind.rstrip(b"\0") == b"kmer"
+    raw = lz4_frame_decode(d[41:]) if comp else d[41:]
+    rec = 8 * slots + cbytes
+    n = len(raw) // rec
+    a = np.frombuffer(raw, dtype=np.uint8, count=n * rec).reshape(n, rec)
+    kmers = a[:, :8].copy().view("<u8").reshape(n)
+    cdt = {1: "<u1", 2: "<u2", 4: "<u4"}[cbytes]
+    counts = a[:, 8 * slots:8 * slots + cbytes].copy().view(cdt).reshape(n).astype(np.uint32)
+    return {"k": k, "slots": slots, "count_bytes": cbytes, "sample_id": sid, "partition": part}, kmers, counts
+
+
+def write_kmer_file(path, k, sample_id, partition, kmers, counts, count_bytes=4, compressed=True):
+    kmers = np.asarray(kmers, dtype="<u8")
+    counts = np.asarray(counts).astype({1: "<u1", 2: "<u2", 4: "<u4"}[count_bytes])
+    n = len(kmers)
+    rec = np.zeros((n, 8 + count_bytes), dtype=np.uint8)
+    rec[:, :8] = kmers.view(np.uint8).reshape(n, 8)
+    rec[:, 8:] = counts.view(np.uint8).reshape(n, count_bytes)
+    raw = rec.tobytes()
+    hdr = struct.pack("<8sIB8sIIIII", b"kmtricks", 0, 1 if compressed else 0, b"kmer\0\0\0\0", k, 1,
+                      count_bytes, sample_id, partition)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(hdr + (lz4_frame_encode(raw) if compressed else raw))
+
+
+def read_hist(path):
+    d = open(path, "rb").read()
+    magic, _, comp, kind = struct.unpack("<8sIB8s", d[:21])
+    assert magic == b"kmtricks" and kind.rstrip(b"\0") == b"khist"
+    k, sid = struct.unpack("<II", d[21:29])
+    lower, upper, uniq, total, oob_lu, oob_uu, oob_ln, oob_un = struct.unpack("<8Q", d[29:93])
+    n = upper - lower + 1
+    hist_u = np.frombuffer(d, dtype="<u8", count=n, offset=93)
+    hist_n = np.frombuffer(d, dtype="<u8", count=n, offset=93 + 8 * n)
+    return {"k": k, "id": sid, "lower": lower, "upper": upper, "uniq": uniq, "total": total,
+            "hist_u": hist_u.copy(), "hist_n": hist_n.copy()}
+
+
+def write_hist(path, k, sample_id, counts, lower=1, upper=255):
+    counts = np.asarray(counts, dtype=np.uint64)
+    counts = counts[counts > 0]
+    n = upper - lower + 1
+    hu = np.zeros(n, dtype="<u8")
+    hn = np.zeros(n, dtype="<u8")
+    inb = counts[(counts >= lower) & (counts <= upper)]
+    np.add.at(hu, (inb - lower).astype(np.int64), 1)
+    np.add.at(hn, (inb - lower).astype(np.int64), inb)
+    hi = counts[counts > upper]
+    hdr = struct.pack("<8sIB8sII8Q", b"kmtricks", 0, 0, b"khist\0\0\0", k, sample_id, lower, upper,
+                      len(counts), int(counts.sum()), 0, len(hi), 0, int(hi.sum()))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(hdr + hu.tobytes() + hn.tobytes())
+
+
+def read_fof(path):
+    ids = []
+    for line in open(path):
+        line = line.strip()
+        if line:
+            ids.append(line.split(":")[0].strip())
+    return ids
+
+
+def write_run_dir(root, k, sample_ids, partitions, abundance_min=1):
+    """partitions: list over partitions of a list over samples of (kmers, counts)."""
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, "kmtricks.fof"), "w") as f:
+        for s in sample_ids:
+            f.write("%s : ./fasta/%s.fasta\n" % (s, s))
+    with open(os.path.join(root, "kmdiff-count.opt"), "w") as f:
+        f.write("Options: verbosity=info,nb_threads=8,file=fof.txt,dir=%s,kmer_size=%d,abundance_min=%d,"
+                "recurrence_min=1,memory=0,minimizer_type=0,minimizer_size=10,repartition_type=0,"
+                "nb_partitions=0,\n" % (root, k, abundance_min))
+    per_sample = [[] for _ in sample_ids]
+    for p, streams in enumerate(partitions):
+        for s, (km, ct) in enumerate(streams):
+            write_kmer_file(os.path.join(root, "counts", "partition_%d" % p, "%s.kmer.lz4" % sample_ids[s]),
+                            k, s, p, km, ct)
+            per_sample[s].append(np.asarray(ct, dtype=np.uint64))
+    for s, name in enumerate(sample_ids):
+        allc = np.concatenate(per_sample[s]) if per_sample[s] else np.zeros(0, np.uint64)
+        write_hist(os.path.join(root, "histograms", "%s.hist" % name), k, s, allc)
+    os.makedirs(os.path.join(root, "matrices"), exist_ok=True)
+
+
+def kmer_to_string(v, k):
+    return "".join("ACTG"[(int(v) >> (2 * (k - 1 - i))) & 3] for i in range(k))

@@ -47,6 +47,8 @@ class Oracle:
         L.kmdo_popstrat_pvalue.restype = d
         L.kmdo_popstrat_pvalue.argtypes = [vp, i, i, vp, vp, vp, vp, i]
 
+        L.kmdo_merge_partition.restype = sz
+        L.kmdo_merge_partition.argtypes = [i, vp, vp, vp, vp, vp, sz]
         L.kmdo_popstrat_features.argtypes = [i, i, vp, vp, vp, i, i, i, vp, vp, vp]
 
         class Corr(C.Structure):
@@ -123,6 +125,21 @@ class Oracle:
         keep = np.zeros(max(len(p), 1), dtype=np.uint8)
         self.L.kmdo_aggregate(ctype, float(threshold), int(total), p.ctypes.data, len(p), keep.ctypes.data)
         return keep[:len(p)]
+
+    # ---- R1
+    def merge_partition(self, streams):
+        S = len(streams)
+        offs = np.zeros(S + 1, dtype=np.uint64)
+        for s, (k, c) in enumerate(streams):
+            offs[s + 1] = offs[s] + len(k)
+        total = int(offs[-1])
+        kmers = np.concatenate([np.asarray(k, dtype=np.uint64) for k, _ in streams]) if total else np.zeros(1, np.uint64)
+        counts = np.concatenate([np.asarray(c, dtype=np.uint32) for _, c in streams]) if total else np.zeros(1, np.uint32)
+        mat = np.zeros((max(total, 1), S), dtype=np.uint32)
+        ko = np.zeros(max(total, 1), dtype=np.uint64)
+        n = self.L.kmdo_merge_partition(S, kmers.ctypes.data, counts.ctypes.data, offs.ctypes.data,
+                                        mat.ctypes.data, ko.ctypes.data, max(total, 1))
+        return mat[:n].copy(), ko[:n].copy()
 
     # ---- R9
     def popstrat_setup(self, nc, nk, totals_c, totals_k, Z, npc, standardize=True, max_iter=100):

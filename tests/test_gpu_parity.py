@@ -335,6 +335,61 @@ def test_gather_counts_of_survivors(K, oracle):
 
 
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout_name", ["tiled", "soa", "rows"])
+@pytest.mark.parametrize("count_bytes", [4, 2, 1])
+def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes):
+    """km::KmerMerger as driven at merge.hpp:265-289: device merge == oracle merge."""
+    rng = np.random.default_rng(17)
+    universe = np.unique(rng.integers(0, 1 << 62, 60000, dtype=np.uint64))
+    S = 9
+    streams = []
+    for s in range(S):
+        pick = rng.random(len(universe)) < (0.05 + 0.1 * s)
+        cnt = rng.integers(1, 70000 if s % 2 else 200, pick.sum()).astype(np.uint32)
+        streams.append((universe[pick], cnt))
+    streams[4] = (np.zeros(0, np.uint64), np.zeros(0, np.uint32))            # a sample with no k-mer here
+    want, kmers = oracle.merge_partition(streams)
+    m = K.merge_partition(streams, count_bytes=count_bytes, layout=layout_of(K, layout_name))
+    assert m.n_rows == want.shape[0]
+    cmax = {1: 255, 2: 65535, 4: 2 ** 32 - 1}[count_bytes]
+    assert (m.to_host() == np.minimum(want, cmax)).all()
+    assert (m.kmers_to_host()[0] == kmers).all()
+    # empty partition
+    e = K.merge_partition([(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * 3)
+    assert e.n_rows == 0
+
+
+def test_reference_fixture_end_to_end(K, oracle):
+    """tests/merge_test.cpp:12-46 on the device: the reference's 4-partition fixture through
+    merge + Poisson filter: totals 160/160, 320 rows, 0 significant at 0.05/10000."""
+    import test_kmtricks_fixture as F
+    ids, parts, totals = F.load_fixture()
+    model = K.PoissonLikelihood(1, 1, totals[:1], totals[1:], 10000)
+    rows = sig = 0
+    for streams in parts:
+        m = K.merge_partition(streams)
+        want, kmers = oracle.merge_partition(streams)
+        assert (m.to_host() == want).all() and (m.kmers_to_host()[0] == kmers).all()
+        acc = K.SurvivorAccumulator(max(m.n_rows, 1))
+        obs = K.diff_observer(model, acc, 0.05 / 10000)
+        obs.process(m)
+        sig += acc.finish()
+        rows += obs.total()
+    assert (rows, sig) == (320, 0)
+
+
+def test_merge_then_filter_equals_matrix_path(K, oracle):
+    """Streams cut out of a synthetic matrix, merged on the device, give the survivors of the
+    matrix itself (rows that are all-zero never exist in the generator)."""
+    n, nc, nk = 60_000, 5, 4
+    host, lo, _ = oracle.synth_rows(SEED, 21, 0, n, nc, nk, 4)
+    streams = [(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(nc + nk)]
+    m = K.merge_partition(streams)
+    assert m.n_rows == n and (m.to_host() == host).all()
+    check_against_oracle(K, oracle, m, host, (lo, None), nc, nk, 10000, 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nc,nk,npc,stand", [(20, 20, 2, True), (12, 9, 2, False), (30, 34, 4, True), (100, 100, 2, True)])
 def test_popstrat_retest_matches_oracle(K, oracle, nc, nk, npc, stand):
     """pop_strat_corrector::apply (popstrat.hpp:249-333) over the survivors of one partition:
