@@ -1,0 +1,286 @@
+// kmdiff-hip -- the `kmdiff diff` command over libkmdiff_hip.so.
+//
+// Keeps the flag set of the reference's `diff` sub-command (src/cli.cpp:148-362) and the stage
+// order of main_diff (include/kmdiff/cmd/diff.hpp:262-377): do_diff (merge + Poisson test +
+// threshold, per partition) -> optional do_pop (re-test of the survivors) -> do_correction
+// (corrector + control/case split) -> control_kmers.fasta / case_kmers.fasta.  Every number is
+// computed by the HIP library through the C-ABI of include/kmdiff_hip.h; this file only moves
+// bytes (kmtricks files -> HBM, survivors -> FASTA) and parses flags.  No CPU compute path:
+// without a device the command fails.
+//
+// Not carried over (out of scope): `count`/`infos` sub-commands, --cmodel plugins,
+// KFF output, --save-sk, resume files, the smartpca front end (give --pcs FILE with the
+// principal components instead), progress bars.
+#include <algorithm>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/kmdiff_hip.h"
+#include "kmtricks_io.hpp"
+
+namespace fs = std::filesystem;
+using namespace kmd_host;
+
+namespace {
+
+struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-40
+{
+  std::string kmtricks_dir, output_directory = "./kmdiff_output", correction = "bonferroni", pcs;
+  size_t nb_controls = 0, nb_cases = 0, cutoff = 100000, log_size = 10000, npc = 2, max_iteration = 0;
+  double threshold = 0.05;
+  bool pop_correction = false, stand = true, keep_tmp = false;
+  int device = 0, verbose = 1;
+};
+
+[[noreturn]] void die(const std::string& msg)
+{
+  std::fprintf(stderr, "[kmdiff-hip] error: %s\n", msg.c_str());
+  std::exit(1);
+}
+
+void ck(int rc, const char* what)
+{
+  if (rc != KMD_OK) die(std::string(what) + ": " + kmd_last_error() + " (" + kmd_status_string(rc) + ")");
+}
+
+void usage()
+{
+  std::puts("kmdiff-hip diff -d DIR -1 INT -2 INT [-o DIR] [-s FLOAT] [-u INT] [-c STR] [--log-factorial INT]\n"
+            "                [--pop-correction --pcs FILE [--n-pc INT] [--max-iteration INT]] [--device INT] [-v STR]\n"
+            "  -d/--km-run        kmtricks run directory\n"
+            "  -o/--output-dir    output directory {./kmdiff_output}\n"
+            "  -1/--nb-controls   number of controls\n"
+            "  -2/--nb-cases      number of cases\n"
+            "  -s/--significance  significance threshold {0.05}\n"
+            "  -u/--cutoff        divide the significance threshold by N for the first pass {100000}\n"
+            "  -c/--correction    bonferroni|benjamini|sidak|holm|disabled {bonferroni}\n"
+            "  --log-factorial    size of the log-factorial table {10000}\n"
+            "  --pop-correction   re-test the survivors with the population-stratification model\n"
+            "  --pcs FILE         principal components (pcs.evec: one row per sample, 10 columns)\n"
+            "  --n-pc             number of principal components in [2, 10] {2}\n"
+            "  --device           GPU index {0}\n"
+            "  -t/--threads, -f, -m, -r, --keep-tmp, --save-sk: accepted for compatibility, ignored");
+}
+
+diff_options parse(int argc, char** argv)
+{
+  diff_options o;
+  if (argc < 2 || std::string(argv[1]) != "diff") { usage(); std::exit(argc < 2 ? 1 : (std::string(argv[1]) == "--help" ? 0 : 1)); }
+  auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]); return argv[++i]; };
+  for (int i = 2; i < argc; ++i)
+  {
+    const std::string a = argv[i];
+    if (a == "-d" || a == "--km-run") o.kmtricks_dir = need(i);
+    else if (a == "-o" || a == "--output-dir") o.output_directory = need(i);
+    else if (a == "-1" || a == "--nb-controls") o.nb_controls = std::stoull(need(i));
+    else if (a == "-2" || a == "--nb-cases") o.nb_cases = std::stoull(need(i));
+    else if (a == "-s" || a == "--significance") o.threshold = std::stod(need(i));
+    else if (a == "-u" || a == "--cutoff") o.cutoff = std::stoull(need(i));
+    else if (a == "-c" || a == "--correction") o.correction = need(i);
+    else if (a == "--log-factorial") o.log_size = std::stoull(need(i));
+    else if (a == "--pop-correction") o.pop_correction = true;
+    else if (a == "--pcs") o.pcs = need(i);
+    else if (a == "--n-pc") o.npc = std::stoull(need(i));
+    else if (a == "--max-iteration") o.max_iteration = std::stoull(need(i));
+    else if (a == "--device") o.device = std::stoi(need(i));
+    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" || a == "--kmer-pca" || a == "--ploidy" ||
+             a == "--gender" || a == "--random-seed" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
+    else if (a == "-f" || a == "--kff-output" || a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
+             a == "--keep-tmp" || a == "--save-sk" || a == "--stand" || a == "--irls") {}
+    else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
+    else die("unknown option " + a);
+  }
+  if (o.kmtricks_dir.empty()) die("-d/--km-run is required");
+  if (!o.nb_controls || !o.nb_cases) die("-1/--nb-controls and -2/--nb-cases are required");
+  if (!(o.threshold >= 0.0 && o.threshold <= 1.0)) die("-s/--significance must be in [0, 1]");          // cli.cpp:191-199
+  static const std::map<std::string, int> ok = { {"bonferroni", 1}, {"benjamini", 2}, {"sidak", 3}, {"holm", 4}, {"disabled", 0} };
+  if (!ok.count(o.correction)) die("-c/--correction must be bonferroni|benjamini|sidak|holm|disabled");
+  if (o.pop_correction && o.pcs.empty()) die("--pop-correction needs --pcs FILE (the smartpca front end is not part of this build)");
+  if (o.npc < 2 || o.npc > 10) die("--n-pc must be in [2, 10]");
+  return o;
+}
+
+int correction_type(const std::string& c)
+{
+  return c == "bonferroni" ? KMD_CORR_BONFERRONI : c == "benjamini" ? KMD_CORR_BENJAMINI :
+         c == "sidak" ? KMD_CORR_SIDAK : c == "holm" ? KMD_CORR_HOLM : KMD_CORR_NOTHING;
+}
+
+// fmt's "{}" for a double: shortest representation that round-trips (aggregator.hpp:51-55 formats
+// m_mean_case with it)
+std::string shortest(double v)
+{
+  char buf[64];
+  for (int prec = 1; prec <= 17; ++prec)
+  {
+    std::snprintf(buf, sizeof buf, "%.*g", prec, v);
+    if (std::strtod(buf, nullptr) == v) break;
+  }
+  return buf;
+}
+
+struct dev_buf
+{
+  void* p = nullptr; size_t cap = 0;
+  void reserve(size_t bytes) { if (bytes > cap) { if (p) kmd_free(p); ck(kmd_malloc(&p, bytes), "kmd_malloc"); cap = bytes; } }
+  ~dev_buf() { if (p) kmd_free(p); }
+};
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+  diff_options opt = parse(argc, argv);
+  try
+  {
+    int ndev = 0;
+    if (kmd_device_count(&ndev) != KMD_OK || ndev < 1) die("no HIP device: kmdiff-hip has no CPU path");
+    ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
+    char dn[256]; ck(kmd_device_name(dn, sizeof dn), "kmd_device_name");
+    std::fprintf(stderr, "[kmdiff-hip] device %d: %s\n", opt.device % ndev, dn);
+
+    const kmtricks_config cfg = get_kmtricks_config(opt.kmtricks_dir);                       // src/main.cc:74
+    if (cfg.kmer_size > 32) die("k > 32 is not supported by the file reader yet");
+    const auto fof = read_fof(opt.kmtricks_dir);
+    const size_t S = opt.nb_controls + opt.nb_cases;
+    if (fof.size() < S) die("kmtricks.fof has fewer samples than -1 + -2");
+    std::vector<uint64_t> total_controls(opt.nb_controls), total_cases(opt.nb_cases);       // cmd/diff.hpp:111
+    for (size_t i = 0; i < opt.nb_controls; ++i) total_controls[i] = sample_total(opt.kmtricks_dir, fof[i], cfg.abundance_min);
+    for (size_t i = 0; i < opt.nb_cases; ++i) total_cases[i] = sample_total(opt.kmtricks_dir, fof[opt.nb_controls + i], cfg.abundance_min);
+
+    kmd_model* model = nullptr;                                                               // cmd/diff.hpp:117-123
+    ck(kmd_model_create(&model, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
+       "kmd_model_create");
+    const double first_threshold = opt.threshold / (double)opt.cutoff;                       // cmd/diff.hpp:147
+
+    // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
+    std::fprintf(stderr, "[kmdiff-hip] Process partitions\n");
+    std::vector<uint64_t> s_kmer; std::vector<double> s_p, s_mc, s_mk; std::vector<int32_t> s_sign;
+    std::vector<double> s_counts;                // [n][S] when --pop-correction
+    uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+    dev_buf d_kmers, d_counts, d_matrix, d_kmer_col, d_cnt, d_srow, d_skmer, d_sp, d_ssign, d_smc, d_smk, d_sc;
+    const size_t T = 4096;
+    for (size_t p = 0; p < cfg.nb_partitions; ++p)
+    {
+      std::vector<uint64_t> kmers; std::vector<uint32_t> counts; std::vector<uint64_t> offs(S + 1, 0);
+      for (size_t s = 0; s < S; ++s)                                                          // KmDir::get_files_to_merge
+      {
+        read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s].id), cfg.kmer_size, kmers, counts);
+        offs[s + 1] = kmers.size();
+      }
+      const size_t n = kmers.size();
+      if (n == 0) continue;
+      d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
+      ck(kmd_memcpy_h2d(d_kmers.p, kmers.data(), n * 8, nullptr), "h2d");
+      ck(kmd_memcpy_h2d(d_counts.p, counts.data(), n * 4, nullptr), "h2d");
+      d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
+      uint64_t n_rows = 0;
+      ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, (const uint32_t*)d_counts.p, offs.data(), 4,
+                             KMD_LAYOUT_TILED, T, n, d_matrix.p, (uint64_t*)d_kmer_col.p, &n_rows, nullptr), "kmd_merge_partition");
+      // survivor sink sized for the worst case of this partition (every row)
+      d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
+      d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
+      ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
+      kmd_tile tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p, nullptr, (size_t)n_rows, 0 };
+      kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
+                         (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
+      ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
+      uint64_t c[KMD_NCOUNTERS];
+      ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+      const size_t ns = (size_t)c[KMD_CNT_SIG];
+      ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                         // reference push order
+      const size_t base = s_p.size();
+      s_kmer.resize(base + ns); s_p.resize(base + ns); s_sign.resize(base + ns); s_mc.resize(base + ns); s_mk.resize(base + ns);
+      if (ns)
+      {
+        ck(kmd_memcpy_d2h(s_kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(s_p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(s_sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(s_mc.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(s_mk.data() + base, d_smk.p, ns * 8, nullptr), "d2h");
+        if (opt.pop_correction)                                                               // merge.hpp:91-92
+        {
+          d_sc.reserve(ns * S * 8);
+          ck(kmd_survivors_gather_counts(&tile, (int)S, (const uint64_t*)d_srow.p, ns, (double*)d_sc.p, nullptr), "gather_counts");
+          s_counts.resize((base + ns) * S);
+          ck(kmd_memcpy_d2h(s_counts.data() + base * S, d_sc.p, ns * S * 8, nullptr), "d2h");
+        }
+      }
+      total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
+    }
+    std::fprintf(stderr, "[kmdiff-hip] %" PRIu64 "/%" PRIu64 " significant k-mers.\n", n_sig, total_kmers);      // cmd/diff.hpp:160
+    std::fprintf(stderr, "[kmdiff-hip] Before correction: %" PRIu64 " (control), %" PRIu64 " (case).\n", n_sig_control, n_sig_case);
+
+    const size_t n = s_p.size();
+    dev_buf d_p, d_sign, d_keep;
+    d_p.reserve(std::max<size_t>(n, 1) * 8); d_sign.reserve(std::max<size_t>(n, 1) * 4); d_keep.reserve(std::max<size_t>(n, 1));
+
+    // ---- stage 2: do_pop (cmd/diff.hpp:167-224) with externally computed principal components
+    if (opt.pop_correction && n)
+    {
+      std::ifstream zin(opt.pcs);
+      if (!zin) die("cannot open " + opt.pcs);
+      std::vector<double> Z(S * 10, 0.0), Y(S, 0.0);
+      for (size_t i = 0; i < S * 10; ++i) if (!(zin >> Z[i])) die(opt.pcs + ": expected 10 values per sample");   // popstrat.cpp:153-161
+      for (size_t i = 0; i < opt.nb_controls; ++i) Y[i] = 1.0;                                                       // popstrat.cpp:168
+      kmd_popstrat* ps = nullptr;
+      ck(kmd_popstrat_create(&ps, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), Z.data(), 10,
+                             (int)opt.npc, Y.data(), opt.stand ? 1 : 0, (int)opt.max_iteration), "kmd_popstrat_create");
+      dev_buf d_c; d_c.reserve(n * S * 8);
+      ck(kmd_memcpy_h2d(d_c.p, s_counts.data(), n * S * 8, nullptr), "h2d");
+      ck(kmd_popstrat_apply(ps, (const double*)d_c.p, 0, 0, n, (double*)d_p.p, nullptr), "kmd_popstrat_apply");
+      ck(kmd_memcpy_d2h(s_p.data(), d_p.p, n * 8, nullptr), "d2h");                                                  // ks.set_pval
+      kmd_popstrat_destroy(ps);
+      std::fprintf(stderr, "[kmdiff-hip] Population correction done.\n");
+    }
+
+    // ---- stage 3: do_correction (cmd/diff.hpp:227-260)
+    uint64_t kept = 0, c_controls = 0, c_cases = 0;
+    std::vector<uint8_t> keep(n, 0);
+    if (n)
+    {
+      ck(kmd_memcpy_h2d(d_p.p, s_p.data(), n * 8, nullptr), "h2d");
+      ck(kmd_memcpy_h2d(d_sign.p, s_sign.data(), n * 4, nullptr), "h2d");
+      ck(kmd_correct(correction_type(opt.correction), opt.threshold, total_kmers, (const double*)d_p.p, (const int32_t*)d_sign.p, n,
+                     (uint8_t*)d_keep.p, &kept, &c_controls, &c_cases, nullptr), "kmd_correct");
+      ck(kmd_memcpy_d2h(keep.data(), d_keep.p, n, nullptr), "d2h");
+    }
+    fs::create_directories(opt.output_directory);
+    // writers (aggregator.hpp:26-71).  BH/Holm emit in ascending p (the order the sorted
+    // aggregator pops them); the stateless correctors in partition order.
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    if (opt.correction == "benjamini" || opt.correction == "holm")
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return s_p[a] < s_p[b]; });
+    std::ofstream fc(opt.output_directory + "/control_kmers.fasta"), fk(opt.output_directory + "/case_kmers.fasta");
+    size_t ic = 0, ik = 0;
+    for (size_t i : order)
+    {
+      if (!keep[i]) continue;
+      const bool control = s_sign[i] == KMD_SIGN_CONTROL;                                     // aggregator.hpp:155-162
+      std::ofstream& f = control ? fc : fk;
+      size_t& idx = control ? ic : ik;
+      char pv[64]; std::snprintf(pv, sizeof pv, "%g", s_p[i]);                               // {:g}
+      f << '>' << idx << "_pval=" << pv << "_control=" << (uint64_t)s_mc[i] << "_case=" << shortest(s_mk[i]) << '\n'
+        << kmer_to_string(s_kmer[i], cfg.kmer_size) << '\n';
+      ++idx;
+    }
+    std::fprintf(stderr, "[kmdiff-hip] Significant k-mers: %" PRIu64 " (control), %" PRIu64 " (case).\n", c_controls, c_cases);   // cmd/diff.hpp:259
+    // machine-readable summary for tests and scripts
+    std::ofstream js(opt.output_directory + "/summary.json");
+    js << "{\"total_kmers\": " << total_kmers << ", \"n_sig\": " << n_sig << ", \"n_sig_control\": " << n_sig_control
+       << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
+       << ", \"kept_case\": " << c_cases << ", \"kmer_size\": " << cfg.kmer_size << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
+    kmd_model_destroy(model);
+  }
+  catch (const std::exception& e) { die(e.what()); }                                          // src/main.cc:93-102 logs and exits
+  return 0;
+}

@@ -1,0 +1,128 @@
+"""The C++ host (`kmdiff-hip diff`, kmdiff_amd/host/main.cpp) end to end on kmtricks run
+directories: the reference's fixture and run directories fabricated from synthetic matrices,
+checked against the oracle pipeline (merge -> Poisson test -> threshold -> corrector -> FASTA)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kmtricks_files as KF
+import oracle_lib as OL
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
+SEED = 0x6B6D64696666
+
+
+def run_cli(args, out):
+    r = subprocess.run([CLI, "diff", "-o", str(out)] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return json.load(open(os.path.join(str(out), "summary.json"))), r.stderr
+
+
+def read_fasta(path):
+    recs = []
+    lines = open(path).read().split("\n")
+    for i in range(0, len(lines) - 1, 2):
+        recs.append((lines[i], lines[i + 1]))
+    return recs
+
+
+def fmt_shortest(v):
+    for prec in range(1, 18):
+        s = "%.*g" % (prec, v)
+        if float(s) == v:
+            return s
+    return repr(v)
+
+
+def test_cli_on_reference_fixture(tmp_path):
+    """tests/merge_test.cpp:39-45: 320 merged rows, 0 significant."""
+    s, err = run_cli(["-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", 1, "-2", 1, "-u", 10000], tmp_path / "o")
+    assert (s["total_kmers"], s["n_sig"], s["kept"], s["kmer_size"], s["nb_partitions"]) == (320, 0, 0, 20, 4)
+    assert "0/320 significant k-mers." in err
+    assert read_fasta(tmp_path / "o" / "control_kmers.fasta") == [] and read_fasta(tmp_path / "o" / "case_kmers.fasta") == []
+
+
+@pytest.fixture(scope="module")
+def synth_run(tmp_path_factory):
+    """3 partitions x 40 000 rows, 5 controls + 4 cases, written in kmtricks' formats."""
+    o = OL.load()
+    nc, nk, n, k = 5, 4, 40_000, 31
+    root = tmp_path_factory.mktemp("run")
+    parts, mats, kms = [], [], []
+    for p in range(3):
+        host, lo, _ = o.synth_rows(SEED, p, 0, n, nc, nk, 4)
+        parts.append([(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(nc + nk)])
+        mats.append(host)
+        kms.append(lo)
+    ids = ["C%d" % i for i in range(nc)] + ["K%d" % i for i in range(nk)]
+    KF.write_run_dir(str(root / "km"), k, ids, parts)
+    return str(root / "km"), nc, nk, k, mats, kms
+
+
+def oracle_pipeline(o, nc, nk, mats, kms, thr1, correction, alpha):
+    totals = np.sum([m.sum(axis=0, dtype=np.uint64) for m in mats], axis=0)
+    lf = o.lf_table(10000)
+    surv = {"kmer": [], "p": [], "sign": [], "mc": [], "mk": []}
+    total = 0
+    for m, km in zip(mats, kms):
+        out = o.diff_partition(m, OL.LAYOUT_ROWS, nc, nk, int(totals[:nc].sum()), int(totals[nc:].sum()), lf, thr1)
+        idx = out["row"].astype(np.int64)
+        surv["kmer"] += km[idx].tolist(); surv["p"] += out["pvalue"].tolist(); surv["sign"] += out["sign"].tolist()
+        surv["mc"] += out["mean_control"].tolist(); surv["mk"] += out["mean_case"].tolist()
+        total += m.shape[0]
+    keep = o.aggregate({"disabled": 0, "bonferroni": 1, "benjamini": 2, "sidak": 3, "holm": 4}[correction], alpha, total,
+                       np.array(surv["p"]))
+    return surv, keep, total
+
+
+@pytest.mark.parametrize("correction", ["bonferroni", "benjamini", "disabled"])
+def test_cli_matches_oracle_pipeline(synth_run, tmp_path, correction):
+    run_dir, nc, nk, k, mats, kms = synth_run
+    o = OL.load()
+    s, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-c", correction, "-s", 0.05, "-u", 1000], tmp_path / "o")
+    surv, keep, total = oracle_pipeline(o, nc, nk, mats, kms, 0.05 / 1000, correction, 0.05)
+    assert s["total_kmers"] == total and s["n_sig"] == len(surv["p"]) and s["kept"] == int(keep.sum())
+    assert s["n_sig"] > 10
+    order = list(range(len(keep)))
+    if correction == "benjamini":
+        order.sort(key=lambda i: surv["p"][i])
+    want = {"control": [], "case": []}
+    for i in order:
+        if keep[i]:
+            want["control" if surv["sign"][i] == 0 else "case"].append(i)
+    for name in ("control", "case"):
+        got = read_fasta(tmp_path / "o" / ("%s_kmers.fasta" % name))
+        assert len(got) == len(want[name])
+        for j, (i, (hdr, seq)) in enumerate(zip(want[name], got)):
+            assert seq == KF.kmer_to_string(surv["kmer"][i], k)
+            f = hdr[1:].split("_")
+            assert f[0] == str(j) and f[2] == "control=%d" % int(surv["mc"][i]) and f[3] == "case=" + fmt_shortest(surv["mk"][i])
+            pv = float(f[1].split("=")[1])
+            assert abs(pv - surv["p"][i]) <= 1e-5 * surv["p"][i] + 1e-300          # %g keeps 6 digits
+
+
+def test_cli_pop_correction(synth_run, tmp_path):
+    run_dir, nc, nk, k, mats, kms = synth_run
+    o = OL.load()
+    rng = np.random.default_rng(2)
+    Z = rng.normal(0, 0.1, size=(nc + nk, 10))
+    np.savetxt(tmp_path / "pcs.evec", Z, fmt="%.17g")
+    s, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-c", "bonferroni", "-u", 1000, "--pop-correction", "--pcs",
+                    tmp_path / "pcs.evec"], tmp_path / "o")
+    surv, _, total = oracle_pipeline(o, nc, nk, mats, kms, 0.05 / 1000, "bonferroni", 0.05)
+    totals = np.sum([m.sum(axis=0, dtype=np.uint64) for m in mats], axis=0)
+    Zr = np.loadtxt(tmp_path / "pcs.evec")
+    alt, null_model, tot_d, y = o.popstrat_setup(nc, nk, totals[:nc], totals[nc:], Zr, 2, True)
+    rows = []
+    for m, km in zip(mats, kms):
+        lut = {int(v): i for i, v in enumerate(km)}
+        rows.append((m, lut))
+    counts = np.array([next(m[lut[kv]] for m, lut in rows if kv in lut) for kv in surv["kmer"]], dtype=np.float64)
+    p2 = o.popstrat_pvalues(alt, null_model, tot_d, y, counts)
+    keep = o.aggregate(1, 0.05, total, p2)
+    assert s["kept"] == int(keep.sum()) and s["n_sig"] == len(p2)
