@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace {
 thread_local std::string g_last_error;
@@ -168,12 +169,24 @@ int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
     for (size_t k = i; k > 1; --k) res += std::log(static_cast<double>(k));
     m->h_lf[i] = res;
   }
-  m->d_lf = nullptr;
+  m->d_lf = nullptr; m->d_tab = nullptr;
+  // the kernels read {lf[k], log(k)} pairs: log(double(k)) is what the reference evaluates for
+  // the alternative hypothesis (model.hpp:152-153, lambda = the integer count sum), taken here
+  // from the same host libm
+  std::vector<double> tab(2 * n, 0.0);
+  for (size_t i = 0; i < log_factorial_size; ++i)
+  {
+    tab[2 * i] = m->h_lf[i];
+    tab[2 * i + 1] = i ? std::log(static_cast<double>(i)) : 0.0;
+  }
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_lf), n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_tab), 2 * n * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m->d_lf, m->h_lf, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_tab, tab.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess)
   {
     if (m->d_lf) (void)hipFree(m->d_lf);
+    if (m->d_tab) (void)hipFree(m->d_tab);
     std::free(m->h_lf); delete m;
     return kmd::hip_fail(e, "upload log-factorial table", __FILE__, __LINE__);
   }
@@ -185,6 +198,7 @@ int kmd_model_destroy(kmd_model* m)
 {
   if (!m) return KMD_OK;
   if (m->d_lf) (void)hipFree(m->d_lf);
+  if (m->d_tab) (void)hipFree(m->d_tab);
   std::free(m->h_lf);
   delete m;
   return KMD_OK;

@@ -25,7 +25,10 @@
 namespace {
 
 #ifndef KMD_BLOCK
-#define KMD_BLOCK 512
+#define KMD_BLOCK 1024
+#endif
+#ifndef KMD_BLOCKS_PER_CU
+#define KMD_BLOCKS_PER_CU 1
 #endif
 #ifndef KMD_MINWAVES
 #define KMD_MINWAVES 4
@@ -59,9 +62,10 @@ struct filter_params
   const uint64_t* kmer_hi;
   int nc, nk;
   double dT, dTc, dTk, lg_half, lr_cut, threshold;
-  const double* lf;
+  const double* lf;         // lf[k]                        (k_process_all)
+  const double2* tab;       // { lf[k], log(double(k)) }    (filter kernels; head staged in LDS)
   uint32_t lf_n;
-  uint32_t lds_n;
+  uint32_t lds_n;           // table entries held in LDS
   kmd_survivors out;
   unsigned long long* counters;
 };
@@ -118,44 +122,47 @@ struct row_state
 
 // One row from its two count sums to the survivor sink.  Must be called by all 64 lanes of
 // the wave together (ballots / cooperative fallback inside).
-__device__ __forceinline__ void finish_row(const filter_params& P, const double* s_lf,
+__device__ __forceinline__ void finish_row(const filter_params& P, const double2* s_tab,
                                            const row_state& st, uint32_t& n_beyond)
 {
 #ifdef KMD_ABLATE_MATH   // dev only: memory-side ceiling of the load loop (results are wrong)
   if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
   return;
 #endif
+  // table entry of each sum: { lf[k], log(k) }.  k = table_index(sum) (model.hpp:152-156);
+  // sums beyond the table (or >= 2^31, where k wraps to 0 but lambda does not) take the
+  // logarithm on the device.
   const uint32_t kc = kmd::table_index(st.sum_c);
   const uint32_t kk = kmd::table_index(st.sum_k);
-  double lf_c = 0, lf_k = 0;
-  if (kc < P.lds_n) lf_c = s_lf[kc]; else if (kc < P.lf_n) lf_c = P.lf[kc];
-  if (kk < P.lds_n) lf_k = s_lf[kk]; else if (kk < P.lf_n) lf_k = P.lf[kk];
-
-  // table misses (rare with the default 10000-entry table)
-  const bool miss_c = st.valid && kc >= P.lf_n;
-  const bool miss_k = st.valid && kk >= P.lf_n;
-  if (miss_c | miss_k)
+  double2 tc = make_double2(0.0, 0.0), tk = make_double2(0.0, 0.0);
+  if (kc < P.lds_n) tc = s_tab[kc]; else if (kc < P.lf_n) tc = P.tab[kc];
+  if (kk < P.lds_n) tk = s_tab[kk]; else if (kk < P.lf_n) tk = P.tab[kk];
+  const bool big_c = st.valid && st.sum_c >= P.lf_n;
+  const bool big_k = st.valid && st.sum_k >= P.lf_n;
+  if (big_c | big_k)                     // rare with the default 10000-entry table
   {
-    if (miss_c) lf_c = lf_beyond_table(kc);
-    if (miss_k) lf_k = (kk == kc && miss_c) ? lf_c : lf_beyond_table(kk);
+    if (big_c) { if (kc >= P.lf_n) tc.x = lf_beyond_table(kc); tc.y = ::log((double)st.sum_c); }
+    if (big_k) { if (kk >= P.lf_n) tk.x = lf_beyond_table(kk); tk.y = ::log((double)st.sum_k); }
     ++n_beyond;        // flushed once per wave at kernel end: with many samples most waves
                        // see such rows, and a global atomic per wave serialises the chip
   }
 
-  const kmd::lrt_result r = kmd::lrt_from_sums(st.sum_c, st.sum_k, lf_c, lf_k, P.dT, P.dTc, P.dTk);
-  const bool cand = st.valid && (r.lr >= P.lr_cut);
-  bool surv = false;
-  double p = 1.0;
+  const double lr = kmd::lr_from_sums(st.sum_c, st.sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
+  const bool cand = st.valid && (lr >= P.lr_cut);
   const unsigned long long cand_mask = __ballot(cand);
   if (cand_mask)
   {
+    bool surv = false;
+    double p = 1.0, mean_control = 0.0;
+    int sign = KMD_SIGN_NO;
     if (cand)
     {
-      p = kmd::igamc_half(r.lr, P.lg_half);                 // model.hpp:161
+      p = kmd::igamc_half(lr, P.lg_half);                   // model.hpp:161
       surv = (p <= P.threshold);                            // merge.hpp:78
+      kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, mean_control, sign);
     }
     const unsigned long long surv_mask = __ballot(surv);
-    const unsigned long long ctrl_mask = __ballot(surv && r.sign == KMD_SIGN_CONTROL);
+    const unsigned long long ctrl_mask = __ballot(surv && sign == KMD_SIGN_CONTROL);
     const int lane = __lane_id();
     const int leader = __ffsll((long long)cand_mask) - 1;
     unsigned long long base = 0;
@@ -184,8 +191,8 @@ __device__ __forceinline__ void finish_row(const filter_params& P, const double*
           if (P.out.d_kmer_lo && P.kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[st.row];
           if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[st.row];
           if (P.out.d_pvalue) P.out.d_pvalue[slot] = p;
-          if (P.out.d_sign) P.out.d_sign[slot] = r.sign;
-          if (P.out.d_mean_control) P.out.d_mean_control[slot] = r.mean_control;
+          if (P.out.d_sign) P.out.d_sign[slot] = sign;
+          if (P.out.d_mean_control) P.out.d_mean_control[slot] = mean_control;
           if (P.out.d_mean_case) P.out.d_mean_case[slot] = (double)st.sum_k;
         }
       }
@@ -201,9 +208,9 @@ __device__ __forceinline__ void flush_beyond(const filter_params& P, uint32_t n_
     atomicAdd(&P.counters[KMD_CNT_DEFERRED], (unsigned long long)n_beyond);
 }
 
-__device__ __forceinline__ void stage_table(const filter_params& P, double* s_lf)
+__device__ __forceinline__ void stage_table(const filter_params& P, double2* s_tab)
 {
-  for (uint32_t i = threadIdx.x; i < P.lds_n; i += blockDim.x) s_lf[i] = P.lf[i];
+  for (uint32_t i = threadIdx.x; i < P.lds_n; i += blockDim.x) s_tab[i] = P.tab[i];
   __syncthreads();
 }
 
@@ -342,7 +349,7 @@ __device__ __forceinline__ const CT* tile_base(const filter_params& P, const CT*
 template <typename CT, int RPL>
 __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filter_params P)
 {
-  extern __shared__ double s_lf[];
+  extern __shared__ double2 s_lf[];
   stage_table(P, s_lf);
   uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
 
@@ -458,8 +465,8 @@ template <typename CT, int VEC>
 __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params P, const uint32_t pitch_dw,
                                                             const uint32_t chunk_dw)
 {
-  extern __shared__ double s_all[];
-  double* s_lf = s_all;
+  extern __shared__ double2 s_all[];
+  double2* s_lf = s_all;
   uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_all + P.lds_n);
   stage_table(P, s_lf);
   uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
@@ -536,7 +543,7 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params 
 template <typename CT>
 __global__ void __launch_bounds__(kRowsBlock) k_filter_rows_direct(const filter_params P)
 {
-  extern __shared__ double s_lf[];
+  extern __shared__ double2 s_lf[];
   stage_table(P, s_lf);
   uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
   const CT* __restrict__ base = static_cast<const CT*>(P.counts);
@@ -623,7 +630,7 @@ int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double 
     m->cut_valid = true;
   }
   P.lr_cut = m->cut_value;
-  P.lf = m->d_lf; P.lf_n = (uint32_t)m->lf_n;
+  P.lf = m->d_lf; P.tab = reinterpret_cast<const double2*>(m->d_tab); P.lf_n = (uint32_t)m->lf_n;
   P.lds_n = 0;
   P.counters = nullptr;
   P.out = kmd_survivors{};
@@ -632,40 +639,45 @@ int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double 
 
 template <typename K> int allow_big_lds(K kernel, size_t lds_bytes);
 
-template <typename CT>
-int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int blocks_per_cu,
-               bool tiled, hipStream_t stream)
+template <typename CT, int RPL>
+int launch_soa_rpl(const filter_params& P, const kmd_model* m, size_t lds_bytes, int blocks_per_cu,
+                   bool tiled, hipStream_t stream)
 {
-  constexpr int vec = sizeof(CT) == 4 ? KMD_RPL_U32 : sizeof(CT) == 2 ? KMD_RPL_U16 : KMD_RPL_U8;
-  constexpr size_t vbytes = vec * sizeof(CT);
-  const bool aligned = ((reinterpret_cast<uintptr_t>(P.counts) % vbytes) == 0) &&
-                       ((P.ld * sizeof(CT)) % vbytes == 0);
-  const size_t rpl = aligned ? vec : 1;
-  const size_t tile_rows = (size_t)kBlock * rpl;
+  const size_t tile_rows = (size_t)kBlock * RPL;
   filter_params Q = P;
   if (tiled)
   {
-    Q.tiles_per_blk = P.ld / tile_rows;               // ld = T, a multiple of 4096 >= tile_rows
+    Q.tiles_per_blk = P.ld / tile_rows;               // ld = T, a multiple of tile_rows (checked by the caller)
     Q.blk_stride = (size_t)(P.nc + P.nk) * P.ld;
   }
   size_t n_tiles = (P.n_rows + tile_rows - 1) / tile_rows;
   size_t grid = (size_t)m->n_cu * blocks_per_cu;
   if (grid > n_tiles) grid = n_tiles;
   if (grid == 0) grid = 1;
-  if (aligned)
-  {
-    int rc = allow_big_lds(k_filter_soa<CT, vec>, lds_bytes);
-    if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_soa<CT, vec>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, Q);
-  }
-  else
-  {
-    int rc = allow_big_lds(k_filter_soa<CT, 1>, lds_bytes);
-    if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_soa<CT, 1>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, Q);
-  }
+  int rc = allow_big_lds(k_filter_soa<CT, RPL>, lds_bytes);
+  if (rc != KMD_OK) return rc;
+  hipLaunchKernelGGL((k_filter_soa<CT, RPL>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, Q);
   KMD_HIP(hipGetLastError());
   return KMD_OK;
+}
+
+// rows per lane: the widest vector (8 bytes per lane; KMD_RPL_*) the alignment allows and,
+// for the tiled layout, that keeps a kernel tile (kBlock * RPL rows) inside one T-row block
+template <typename CT>
+int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int blocks_per_cu,
+               bool tiled, hipStream_t stream)
+{
+  constexpr int vec = sizeof(CT) == 4 ? KMD_RPL_U32 : sizeof(CT) == 2 ? KMD_RPL_U16 : KMD_RPL_U8;
+  constexpr int half = vec >= 2 ? vec / 2 : 1;        // 4 bytes per lane
+  auto ok = [&](int rpl) {
+    const size_t vbytes = (size_t)rpl * sizeof(CT);
+    if ((reinterpret_cast<uintptr_t>(P.counts) % vbytes) || ((P.ld * sizeof(CT)) % vbytes)) return false;
+    return !tiled || (P.ld % ((size_t)kBlock * rpl) == 0);
+  };
+  if (ok(vec)) return launch_soa_rpl<CT, vec>(P, m, lds_bytes, blocks_per_cu, tiled, stream);
+  if (half != vec && half != 1 && ok(half)) return launch_soa_rpl<CT, half>(P, m, lds_bytes, blocks_per_cu, tiled, stream);
+  if (tiled) KMD_REQUIRE(P.ld % (size_t)kBlock == 0, "kmd: tiled block rows must be a multiple of the workgroup size");
+  return launch_soa_rpl<CT, 1>(P, m, lds_bytes, blocks_per_cu, tiled, stream);
 }
 
 template <typename K>
@@ -697,9 +709,9 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   const bool dword_rows = (P.ld % per == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 3u) == 0);
   if (!dword_rows)
   {
-    size_t want = (size_t)P.lf_n * sizeof(double);
-    if (want > half) want = half / sizeof(double) * sizeof(double);
-    P.lds_n = (uint32_t)(want / sizeof(double));
+    size_t want = (size_t)P.lf_n * sizeof(double2);
+    if (want > half) want = half / sizeof(double2) * sizeof(double2);
+    P.lds_n = (uint32_t)(want / sizeof(double2));
     size_t grid = (size_t)m->n_cu * 4;
     if (grid > n_tiles) grid = n_tiles;
     int rc = allow_big_lds(k_filter_rows_direct<CT>, want);
@@ -716,10 +728,10 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   uint32_t chunk_dw = row_dw <= 47 ? row_dw : 44;
   const uint32_t pitch = chunk_dw | 1u;                 // odd dword pitch: conflict-free walk
   const size_t tile_bytes = (size_t)kRowsBlock * pitch * 4;
-  size_t want = (size_t)P.lf_n * sizeof(double);
+  size_t want = (size_t)P.lf_n * sizeof(double2);
   const size_t avail = half - tile_bytes;
-  if (want > avail) want = avail / sizeof(double) * sizeof(double);
-  P.lds_n = (uint32_t)(want / sizeof(double));
+  if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
+  P.lds_n = (uint32_t)(want / sizeof(double2));
   const size_t lds = want + tile_bytes;
   size_t grid = (size_t)m->n_cu * 2;
   if (grid > n_tiles) grid = n_tiles;
@@ -774,11 +786,13 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
   if (tile->layout == KMD_LAYOUT_SOA || tile->layout == KMD_LAYOUT_TILED)
   {
     const bool tiled = tile->layout == KMD_LAYOUT_TILED;
-    size_t want = m->lf_n * sizeof(double);
-    int blocks_per_cu = 2;
-    size_t budget = lds_cap / 2 - 256;
-    if (want > budget) want = budget / sizeof(double) * sizeof(double);
-    P.lds_n = (uint32_t)(want / sizeof(double));
+    // the whole default table ({lf, log} pairs, 160 000 B) fits the 160 KiB of one CU: one
+    // workgroup of kBlock threads per CU holds it; larger tables keep their head in LDS
+    size_t want = m->lf_n * sizeof(double2);
+    const int blocks_per_cu = KMD_BLOCKS_PER_CU;
+    const size_t budget = lds_cap / blocks_per_cu - 256;
+    if (want > budget) want = budget / sizeof(double2) * sizeof(double2);
+    P.lds_n = (uint32_t)(want / sizeof(double2));
     switch (tile->count_bytes)
     {
       case 1: return launch_soa<uint8_t>(P, m, want, blocks_per_cu, tiled, st);

@@ -18,6 +18,7 @@ struct kmd_model
   size_t lf_n;              // --log-factorial
   double* h_lf;             // host copy of the table
   double* d_lf;             // device copy
+  double* d_tab;            // device: pairs { lf[k], log(double(k)) }, k < lf_n (16 B each)
   int n_cu;                 // multiProcessorCount
   size_t lds_per_block_max; // sharedMemPerBlock
   // cache of lr_cut_for_threshold (host-side constant of the last threshold used)

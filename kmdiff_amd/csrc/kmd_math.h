@@ -109,26 +109,44 @@ KMD_HD uint32_t table_index(uint64_t sum)
 
 struct lrt_result { double lr; double mean_control; int sign; };
 
-// PoissonLikelihood::process (model.hpp:142-176) from the two integer count sums up to the
-// likelihood ratio and the sign; the tail function is applied by the caller.
+// The likelihood ratio of PoissonLikelihood::process (model.hpp:147-160) from the two count
+// sums.  log_sc / log_sk are log(double(sum_c)) / log(double(sum_k)) -- the two logarithms of
+// the alternative hypothesis, whose arguments are integers: the kernels read them from a table
+// built on the host with the same libm call the reference makes (so they are the reference's
+// own values), only the two null-hypothesis logarithms are evaluated per row.
 // dT = double(Tc + Tk), dTc = double(Tc), dTk = double(Tk).
-KMD_HD lrt_result lrt_from_sums(uint64_t sum_c, uint64_t sum_k, double lf_c, double lf_k,
-                                double dT, double dTc, double dTk)
+KMD_HD double lr_from_sums(uint64_t sum_c, uint64_t sum_k, double lf_c, double lf_k,
+                           double log_sc, double log_sk, double dT, double dTc, double dTk)
 {
   const double sc = (double)sum_c, sk = (double)sum_k;   // exact: sums < 2^53
   const double kc = (double)table_index(sum_c), kk = (double)table_index(sum_k);
   const double mean = (sc + sk) / dT;                                        // :147
   double alt = 0, nul = 0;
-  alt += poisson_prob(kc, sc, lf_c);                                         // :152
-  alt += poisson_prob(kk, sk, lf_k);                                         // :153
+  alt += (sc <= 0) ? 0.0 : (-sc + (kc * log_sc - lf_c));                     // :152 (poisson_prob :133-138)
+  alt += (sk <= 0) ? 0.0 : (-sk + (kk * log_sk - lf_k));                     // :153
   nul += poisson_prob(kc, mean * dTc, lf_c);                                 // :155
   nul += poisson_prob(kk, mean * dTk, lf_k);                                 // :156
   double lr = alt - nul;                                                     // :158
   if (lr < 0) lr = 0;                                                        // :160
+  return lr;
+}
+
+// model.hpp:165-172: normalised control sum and the sign
+KMD_HD void sign_of(uint64_t sum_c, uint64_t sum_k, double dTc, double dTk, double& mean_control, int& sign)
+{
+  const double sc = (double)sum_c, sk = (double)sum_k;
+  mean_control = sc * dTk / dTc;                                             // :165
+  sign = (mean_control < sk) ? 1 : (mean_control > sk) ? 0 : 2;              // :167-172
+}
+
+// everything at once, logarithms evaluated here (k_process_all, host-side uses)
+KMD_HD lrt_result lrt_from_sums(uint64_t sum_c, uint64_t sum_k, double lf_c, double lf_k,
+                                double dT, double dTc, double dTk)
+{
   lrt_result r;
-  r.lr = lr;
-  r.mean_control = sc * dTk / dTc;                                           // :165
-  r.sign = (r.mean_control < sk) ? 1 : (r.mean_control > sk) ? 0 : 2;        // :167-172
+  const double lc = sum_c ? KMD_LOG((double)sum_c) : 0.0, lk = sum_k ? KMD_LOG((double)sum_k) : 0.0;
+  r.lr = lr_from_sums(sum_c, sum_k, lf_c, lf_k, lc, lk, dT, dTc, dTk);
+  sign_of(sum_c, sum_k, dTc, dTk, r.mean_control, r.sign);
   return r;
 }
 
