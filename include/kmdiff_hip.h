@@ -174,16 +174,18 @@ int kmd_correct(int correction, double threshold, uint64_t total_kmers,
  * dependency): S per-sample streams of (k-mer, count) records, each sorted by ascending
  * 2-bit-packed k-mer (A=0 C=1 T=2 G=3, first base most significant), are merged into the
  * count matrix: one row per distinct k-mer, ascending; count of each sample, 0 when absent.
- *   d_kmers / d_counts : all streams concatenated in sample order (k <= 32: one u64 per k-mer)
+ *   d_kmers / d_counts : all streams concatenated in sample order; d_kmers holds the low 64
+ *                        bits of each k-mer, d_kmers_hi the high 64 bits (NULL for k <= 32)
  *   offsets            : host array of n_samples+1 record offsets into them
  *   d_matrix           : output, `layout`/`ld` as in kmd_tile, room for row_capacity rows
- *   d_kmer_out         : output k-mer column (row_capacity entries), may be NULL
+ *   d_kmer_out / d_kmer_hi_out : output k-mer columns (row_capacity entries), may be NULL
  *   n_rows_out         : host output, number of merged rows
  * Synchronous.  KMD_E_OVERFLOW (with *n_rows_out = rows needed) if row_capacity is too small. */
-int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
-                        const uint64_t* offsets, int count_bytes, int layout, size_t ld,
-                        size_t row_capacity, void* d_matrix, uint64_t* d_kmer_out,
-                        uint64_t* n_rows_out, void* stream);
+int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                        const uint32_t* d_counts, const uint64_t* offsets, int count_bytes,
+                        int layout, size_t ld, size_t row_capacity, void* d_matrix,
+                        uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out,
+                        void* stream);
 
 /* ---- stage 2 (optional): population-stratification re-test ---------------------------------
  * Replaces pop_strat_corrector (include/kmdiff/popstrat.hpp:148-367): constructor

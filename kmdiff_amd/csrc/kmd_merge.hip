@@ -32,16 +32,32 @@ __global__ void __launch_bounds__(256) k_tag(const uint32_t* __restrict__ counts
   if (i < end) vals[i] = ((uint64_t)sample << 32) | counts[i];
 }
 
-__global__ void __launch_bounds__(256) k_heads(const uint64_t* __restrict__ keys, size_t n, uint32_t* __restrict__ flag)
+__global__ void __launch_bounds__(256) k_heads(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                               size_t n, uint32_t* __restrict__ flag)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1] || (keys_hi && keys_hi[i] != keys_hi[i - 1])) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_iota32(uint32_t* v, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_gather64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                  size_t n, uint64_t* __restrict__ dst)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
 }
 
 template <typename CT>
-__global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals,
+__global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                 const uint64_t* __restrict__ vals,
                                                  const uint32_t* __restrict__ rank, size_t n, int layout, size_t ld,
-                                                 int S, CT* __restrict__ matrix, uint64_t* __restrict__ kmer_out)
+                                                 int S, CT* __restrict__ matrix, uint64_t* __restrict__ kmer_out,
+                                                 uint64_t* __restrict__ kmer_hi_out)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -52,21 +68,26 @@ __global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ ke
   constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
   if (c > cmax) c = cmax;
   matrix[kmd::count_index(layout, ld, S, row, s)] = (CT)c;
-  if (kmer_out && (i == 0 || keys[i] != keys[i - 1])) kmer_out[row] = keys[i];
+  if (i == 0 || rank[i] != rank[i - 1])                 // head of its run
+  {
+    if (kmer_out) kmer_out[row] = keys[i];
+    if (kmer_hi_out && keys_hi) kmer_hi_out[row] = keys_hi[i];
+  }
 }
 
 struct scratch
 {
-  void* p[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  void* p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   ~scratch() { for (void* q : p) if (q) (void)hipFree(q); }
 };
 
 } // namespace
 
-extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
-                                   const uint64_t* offsets, int count_bytes, int layout, size_t ld,
-                                   size_t row_capacity, void* d_matrix, uint64_t* d_kmer_out,
-                                   uint64_t* n_rows_out, void* stream)
+extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                                   const uint32_t* d_counts, const uint64_t* offsets, int count_bytes,
+                                   int layout, size_t ld, size_t row_capacity, void* d_matrix,
+                                   uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out,
+                                   void* stream)
 {
   KMD_REQUIRE(n_samples > 0 && n_samples <= 65535 && offsets && n_rows_out, "kmd_merge_partition: arguments");
   KMD_REQUIRE(count_bytes == 1 || count_bytes == 2 || count_bytes == 4, "kmd_merge_partition: count_bytes");
@@ -101,13 +122,41 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
   }
   KMD_HIP(hipGetLastError());
 
-  size_t tmp_sort = 0, tmp_scan = 0;
+  size_t tmp_sort = 0, tmp_scan = 0, tmp_sort32 = 0;
+  const uint64_t* keys_hi_s = nullptr;
   KMD_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort, d_kmers, keys_s, vals, vals_s, n, 0, 64, st));
   KMD_HIP(rocprim::inclusive_scan(nullptr, tmp_scan, flag, rank, n, rocprim::plus<uint32_t>(), st));
-  const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+  if (d_kmers_hi)
+    KMD_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort32, d_kmers, keys_s, flag, rank, n, 0, 64, st));
+  size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+  if (tmp_sort32 > tmp) tmp = tmp_sort32;
   KMD_HIP(hipMalloc(&sc.p[5], tmp ? tmp : 1));
-  KMD_HIP(rocprim::radix_sort_pairs(sc.p[5], tmp_sort, d_kmers, keys_s, vals, vals_s, n, 0, 64, st));
-  hipLaunchKernelGGL(k_heads, dim3(blocks_for(n)), dim3(256), 0, st, keys_s, n, flag);
+  if (!d_kmers_hi)
+  {
+    KMD_HIP(rocprim::radix_sort_pairs(sc.p[5], tmp_sort, d_kmers, keys_s, vals, vals_s, n, 0, 64, st));
+  }
+  else
+  {
+    // 128-bit keys (32 < k <= 64): LSD order -- stable sort by the low limb carrying the
+    // record index, then stable sort by the high limb; gather everything by the result
+    KMD_HIP(hipMalloc(&sc.p[6], n * 8));     // hi gathered by perm1, later lo gathered by perm
+    KMD_HIP(hipMalloc(&sc.p[7], n * 8));     // hi sorted
+    KMD_HIP(hipMalloc(&sc.p[8], n * 4));     // perm1
+    KMD_HIP(hipMalloc(&sc.p[9], n * 4));     // perm
+    uint64_t* hi_g = static_cast<uint64_t*>(sc.p[6]);
+    uint64_t* hi_s = static_cast<uint64_t*>(sc.p[7]);
+    uint32_t* perm1 = static_cast<uint32_t*>(sc.p[8]);
+    uint32_t* perm = static_cast<uint32_t*>(sc.p[9]);
+    hipLaunchKernelGGL(k_iota32, dim3(blocks_for(n)), dim3(256), 0, st, flag, n);
+    KMD_HIP(rocprim::radix_sort_pairs(sc.p[5], tmp_sort32, d_kmers, keys_s, flag, perm1, n, 0, 64, st));
+    hipLaunchKernelGGL(k_gather64, dim3(blocks_for(n)), dim3(256), 0, st, d_kmers_hi, perm1, n, hi_g);
+    KMD_HIP(rocprim::radix_sort_pairs(sc.p[5], tmp_sort32, hi_g, hi_s, perm1, perm, n, 0, 64, st));
+    hipLaunchKernelGGL(k_gather64, dim3(blocks_for(n)), dim3(256), 0, st, d_kmers, perm, n, keys_s);
+    hipLaunchKernelGGL(k_gather64, dim3(blocks_for(n)), dim3(256), 0, st, vals, perm, n, vals_s);
+    KMD_HIP(hipGetLastError());
+    keys_hi_s = hi_s;
+  }
+  hipLaunchKernelGGL(k_heads, dim3(blocks_for(n)), dim3(256), 0, st, keys_s, keys_hi_s, n, flag);
   KMD_HIP(hipGetLastError());
   KMD_HIP(rocprim::inclusive_scan(sc.p[5], tmp_scan, flag, rank, n, rocprim::plus<uint32_t>(), st));
   uint32_t n_rows32 = 0;
@@ -128,9 +177,9 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
   KMD_HIP(hipMemsetAsync(d_matrix, 0, n_el * (size_t)count_bytes, st));
   switch (count_bytes)
   {
-    case 1: hipLaunchKernelGGL((k_scatter<uint8_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint8_t*>(d_matrix), d_kmer_out); break;
-    case 2: hipLaunchKernelGGL((k_scatter<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint16_t*>(d_matrix), d_kmer_out); break;
-    default: hipLaunchKernelGGL((k_scatter<uint32_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint32_t*>(d_matrix), d_kmer_out); break;
+    case 1: hipLaunchKernelGGL((k_scatter<uint8_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, keys_hi_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint8_t*>(d_matrix), d_kmer_out, d_kmer_hi_out); break;
+    case 2: hipLaunchKernelGGL((k_scatter<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, keys_hi_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint16_t*>(d_matrix), d_kmer_out, d_kmer_hi_out); break;
+    default: hipLaunchKernelGGL((k_scatter<uint32_t>), dim3(blocks_for(n)), dim3(256), 0, st, keys_s, keys_hi_s, vals_s, rank, n, layout, ld, n_samples, static_cast<uint32_t*>(d_matrix), d_kmer_out, d_kmer_hi_out); break;
   }
   KMD_HIP(hipGetLastError());
   KMD_HIP(hipStreamSynchronize(st));

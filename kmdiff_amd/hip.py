@@ -343,21 +343,25 @@ class diff_observer:
 
 def merge_partition(streams, n_samples=None, count_bytes=4, layout=N.LAYOUT_TILED, row_capacity=None):
     """km::KmerMerger over one partition (merge.hpp:265-289): `streams` is a list, one entry per
-    sample in fof order, of (kmers uint64[], counts uint32[]) sorted by k-mer.  Returns a
-    CountMatrix (with its k-mer column) resident on the device."""
+    sample in fof order, of (kmers uint64[], counts uint32[]) -- or (kmers_lo, counts, kmers_hi)
+    for 32 < k <= 64 -- sorted by k-mer.  Returns a CountMatrix (with its k-mer column(s))
+    resident on the device."""
     n_samples = len(streams) if n_samples is None else n_samples
+    two = any(len(t) == 3 for t in streams)
     offs = np.zeros(n_samples + 1, dtype=np.uint64)
-    for s, (k, c) in enumerate(streams):
-        offs[s + 1] = offs[s] + len(k)
+    for s, t in enumerate(streams):
+        offs[s + 1] = offs[s] + len(t[0])
     total = int(offs[-1])
-    kmers = np.concatenate([np.asarray(k, dtype=np.uint64) for k, _ in streams]) if total else np.zeros(0, np.uint64)
-    counts = np.concatenate([np.asarray(c, dtype=np.uint32) for _, c in streams]) if total else np.zeros(0, np.uint32)
+    cat = lambda i, dt: (np.concatenate([np.asarray(t[i], dtype=dt) for t in streams]) if total else np.zeros(0, dt))
+    kmers, counts = cat(0, np.uint64), cat(1, np.uint32)
     cap = total if row_capacity is None else int(row_capacity)
-    m = CountMatrix(max(cap, 1), n_samples, count_bytes, layout, with_kmers=True)
+    m = CountMatrix(max(cap, 1), n_samples, count_bytes, layout, with_kmers=True, kmer_limbs=2 if two else 1)
     dk, dc = DeviceBuffer.from_host(kmers), DeviceBuffer.from_host(counts)
+    dh = DeviceBuffer.from_host(cat(2, np.uint64)) if two else None
     n_rows = C.c_uint64(0)
-    check(lib().kmd_merge_partition(n_samples, dk.ptr if total else None, dc.ptr if total else None,
-                                    offs.ctypes.data, count_bytes, layout, m.ld, cap, m.counts.ptr, m.kmer_lo.ptr,
+    check(lib().kmd_merge_partition(n_samples, dk.ptr if total else None, dh.ptr if (two and total) else None,
+                                    dc.ptr if total else None, offs.ctypes.data, count_bytes, layout, m.ld, cap,
+                                    m.counts.ptr, m.kmer_lo.ptr, m.kmer_hi.ptr if two else None,
                                     C.byref(n_rows), None), "kmd_merge_partition")
     m.n_rows = int(n_rows.value)
     return m

@@ -183,8 +183,9 @@ int main(int argc, char** argv)
       ck(kmd_memcpy_h2d(d_counts.p, counts.data(), n * 4, nullptr), "h2d");
       d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
       uint64_t n_rows = 0;
-      ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, (const uint32_t*)d_counts.p, offs.data(), 4,
-                             KMD_LAYOUT_TILED, T, n, d_matrix.p, (uint64_t*)d_kmer_col.p, &n_rows, nullptr), "kmd_merge_partition");
+      ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, nullptr, (const uint32_t*)d_counts.p, offs.data(), 4,
+                             KMD_LAYOUT_TILED, T, n, d_matrix.p, (uint64_t*)d_kmer_col.p, nullptr, &n_rows, nullptr),
+         "kmd_merge_partition");
       // survivor sink sized for the worst case of this partition (every row)
       d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
       d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);

@@ -786,23 +786,37 @@ void kmdo_popstrat_features(int nc, int nk, const uint64_t* totals_c, const uint
 size_t kmdo_merge_partition(int S, const uint64_t* kmers, const uint32_t* counts, const uint64_t* offsets,
                             uint32_t* matrix_rows, uint64_t* kmer_out, size_t cap)
 {
+  return kmdo_merge_partition2(S, kmers, NULL, counts, offsets, matrix_rows, kmer_out, NULL, cap);
+}
+
+/* the same for k-mers of two 64-bit limbs (32 < k <= 64): (hi, lo) compared as one 128-bit
+ * number; hi == NULL means one limb */
+size_t kmdo_merge_partition2(int S, const uint64_t* kmers, const uint64_t* kmers_hi, const uint32_t* counts,
+                             const uint64_t* offsets, uint32_t* matrix_rows, uint64_t* kmer_out,
+                             uint64_t* kmer_hi_out, size_t cap)
+{
   uint64_t* pos = malloc(sizeof(uint64_t) * (size_t)S);
   for (int s = 0; s < S; s++) pos[s] = offsets[s];
   size_t row = 0;
   for (;;)
   {
     int any = 0;
-    uint64_t best = 0;
+    uint64_t best = 0, best_hi = 0;
     for (int s = 0; s < S; s++)
-      if (pos[s] < offsets[s + 1] && (!any || kmers[pos[s]] < best)) { best = kmers[pos[s]]; any = 1; }
+      if (pos[s] < offsets[s + 1])
+      {
+        uint64_t lo = kmers[pos[s]], hi = kmers_hi ? kmers_hi[pos[s]] : 0;
+        if (!any || hi < best_hi || (hi == best_hi && lo < best)) { best = lo; best_hi = hi; any = 1; }
+      }
     if (!any) break;
     if (row < cap)
     {
       if (kmer_out) kmer_out[row] = best;
+      if (kmer_hi_out) kmer_hi_out[row] = best_hi;
       for (int s = 0; s < S; s++) matrix_rows[row * (size_t)S + (size_t)s] = 0;
     }
     for (int s = 0; s < S; s++)
-      if (pos[s] < offsets[s + 1] && kmers[pos[s]] == best)
+      if (pos[s] < offsets[s + 1] && kmers[pos[s]] == best && (!kmers_hi || kmers_hi[pos[s]] == best_hi))
       {
         if (row < cap) matrix_rows[row * (size_t)S + (size_t)s] = counts[pos[s]];
         pos[s]++;

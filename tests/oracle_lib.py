@@ -49,6 +49,8 @@ class Oracle:
 
         L.kmdo_merge_partition.restype = sz
         L.kmdo_merge_partition.argtypes = [i, vp, vp, vp, vp, vp, sz]
+        L.kmdo_merge_partition2.restype = sz
+        L.kmdo_merge_partition2.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz]
         L.kmdo_popstrat_features.argtypes = [i, i, vp, vp, vp, i, i, i, vp, vp, vp]
 
         class Corr(C.Structure):
@@ -140,6 +142,22 @@ class Oracle:
         n = self.L.kmdo_merge_partition(S, kmers.ctypes.data, counts.ctypes.data, offs.ctypes.data,
                                         mat.ctypes.data, ko.ctypes.data, max(total, 1))
         return mat[:n].copy(), ko[:n].copy()
+
+    def merge_partition2(self, streams):
+        """streams of (kmers_lo, counts, kmers_hi)."""
+        S = len(streams)
+        offs = np.zeros(S + 1, dtype=np.uint64)
+        for s, t in enumerate(streams):
+            offs[s + 1] = offs[s] + len(t[0])
+        total = max(int(offs[-1]), 1)
+        cat = lambda i, dt: np.concatenate([np.asarray(t[i], dtype=dt) for t in streams] + [np.zeros(1, dt)])
+        lo, ct, hi = cat(0, np.uint64), cat(1, np.uint32), cat(2, np.uint64)
+        mat = np.zeros((total, S), dtype=np.uint32)
+        klo = np.zeros(total, dtype=np.uint64)
+        khi = np.zeros(total, dtype=np.uint64)
+        n = self.L.kmdo_merge_partition2(S, lo.ctypes.data, hi.ctypes.data, ct.ctypes.data, offs.ctypes.data,
+                                         mat.ctypes.data, klo.ctypes.data, khi.ctypes.data, total)
+        return mat[:n].copy(), klo[:n].copy(), khi[:n].copy()
 
     # ---- R9
     def popstrat_setup(self, nc, nk, totals_c, totals_k, Z, npc, standardize=True, max_iter=100):

@@ -359,6 +359,29 @@ def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes):
     assert e.n_rows == 0
 
 
+def test_merge_partition_two_limb_kmers(K, oracle):
+    """32 < k <= 64: k-mers are (hi, lo) pairs compared as 128-bit numbers."""
+    rng = np.random.default_rng(23)
+    n = 30000
+    hi = rng.integers(0, 50, n, dtype=np.uint64)                 # many equal high limbs
+    lo = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    order = np.lexsort((lo, hi))
+    hi, lo = hi[order], lo[order]
+    keep = np.ones(n, dtype=bool)
+    keep[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+    hi, lo = hi[keep], lo[keep]
+    streams = []
+    for s in range(6):
+        pick = rng.random(len(lo)) < 0.4
+        streams.append((lo[pick], rng.integers(1, 500, pick.sum()).astype(np.uint32), hi[pick]))
+    want, wlo, whi = oracle.merge_partition2(streams)
+    m = K.merge_partition(streams)
+    assert m.n_rows == want.shape[0] and (m.to_host() == want).all()
+    glo, ghi = m.kmers_to_host()
+    assert (glo == wlo).all() and (ghi == whi).all()
+    assert ((np.diff(whi.astype(np.int64)) > 0) | ((np.diff(whi.astype(np.int64)) == 0) & (wlo[1:] > wlo[:-1]))).all()
+
+
 def test_reference_fixture_end_to_end(K, oracle):
     """tests/merge_test.cpp:12-46 on the device: the reference's 4-partition fixture through
     merge + Poisson filter: totals 160/160, 320 rows, 0 significant at 0.05/10000."""

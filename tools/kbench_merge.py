@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""K2 micro-benchmark: kmd_merge_partition on streams cut out of a synthetic matrix."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kmdiff_amd as K
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=4_000_000)
+ap.add_argument("--nc", type=int, default=20)
+ap.add_argument("--nk", type=int, default=20)
+ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+S = a.nc + a.nk
+lib = K._native.lib()
+mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, a.nc, a.nk, 4, K.LAYOUT_ROWS)
+host = mat.to_host()
+lo = mat.kmers_to_host()[0]
+offs = np.zeros(S + 1, dtype=np.uint64)
+ks, cs = [], []
+for s in range(S):
+    sel = host[:, s] > 0
+    ks.append(lo[sel]); cs.append(host[sel, s]); offs[s + 1] = offs[s] + int(sel.sum())
+kmers = np.concatenate(ks); counts = np.concatenate(cs).astype(np.uint32)
+n = len(kmers)
+dk, dc = K.DeviceBuffer.from_host(kmers), K.DeviceBuffer.from_host(counts)
+out = K.CountMatrix(a.rows, S, 4, K.LAYOUT_TILED, with_kmers=True)
+nr = C.c_uint64(0)
+ts = []
+for _ in range(a.iters + 1):
+    lib.kmd_stream_sync(None)
+    t0 = time.perf_counter()
+    K._native.check(lib.kmd_merge_partition(S, dk.ptr, None, dc.ptr, offs.ctypes.data, 4, K.LAYOUT_TILED, out.ld, a.rows,
+                                            out.counts.ptr, out.kmer_lo.ptr, None, C.byref(nr), None))
+    ts.append(time.perf_counter() - t0)
+t = min(ts[1:])
+assert nr.value == a.rows
+out.n_rows = a.rows
+assert (out.to_host()[:1000] == host[:1000]).all()
+inb = n * 12
+print("merge S=%d rows=%d records=%d  %.2f ms  %.3e records/s  %.3e rows/s  input %.1f GB/s (12 B/record)"
+      % (S, a.rows, n, t * 1e3, n / t, a.rows / t, inb / t / 1e9))
