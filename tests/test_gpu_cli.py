@@ -126,3 +126,29 @@ def test_cli_pop_correction(synth_run, tmp_path):
     p2 = o.popstrat_pvalues(alt, null_model, tot_d, y, counts)
     keep = o.aggregate(1, 0.05, total, p2)
     assert s["kept"] == int(keep.sum()) and s["n_sig"] == len(p2)
+
+
+@pytest.mark.parametrize("bits,dtype", [(32, np.uint32), (16, np.uint16), (8, np.uint8)])
+def test_imodel_plugin_loaded_like_the_reference_does(tmp_path, bits, dtype):
+    """libkmdiff_hip_model.so through a dlopen / plugin_name / create<bits> / configure / process
+    host (model_manager.hpp:33-94): per-row results == oracle."""
+    o = OL.load()
+    nc, nk, n = 4, 3, 60
+    host, _, _ = o.synth_rows(SEED, 4, 0, n, nc, nk, np.dtype(dtype).itemsize)
+    totals = host.sum(axis=0, dtype=np.uint64) * 1000 + 17
+    cfg = "controls=%d;cases=%d;total_controls=%s;total_cases=%s;log_factorial=500" % (
+        nc, nk, ",".join(str(int(t)) for t in totals[:nc]), ",".join(str(int(t)) for t in totals[nc:]))
+    plugin = os.path.join(ROOT, "kmdiff_amd", "lib", "libkmdiff_hip_model.so")
+    harness = os.path.join(ROOT, "kmdiff_amd", "bin", "plugin_host")
+    rows_txt = "\n".join(" ".join(str(int(v)) for v in r) for r in host) + "\n"
+    r = subprocess.run([harness, plugin, str(bits), cfg, str(nc), str(nk)], input=rows_txt, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "plugin: kmdiff_hip_poisson" in r.stderr
+    got = [line.split() for line in r.stdout.strip().split("\n")]
+    assert len(got) == n
+    p, s, mc, mk = o.poisson_rows(host, OL.LAYOUT_ROWS, nc, nk, int(totals[:nc].sum()), int(totals[nc:].sum()),
+                                  o.lf_table(500))
+    for i, g in enumerate(got):
+        assert int(g[1]) == s[i] and float.fromhex(g[2]) == mc[i] and float.fromhex(g[3]) == mk[i]
+        assert abs(float.fromhex(g[0]) - p[i]) <= 1e-10 and abs(float.fromhex(g[0]) - p[i]) <= 1e-9 * p[i] + 1e-300
