@@ -490,3 +490,114 @@ def test_full_size_config2_properties(K, oracle):
         assert got["sign"][sel].tolist() == want["sign"].tolist()
         assert got["kmer_lo"][sel].tolist() == lo[want["row"].astype(np.int64)].tolist()
         assert_p_close(got["pvalue"][sel], want["pvalue"])
+
+
+def replay_windows(K, oracle, part, n, nc, nk, limbs, tot, got, starts, thr=THR, width=2048):
+    """Exact oracle replay of row windows of a synthetic partition against the device survivors."""
+    lf = oracle.lf_table(10000)
+    tc, tk = int(tot[:nc].sum()), int(tot[nc:].sum())
+    srows = got["row"].astype(np.int64)
+    for s in starts:
+        host, lo, hi = oracle.synth_rows(SEED, part, int(s), width, nc, nk, 4, kmer_limbs=limbs)
+        want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, tc, tk, lf, thr)
+        sel = (srows >= s) & (srows < s + width)
+        assert (srows[sel] - s).tolist() == want["row"].tolist()
+        assert got["sign"][sel].tolist() == want["sign"].tolist()
+        idx = want["row"].astype(np.int64)
+        assert got["kmer_lo"][sel].tolist() == lo[idx].tolist()
+        if limbs == 2:
+            assert got["kmer_hi"][sel].tolist() == hi[idx].tolist()
+        assert got["mean_control"][sel].tolist() == want["mean_control"].tolist()
+        assert_p_close(got["pvalue"][sel], want["pvalue"])
+
+
+def test_full_size_config3_256_partitions(K, oracle):
+    """BASELINE.json configs[2]: 256 partitions x 39 062 500 rows (10^10 rows), 20v20, k=31,
+    streamed one partition at a time through one GPU.  Whole-job invariants (a checksum of the
+    per-partition checksums) + exact oracle replay of windows in sampled partitions."""
+    nc, nk, rows, parts = 20, 20, 39_062_500, 256
+    lib = K._native.lib()
+    mat = K.CountMatrix(rows, nc + nk, 4, K.LAYOUT_TILED, with_kmers=True)
+    # totals from a sample of partitions (the model only needs the same constants on both sides)
+    totb = K.DeviceBuffer((nc + nk) * 8).zero()
+    for p in (0, 100, 255):
+        K._native.check(lib.kmd_synth_fill(SEED, p, 0, rows, nc, nk, 4, K.LAYOUT_TILED, mat.ld, mat.counts.ptr,
+                                           mat.kmer_lo.ptr, None, None))
+        K.column_sums(mat, totb)
+    K._native.check(lib.kmd_stream_sync(None))
+    tot = totb.to_host(np.uint64, nc + nk)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    rng = np.random.default_rng(99)
+    check_parts = {0, 255} | set(int(x) for x in rng.integers(1, 255, 4))
+    total = n_sig = n_ctrl = n_case = 0
+    per_part = []
+    for p in range(parts):
+        K._native.check(lib.kmd_synth_fill(SEED, p, 0, rows, nc, nk, 4, K.LAYOUT_TILED, mat.ld, mat.counts.ptr,
+                                           mat.kmer_lo.ptr, None, None))
+        acc = K.SurvivorAccumulator(rows // 500)
+        K.diff_observer(model, acc, THR).process(mat)
+        c = acc.read_counters()
+        assert int(c[0]) == rows and int(c[1]) == int(c[2]) + int(c[3]) and int(c[1]) < rows // 500
+        total += int(c[0]); n_sig += int(c[1]); n_ctrl += int(c[2]); n_case += int(c[3])
+        per_part.append(int(c[1]))
+        if p in check_parts:
+            acc.finish()
+            got = acc.get()
+            assert (np.diff(got["kmer_lo"].astype(np.int64)) > 0).all()
+            assert int(got["kmer_lo"].min()) >> 54 == p and int(got["kmer_lo"].max()) >> 54 == p   # partition id bits
+            starts = np.concatenate([[0, rows - 2048], rng.integers(0, rows - 2048, 6)])
+            replay_windows(K, oracle, p, rows, nc, nk, 1, tot, got, starts)
+    assert total == 10_000_000_000 and n_sig == n_ctrl + n_case == sum(per_part)
+    assert 0.5e-4 < n_sig / total < 5e-4
+    assert max(per_part) < 1.5 * (n_sig / parts) and min(per_part) > 0.6 * (n_sig / parts)     # partitions look alike
+
+
+def test_full_size_config4_k63_50v50(K, oracle):
+    """BASELINE.json configs[3]: k = 63 (two 64-bit limbs), 50 + 50 samples, 4-byte counts."""
+    nc, nk, rows = 50, 50, 16_000_000
+    mat = K.synth_matrix(SEED, 3, rows, nc, nk, 4, K.LAYOUT_TILED, kmer_limbs=2)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(rows // 200, kmer_limbs=2)
+    obs = K.diff_observer(model, acc, THR)
+    obs.process(mat)
+    ns = acc.finish()
+    c = acc.read_counters()
+    assert int(c[0]) == rows and ns == int(c[2]) + int(c[3]) and ns > 100
+    got = acc.get()
+    assert (np.diff(got["kmer_hi"].astype(np.int64)) > 0).all()      # 128-bit k-mers ascending (hi limb strictly)
+    assert int(c[5]) > 0                                             # 50-sample sums do leave the 10000-entry table
+    rng = np.random.default_rng(4)
+    replay_windows(K, oracle, 3, rows, nc, nk, 2, tot, got, np.concatenate([[0, rows - 2048], rng.integers(0, rows - 2048, 10)]))
+
+
+def test_full_size_config5_popstrat_100v100(K, oracle):
+    """BASELINE.json configs[4]: 100 + 100 samples, k = 31, population-stratification re-test on."""
+    nc, nk, rows, npc = 100, 100, 4_000_000, 2
+    mat = K.synth_matrix(SEED, 1, rows, nc, nk, 4, K.LAYOUT_TILED)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(rows // 100)
+    K.diff_observer(model, acc, THR).process(mat)
+    ns = acc.finish()
+    got = acc.get()
+    assert ns > 100
+    rng = np.random.default_rng(8)
+    Z = rng.normal(0, 0.1, size=(nc + nk, 10))
+    pop = K.pop_strat_corrector(nc, nk, tot[:nc], tot[nc:], npc, Z)
+    counts = K.gather_counts(mat, acc.bufs["row"], ns)
+    p_dev = pop.apply(counts, ns)
+    assert ((p_dev >= 0) & (p_dev <= 1)).all()
+    # stage 1 windows + stage 2 on a sample of the survivors
+    replay_windows(K, oracle, 1, rows, nc, nk, 1, tot, got, np.concatenate([[0], rng.integers(0, rows - 2048, 6)]))
+    alt, null_model, totals_o, y = oracle.popstrat_setup(nc, nk, tot[:nc], tot[nc:], Z, npc, True)
+    pick = rng.choice(ns, size=min(ns, 150), replace=False)
+    rows_pick = got["row"].astype(np.int64)[pick]
+    host = np.stack([oracle.synth_rows(SEED, 1, int(r), 1, nc, nk, 4)[0][0] for r in rows_pick])
+    p_ref = oracle.popstrat_pvalues(alt, null_model, totals_o, y, host)
+    assert np.abs(p_dev[pick] - p_ref).max() <= P_ABS_TOL
+    nz = p_ref > 1e-300
+    assert (np.abs(p_dev[pick][nz] - p_ref[nz]) / p_ref[nz]).max(initial=0.0) <= 1e-7
+    # the re-tested p-values feed the corrector like the Poisson ones do
+    keep, n_ctrl, n_case = K.aggregate("benjamini", 0.05, rows, pop.last_pvalues, acc.bufs["sign"], ns)
+    assert keep.tolist() == oracle.aggregate(2, 0.05, rows, p_dev).tolist()
