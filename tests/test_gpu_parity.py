@@ -335,10 +335,13 @@ def test_gather_counts_of_survivors(K, oracle):
 
 
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["fast", "sort"])
 @pytest.mark.parametrize("layout_name", ["tiled", "soa", "rows"])
 @pytest.mark.parametrize("count_bytes", [4, 2, 1])
-def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes):
-    """km::KmerMerger as driven at merge.hpp:265-289: device merge == oracle merge."""
+def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes, path, monkeypatch):
+    """km::KmerMerger as driven at merge.hpp:265-289: device merge == oracle merge, through
+    both device implementations (bucketed LDS merge, sort-based)."""
+    monkeypatch.setenv("KMD_MERGE_PATH", path)
     rng = np.random.default_rng(17)
     universe = np.unique(rng.integers(0, 1 << 62, 60000, dtype=np.uint64))
     S = 9
@@ -357,6 +360,35 @@ def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes):
     # empty partition
     e = K.merge_partition([(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * 3)
     assert e.n_rows == 0
+
+
+def test_merge_partition_clustered_keys_and_extremes(K, oracle, monkeypatch):
+    """Heavily clustered keys overflow a bucket of the LDS merge: it must hand over to the sort
+    path and still be exact; the all-ones key (k = 32, GGG...G) is a legal k-mer."""
+    rng = np.random.default_rng(31)
+    cluster = np.unique(rng.integers(1 << 40, (1 << 40) + 300000, 200000, dtype=np.uint64))
+    spread = np.unique(rng.integers(0, 1 << 63, 50000, dtype=np.uint64))
+    universe = np.unique(np.concatenate([cluster, spread, np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
+    streams = []
+    for s in range(5):
+        pick = rng.random(len(universe)) < 0.5
+        pick[-1] = s in (1, 3)                                    # the all-ones key in two samples
+        streams.append((universe[pick], rng.integers(1, 9, pick.sum()).astype(np.uint32)))
+    want, kmers = oracle.merge_partition(streams)
+    for path in ("fast", "sort"):
+        monkeypatch.setenv("KMD_MERGE_PATH", path)
+        m = K.merge_partition(streams)
+        assert m.n_rows == want.shape[0] and (m.to_host() == want).all() and (m.kmers_to_host()[0] == kmers).all()
+    # spread keys only, including the extremes: served by the LDS merge itself
+    uni2 = np.unique(np.concatenate([spread, np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
+    st2 = [(uni2[rng.random(len(uni2)) < 0.6], None) for _ in range(4)]
+    st2 = [(k, rng.integers(1, 9, len(k)).astype(np.uint32)) for k, _ in st2]
+    st2[0] = (np.concatenate([st2[0][0][st2[0][0] != 2 ** 64 - 1], [np.uint64(2 ** 64 - 1)]]).astype(np.uint64),
+              np.concatenate([st2[0][1][st2[0][0] != 2 ** 64 - 1], [7]]).astype(np.uint32))
+    want2, k2 = oracle.merge_partition(st2)
+    monkeypatch.setenv("KMD_MERGE_PATH", "fast")
+    m2 = K.merge_partition(st2)
+    assert m2.n_rows == want2.shape[0] and (m2.to_host() == want2).all() and (m2.kmers_to_host()[0] == k2).all()
 
 
 def test_merge_partition_two_limb_kmers(K, oracle):
