@@ -168,6 +168,21 @@ int kmd_correct(int correction, double threshold, uint64_t total_kmers,
                 const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
                 uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream);
 
+/* Sharded BH / Holm (one process per GPU): the ascending walk over ALL ranks' survivors is
+ * reproduced from (1) a 4096-bin log-spaced histogram of the p-values (top 12 magnitude bits of
+ * the double; all-gathered / summed over ranks, 32 KB each), (2) the first bin the walk cannot
+ * accept wholesale, and (3) the exact walk over the p-values of that bin and the ones after it
+ * only, started at the rank the earlier bins already consumed (kmdiff_amd/dist.py). */
+int kmd_pvalue_histogram(const double* d_pvalue, size_t n, uint64_t* d_hist /* [4096], accumulates */,
+                         void* stream);
+int kmd_correct_critical_bin(int correction, double threshold, uint64_t total_kmers,
+                             const uint64_t* d_hist, uint32_t* bin, uint64_t* n_before, void* stream);
+/* kmd_correct with `rank_offset` applies already made (BH: m_rank starts at 1 + offset,
+ * Holm: m_total at N - offset; src/corrector.cpp:27-35,68-71).  Synchronous. */
+int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers, uint64_t rank_offset,
+                          const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
+                          uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream);
+
 /* ---- stage 0: k-way merge of one partition -------------------------------------------------
  * Replaces km::KmerMerger<KSIZE,CMAX>(paths, ab_mins = 1.., k, r_min = 1, save_if = 0).merge(obs)
  * as kmdiff drives it (include/kmdiff/merge.hpp:265-289; kmtricks is an un-vendored

@@ -66,6 +66,10 @@ SIGNATURES = {
     "kmd_survivors_gather_counts": (_i, [C.POINTER(Tile), _i, _vp, _sz, _vp, _vp]),
     "kmd_correct": (_i, [_i, _d, _u64, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
                          C.POINTER(_u64), _vp]),
+    "kmd_pvalue_histogram": (_i, [_vp, _sz, _vp, _vp]),
+    "kmd_correct_critical_bin": (_i, [_i, _d, _u64, _vp, C.POINTER(C.c_uint32), C.POINTER(_u64), _vp]),
+    "kmd_correct_from_rank": (_i, [_i, _d, _u64, _u64, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
+                                   C.POINTER(_u64), _vp]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_popstrat_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i]),
     "kmd_popstrat_destroy": (_i, [_vp]),

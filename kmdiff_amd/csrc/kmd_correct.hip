@@ -24,6 +24,7 @@ struct corr_params
   uint64_t total;
   double bonf_cut;    // threshold / total             (corrector.cpp:11)
   double sidak_cut;   // 1 - pow(1 - threshold, 1/N)   (corrector.cpp:52)
+  uint64_t rank0;     // BH / Holm: survivors already accepted before this list (sharded runs)
 };
 
 // stateless correctors: one predicate per survivor (aggregator.hpp:146-166)
@@ -63,10 +64,11 @@ __global__ void __launch_bounds__(256) k_first_reject(corr_params C, const uint6
   if (j >= n) return;
   const double pv = __longlong_as_double((long long)p_sorted_bits[j]);
   bool ok;
+  const uint64_t r = C.rank0 + j;                      // applies made before this one
   if (C.type == KMD_CORR_BENJAMINI)
-    ok = pv < (((double)(j + 1) / (double)C.total) * C.threshold);
+    ok = pv < (((double)(r + 1) / (double)C.total) * C.threshold);
   else
-    ok = pv < (C.threshold / (double)(C.total - j));
+    ok = pv < (C.threshold / (double)(C.total - r));
   if (!ok) atomicMin(first_reject, (unsigned long long)j);
 }
 
@@ -122,6 +124,40 @@ __global__ void __launch_bounds__(256) k_gather_counts(const CT* __restrict__ co
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
+// 4096 log-spaced bins: the top 12 magnitude bits of the double (11 exponent bits + 1 mantissa
+// bit); monotone in p for p >= 0
+__global__ void __launch_bounds__(256) k_p_histogram(const double* __restrict__ p, size_t n,
+                                                     unsigned long long* __restrict__ hist)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(p[i]);
+  atomicAdd(&hist[(bits >> 51) & 4095ull], 1ull);
+}
+
+// First bin that is NOT accepted wholesale by the ascending walk of BH / Holm: a bin whose
+// upper bound is <= the cut of the first rank it can occupy passes entirely, whatever the order
+// inside it (the cut grows with the rank).  out[0] = bin, out[1] = survivors before it.
+__global__ void k_critical_bin(corr_params C, const unsigned long long* __restrict__ hist,
+                               unsigned long long* __restrict__ out)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long before = 0;
+  unsigned int b = 0;
+  for (; b < 4096; ++b)
+  {
+    const unsigned long long c = hist[b];
+    if (c == 0) continue;
+    const double hi = __longlong_as_double((long long)(((unsigned long long)b + 1ull) << 51));   // exclusive upper bound
+    const unsigned long long r = C.rank0 + before;              // applies made before the bin's first element
+    const double cut = (C.type == KMD_CORR_BENJAMINI) ? (((double)(r + 1) / (double)C.total) * C.threshold)
+                                                      : (C.threshold / (double)(C.total - r));
+    if (!(hi <= cut)) break;
+    before += c;
+  }
+  out[0] = b; out[1] = before;
+}
+
 // order[] = permutation sorting keys ascending (stable); keys_sorted optional output
 int sort_order_u64(const uint64_t* d_keys, size_t n, uint64_t* d_keys_sorted, uint32_t* d_order,
                    hipStream_t st)
@@ -168,6 +204,44 @@ int kmd_correct(int correction, double threshold, uint64_t total_kmers,
                 const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
                 uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream)
 {
+  return kmd_correct_from_rank(correction, threshold, total_kmers, 0, d_pvalue, d_sign, n, d_keep,
+                               n_kept, n_control, n_case, stream);
+}
+
+int kmd_pvalue_histogram(const double* d_pvalue, size_t n, uint64_t* d_hist, void* stream)
+{
+  KMD_REQUIRE(d_hist && (n == 0 || d_pvalue), "kmd_pvalue_histogram: NULL");
+  if (n == 0) return KMD_OK;
+  hipLaunchKernelGGL(k_p_histogram, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_pvalue, n,
+                     reinterpret_cast<unsigned long long*>(d_hist));
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+int kmd_correct_critical_bin(int correction, double threshold, uint64_t total_kmers, const uint64_t* d_hist,
+                             uint32_t* bin, uint64_t* n_before, void* stream)
+{
+  KMD_REQUIRE(correction == KMD_CORR_BENJAMINI || correction == KMD_CORR_HOLM, "kmd_correct_critical_bin: BH or Holm only");
+  KMD_REQUIRE(d_hist && bin && n_before, "kmd_correct_critical_bin: NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  corr_params C;
+  C.type = correction; C.threshold = threshold; C.total = total_kmers; C.bonf_cut = 0; C.sidak_cut = 0; C.rank0 = 0;
+  unsigned long long* d_out = nullptr;
+  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_out), 16));
+  hipLaunchKernelGGL(k_critical_bin, dim3(1), dim3(64), 0, st, C, reinterpret_cast<const unsigned long long*>(d_hist), d_out);
+  unsigned long long h[2] = { 0, 0 };
+  hipError_t e = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return kmd::hip_fail(e, "kmd_correct_critical_bin", __FILE__, __LINE__);
+  *bin = (uint32_t)h[0]; *n_before = h[1];
+  return KMD_OK;
+}
+
+int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers, uint64_t rank_offset,
+                          const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
+                          uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream)
+{
   KMD_REQUIRE(correction >= KMD_CORR_NOTHING && correction <= KMD_CORR_HOLM, "kmd_correct: bad correction type");
   KMD_REQUIRE(n == 0 || d_pvalue, "kmd_correct: NULL p-values");
   KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_correct: too many survivors");
@@ -179,6 +253,7 @@ int kmd_correct(int correction, double threshold, uint64_t total_kmers,
     C.type = correction; C.threshold = threshold; C.total = total_kmers;
     C.bonf_cut = threshold / (double)total_kmers;                       // corrector.cpp:11
     C.sidak_cut = 1 - std::pow(1 - threshold, 1.0 / (double)total_kmers); // corrector.cpp:52
+    C.rank0 = rank_offset;
     unsigned long long* d_t = nullptr;       // [0] kept, [1] kept controls, [2] first reject
     KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_t), 3 * sizeof(unsigned long long)));
     hipError_t e = hipMemcpyAsync(d_t, h_t, sizeof h_t, hipMemcpyHostToDevice, st);

@@ -11,9 +11,10 @@ exactly one partition), so here:
   * after stage 1, ONE all-reduce of the four counters gives N = total_kmers, which every
     corrector needs (cmd/diff.hpp:249);
   * Bonferroni / Sidak / threshold then filter locally;
-  * Benjamini-Hochberg / Holm need the global ascending-p order: an all-gather of the
-    survivors' p-values (KBs-MBs, latency-bound on xGMI), after which every rank runs the
-    same device correction (kmd_correct) over the global list and keeps its own slice.
+  * Benjamini-Hochberg / Holm need the global ascending-p order: an all-gather of the ranks'
+    4096-bin p-value histograms (32 KB each) locates the first bin the walk cannot accept
+    wholesale; only the p-values from that bin on are all-gathered and walked exactly, on
+    every rank, by the device corrector (kmd_correct_from_rank).
 
 Collectives go through torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU
 tests).  Tensors are CUDA tensors under nccl and CPU tensors under gloo; nothing here
@@ -91,10 +92,57 @@ def barrier():
         dist.barrier()
 
 
+N_HIST_BINS = 4096
+
+
+def pvalue_histogram(K, p_t):
+    """4096-bin log-spaced histogram (device) of a CUDA float64 tensor of p-values."""
+    hist = torch.zeros(N_HIST_BINS, dtype=torch.int64, device=p_t.device)
+    if p_t.numel():
+        K._native.check(K._native.lib().kmd_pvalue_histogram(p_t.data_ptr(), int(p_t.numel()), hist.data_ptr(), None),
+                        "kmd_pvalue_histogram")
+    torch.cuda.synchronize()
+    return hist
+
+
+def critical_bin(K, correction, threshold, total_kmers, hist_global):
+    """(first bin the BH/Holm walk cannot accept wholesale, survivors before it) -- device."""
+    import ctypes as C
+    b, before = C.c_uint32(0), C.c_uint64(0)
+    K._native.check(K._native.lib().kmd_correct_critical_bin(int(correction), float(threshold), int(total_kmers),
+                                                             hist_global.data_ptr(), C.byref(b), C.byref(before), None),
+                    "kmd_correct_critical_bin")
+    return int(b.value), int(before.value)
+
+
+def tail_of(p_t, first_bin):
+    """Indices of the p-values whose histogram bin is >= first_bin (device ops)."""
+    bins = (p_t.view(torch.int64) >> 51) & (N_HIST_BINS - 1)
+    return torch.nonzero(bins >= first_bin, as_tuple=False).flatten()
+
+
+def walk_tail(K, correction, threshold, total_kmers, rank_offset, p_all, s_all):
+    """The exact ascending walk (kmd_correct_from_rank) over the gathered tail."""
+    import ctypes as C
+    n = int(p_all.numel())
+    keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=p_all.device)
+    nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    K._native.check(K._native.lib().kmd_correct_from_rank(
+        int(correction), float(threshold), int(total_kmers), int(rank_offset), p_all.data_ptr() if n else None,
+        s_all.data_ptr() if n else None, n, keep.data_ptr(), C.byref(nk), C.byref(nc), C.byref(nca), None),
+        "kmd_correct_from_rank")
+    return keep[:n]
+
+
 def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_buf, n_local):
     """Stage 3 across ranks.  Returns (keep mask for the local survivors, global counters,
-    (n_control, n_case) kept locally)."""
-    import ctypes as C
+    (n_control, n_case) kept locally).
+
+    BH / Holm walk the survivors of ALL ranks in ascending p and stop at the first rejection
+    (aggregator.hpp:286-310).  Reproduced without moving every survivor: all-gather the 32 KB
+    p-value histograms, find the first bin the walk cannot accept wholesale, all-gather only
+    the p-values from that bin on, and walk those exactly on every rank (same list, same
+    order: rank-major, then local order) starting at the rank the earlier bins consumed."""
     if isinstance(correction, str):
         correction = K.CORRECTION_BY_NAME[correction.lower()]
     g = allreduce_counters(local_counters)
@@ -103,7 +151,6 @@ def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_b
     if world == 1 or correction not in (K.CORR_BENJAMINI, K.CORR_HOLM):
         keep, n_ctrl, n_case = K.aggregate(correction, threshold, total_kmers, pvalue_buf, sign_buf, n_local)
         return keep, g, (n_ctrl, n_case)
-    # BH / Holm: global ascending-p walk (aggregator.hpp:286-310) over all ranks' survivors
     dev = _dev()
     if dev.type != "cuda":
         raise RuntimeError("correct_sharded(BH/Holm) needs the HIP library: no CPU decision path")
@@ -113,17 +160,20 @@ def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_b
     else:
         p_local = torch.empty(0, dtype=torch.float64, device=dev)
         s_local = torch.empty(0, dtype=torch.int32, device=dev)
-    p_all, offs = allgather_varlen(p_local)
-    s_all, _ = allgather_varlen(s_local)
-    rank = dist.get_rank()
+    hist = pvalue_histogram(K, p_local)
+    hists = [torch.empty_like(hist) for _ in range(world)]
+    dist.all_gather(hists, hist)                                   # per-rank histograms over xGMI
+    hist_global = torch.stack(hists).sum(dim=0).contiguous()
+    first_bin, before = critical_bin(K, correction, threshold, total_kmers, hist_global)
+    idx = tail_of(p_local, first_bin)
+    p_all, offs = allgather_varlen(p_local[idx].contiguous())
+    s_all, _ = allgather_varlen(s_local[idx].contiguous())
     torch.cuda.synchronize()
-    keep_all = torch.empty(max(int(p_all.numel()), 1), dtype=torch.uint8, device=dev)
-    nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-    K._native.check(K._native.lib().kmd_correct(
-        int(correction), float(threshold), total_kmers, p_all.data_ptr() if p_all.numel() else None,
-        s_all.data_ptr() if p_all.numel() else None, int(p_all.numel()), keep_all.data_ptr(),
-        C.byref(nk), C.byref(nc), C.byref(nca), None), "kmd_correct")
-    keep = keep_all[offs[rank]:offs[rank + 1]].cpu().numpy()
+    keep_tail = walk_tail(K, correction, threshold, total_kmers, before, p_all, s_all)
+    rank = dist.get_rank()
+    keep_t = torch.ones(n_local, dtype=torch.uint8, device=dev)    # bins before the critical one: accepted
+    keep_t[idx] = keep_tail[offs[rank]:offs[rank + 1]]
+    keep = keep_t.cpu().numpy()
     mine_sign = s_local.cpu().numpy()
     n_ctrl = int(((mine_sign == 0) & (keep == 1)).sum())
     return keep, g, (n_ctrl, int(keep.sum()) - n_ctrl)

@@ -297,6 +297,50 @@ def test_correction_matches_oracle(K, oracle, name):
     assert len(keep) == 0
 
 
+@pytest.mark.parametrize("name", ["benjamini", "holm"])
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_sharded_bh_holm_equals_single_list(K, name, n_ranks):
+    """The histogram exchange of kmdiff_amd/dist.py, emulated with virtual ranks on one GPU
+    (the collectives replaced by local sums / concatenations): identical decisions to
+    kmd_correct over the whole list in rank-major order."""
+    import torch
+    from kmdiff_amd import dist as D
+    n, nc, nk = 400_000, 4, 4
+    mat = K.synth_matrix(SEED, 14, n, nc, nk, 4, K.LAYOUT_TILED)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(n)
+    K.diff_observer(model, acc, 2e-3).process(mat)
+    ns = acc.finish()
+    assert ns > 500
+    ctype = K.CORRECTION_BY_NAME[name]
+    dev = torch.device("cuda", 0)
+    p_all = torch.as_tensor(D._CudaView(acc.bufs["pvalue"].ptr, ns, "<f8"), device=dev).clone()
+    s_all = torch.as_tensor(D._CudaView(acc.bufs["sign"].ptr, ns, "<i4"), device=dev).clone()
+    p_all[5] = p_all[900]                                   # ties across ranks
+    cuts = [0] + sorted(np.random.default_rng(n_ranks).choice(np.arange(1, ns), n_ranks - 1, replace=False).tolist()) + [ns]
+    for total in (n, 40 * n):                                # one late, one early stopping point
+        want, _, _ = K.aggregate(name, 0.05, total, K.DeviceBuffer.from_host(p_all.cpu().numpy()),
+                                 K.DeviceBuffer.from_host(s_all.cpu().numpy()), ns)
+        parts = [(p_all[a:b], s_all[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        hist = sum(D.pvalue_histogram(K, p) for p, _ in parts)          # "all-gather + sum"
+        first_bin, before = D.critical_bin(K, ctype, 0.05, total, hist.contiguous())
+        idxs = [D.tail_of(p, first_bin) for p, _ in parts]
+        tail_p = torch.cat([p[i] for (p, _), i in zip(parts, idxs)]).contiguous()   # "all-gather" of the tails
+        tail_s = torch.cat([s[i] for (_, s), i in zip(parts, idxs)]).contiguous()
+        keep_tail = D.walk_tail(K, ctype, 0.05, total, before, tail_p, tail_s)
+        got, o = [], 0
+        for (p, _), i in zip(parts, idxs):
+            k = torch.ones(p.numel(), dtype=torch.uint8, device=dev)
+            k[i] = keep_tail[o:o + i.numel()]
+            o += i.numel()
+            got.append(k)
+        got = torch.cat(got).cpu().numpy()
+        assert got.tolist() == want.tolist()
+        assert before + int(keep_tail.sum()) == int(want.sum())
+        assert int(tail_p.numel()) < ns                      # the exchange moved only a tail
+
+
 def test_correction_golden_streams(K, golden_dir):
     """The reference's own corrector decisions (golden) on ascending streams: for BH/Holm the
     kept set is the prefix before the first rejection; for the stateless ones apply()."""
