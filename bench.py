@@ -13,8 +13,9 @@ all-gather) and the significance correction (stage 3) run inside the timed regio
 Sharding: partition p belongs to rank p % N (weak scaling: every rank does K steps).
 
 The JSON line also carries
-  roofline     : algorithmic bytes (168 B/row) / average kernel duration, measured with HIP
-                 events around each launch, against the 8 TB/s HBM3E peak;
+  roofline     : algorithmic bytes (168 B/row) / average kernel duration, measured with one HIP
+                 event pair around the K back-to-back launches (duration / K), against the
+                 8 TB/s HBM3E peak;
   cpu_baseline : the reference's own arithmetic (oracle/_ref, kind "reference") or the C
                  restatement (kind "port") on the host cores, on a bounded sample of the same
                  workload, tail function evaluated for every row as the reference does.
@@ -132,20 +133,24 @@ def main():
 
     for i in range(args.warmup):
         obs.process(mats[i % n_res])
+    if args.warmup:
+        # warm the end-of-job path too (first-use cost of the sort / correction kernels)
+        n_w = acc.finish(sort=True)
+        D.correct_sharded(K, args.correction, THRESHOLD, acc.read_counters(), acc.bufs["pvalue"], acc.bufs["sign"], n_w)
     K._native.check(lib.kmd_stream_sync(None))
     acc.counters.zero()
     K._native.check(lib.kmd_stream_sync(None))
 
-    ev = [(K.Event(), K.Event()) for _ in range(args.steps)]
+    ev0, ev1 = K.Event(), K.Event()       # one HIP-event pair around the K launches (same stream)
 
     # ---- timed region: exactly K steps + the job's exchange and correction -------------------
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        ev[i][0].record()
         obs.process(mats[i % n_res])
-        ev[i][1].record()
+    ev1.record()
     n_surv = acc.finish(sort=True)
     keep, g_counters, (n_ctrl, n_case) = D.correct_sharded(K, args.correction, THRESHOLD, acc.read_counters(),
                                                           acc.bufs["pvalue"], acc.bufs["sign"], n_surv)
@@ -154,8 +159,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed)
 
-    kernel_ms = [a.elapsed_ms(b) for a, b in ev]
-    avg_kernel_ms = D.max_over_ranks(sum(kernel_ms) / len(kernel_ms))
+    avg_kernel_ms = D.max_over_ranks(ev0.elapsed_ms(ev1) / args.steps)    # back-to-back launches
     kept = D.allreduce_counters([int(keep.sum()), n_ctrl, n_case])
 
     if rank == 0:

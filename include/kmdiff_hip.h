@@ -69,6 +69,9 @@ int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream);
 int kmd_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream);
 int kmd_memset(void* d_dst, int value, size_t bytes, void* stream);
 int kmd_stream_sync(void* stream);
+/* The library parks its internal scratch buffers (sort keys, flags, tallies) instead of
+ * returning them to the driver after every call; this frees the parked ones. */
+int kmd_release_cache(void);
 /* elapsed milliseconds of `fn`-independent timing helpers: HIP events on `stream` */
 int kmd_event_create(void** ev);
 int kmd_event_destroy(void* ev);

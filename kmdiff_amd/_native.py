@@ -51,6 +51,7 @@ SIGNATURES = {
     "kmd_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "kmd_memset": (_i, [_vp, _i, _sz, _vp]),
     "kmd_stream_sync": (_i, [_vp]),
+    "kmd_release_cache": (_i, []),
     "kmd_event_create": (_i, [C.POINTER(_vp)]),
     "kmd_event_destroy": (_i, [_vp]),
     "kmd_event_record": (_i, [_vp, _vp]),

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -17,6 +19,73 @@ thread_local std::string g_last_error;
 }
 
 void kmd::set_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+struct scratch_cache
+{
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> parked;      // (device, size class) -> block
+  std::map<void*, std::pair<int, size_t>> live;             // block -> (device, size class)
+  size_t parked_bytes = 0;
+};
+scratch_cache& cache() { static scratch_cache c; return c; }
+constexpr size_t kMaxParked = 8ull << 30;                   // beyond this, free for real
+}
+
+hipError_t kmd::scratch_alloc(void** p, size_t bytes)
+{
+  size_t cls = 256;
+  while (cls < bytes) cls <<= 1;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  scratch_cache& c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.parked.find({ dev, cls });
+    if (it != c.parked.end())
+    {
+      *p = it->second;
+      c.parked.erase(it);
+      c.parked_bytes -= cls;
+      c.live[*p] = { dev, cls };
+      return hipSuccess;
+    }
+  }
+  e = hipMalloc(p, cls);
+  if (e != hipSuccess)
+  {
+    kmd::scratch_release_all();                              // give parked memory back and retry once
+    e = hipMalloc(p, cls);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lock(c.mu);
+  c.live[*p] = { dev, cls };
+  return hipSuccess;
+}
+
+void kmd::scratch_free(void* p)
+{
+  if (!p) return;
+  scratch_cache& c = cache();
+  std::unique_lock<std::mutex> lock(c.mu);
+  auto it = c.live.find(p);
+  if (it == c.live.end()) { lock.unlock(); (void)hipFree(p); return; }
+  const auto key = it->second;
+  c.live.erase(it);
+  if (c.parked_bytes + key.second > kMaxParked) { lock.unlock(); (void)hipFree(p); return; }
+  c.parked.insert({ key, p });
+  c.parked_bytes += key.second;
+}
+
+void kmd::scratch_release_all()
+{
+  scratch_cache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  for (auto& kv : c.parked) (void)hipFree(kv.second);
+  c.parked.clear();
+  c.parked_bytes = 0;
+}
 
 int kmd::hip_fail(hipError_t e, const char* what, const char* file, int line)
 {
@@ -95,6 +164,7 @@ int kmd_memset(void* d_dst, int value, size_t bytes, void* stream)
   KMD_HIP(hipMemsetAsync(d_dst, value, bytes, static_cast<hipStream_t>(stream)));
   return KMD_OK;
 }
+int kmd_release_cache(void) { kmd::scratch_release_all(); return KMD_OK; }
 int kmd_stream_sync(void* stream) { KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return KMD_OK; }
 
 int kmd_event_create(void** ev)

@@ -167,21 +167,21 @@ int sort_order_u64(const uint64_t* d_keys, size_t n, uint64_t* d_keys_sorted, ui
   uint64_t* d_ks = d_keys_sorted;
   bool own_ks = false;
   size_t tmp_bytes = 0;
-  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_iota), n * sizeof(uint32_t)));
+  KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_iota), n * sizeof(uint32_t)));
   if (!d_ks)
   {
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_ks), n * sizeof(uint64_t));
-    if (e != hipSuccess) { (void)hipFree(d_iota); return kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    hipError_t e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_ks), n * sizeof(uint64_t));
+    if (e != hipSuccess) { kmd::scratch_free(d_iota); return kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     own_ks = true;
   }
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(256), 0, st, d_iota, n);
   hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_ks, d_iota, d_order, n, 0, 64, st);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = kmd::scratch_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_ks, d_iota, d_order, n, 0, 64, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_iota);
-  if (d_tmp) (void)hipFree(d_tmp);
-  if (own_ks) (void)hipFree(d_ks);
+  kmd::scratch_free(d_iota);
+  if (d_tmp) kmd::scratch_free(d_tmp);
+  if (own_ks) kmd::scratch_free(d_ks);
   if (e != hipSuccess) return kmd::hip_fail(e, "radix sort", __FILE__, __LINE__);
   return KMD_OK;
 }
@@ -227,12 +227,12 @@ int kmd_correct_critical_bin(int correction, double threshold, uint64_t total_km
   corr_params C;
   C.type = correction; C.threshold = threshold; C.total = total_kmers; C.bonf_cut = 0; C.sidak_cut = 0; C.rank0 = 0;
   unsigned long long* d_out = nullptr;
-  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_out), 16));
+  KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_out), 16));
   hipLaunchKernelGGL(k_critical_bin, dim3(1), dim3(64), 0, st, C, reinterpret_cast<const unsigned long long*>(d_hist), d_out);
   unsigned long long h[2] = { 0, 0 };
   hipError_t e = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_out);
+  kmd::scratch_free(d_out);
   if (e != hipSuccess) return kmd::hip_fail(e, "kmd_correct_critical_bin", __FILE__, __LINE__);
   *bin = (uint32_t)h[0]; *n_before = h[1];
   return KMD_OK;
@@ -255,7 +255,7 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
     C.sidak_cut = 1 - std::pow(1 - threshold, 1.0 / (double)total_kmers); // corrector.cpp:52
     C.rank0 = rank_offset;
     unsigned long long* d_t = nullptr;       // [0] kept, [1] kept controls, [2] first reject
-    KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_t), 3 * sizeof(unsigned long long)));
+    KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_t), 3 * sizeof(unsigned long long)));
     hipError_t e = hipMemcpyAsync(d_t, h_t, sizeof h_t, hipMemcpyHostToDevice, st);
     int rc = KMD_OK;
     if (e != hipSuccess) rc = kmd::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
@@ -264,8 +264,8 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
       if (correction == KMD_CORR_BENJAMINI || correction == KMD_CORR_HOLM)      // aggregator.hpp:358-360
       {
         uint32_t* d_order = nullptr; uint64_t* d_ps = nullptr;
-        e = hipMalloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ps), n * sizeof(uint64_t));
+        e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t));
+        if (e == hipSuccess) e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_ps), n * sizeof(uint64_t));
         if (e != hipSuccess) rc = kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__);
         // p >= 0: the IEEE bit pattern orders like the value
         if (rc == KMD_OK) rc = sort_order_u64(reinterpret_cast<const uint64_t*>(d_pvalue), n, d_ps, d_order, st);
@@ -276,8 +276,8 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
           e = hipGetLastError();
           if (e != hipSuccess) rc = kmd::hip_fail(e, "launch", __FILE__, __LINE__);
         }
-        if (d_order) (void)hipFree(d_order);
-        if (d_ps) (void)hipFree(d_ps);
+        if (d_order) kmd::scratch_free(d_order);
+        if (d_ps) kmd::scratch_free(d_ps);
       }
       else
       {
@@ -292,7 +292,7 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) rc = kmd::hip_fail(e, "read tallies", __FILE__, __LINE__);
     }
-    (void)hipFree(d_t);
+    kmd::scratch_free(d_t);
     if (rc != KMD_OK) return rc;
   }
   if (n_kept) *n_kept = h_t[0];
@@ -309,9 +309,9 @@ int kmd_survivors_sort_by_row(const kmd_survivors* s, size_t n, void* stream)
   if (n < 2) return KMD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   uint32_t* d_order = nullptr; void* d_scratch = nullptr;
-  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t)));
-  hipError_t e = hipMalloc(&d_scratch, n * sizeof(uint64_t));
-  if (e != hipSuccess) { (void)hipFree(d_order); return kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+  KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t)));
+  hipError_t e = kmd::scratch_alloc(&d_scratch, n * sizeof(uint64_t));
+  if (e != hipSuccess) { kmd::scratch_free(d_order); return kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
   int rc = sort_order_u64(s->d_row, n, nullptr, d_order, st);
   if (rc == KMD_OK) rc = permute_in_place(s->d_row, d_order, n, d_scratch, st);
   if (rc == KMD_OK) rc = permute_in_place(s->d_kmer_lo, d_order, n, d_scratch, st);
@@ -321,7 +321,7 @@ int kmd_survivors_sort_by_row(const kmd_survivors* s, size_t n, void* stream)
   if (rc == KMD_OK) rc = permute_in_place(s->d_mean_control, d_order, n, d_scratch, st);
   if (rc == KMD_OK) rc = permute_in_place(s->d_mean_case, d_order, n, d_scratch, st);
   hipError_t e2 = hipStreamSynchronize(st);
-  (void)hipFree(d_order); (void)hipFree(d_scratch);
+  kmd::scratch_free(d_order); kmd::scratch_free(d_scratch);
   if (rc != KMD_OK) return rc;
   if (e2 != hipSuccess) return kmd::hip_fail(e2, "sync", __FILE__, __LINE__);
   return KMD_OK;

@@ -643,13 +643,16 @@ int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double 
   P.dT = m->dT; P.dTc = m->dTc; P.dTk = m->dTk; P.lg_half = m->lg_half;
   P.threshold = threshold;
   // the cut only depends on the threshold: cache the last one (hot loop calls reuse it)
-  if (!(m->cut_valid && m->cut_threshold_bits == kmd::bits_of(threshold)))
   {
-    m->cut_value = kmd::lr_cut_for_threshold(threshold, m->lg_half);
-    m->cut_threshold_bits = kmd::bits_of(threshold);
-    m->cut_valid = true;
+    std::lock_guard<std::mutex> lock(m->cut_mu);
+    if (!(m->cut_valid && m->cut_threshold_bits == kmd::bits_of(threshold)))
+    {
+      m->cut_value = kmd::lr_cut_for_threshold(threshold, m->lg_half);
+      m->cut_threshold_bits = kmd::bits_of(threshold);
+      m->cut_valid = true;
+    }
+    P.lr_cut = m->cut_value;
   }
-  P.lr_cut = m->cut_value;
   P.dTcTk = m->dTc * m->dTk;
   // pre-filter (finish_row): on when the rounding of the bound is far inside its factor-2
   // slack: cut not tiny, totals of comparable size, totals large enough that count sums up to

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 
 #include "../../include/kmdiff_hip.h"
@@ -21,7 +22,9 @@ struct kmd_model
   double* d_tab;            // device: pairs { lf[k], log(double(k)) }, k < lf_n (16 B each)
   int n_cu;                 // multiProcessorCount
   size_t lds_per_block_max; // sharedMemPerBlock
-  // cache of lr_cut_for_threshold (host-side constant of the last threshold used)
+  // cache of lr_cut_for_threshold (host-side constant of the last threshold used); one model
+  // is shared by all partition tasks in the reference (merge.hpp:418), so guard it
+  mutable std::mutex cut_mu;
   mutable bool cut_valid;
   mutable uint64_t cut_threshold_bits;
   mutable double cut_value;
@@ -60,6 +63,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define KMD_REQUIRE(cond, msg)                                              \
   do { if (!(cond)) { kmd::set_error(msg); return KMD_E_INVALID; } } while (0)
+
+// Caching device allocator for the library's internal scratch (sort buffers, flags, tallies):
+// hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the device, which showed up
+// as several ms per job in bench.py.  Blocks are rounded to a power of two and parked on free;
+// every internal user synchronises its stream before freeing.  kmd_release_cache() trims.
+hipError_t scratch_alloc(void** p, size_t bytes);
+void scratch_free(void* p);
+void scratch_release_all();
 
 // smallest LR at which igamc(1/2, LR) <= threshold, minus a safety margin; rows with a
 // likelihood ratio below it cannot pass `p <= threshold` (kmd_filter.hip).

@@ -88,11 +88,7 @@ KMD_HD double igamc_half(double x, double lg_half)
 
 // PoissonLikelihood::poisson_prob (include/kmdiff/model.hpp:133-138) with the table value
 // lf[k] already looked up.
-#ifdef KMD_FAKE_LOG   // dev only (ablation): wrong results
-#define KMD_LOG(x) ((x) * 0.5)
-#else
 #define KMD_LOG(x) ::log(x)
-#endif
 KMD_HD double poisson_prob(double k, double lambda, double lf_k)
 {
   if (lambda <= 0) return 0;

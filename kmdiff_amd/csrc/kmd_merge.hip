@@ -336,7 +336,7 @@ __global__ void k_key_range(const uint64_t* __restrict__ keys, const uint64_t* _
 struct scratch
 {
   void* p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  ~scratch() { for (void* q : p) if (q) (void)hipFree(q); }
+  ~scratch() { for (void* q : p) if (q) kmd::scratch_free(q); }
 };
 
 // The bucketed LDS merge.  *used = false (and nothing written) when the input does not suit
@@ -351,7 +351,7 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
   const bool dbg = std::getenv("KMD_DEBUG") != nullptr;
 #define KMD_DBG(msg) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[merge_fast] %s: %s\n", msg, hipGetErrorString(e_)); } } while (0)
   scratch sc;   // [0] device offsets + key range, [1] start table, [2] distinct, [3] row_base, [4] overflow, [5] temp
-  KMD_HIP(hipMalloc(&sc.p[0], ((size_t)S + 1 + 2) * 8));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[0], ((size_t)S + 1 + 2) * 8));
   uint64_t* d_offs = static_cast<uint64_t*>(sc.p[0]);
   uint64_t* d_range = d_offs + S + 1;
   KMD_HIP(hipMemcpyAsync(d_offs, offsets, ((size_t)S + 1) * 8, hipMemcpyHostToDevice, st));
@@ -372,10 +372,10 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
   if (dbg) std::fprintf(stderr, "[merge_fast] n=%zu kmin=%llu kmax=%llu shift=%u nb=%zu\n", n,
                         (unsigned long long)range[0], (unsigned long long)range[1], B.shift, nb);
 
-  KMD_HIP(hipMalloc(&sc.p[1], (nb + 1) * (size_t)S * 4));
-  KMD_HIP(hipMalloc(&sc.p[2], nb * 4));
-  KMD_HIP(hipMalloc(&sc.p[3], nb * 4));
-  KMD_HIP(hipMalloc(&sc.p[4], 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[1], (nb + 1) * (size_t)S * 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[2], nb * 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[3], nb * 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[4], 4));
   uint32_t* start = static_cast<uint32_t*>(sc.p[1]);
   uint32_t* distinct = static_cast<uint32_t*>(sc.p[2]);
   uint32_t* row_base = static_cast<uint32_t*>(sc.p[3]);
@@ -400,7 +400,7 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
   KMD_DBG("pass2");
   size_t tmp = 0;
   KMD_HIP(rocprim::exclusive_scan(nullptr, tmp, distinct, row_base, 0u, nb, rocprim::plus<uint32_t>(), st));
-  KMD_HIP(hipMalloc(&sc.p[5], tmp ? tmp : 1));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[5], tmp ? tmp : 1));
   KMD_HIP(rocprim::exclusive_scan(sc.p[5], tmp, distinct, row_base, 0u, nb, rocprim::plus<uint32_t>(), st));
   uint32_t h[3] = { 0, 0, 0 };
   KMD_HIP(hipMemcpyAsync(&h[0], overflow, 4, hipMemcpyDeviceToHost, st));
@@ -467,11 +467,11 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
   }
 
   scratch sc;   // [0] vals, [1] keys sorted, [2] vals sorted, [3] flags, [4] ranks, [5] rocprim temp
-  KMD_HIP(hipMalloc(&sc.p[0], n * 8));
-  KMD_HIP(hipMalloc(&sc.p[1], n * 8));
-  KMD_HIP(hipMalloc(&sc.p[2], n * 8));
-  KMD_HIP(hipMalloc(&sc.p[3], n * 4));
-  KMD_HIP(hipMalloc(&sc.p[4], n * 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[0], n * 8));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[1], n * 8));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[2], n * 8));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[3], n * 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[4], n * 4));
   uint64_t* vals = static_cast<uint64_t*>(sc.p[0]);
   uint64_t* keys_s = static_cast<uint64_t*>(sc.p[1]);
   uint64_t* vals_s = static_cast<uint64_t*>(sc.p[2]);
@@ -494,7 +494,7 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
     KMD_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort32, d_kmers, keys_s, flag, rank, n, 0, 64, st));
   size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
   if (tmp_sort32 > tmp) tmp = tmp_sort32;
-  KMD_HIP(hipMalloc(&sc.p[5], tmp ? tmp : 1));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[5], tmp ? tmp : 1));
   if (!d_kmers_hi)
   {
     KMD_HIP(rocprim::radix_sort_pairs(sc.p[5], tmp_sort, d_kmers, keys_s, vals, vals_s, n, 0, 64, st));
@@ -503,10 +503,10 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
   {
     // 128-bit keys (32 < k <= 64): LSD order -- stable sort by the low limb carrying the
     // record index, then stable sort by the high limb; gather everything by the result
-    KMD_HIP(hipMalloc(&sc.p[6], n * 8));     // hi gathered by perm1, later lo gathered by perm
-    KMD_HIP(hipMalloc(&sc.p[7], n * 8));     // hi sorted
-    KMD_HIP(hipMalloc(&sc.p[8], n * 4));     // perm1
-    KMD_HIP(hipMalloc(&sc.p[9], n * 4));     // perm
+    KMD_HIP(kmd::scratch_alloc(&sc.p[6], n * 8));     // hi gathered by perm1, later lo gathered by perm
+    KMD_HIP(kmd::scratch_alloc(&sc.p[7], n * 8));     // hi sorted
+    KMD_HIP(kmd::scratch_alloc(&sc.p[8], n * 4));     // perm1
+    KMD_HIP(kmd::scratch_alloc(&sc.p[9], n * 4));     // perm
     uint64_t* hi_g = static_cast<uint64_t*>(sc.p[6]);
     uint64_t* hi_s = static_cast<uint64_t*>(sc.p[7]);
     uint32_t* perm1 = static_cast<uint32_t*>(sc.p[8]);

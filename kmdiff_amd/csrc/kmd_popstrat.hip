@@ -408,7 +408,7 @@ int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sampl
   {
     // [n][S] as gathered for KmerSign::m_counts_ratio -> sample-major so lanes read coalesced
     KMD_REQUIRE(ld == 0 || ld == (size_t)ps->n, "kmd_popstrat_apply: survivor-major counts must be dense [n][S]");
-    KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_t), n * (size_t)ps->n * sizeof(double)));
+    KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_t), n * (size_t)ps->n * sizeof(double)));
     const size_t total = n * (size_t)ps->n;
     hipLaunchKernelGGL(k_transpose_counts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_counts, n, ps->n, n, d_t);
     counts = d_t; ld = n;
@@ -433,7 +433,7 @@ int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sampl
   if (d_t)
   {
     hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(d_t);
+    kmd::scratch_free(d_t);
     if (e == hipSuccess) e = e2;
   }
   if (e != hipSuccess) return kmd::hip_fail(e, "kmd_popstrat_apply", __FILE__, __LINE__);

@@ -253,6 +253,26 @@ def test_bad_arguments_fail_loudly(K):
     assert rc == -1 and b"count_bytes" in K._native.lib().kmd_last_error()
 
 
+def test_random_shapes_fuzz(K, oracle):
+    """60 random (samples, rows, count width, layout, table size, threshold) combinations,
+    each checked row for row against the oracle."""
+    rng = np.random.default_rng(20261001)
+    layouts = [K.LAYOUT_SOA, K.LAYOUT_ROWS, K.LAYOUT_TILED]
+    for it in range(60):
+        nc, nk = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+        n = int(rng.integers(1, 9000))
+        cb = int(rng.choice([1, 2, 4]))
+        layout = layouts[int(rng.integers(0, 3))]
+        preload = int(rng.choice([0, 3, 40, 700, 10000]))
+        thr = float(rng.choice([1.0, 0.3, 1e-2, 1e-4, 5e-7, 1e-12]))
+        part = int(rng.integers(0, 256))
+        row0 = int(rng.integers(0, 10 ** 9))
+        mat = K.synth_matrix(SEED + it, part, n, nc, nk, cb, layout, row0=row0)
+        host, lo, _ = oracle.synth_rows(SEED + it, part, row0, n, nc, nk, cb)
+        assert (mat.to_host() == host).all()
+        check_against_oracle(K, oracle, mat, host, (lo, None), nc, nk, preload, thr)
+
+
 def test_two_tiles_equal_one_partition(K, oracle):
     """A partition streamed as two tiles (row_base) accumulates to the same survivors."""
     n, nc, nk = 100_000, 4, 4
