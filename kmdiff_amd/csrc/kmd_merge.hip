@@ -84,24 +84,27 @@ __global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ ke
 //   pass 1  k_bucket_starts : one streaming pass over the keys; because every stream is sorted,
 //           the first record of bucket j in stream s is where bucket(key) changes: a
 //           [bucket][sample] table of start offsets, no searching.
-//   pass 2  k_bucket_merge<false> : one wave per bucket inserts the bucket's keys (S short
-//           segments, <= kWaveCap records) into an LDS hash set -> number of distinct k-mers.
-//           (exclusive scan over buckets -> first row of every bucket)
-//   pass 3  k_bucket_merge<true>  : the same hash set again, distinct keys compacted and sorted
-//           in LDS (bitonic), k-mer column written, every record binary-searches its row and
-//           scatters its count into the zero-filled matrix.
+//   pass 2  k_bucket_merge : one WAVE per bucket inserts the bucket's keys (S short segments,
+//           <= kWaveCap records, kept in registers) into an LDS hash set -> number of distinct
+//           k-mers; the first row of the bucket comes from a decoupled look-back over the
+//           lower-numbered buckets' status words (single pass, persistent grid); distinct keys
+//           are compacted and bitonic-sorted in LDS, every record binary-searches its row, the
+//           bucket's d x S block of the matrix is assembled in LDS and written out whole.
 // Buckets are equal slices of [min key, max key]; a bucket holding more than kWaveCap records
 // (heavily clustered keys) raises a flag and the caller falls back to the sort-based path.
 constexpr uint64_t kEmpty = ~0ull;
 
-struct bucket_map { uint64_t kmin; uint32_t shift; uint32_t nb; };
+// bucket(key) = floor((key - kmin) * nb / (span + 1)) as a 64x64 -> high-64 multiply: equal
+// slices of the key range for ANY bucket count (a power-of-two slice width would make the
+// average bucket anything between 1x and 2x the target)
+struct bucket_map { uint64_t kmin; uint64_t mult; uint32_t nb; };
 
 __device__ __forceinline__ uint32_t bucket_of(const bucket_map& B, uint64_t key)
 {
-  return (uint32_t)((key - B.kmin) >> B.shift);
+  return (uint32_t)__umul64hi(key - B.kmin, B.mult);
 }
 
-// start[j * S + s] = index of the first record of stream s whose bucket is >= j   (j in [0, nb]);
+// start[s * (nb + 1) + j] (stream-major: the writes of a stream are consecutive) = index of the first record of stream s whose bucket is >= j   (j in [0, nb]);
 // one launch for all streams: blockIdx.y = stream, grid-stride over its records
 __global__ void __launch_bounds__(256) k_bucket_starts(const uint64_t* __restrict__ keys,
                                                        const uint64_t* __restrict__ offs, uint32_t S,
@@ -113,16 +116,35 @@ __global__ void __launch_bounds__(256) k_bucket_starts(const uint64_t* __restric
   {
     // empty stream: every bucket starts (and ends) at its offset
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j <= B.nb; j += (size_t)gridDim.x * blockDim.x)
-      start[j * S + s] = (uint32_t)begin;
+      start[(size_t)s * (B.nb + 1) + j] = (uint32_t)begin;
     return;
   }
   for (size_t i = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (size_t)gridDim.x * blockDim.x)
   {
     const uint32_t bi = bucket_of(B, keys[i]);
     const int64_t bprev = (i == begin) ? -1 : (int64_t)bucket_of(B, keys[i - 1]);
-    for (int64_t j = bprev + 1; j <= (int64_t)bi; ++j) start[(size_t)j * S + s] = (uint32_t)i;
+    for (int64_t j = bprev + 1; j <= (int64_t)bi; ++j) start[(size_t)s * (B.nb + 1) + (size_t)j] = (uint32_t)i;
     if (i == end - 1)
-      for (uint32_t j = bi + 1; j <= B.nb; ++j) start[(size_t)j * S + s] = (uint32_t)end;
+      for (uint32_t j = bi + 1; j <= B.nb; ++j) start[(size_t)s * (B.nb + 1) + j] = (uint32_t)end;
+  }
+}
+
+// [S][nb + 1] (what k_bucket_starts writes, coalesced) -> [nb + 1][S] (what a bucket reads: its S
+// start offsets in one contiguous span), 64 x 64 tiles through LDS
+__global__ void __launch_bounds__(256) k_transpose_starts(const uint32_t* __restrict__ sm, uint32_t S, uint32_t nb1,
+                                                          uint32_t* __restrict__ start)
+{
+  __shared__ uint32_t tile[64][65];
+  const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  for (uint32_t s0 = 0; s0 < S; s0 += 64)
+  {
+    for (uint32_t ss = ty; ss < 64; ss += 4)
+      if (s0 + ss < S && j0 + tx < nb1) tile[ss][tx] = sm[(size_t)(s0 + ss) * nb1 + j0 + tx];
+    __syncthreads();
+    for (uint32_t jj = ty; jj < 64; jj += 4)
+      if (s0 + tx < S && j0 + jj < nb1) start[(j0 + jj) * S + s0 + tx] = tile[tx][jj];
+    __syncthreads();
   }
 }
 
@@ -134,12 +156,11 @@ __device__ __forceinline__ uint32_t hash_slot(uint64_t k)
 
 // One WAVE per bucket: a bucket is small (~128 records in S short segments), so a workgroup
 // per bucket spends its time in barriers and dependent-load latency.  A wave needs no
-// workgroup barrier (its LDS operations execute in order), and 14 KB of LDS per wave keeps
-// ~10 buckets in flight per CU.
+// workgroup barrier (its LDS operations execute in order), and 8 KB of LDS per wave keeps
+// ~20 buckets in flight per CU: the kernel is bound by dependent-load latency per bucket.
 constexpr uint32_t kMaxFastSamples = 256;    // segment tables of one bucket live in LDS
-constexpr uint32_t kWaveCap = 512;           // records per bucket
-constexpr uint32_t kWaveSlots = 1024;        // hash slots
-constexpr int kWavesPerBlock = 2;
+// CAP = records a bucket may hold (hash slots = 2 CAP; the average bucket is CAP / 2, see
+// merge_fast), WPB = waves per workgroup: template parameters of the kernel, picked by sample count
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -150,31 +171,150 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool EMIT, typename CT>
+// Single-pass row numbering, two-level decoupled look-back.  A persistent grid keeps thousands of
+// buckets in flight in near lock-step, so a flat look-back would have to add up thousands of
+// "own count" words per bucket; instead buckets are grouped 64 at a time:
+//   status[j]        bit 63 = published, bits 31..0 = distinct keys of bucket j
+//   group[g].agg     bits 63..56 = buckets of group g that have published, bits 55..0 = their sum
+//                    (one atomicAdd per bucket: count and sum can never be seen out of step)
+//   group[g].base    bit 63 = published, bits 62..0 = rows in groups 0..g-1
+// The wave that owns a group's first bucket walks back over the earlier groups (64 per load) to the
+// nearest published base and publishes its own group's base; the other 63 buckets of the group
+// only read that one word plus the own counts of the group's earlier buckets.  One group per
+// 128-byte line, so the polling of the few dozen groups in flight spreads over the L2 channels.
+constexpr unsigned long long kStFlag = 1ull << 63, kStMask = kStFlag - 1;
+constexpr int kGroupShift = 56;
+constexpr unsigned long long kGroupSumMask = (1ull << kGroupShift) - 1;
+struct alignas(128) merge_group { unsigned long long agg, base, pad[14]; };
+
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x)
+{
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return __shfl(x, 0, 64);
+}
+
+__device__ __forceinline__ unsigned long long rows_before(const unsigned long long* status, merge_group* group,
+                                                          uint32_t j, uint32_t lane)
+{
+  const uint32_t g = j >> 6, r = j & 63;
+  unsigned long long base = 0;
+  if (r == 0)
+  {
+    // ---- group leader: earlier groups, nearest first
+    uint32_t pos = g;                                 // groups not yet accounted for: [0, pos)
+    while (pos > 0)
+    {
+      const bool valid = lane < pos;
+      unsigned long long bs = kStFlag, agg = 0;       // before group 0: base 0
+      if (valid)
+      {
+        // base of group h+1 = rows in groups 0..h: look it up one slot to the right
+        const uint32_t h = pos - 1 - lane;
+        bs = h + 1 < g ? __hip_atomic_load(&group[h + 1].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        agg = __hip_atomic_load(&group[h].agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const bool is_incl = (bs & kStFlag) != 0;       // rows in groups 0..h known
+      const bool is_full = (agg >> kGroupShift) == 64;
+      const unsigned long long m_none = __ballot(!is_incl && !is_full);
+      const unsigned long long m_incl = __ballot(is_incl);
+      const int first_none = m_none ? (__ffsll((long long)m_none) - 1) : 64;
+      const int first_incl = m_incl ? (__ffsll((long long)m_incl) - 1) : 64;
+      if (first_none < first_incl) { __builtin_amdgcn_s_sleep(2); continue; }   // a nearer group is not complete yet
+      unsigned long long x = 0;
+      if ((int)lane < first_incl) x = agg & kGroupSumMask;
+      else if ((int)lane == first_incl) x = bs & kStMask;
+      base += wave_sum64(x);
+      if (first_incl < 64) break;
+      pos = pos > 64 ? pos - 64 : 0;
+    }
+    if (lane == 0) __hip_atomic_store(&group[g].base, kStFlag | base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return base;
+  }
+  // ---- the group's base and the earlier buckets of the group
+  unsigned long long v = lane < r ? 0ull : kStFlag, bs = 0;
+  for (;;)
+  {
+    if ((v & kStFlag) == 0)
+      v = __hip_atomic_load(&status[(size_t)g * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((bs & kStFlag) == 0) bs = __hip_atomic_load(&group[g].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__ballot((v & kStFlag) == 0) == 0 && (bs & kStFlag) != 0) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  uint32_t own = lane < r ? (uint32_t)v : 0u;
+  for (int o = 32; o > 0; o >>= 1) own += __shfl_down(own, o, 64);
+  return (bs & kStMask) + (unsigned long long)__shfl(own, 0, 64);
+}
+
+// What stage A (count) of a bucket hands to its stage B (emit): the records (count, sample, row
+// within the bucket) stay in registers, the sorted distinct keys in one of the wave's two LDS
+// key buffers.
+template <int PER_LANE>
+struct bucket_state
+{
+  uint32_t j, n, d;
+  bool work;
+  uint32_t cnt_r[PER_LANE], smp_r[PER_LANE], row_r[PER_LANE];   // count, sample, row within the bucket
+};
+
+// One pass: every wave owns a bucket -- hash set, distinct count, sort (stage A); row number by
+// look-back, LDS block, write-out (stage B).  The two stages are software-pipelined: a wave runs
+// stage A of its NEXT bucket -- which publishes that bucket's distinct count -- before stage B of
+// the current one, so that by the time a bucket looks back, its predecessors' counts have been
+// out for a whole iteration and nobody waits for the slowest wave of the sweep.
+// The grid must be fully resident (persistent): a wave waits on the status words of
+// lower-numbered buckets, which are always being worked on by resident waves.
+template <typename CT, uint32_t kWaveCap, int kWavesPerBlock>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint64_t* __restrict__ keys,
                                                               const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ start, uint32_t S,
-                                                              uint32_t nb, uint32_t* __restrict__ distinct,
-                                                              const uint32_t* __restrict__ row_base,
-                                                              int layout, size_t ld, CT* __restrict__ matrix,
+                                                              uint32_t nb, unsigned long long* __restrict__ status,
+                                                              merge_group* __restrict__ group,
+                                                              int layout, size_t ld, size_t row_capacity,
+                                                              CT* __restrict__ matrix,
                                                               uint64_t* __restrict__ kmer_out,
                                                               uint32_t* __restrict__ overflow)
 {
+  constexpr uint32_t kWaveSlots = 2 * kWaveCap;
   __shared__ unsigned long long s_hash_all[kWavesPerBlock][kWaveSlots];
-  __shared__ unsigned long long s_keys_all[kWavesPerBlock][EMIT ? kWaveCap : 1];
-  __shared__ uint32_t s_beg_all[kWavesPerBlock][kMaxFastSamples];
-  __shared__ uint32_t s_pref_all[kWavesPerBlock][kMaxFastSamples + 1];
+  __shared__ unsigned long long s_keys_all[kWavesPerBlock][2][kWaveCap];
+  // segment tables while the records are loaded; afterwards the same memory holds the unsorted
+  // distinct keys and then the slot -> row table
+  __shared__ unsigned long long s_seg_all[kWavesPerBlock][kWaveCap + 2];
+  static_assert(sizeof(unsigned long long) * (kWaveCap + 2) >= sizeof(uint32_t) * (2 * kMaxFastSamples + 1), "segment tables");
+  static_assert(sizeof(unsigned long long) * kWaveCap >= sizeof(uint16_t) * kWaveSlots, "slot -> row table");
   constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  constexpr int kPerLane = kWaveCap / 64;               // records of a bucket held by one lane
+  using state_t = bucket_state<kPerLane>;
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned long long* s_hash = s_hash_all[w];
-  unsigned long long* s_keys = s_keys_all[w];
-  uint32_t* s_beg = s_beg_all[w];
-  uint32_t* pref = s_pref_all[w];
+  uint32_t* s_beg = reinterpret_cast<uint32_t*>(s_seg_all[w]);
+  uint32_t* pref = s_beg + kMaxFastSamples;
+  unsigned long long* s_tmp = s_seg_all[w];                          // unsorted distinct keys
+  uint16_t* s_rank = reinterpret_cast<uint16_t*>(s_seg_all[w]);      // hash slot -> row within the bucket
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t j_first = blockIdx.x * kWavesPerBlock + w;
+  if (j_first >= nb) return;
 
-  for (uint32_t j = blockIdx.x * kWavesPerBlock + w; j < nb; j += n_waves)
+  // segment bounds of the wave's first bucket; those of the next bucket are fetched while the
+  // current one is processed (one dependent global round trip less per bucket)
+  uint32_t nb_beg[4] = { 0, 0, 0, 0 }, nb_end[4] = { 0, 0, 0, 0 };
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
   {
-    // ---- the S segments of this bucket; exclusive prefix of their lengths (4 samples per lane)
+    const uint32_t s = lane * 4 + q;
+    if (s < S) { nb_beg[q] = start[(size_t)j_first * S + s]; nb_end[q] = start[(size_t)(j_first + 1) * S + s]; }
+  }
+
+#ifdef KMD_MERGE_TIMING   // dev only: per-phase cycles of one wave, printed with KMD_DEBUG=1
+  unsigned long long T[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = __builtin_readcyclecounter();
+#define TICK(i) do { unsigned long long tn = __builtin_readcyclecounter(); T[i] += tn - tprev; tprev = tn; } while (0)
+#else
+#define TICK(i) do { } while (0)
+#endif
+  // ---------------- stage A: records -> registers, hash set, distinct count (published), sorted keys
+  auto stage_a = [&](uint32_t j, state_t& st, unsigned long long* s_keys)
+  {
+    // the S segments of this bucket; exclusive prefix of their lengths (4 samples per lane)
     uint32_t len[4], lsum = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -183,11 +323,22 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
       len[q] = 0;
       if (s < S)
       {
-        const uint32_t b = start[(size_t)j * S + s];
-        s_beg[s] = b;
-        len[q] = start[(size_t)(j + 1) * S + s] - b;
+        s_beg[s] = nb_beg[q];
+        len[q] = nb_end[q] - nb_beg[q];
       }
       lsum += len[q];
+    }
+    {
+      const uint32_t jn = j + n_waves;                  // prefetch the next bucket of this wave
+      if (jn < nb)
+      {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+          const uint32_t s = lane * 4 + q;
+          if (s < S) { nb_beg[q] = start[(size_t)jn * S + s]; nb_end[q] = start[(size_t)(jn + 1) * S + s]; }
+        }
+      }
     }
     uint32_t incl = lsum;
 #pragma unroll
@@ -206,114 +357,231 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
     }
     if (lane == 63) pref[S] = incl;                     // pref[S] = n
     const uint32_t n = __shfl(incl, 63, 64);
-    if (n == 0) { if (!EMIT && lane == 0) distinct[j] = 0; continue; }
-    if (n > kWaveCap)
-    {
-      if (lane == 0) { atomicAdd(overflow, 1u); if (!EMIT) distinct[j] = 0; }
-      continue;
-    }
-    // ---- hash set sized to the bucket (power of two >= 2n)
-    uint32_t slots = 64;
-    while (slots < 2 * n) slots <<= 1;
-    const uint32_t mask = slots - 1;
-    for (uint32_t t = lane; t < slots; t += 64) s_hash[t] = kEmpty;
-    wave_sync();
-    uint32_t d = 0;
-    bool has_max_key = false;                           // the key equal to the empty marker, if present
-    for (uint32_t f0 = 0; f0 < n; f0 += 64)
-    {
-      const uint32_t f = f0 + lane;
-      bool fresh = false;
-      if (f < n)
-      {
-        uint32_t lo = 0, hi = S;                        // last q with pref[q] <= f
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= f) lo = mid; else hi = mid; }
-        const uint64_t k = keys[s_beg[lo] + (f - pref[lo])];
-        if (k == kEmpty) has_max_key = true;
-        else
-        {
-          uint32_t h = hash_slot(k) & mask;
-          for (;;)
-          {
-            const unsigned long long old = atomicCAS(&s_hash[h], kEmpty, (unsigned long long)k);
-            if (old == kEmpty) { fresh = true; break; }
-            if (old == k) break;
-            h = (h + 1) & mask;
-          }
-        }
-      }
-      d += (uint32_t)__popcll(__ballot(fresh));
-    }
-    const bool any_max = __ballot(has_max_key) != 0;
-    d += any_max ? 1u : 0u;
-    if (!EMIT) { if (lane == 0) distinct[j] = d; continue; }
+    const bool too_big = n > kWaveCap;
+    if (too_big && lane == 0) atomicAdd(overflow, 1u);  // the caller falls back to the sort path
 
-    // ---- EMIT: compact the distinct keys (ballot prefix), sort them, write the k-mer column
-    wave_sync();
-    uint32_t filled = 0;
-    for (uint32_t t0 = 0; t0 < slots; t0 += 64)
+    TICK(0);
+    // hash set sized to the bucket; every lane keeps its records in registers
+    uint32_t d = 0;
+    bool any_max = false;
+    uint32_t slots = 64;
+    uint64_t key_r[kPerLane];
+    uint32_t slot_r[kPerLane];                          // hash slot of the record's key (kNoSlot: the empty-marker key)
+    constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+    if (n > 0 && !too_big)
     {
-      const unsigned long long k = s_hash[t0 + lane];
-      const bool occ = k != kEmpty;
-      const unsigned long long m = __ballot(occ);
-      if (occ) s_keys[filled + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
-      filled += (uint32_t)__popcll(m);
-    }
-    if (any_max && lane == 0) s_keys[filled] = kEmpty;              // sorts last
-    uint32_t p2 = 1;
-    while (p2 < d) p2 <<= 1;
-    for (uint32_t t = d + lane; t < p2; t += 64) s_keys[t] = kEmpty;      // padding (>= every key)
-    wave_sync();
-    for (uint32_t k2 = 2; k2 <= p2; k2 <<= 1)
-      for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+      while (slots < 2 * n) slots <<= 1;
+      const uint32_t mask = slots - 1;
+      for (uint32_t t = lane; t < slots; t += 64) s_hash[t] = kEmpty;
+      wave_sync();
+      bool has_max_key = false;                         // the key equal to the empty marker, if present
+      // all loads of the bucket first (independent: one memory round trip), then the inserts
+#pragma unroll
+      for (int r = 0; r < kPerLane; ++r)
       {
-        for (uint32_t t = lane; t < p2; t += 64)
+        const uint32_t f = (uint32_t)r * 64 + lane;
+        key_r[r] = 0; st.cnt_r[r] = 0; st.smp_r[r] = 0; slot_r[r] = kNoSlot;
+        if (f < n)
         {
-          const uint32_t l = t ^ j2;
-          if (l > t)
+          uint32_t lo = 0, hi = S;                      // last q with pref[q] <= f
+          while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= f) lo = mid; else hi = mid; }
+          const uint32_t i = s_beg[lo] + (f - pref[lo]);
+          key_r[r] = keys[i]; st.cnt_r[r] = counts[i]; st.smp_r[r] = lo;
+        }
+      }
+#ifdef KMD_MERGE_TIMING
+      if (key_r[0] == 12345 && st.cnt_r[0] == 77) T[7]++;   // forces the loads to complete here
+#endif
+      TICK(1);
+#pragma unroll
+      for (int r = 0; r < kPerLane; ++r)
+      {
+        const uint32_t f = (uint32_t)r * 64 + lane;
+        bool fresh = false;
+        if (f < n)
+        {
+          const uint64_t k = key_r[r];
+          if (k == kEmpty) has_max_key = true;
+          else
           {
-            const unsigned long long a = s_keys[t], b = s_keys[l];
-            const bool up = ((t & k2) == 0);
-            if ((a > b) == up) { s_keys[t] = b; s_keys[l] = a; }
+            uint32_t h = hash_slot(k) & mask;
+            for (;;)
+            {
+              const unsigned long long old = atomicCAS(&s_hash[h], kEmpty, (unsigned long long)k);
+              if (old == kEmpty) { fresh = true; break; }
+              if (old == k) break;
+              h = (h + 1) & mask;
+            }
+            slot_r[r] = h;
           }
         }
-        wave_sync();
+        if ((uint32_t)r * 64 < n) d += (uint32_t)__popcll(__ballot(fresh));
       }
-    const uint32_t rb = row_base[j];
+      any_max = __ballot(has_max_key) != 0;
+      d += any_max ? 1u : 0u;
+    }
+    // publish the bucket's own count (all that successors need of this bucket)
+    if (lane == 0)
+    {
+      __hip_atomic_store(&status[j], kStFlag | (unsigned long long)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&group[j >> 6].agg, (1ull << kGroupShift) | (unsigned long long)d, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool work = n > 0 && !too_big;
+    st.j = j; st.n = n; st.d = d; st.work = work;
+
+    TICK(2);
+    // rank the distinct keys: compact them (ballot prefix), every lane counts how many are
+    // smaller than its own (broadcast LDS reads, no dependent chain -- a bitonic sort of ~100
+    // keys is ~30 dependent LDS round trips); rank = row within the bucket
+    wave_sync();
+    if (work)
+    {
+      uint16_t* s_tslot = reinterpret_cast<uint16_t*>(s_keys);      // slot of each compacted key (s_keys is written last)
+      uint32_t filled = 0;
+      for (uint32_t t0 = 0; t0 < slots; t0 += 64)
+      {
+        const unsigned long long k = s_hash[t0 + lane];
+        const bool occ = k != kEmpty;
+        const unsigned long long m = __ballot(occ);
+        if (occ)
+        {
+          const uint32_t e = filled + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          s_tmp[e] = k;
+          s_tslot[e] = (uint16_t)(t0 + lane);
+        }
+        filled += (uint32_t)__popcll(m);
+      }
+      wave_sync();
+      unsigned long long mk[kPerLane];
+      uint32_t ms[kPerLane], below[kPerLane];
+#pragma unroll
+      for (int q = 0; q < kPerLane; ++q)
+      {
+        const uint32_t e = (uint32_t)q * 64 + lane;
+        mk[q] = e < filled ? s_tmp[e] : 0ull;
+        ms[q] = e < filled ? (uint32_t)s_tslot[e] : 0u;
+        below[q] = 0;
+      }
+      const uint32_t nq = (filled + 63) >> 6;           // key registers in use (wave-uniform)
+#pragma unroll 4
+      for (uint32_t e = 0; e < filled; ++e)
+      {
+        const unsigned long long v = s_tmp[e];
+#pragma unroll
+        for (int q = 0; q < kPerLane; ++q)
+          if ((uint32_t)q < nq) below[q] += v < mk[q] ? 1u : 0u;
+      }
+      wave_sync();
+#pragma unroll
+      for (int q = 0; q < kPerLane; ++q)
+      {
+        const uint32_t e = (uint32_t)q * 64 + lane;
+        if (e < filled) { s_keys[below[q]] = mk[q]; s_rank[ms[q]] = (uint16_t)below[q]; }
+      }
+      if (any_max && lane == 0) s_keys[d - 1] = kEmpty;               // the largest key there is
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < kPerLane; ++r)
+      {
+        st.row_r[r] = 0;
+        if ((uint32_t)r * 64 + lane < n) st.row_r[r] = slot_r[r] == kNoSlot ? d - 1 : (uint32_t)s_rank[slot_r[r]];
+      }
+      wave_sync();                                      // the segment tables of the next bucket go here
+    }
+  };
+
+  // ---------------- stage B: row number by look-back, LDS block, write-out
+  auto stage_b = [&](const state_t& st, const unsigned long long* s_keys)
+  {
+    const uint32_t j = st.j, n = st.n, d = st.d;
+    TICK(3);
+    const unsigned long long rb64 = rows_before(status, group, j, lane);
+    TICK(4);
+    if (lane == 0 && j == nb - 1) group[(j >> 6) + 1].base = rb64 + d;          // the partition's row count
+    if (!st.work) return;
+    if (rb64 + d > row_capacity) { if (lane == 0) atomicAdd(overflow + 1, 1u); return; }   // counted, not written
+    const size_t rb = (size_t)rb64;
     if (kmer_out)
-      for (uint32_t t = lane; t < d; t += 64) kmer_out[(size_t)rb + t] = s_keys[t];
-    // ---- the bucket's d x S block of the matrix is assembled in LDS (the hash set's memory,
-    // free now) and written out whole: no zero-fill pass over the matrix, no 4-byte scatter;
-    // a block too large for LDS is zero-filled and scattered in place
+      for (uint32_t t = lane; t < d; t += 64) kmer_out[rb + t] = s_keys[t];
+    // the bucket's d x S block of the matrix is assembled in LDS (the hash set's memory, free
+    // between two stage A's) and written out whole: no zero-fill pass over the matrix, no 4-byte
+    // scatter; a block too large for LDS is zero-filled and scattered in place
     const uint32_t cells = d * S;
     const bool in_lds = (size_t)cells * sizeof(CT) <= sizeof(unsigned long long) * kWaveSlots;
     CT* tile = reinterpret_cast<CT*>(s_hash);                        // [sample][row in bucket]
     if (in_lds)
-      for (uint32_t t = lane; t < cells; t += 64) tile[t] = (CT)0;
+    {
+      const uint32_t vecs = (uint32_t)((cells * sizeof(CT) + 15) / 16);
+      for (uint32_t t = lane; t < vecs; t += 64) reinterpret_cast<uint4*>(s_hash)[t] = make_uint4(0, 0, 0, 0);
+    }
     else
-      for (uint32_t t = lane; t < cells; t += 64)
-        matrix[kmd::count_index(layout, ld, (int)S, (size_t)rb + (t % d), (int)(t / d))] = (CT)0;
+    {
+      uint32_t row = lane, smp = 0;
+      for (uint32_t t = lane; t < cells; t += 64, row += 64)
+      {
+        while (row >= d) { row -= d; ++smp; }
+        matrix[kmd::count_index(layout, ld, (int)S, rb + row, (int)smp)] = (CT)0;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // zero-fill before the scatter (global case)
     wave_sync();
-    for (uint32_t f = lane; f < n; f += 64)
+#pragma unroll
+    for (int r = 0; r < kPerLane; ++r)
     {
-      uint32_t lo = 0, hi = S;
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= f) lo = mid; else hi = mid; }
-      const uint32_t i = s_beg[lo] + (f - pref[lo]);
-      const uint64_t k = keys[i];
-      uint32_t a = 0, b = d;                           // first index with s_keys[idx] >= k
-      while (a < b) { const uint32_t mid = (a + b) >> 1; if (s_keys[mid] < k) a = mid + 1; else b = mid; }
-      uint32_t c = counts[i];
-      if (c > cmax) c = cmax;
-      if (in_lds) tile[lo * d + a] = (CT)c;
-      else matrix[kmd::count_index(layout, ld, (int)S, (size_t)rb + a, (int)lo)] = (CT)c;
+      const uint32_t f = (uint32_t)r * 64 + lane;
+      if (f < n)
+      {
+        uint32_t c = st.cnt_r[r];
+        if (c > cmax) c = cmax;
+        if (in_lds) tile[st.smp_r[r] * d + st.row_r[r]] = (CT)c;
+        else matrix[kmd::count_index(layout, ld, (int)S, rb + st.row_r[r], (int)st.smp_r[r])] = (CT)c;
+      }
     }
     wave_sync();
     if (in_lds)
-      for (uint32_t t = lane; t < cells; t += 64)
-        matrix[kmd::count_index(layout, ld, (int)S, (size_t)rb + (t % d), (int)(t / d))] = tile[t];
+    {
+      if (layout == KMD_LAYOUT_ROWS)            // consecutive lanes -> consecutive samples of a row: one contiguous span
+      {
+        uint32_t smp = lane, row = 0;
+        for (uint32_t t = lane; t < cells; t += 64, smp += 64)
+        {
+          while (smp >= S) { smp -= S; ++row; }
+          matrix[(rb + row) * ld + smp] = tile[smp * d + row];
+        }
+      }
+      else                                      // consecutive lanes -> consecutive rows of a sample
+      {
+        uint32_t row = lane, smp = 0;
+        for (uint32_t t = lane; t < cells; t += 64, row += 64)
+        {
+          while (row >= d) { row -= d; ++smp; }
+          matrix[kmd::count_index(layout, ld, (int)S, rb + row, (int)smp)] = tile[t];
+        }
+      }
+    }
     wave_sync();
+  };
+
+  state_t cur;
+  uint32_t buf = 0;
+  stage_a(j_first, cur, s_keys_all[w][0]);
+  for (;;)
+  {
+    const uint32_t jn = cur.j + n_waves;
+    const bool have_next = jn < nb;
+    state_t nxt;
+    if (have_next) stage_a(jn, nxt, s_keys_all[w][buf ^ 1]);
+    stage_b(cur, s_keys_all[w][buf]);
+    if (!have_next) break;
+    cur = nxt;
+    buf ^= 1;
+    TICK(5);
   }
+#ifdef KMD_MERGE_TIMING
+  if (blockIdx.x == 7 && threadIdx.x == 0) for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(overflow)[2 + i] = T[i];
+#endif
+#undef TICK
 }
 
 // min of the first keys / max of the last keys of the non-empty streams
@@ -339,6 +607,8 @@ struct scratch
   ~scratch() { for (void* q : p) if (q) kmd::scratch_free(q); }
 };
 
+inline uint32_t fast_bucket_cap(int S) { return S <= 64 ? 256u : S <= 128 ? 512u : 1024u; }
+
 // The bucketed LDS merge.  *used = false (and nothing written) when the input does not suit
 // it (clustered keys overflow a bucket): the caller then takes the sort-based path.
 template <typename CT>
@@ -360,68 +630,90 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
   KMD_HIP(hipMemcpyAsync(range, d_range, 16, hipMemcpyDeviceToHost, st));
   KMD_HIP(hipStreamSynchronize(st));
   const uint64_t span = range[1] - range[0];                    // kmax - kmin
-  // ~128 records per bucket on average (one wave each); the start table is capped at 1 GiB
-  uint64_t nb_target = n / 128 + 1;
+  // a bucket must hold a few whole rows, and a row has up to S records: capacity by sample count;
+  // half the capacity per bucket on average (one wave each); the start table is capped at 1 GiB
+  const uint32_t cap = fast_bucket_cap(S);
+  uint64_t nb_target = n / (cap / 2) + 1;
   const uint64_t table_cap = (1ull << 30) / (4ull * (uint64_t)S);
   if (nb_target > table_cap) nb_target = table_cap;
+  if (nb_target > 0xFFFFFFF0ull) nb_target = 0xFFFFFFF0ull;
   bucket_map B;
-  B.kmin = range[0]; B.shift = 0;
-  while (B.shift < 63 && (span >> B.shift) >= nb_target) ++B.shift;    // (span >> shift) + 1 <= nb_target, no overflow
-  B.nb = (uint32_t)((span >> B.shift) + 1);
+  B.kmin = range[0];
+  B.nb = (uint32_t)nb_target;
+  // mult = floor(nb * 2^64 / (span + 1)); (span * mult) >> 64 < nb for every key in range
+  if (span == ~0ull) B.mult = nb_target;
+  else B.mult = (uint64_t)((((unsigned __int128)nb_target) << 64) / ((unsigned __int128)span + 1));
+  if (span + 1 != 0 && nb_target > span + 1) { B.nb = (uint32_t)(span + 1); B.mult = (uint64_t)((((unsigned __int128)B.nb) << 64) / ((unsigned __int128)span + 1)); }
   const size_t nb = B.nb;
-  if (dbg) std::fprintf(stderr, "[merge_fast] n=%zu kmin=%llu kmax=%llu shift=%u nb=%zu\n", n,
-                        (unsigned long long)range[0], (unsigned long long)range[1], B.shift, nb);
+  if (dbg) std::fprintf(stderr, "[merge_fast] n=%zu kmin=%llu kmax=%llu mult=%llu nb=%zu\n", n,
+                        (unsigned long long)range[0], (unsigned long long)range[1], (unsigned long long)B.mult, nb);
 
   KMD_HIP(kmd::scratch_alloc(&sc.p[1], (nb + 1) * (size_t)S * 4));
-  KMD_HIP(kmd::scratch_alloc(&sc.p[2], nb * 4));
-  KMD_HIP(kmd::scratch_alloc(&sc.p[3], nb * 4));
-  KMD_HIP(kmd::scratch_alloc(&sc.p[4], 4));
-  uint32_t* start = static_cast<uint32_t*>(sc.p[1]);
-  uint32_t* distinct = static_cast<uint32_t*>(sc.p[2]);
-  uint32_t* row_base = static_cast<uint32_t*>(sc.p[3]);
-  uint32_t* overflow = static_cast<uint32_t*>(sc.p[4]);
-  KMD_HIP(hipMemsetAsync(overflow, 0, 4, st));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[5], (nb + 1) * (size_t)S * 4));
+  const size_t ng = (nb + 63) / 64;                         // look-back groups
+  const size_t status_bytes = ((nb * 8 + 127) / 128) * 128;
+  KMD_HIP(kmd::scratch_alloc(&sc.p[2], status_bytes + (ng + 1) * sizeof(merge_group)));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[4], 128));
+  uint32_t* start = static_cast<uint32_t*>(sc.p[1]);          // [bucket][stream]
+  uint32_t* start_sm = static_cast<uint32_t*>(sc.p[5]);       // [stream][bucket]
+  unsigned long long* status = static_cast<unsigned long long*>(sc.p[2]);
+  uint32_t* overflow = static_cast<uint32_t*>(sc.p[4]);      // [0] bucket too large, [1] row capacity exceeded
+  KMD_HIP(hipMemsetAsync(overflow, 0, 8, st));
+  merge_group* group = reinterpret_cast<merge_group*>(reinterpret_cast<char*>(sc.p[2]) + status_bytes);
+  KMD_HIP(hipMemsetAsync(status, 0, status_bytes + (ng + 1) * sizeof(merge_group), st));
   {
     size_t longest = 1;
     for (int s = 0; s < S; ++s) if (offsets[s + 1] - offsets[s] > longest) longest = offsets[s + 1] - offsets[s];
     if (nb + 1 > longest) longest = nb + 1;
     size_t gx = (longest + 255) / 256;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, d_kmers, d_offs, (uint32_t)S, B, start);
+    hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, d_kmers, d_offs, (uint32_t)S, B, start_sm);
+    hipLaunchKernelGGL(k_transpose_starts, dim3((unsigned)((nb + 1 + 63) / 64)), dim3(256), 0, st, start_sm, (uint32_t)S,
+                       (uint32_t)(nb + 1), start);
   }
   KMD_HIP(hipGetLastError());
   KMD_DBG("starts");
-  size_t grid = (size_t)n_cu * 16;
-  if (grid > (nb + kWavesPerBlock - 1) / kWavesPerBlock) grid = (nb + kWavesPerBlock - 1) / kWavesPerBlock;
-  hipLaunchKernelGGL((k_bucket_merge<false, CT>), dim3((unsigned)grid), dim3(64 * kWavesPerBlock), 0, st, d_kmers, d_counts,
-                     start, (uint32_t)S, (uint32_t)nb, distinct, (const uint32_t*)nullptr, layout, ld,
-                     (CT*)nullptr, (uint64_t*)nullptr, overflow);
-  KMD_HIP(hipGetLastError());
-  KMD_DBG("pass2");
-  size_t tmp = 0;
-  KMD_HIP(rocprim::exclusive_scan(nullptr, tmp, distinct, row_base, 0u, nb, rocprim::plus<uint32_t>(), st));
-  KMD_HIP(kmd::scratch_alloc(&sc.p[5], tmp ? tmp : 1));
-  KMD_HIP(rocprim::exclusive_scan(sc.p[5], tmp, distinct, row_base, 0u, nb, rocprim::plus<uint32_t>(), st));
-  uint32_t h[3] = { 0, 0, 0 };
-  KMD_HIP(hipMemcpyAsync(&h[0], overflow, 4, hipMemcpyDeviceToHost, st));
-  KMD_HIP(hipMemcpyAsync(&h[1], row_base + (nb - 1), 4, hipMemcpyDeviceToHost, st));
-  KMD_HIP(hipMemcpyAsync(&h[2], distinct + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+  // persistent grid: every wave must be resident (look-back waits on lower-numbered buckets)
+  auto launch = [&](auto kernel, int wpb) -> int
+  {
+    int per_cu = 0;
+    KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 1) per_cu -= 1;                            // margin: the API can over-report by one
+    size_t grid = (size_t)n_cu * (size_t)per_cu;
+    if (grid > (nb + wpb - 1) / wpb) grid = (nb + wpb - 1) / wpb;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers, d_counts, start, (uint32_t)S,
+                       (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out, overflow);
+    KMD_HIP(hipGetLastError());
+    return KMD_OK;
+  };
+  int rc_launch;
+  if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2>, 2);
+  else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 2>, 2);
+  else rc_launch = launch(k_bucket_merge<CT, 1024, 1>, 1);
+  if (rc_launch != KMD_OK) return rc_launch;
+  uint32_t h_over[2] = { 0, 0 };
+  unsigned long long h_last = 0;
+  KMD_HIP(hipMemcpyAsync(h_over, overflow, 8, hipMemcpyDeviceToHost, st));
+  KMD_HIP(hipMemcpyAsync(&h_last, &group[ng].base, 8, hipMemcpyDeviceToHost, st));
   KMD_HIP(hipStreamSynchronize(st));
-  if (h[0]) return KMD_OK;                                       // a bucket overflowed: not used
-  const size_t n_rows = (size_t)h[1] + h[2];
+#ifdef KMD_MERGE_TIMING
+  if (dbg)
+  {
+    unsigned long long tt[8];
+    (void)hipMemcpy(tt, reinterpret_cast<char*>(overflow) + 16, 64, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[merge_fast] cycles: segments %llu load %llu insert %llu rank %llu look-back %llu emit %llu\n",
+                 tt[0], tt[1], tt[2], tt[3], tt[4], tt[5]);
+  }
+#endif
+  KMD_DBG("merge");
+  if (h_over[0]) return KMD_OK;                              // a bucket overflowed: not used, caller sorts
+  const size_t n_rows = (size_t)(h_last & kStMask);
   *used = true;
   *n_rows_out = n_rows;
-  if (n_rows > row_capacity) { kmd::set_error("kmd_merge_partition: row capacity exceeded"); return KMD_E_OVERFLOW; }
-  size_t n_el;
-  if (layout == KMD_LAYOUT_SOA) { KMD_REQUIRE(ld >= n_rows, "kmd_merge_partition: SoA ld < rows"); n_el = ld * (size_t)S; }
-  else if (layout == KMD_LAYOUT_ROWS) { KMD_REQUIRE(ld >= (size_t)S, "kmd_merge_partition: ld < samples"); n_el = ld * n_rows; }
-  else n_el = (n_rows + ld - 1) / ld * ld * (size_t)S;
-  (void)n_el;   // every cell of the n_rows rows is written by its bucket's workgroup: no zero-fill pass
-  hipLaunchKernelGGL((k_bucket_merge<true, CT>), dim3((unsigned)grid), dim3(64 * kWavesPerBlock), 0, st, d_kmers, d_counts,
-                     start, (uint32_t)S, (uint32_t)nb, distinct, (const uint32_t*)row_base, layout, ld, d_matrix,
-                     d_kmer_out, overflow);
-  KMD_HIP(hipGetLastError());
-  KMD_HIP(hipStreamSynchronize(st));
+  if (h_over[1] || n_rows > row_capacity) { kmd::set_error("kmd_merge_partition: row capacity exceeded"); return KMD_E_OVERFLOW; }
+  if (layout == KMD_LAYOUT_SOA) KMD_REQUIRE(ld >= n_rows, "kmd_merge_partition: SoA ld < rows");
+  if (layout == KMD_LAYOUT_ROWS) KMD_REQUIRE(ld >= (size_t)S, "kmd_merge_partition: ld < samples");
   return KMD_OK;
 }
 
@@ -442,6 +734,8 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
   for (int s = 0; s < n_samples; ++s)
     KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_partition: offsets must be ascending");
   *n_rows_out = 0;
+  if (layout == KMD_LAYOUT_SOA) KMD_REQUIRE(ld >= row_capacity, "kmd_merge_partition: SoA ld < row_capacity");
+  if (layout == KMD_LAYOUT_ROWS) KMD_REQUIRE(ld >= (size_t)n_samples, "kmd_merge_partition: ld < samples");
   if (n == 0) return KMD_OK;
   KMD_REQUIRE(d_kmers && d_counts && d_matrix, "kmd_merge_partition: NULL device buffers");
   hipStream_t st = static_cast<hipStream_t>(stream);

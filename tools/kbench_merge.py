@@ -16,6 +16,7 @@ ap.add_argument("--rows", type=int, default=4_000_000)
 ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--layout", default="tiled")
 a = ap.parse_args()
 S = a.nc + a.nk
 lib = K._native.lib()
@@ -30,13 +31,14 @@ for s in range(S):
 kmers = np.concatenate(ks); counts = np.concatenate(cs).astype(np.uint32)
 n = len(kmers)
 dk, dc = K.DeviceBuffer.from_host(kmers), K.DeviceBuffer.from_host(counts)
-out = K.CountMatrix(a.rows, S, 4, K.LAYOUT_TILED, with_kmers=True)
+LAY = {"tiled": K.LAYOUT_TILED, "rows": K.LAYOUT_ROWS, "soa": K.LAYOUT_SOA}[a.layout]
+out = K.CountMatrix(a.rows, S, 4, LAY, with_kmers=True)
 nr = C.c_uint64(0)
 ts = []
 for _ in range(a.iters + 1):
     lib.kmd_stream_sync(None)
     t0 = time.perf_counter()
-    K._native.check(lib.kmd_merge_partition(S, dk.ptr, None, dc.ptr, offs.ctypes.data, 4, K.LAYOUT_TILED, out.ld, a.rows,
+    K._native.check(lib.kmd_merge_partition(S, dk.ptr, None, dc.ptr, offs.ctypes.data, 4, LAY, out.ld, a.rows,
                                             out.counts.ptr, out.kmer_lo.ptr, None, C.byref(nr), None))
     ts.append(time.perf_counter() - t0)
 t = min(ts[1:])
