@@ -20,6 +20,7 @@
 
 #include "kmd_internal.h"
 
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -145,6 +146,81 @@ __global__ void __launch_bounds__(256) k_transpose_starts(const uint32_t* __rest
     for (uint32_t jj = ty; jj < 64; jj += 4)
       if (s0 + tx < S && j0 + jj < nb1) start[(j0 + jj) * S + s0 + tx] = tile[tx][jj];
     __syncthreads();
+  }
+}
+
+// Keys are not spread evenly over their range (k-mers of a partition cluster), so some of the
+// equal key slices hold more records than a wave can take.  Those buckets are cut again, on the
+// start table alone, into equal slices of the key range the bucket's records REALLY span (a dense
+// cluster inside a wide slice gets a fine grid of its own); repeated by the host until every
+// bucket fits.  split[j] = slices bucket j becomes (1 = kept), klo/kstep[j] = first key and slice
+// width of a cut bucket, counters[0] += buckets over capacity.
+__global__ void __launch_bounds__(256) k_bucket_split(const uint64_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ start, uint32_t S, uint32_t nb,
+                                                      uint32_t cap, uint32_t* __restrict__ split,
+                                                      uint64_t* __restrict__ klo, uint64_t* __restrict__ kstep,
+                                                      uint32_t* __restrict__ counters)
+{
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  uint32_t n = 0;
+  for (uint32_t s = 0; s < S; ++s) n += start[(j + 1) * S + s] - start[j * S + s];
+  uint32_t m = 1;
+  if (n > cap)
+  {
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t s = 0; s < S; ++s)
+    {
+      const uint32_t b = start[j * S + s], e = start[(j + 1) * S + s];
+      if (e > b)
+      {
+        const uint64_t kb = keys[b], ke = keys[e - 1];
+        lo = kb < lo ? kb : lo;
+        hi = ke > hi ? ke : hi;
+      }
+    }
+    m = (n + cap / 4 - 1) / (cap / 4);
+    klo[j] = lo;
+    kstep[j] = (hi - lo) / m + 1;                       // m slices of this width cover [lo, hi]
+    atomicAdd(counters, 1u);
+  }
+  split[j] = m;
+}
+
+// The refined start table: row first[j] + t = slice t of old bucket j (first = exclusive prefix
+// of split); a kept bucket copies its row, a cut one searches its short segments for the slice
+// boundaries klo + t * kstep (saturating: the same monotone rule for every stream is all it takes)
+__global__ void __launch_bounds__(256) k_refine_starts(const uint64_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ start, uint32_t S, uint32_t nb,
+                                                       const uint32_t* __restrict__ split,
+                                                       const uint64_t* __restrict__ klo,
+                                                       const uint64_t* __restrict__ kstep,
+                                                       const uint32_t* __restrict__ first, uint32_t nb_new,
+                                                       uint32_t* __restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((size_t)nb + 1) * S) return;
+  const size_t j = i / S;
+  const uint32_t s = (uint32_t)(i % S);
+  if (j == nb) { out[(size_t)nb_new * S + s] = start[i]; return; }
+  const uint32_t m = split[j], beg = start[i];
+  const size_t row = first[j];
+  out[row * S + s] = beg;
+  if (m == 1) return;
+  const uint32_t end = start[i + S];
+  const uint64_t k0 = klo[j], step = kstep[j];
+  uint32_t lo = beg;
+  for (uint32_t t = 1; t < m; ++t)
+  {
+    uint64_t bound = k0 + (uint64_t)t * step;
+    if (__umul64hi((uint64_t)t, step) != 0 || bound < k0) bound = ~0ull;
+    uint32_t hi = end;                                   // first record in [lo, end) with key >= bound
+    while (lo < hi)
+    {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (keys[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    out[(row + t) * S + s] = lo;
   }
 }
 
@@ -604,7 +680,18 @@ __global__ void k_key_range(const uint64_t* __restrict__ keys, const uint64_t* _
 struct scratch
 {
   void* p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  ~scratch() { for (void* q : p) if (q) kmd::scratch_free(q); }
+  std::vector<void*> more;                               // buffers of a loop (take)
+  hipError_t take(void** out, size_t bytes)
+  {
+    const hipError_t e = kmd::scratch_alloc(out, bytes);
+    if (e == hipSuccess) more.push_back(*out);
+    return e;
+  }
+  ~scratch()
+  {
+    for (void* q : p) if (q) kmd::scratch_free(q);
+    for (void* q : more) if (q) kmd::scratch_free(q);
+  }
 };
 
 inline uint32_t fast_bucket_cap(int S) { return S <= 64 ? 256u : S <= 128 ? 512u : 1024u; }
@@ -644,35 +731,76 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
   if (span == ~0ull) B.mult = nb_target;
   else B.mult = (uint64_t)((((unsigned __int128)nb_target) << 64) / ((unsigned __int128)span + 1));
   if (span + 1 != 0 && nb_target > span + 1) { B.nb = (uint32_t)(span + 1); B.mult = (uint64_t)((((unsigned __int128)B.nb) << 64) / ((unsigned __int128)span + 1)); }
-  const size_t nb = B.nb;
-  if (dbg) std::fprintf(stderr, "[merge_fast] n=%zu kmin=%llu kmax=%llu mult=%llu nb=%zu\n", n,
-                        (unsigned long long)range[0], (unsigned long long)range[1], (unsigned long long)B.mult, nb);
+  const size_t nb0 = B.nb;                                    // equal key slices; nb = buckets after cutting the heavy ones
+  if (dbg) std::fprintf(stderr, "[merge_fast] n=%zu kmin=%llu kmax=%llu mult=%llu nb0=%zu\n", n,
+                        (unsigned long long)range[0], (unsigned long long)range[1], (unsigned long long)B.mult, nb0);
 
-  KMD_HIP(kmd::scratch_alloc(&sc.p[1], (nb + 1) * (size_t)S * 4));
-  KMD_HIP(kmd::scratch_alloc(&sc.p[5], (nb + 1) * (size_t)S * 4));
-  const size_t ng = (nb + 63) / 64;                         // look-back groups
-  const size_t status_bytes = ((nb * 8 + 127) / 128) * 128;
-  KMD_HIP(kmd::scratch_alloc(&sc.p[2], status_bytes + (ng + 1) * sizeof(merge_group)));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[1], (nb0 + 1) * (size_t)S * 4));
+  KMD_HIP(kmd::scratch_alloc(&sc.p[5], (nb0 + 1) * (size_t)S * 4));
   KMD_HIP(kmd::scratch_alloc(&sc.p[4], 128));
   uint32_t* start = static_cast<uint32_t*>(sc.p[1]);          // [bucket][stream]
   uint32_t* start_sm = static_cast<uint32_t*>(sc.p[5]);       // [stream][bucket]
-  unsigned long long* status = static_cast<unsigned long long*>(sc.p[2]);
-  uint32_t* overflow = static_cast<uint32_t*>(sc.p[4]);      // [0] bucket too large, [1] row capacity exceeded
-  KMD_HIP(hipMemsetAsync(overflow, 0, 8, st));
-  merge_group* group = reinterpret_cast<merge_group*>(reinterpret_cast<char*>(sc.p[2]) + status_bytes);
-  KMD_HIP(hipMemsetAsync(status, 0, status_bytes + (ng + 1) * sizeof(merge_group), st));
+  uint32_t* overflow = static_cast<uint32_t*>(sc.p[4]);      // [0] bucket too large, [1] row capacity exceeded, [2] buckets cut
+  KMD_HIP(hipMemsetAsync(overflow, 0, 16, st));
   {
     size_t longest = 1;
     for (int s = 0; s < S; ++s) if (offsets[s + 1] - offsets[s] > longest) longest = offsets[s + 1] - offsets[s];
-    if (nb + 1 > longest) longest = nb + 1;
+    if (nb0 + 1 > longest) longest = nb0 + 1;
     size_t gx = (longest + 255) / 256;
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, d_kmers, d_offs, (uint32_t)S, B, start_sm);
-    hipLaunchKernelGGL(k_transpose_starts, dim3((unsigned)((nb + 1 + 63) / 64)), dim3(256), 0, st, start_sm, (uint32_t)S,
-                       (uint32_t)(nb + 1), start);
+    hipLaunchKernelGGL(k_transpose_starts, dim3((unsigned)((nb0 + 1 + 63) / 64)), dim3(256), 0, st, start_sm, (uint32_t)S,
+                       (uint32_t)(nb0 + 1), start);
   }
   KMD_HIP(hipGetLastError());
   KMD_DBG("starts");
+  // buckets over capacity are cut into finer slices, level by level (clustered keys); input that
+  // is mostly clusters, or still over capacity after kMaxLevels, goes to the sort path
+  size_t nb = nb0;
+  constexpr int kMaxLevels = 6;
+  for (int level = 0;; ++level)
+  {
+    uint32_t n_over = 0;
+    void *p_split = nullptr, *p_klo = nullptr, *p_kstep = nullptr;
+    KMD_HIP(sc.take(&p_split, (nb + 1) * 4));
+    KMD_HIP(sc.take(&p_klo, nb * 8));
+    KMD_HIP(sc.take(&p_kstep, nb * 8));
+    uint32_t* split = static_cast<uint32_t*>(p_split);
+    KMD_HIP(hipMemsetAsync(overflow + 2, 0, 4, st));
+    hipLaunchKernelGGL(k_bucket_split, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_kmers, start, (uint32_t)S,
+                       (uint32_t)nb, cap, split, static_cast<uint64_t*>(p_klo), static_cast<uint64_t*>(p_kstep),
+                       overflow + 2);
+    KMD_HIP(hipMemcpyAsync(&n_over, overflow + 2, 4, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    if (dbg) std::fprintf(stderr, "[merge_fast] level %d: %u of %zu buckets over capacity\n", level, n_over, nb);
+    if (n_over == 0) break;
+    if (level == kMaxLevels || n_over > nb / 8) return KMD_OK;
+    void *p_first = nullptr, *p_tmp = nullptr, *p_refined = nullptr;
+    KMD_HIP(sc.take(&p_first, (nb + 1) * 4));
+    uint32_t* first = static_cast<uint32_t*>(p_first);
+    size_t tmp = 0;
+    KMD_HIP(rocprim::exclusive_scan(nullptr, tmp, split, first, 0u, nb + 1, rocprim::plus<uint32_t>(), st));
+    KMD_HIP(sc.take(&p_tmp, tmp ? tmp : 1));
+    KMD_HIP(rocprim::exclusive_scan(p_tmp, tmp, split, first, 0u, nb + 1, rocprim::plus<uint32_t>(), st));
+    uint32_t nb_new = 0;
+    KMD_HIP(hipMemcpyAsync(&nb_new, first + nb, 4, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    if ((uint64_t)nb_new > table_cap) return KMD_OK;
+    KMD_HIP(sc.take(&p_refined, ((size_t)nb_new + 1) * (size_t)S * 4));
+    const size_t cells = (nb + 1) * (size_t)S;
+    hipLaunchKernelGGL(k_refine_starts, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_kmers, start,
+                       (uint32_t)S, (uint32_t)nb, split, static_cast<const uint64_t*>(p_klo),
+                       static_cast<const uint64_t*>(p_kstep), first, nb_new, static_cast<uint32_t*>(p_refined));
+    KMD_HIP(hipGetLastError());
+    start = static_cast<uint32_t*>(p_refined);
+    nb = nb_new;
+  }
+  const size_t ng = (nb + 63) / 64;                         // look-back groups
+  const size_t status_bytes = ((nb * 8 + 127) / 128) * 128;
+  KMD_HIP(kmd::scratch_alloc(&sc.p[2], status_bytes + (ng + 1) * sizeof(merge_group)));
+  unsigned long long* status = static_cast<unsigned long long*>(sc.p[2]);
+  merge_group* group = reinterpret_cast<merge_group*>(reinterpret_cast<char*>(sc.p[2]) + status_bytes);
+  KMD_HIP(hipMemsetAsync(status, 0, status_bytes + (ng + 1) * sizeof(merge_group), st));
   // persistent grid: every wave must be resident (look-back waits on lower-numbered buckets)
   auto launch = [&](auto kernel, int wpb) -> int
   {
@@ -741,7 +869,7 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   // bucketed LDS merge when it applies (one limb, enough records); else / on overflow: sort
-  const char* force = std::getenv("KMD_MERGE_PATH");            // "sort" | "fast" (tests, benchmarks)
+  const char* force = std::getenv("KMD_MERGE_PATH");            // "sort" | "fast" | "fast-only" (tests, benchmarks)
   const bool want_fast = !d_kmers_hi && (uint32_t)n_samples <= kMaxFastSamples &&
                          (force ? std::strcmp(force, "sort") != 0 : n >= (1u << 16));
   if (want_fast)
@@ -758,6 +886,8 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
       default: rc = merge_fast<uint32_t>(n_samples, d_kmers, d_counts, offsets, layout, ld, row_capacity, static_cast<uint32_t*>(d_matrix), d_kmer_out, n_rows_out, n_cu, st, &used); break;
     }
     if (rc != KMD_OK || used) return rc;
+    // "fast-only" (tests): report instead of quietly sorting
+    KMD_REQUIRE(!(force && std::strcmp(force, "fast-only") == 0), "kmd_merge_partition: bucketed path not applicable to this input");
   }
 
   scratch sc;   // [0] vals, [1] keys sorted, [2] vals sorted, [3] flags, [4] ranks, [5] rocprim temp

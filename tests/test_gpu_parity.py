@@ -455,6 +455,31 @@ def test_merge_partition_clustered_keys_and_extremes(K, oracle, monkeypatch):
     assert m2.n_rows == want2.shape[0] and (m2.to_host() == want2).all() and (m2.kmers_to_host()[0] == k2).all()
 
 
+@pytest.mark.parametrize("shape", ["random", "mixture"])
+def test_merge_partition_bucket_refinement(K, oracle, shape, monkeypatch):
+    """Random keys give Poisson-sized buckets and real partitions cluster: buckets over the wave
+    capacity are cut again on the start table; "fast-only" makes the library report (instead of
+    quietly sorting) if the bucketed merge did not serve the input."""
+    monkeypatch.setenv("KMD_MERGE_PATH", "fast-only")
+    rng = np.random.default_rng(41)
+    if shape == "random":
+        universe = np.unique(rng.integers(0, 1 << 62, 300_000, dtype=np.uint64))
+    else:
+        dense = [np.unique(rng.integers(c, c + (1 << 22), 30_000, dtype=np.uint64))
+                 for c in (1 << 50, 3 << 59, (1 << 61) + 12345)]
+        universe = np.unique(np.concatenate(dense + [rng.integers(0, 1 << 62, 250_000, dtype=np.uint64)]))
+    S = 40
+    streams = []
+    for s in range(S):
+        pick = rng.random(len(universe)) < 0.65
+        streams.append((universe[pick], rng.integers(1, 300, pick.sum()).astype(np.uint32)))
+    want, kmers = oracle.merge_partition(streams)
+    m = K.merge_partition(streams, count_bytes=2, layout=K.LAYOUT_TILED)
+    assert m.n_rows == want.shape[0]
+    assert (m.kmers_to_host()[0] == kmers).all()
+    assert (m.to_host() == want).all()
+
+
 def test_merge_partition_two_limb_kmers(K, oracle):
     """32 < k <= 64: k-mers are (hi, lo) pairs compared as 128-bit numbers."""
     rng = np.random.default_rng(23)

@@ -17,12 +17,16 @@ ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--layout", default="tiled")
+ap.add_argument("--keys", default="even", help="even: the generator's evenly spaced k-mers | random: uniform random (Poisson-sized buckets)")
 a = ap.parse_args()
 S = a.nc + a.nk
 lib = K._native.lib()
 mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, a.nc, a.nk, 4, K.LAYOUT_ROWS)
 host = mat.to_host()
 lo = mat.kmers_to_host()[0]
+if a.keys == "random":
+    lo = np.unique(np.random.default_rng(5).integers(0, 1 << 62, int(a.rows * 1.02), dtype=np.uint64))[:a.rows]
+    assert len(lo) == a.rows
 offs = np.zeros(S + 1, dtype=np.uint64)
 ks, cs = [], []
 for s in range(S):
@@ -46,5 +50,5 @@ assert nr.value == a.rows
 out.n_rows = a.rows
 assert (out.to_host()[:1000] == host[:1000]).all()
 inb = n * 12
-print("merge S=%d rows=%d records=%d  %.2f ms  %.3e records/s  %.3e rows/s  input %.1f GB/s (12 B/record)"
-      % (S, a.rows, n, t * 1e3, n / t, a.rows / t, inb / t / 1e9))
+print("merge keys=%s S=%d rows=%d records=%d  %.2f ms  %.3e records/s  %.3e rows/s  input %.1f GB/s (12 B/record)"
+      % (a.keys, S, a.rows, n, t * 1e3, n / t, a.rows / t, inb / t / 1e9))
