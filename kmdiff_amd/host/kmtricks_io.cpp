@@ -18,6 +18,14 @@ size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dst, size_t* dstSizePtr, const voi
                        const void* options);
 unsigned LZ4F_isError(size_t code);
 const char* LZ4F_getErrorName(size_t code);
+typedef struct LZ4F_cctx_s LZ4F_cctx;
+size_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version);
+size_t LZ4F_freeCompressionContext(LZ4F_cctx* cctx);
+size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* prefs);
+size_t LZ4F_compressBound(size_t srcSize, const void* prefs);
+size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                           const void* options);
+size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* options);
 }
 
 namespace kmd_host {
@@ -87,6 +95,46 @@ static std::vector<char> slurp(const std::string& path)
   return std::vector<char>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
 }
 
+// one LZ4 frame (what lz4_stream and kmtricks write) starting at d[off]
+static std::vector<char> lz4_frame_decode(const std::vector<char>& d, size_t off, const std::string& path)
+{
+  std::vector<char> raw;
+  LZ4F_dctx* ctx = nullptr;
+  if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
+  std::vector<char> buf(1 << 20);
+  size_t pos = off;
+  while (pos < d.size())
+  {
+    size_t dn = buf.size(), sn = d.size() - pos;
+    size_t r = LZ4F_decompress(ctx, buf.data(), &dn, d.data() + pos, &sn, nullptr);
+    if (LZ4F_isError(r)) { LZ4F_freeDecompressionContext(ctx); throw std::runtime_error(path + ": " + LZ4F_getErrorName(r)); }
+    raw.insert(raw.end(), buf.begin(), buf.begin() + dn);
+    pos += sn;
+    if (r == 0 && sn == 0) break;
+  }
+  LZ4F_freeDecompressionContext(ctx);
+  return raw;
+}
+
+// payload -> one LZ4 frame appended to the stream (default preferences: 64 KB linked blocks)
+static void lz4_frame_encode(std::ostream& out, const char* src, size_t n)
+{
+  LZ4F_cctx* ctx = nullptr;
+  if (LZ4F_isError(LZ4F_createCompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
+  const size_t chunk = 1 << 20;
+  std::vector<char> buf(LZ4F_compressBound(chunk, nullptr) + 64);
+  auto put = [&](size_t r)
+  {
+    if (LZ4F_isError(r)) { LZ4F_freeCompressionContext(ctx); throw std::runtime_error(std::string("LZ4F: ") + LZ4F_getErrorName(r)); }
+    out.write(buf.data(), (std::streamsize)r);
+  };
+  put(LZ4F_compressBegin(ctx, buf.data(), buf.size(), nullptr));
+  for (size_t pos = 0; pos < n; pos += chunk)
+    put(LZ4F_compressUpdate(ctx, buf.data(), buf.size(), src + pos, std::min(chunk, n - pos), nullptr));
+  put(LZ4F_compressEnd(ctx, buf.data(), buf.size(), nullptr));
+  LZ4F_freeCompressionContext(ctx);
+}
+
 template <typename T> static T rd(const std::vector<char>& d, size_t off)
 {
   if (off + sizeof(T) > d.size()) throw std::runtime_error("truncated kmtricks file");
@@ -125,23 +173,7 @@ size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<ui
   if (slots != 1) throw std::runtime_error(path + ": k > 32 is not supported by this reader yet");
   if (cbytes != 1 && cbytes != 2 && cbytes != 4) throw std::runtime_error(path + ": bad count width");
   std::vector<char> raw;
-  if (compressed)
-  {
-    LZ4F_dctx* ctx = nullptr;
-    if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
-    std::vector<char> buf(1 << 20);
-    size_t pos = 41;
-    while (pos < d.size())
-    {
-      size_t dn = buf.size(), sn = d.size() - pos;
-      size_t r = LZ4F_decompress(ctx, buf.data(), &dn, d.data() + pos, &sn, nullptr);
-      if (LZ4F_isError(r)) { LZ4F_freeDecompressionContext(ctx); throw std::runtime_error(path + ": " + LZ4F_getErrorName(r)); }
-      raw.insert(raw.end(), buf.begin(), buf.begin() + dn);
-      pos += sn;
-      if (r == 0 && sn == 0) break;
-    }
-    LZ4F_freeDecompressionContext(ctx);
-  }
+  if (compressed) raw = lz4_frame_decode(d, 41, path);
   else raw.assign(d.begin() + 41, d.end());
   const size_t rec = 8 * slots + cbytes, n = raw.size() / rec;
   kmers.reserve(kmers.size() + n); counts.reserve(counts.size() + n);
@@ -152,6 +184,142 @@ size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<ui
     kmers.push_back(km); counts.push_back(c);
   }
   return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+std::vector<std::string> matrix_paths(const std::string& run_dir)
+{
+  std::vector<std::string> out;
+  const std::string dir = run_dir + "/matrices";
+  if (fs::exists(dir))
+    for (auto& e : fs::directory_iterator(dir)) if (fs::is_regular_file(e.path())) out.push_back(e.path().string());
+  std::sort(out.begin(), out.end());
+  return out;
+}
+
+matrix_rows read_matrix_file(const std::string& path)
+{
+  auto d = slurp(path);
+  if (d.size() < 45 || std::memcmp(d.data(), "kmtricks", 8) != 0 || std::memcmp(d.data() + 13, "matrix", 6) != 0)
+    throw std::runtime_error(path + ": not a kmtricks count matrix");
+  matrix_rows m;
+  const uint8_t compressed = rd<uint8_t>(d, 12);
+  m.kmer_size = rd<uint32_t>(d, 21);
+  const uint32_t slots = rd<uint32_t>(d, 25);
+  m.count_bytes = rd<uint32_t>(d, 29);
+  m.nb_counts = rd<uint32_t>(d, 33);
+  m.partition = rd<uint32_t>(d, 41);
+  if (slots != 1) throw std::runtime_error(path + ": k > 32 is not supported by this reader yet");
+  if (m.count_bytes != 1 && m.count_bytes != 2 && m.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
+  std::vector<char> raw;
+  if (compressed) raw = lz4_frame_decode(d, 45, path); else raw.assign(d.begin() + 45, d.end());
+  const size_t rec = 8 + (size_t)m.count_bytes * m.nb_counts, n = raw.size() / rec;
+  if (n * rec != raw.size()) throw std::runtime_error(path + ": truncated row");
+  m.kmers.resize(n); m.counts.assign(n * m.nb_counts, 0);
+  for (size_t i = 0; i < n; ++i)
+  {
+    const char* r = raw.data() + i * rec;
+    std::memcpy(&m.kmers[i], r, 8);
+    for (uint32_t s = 0; s < m.nb_counts; ++s) std::memcpy(&m.counts[i * m.nb_counts + s], r + 8 + (size_t)s * m.count_bytes, m.count_bytes);
+  }
+  return m;
+}
+
+void write_matrix_file(const std::string& path, const matrix_rows& m)
+{
+  std::ofstream out(path, std::ios::binary);
+  if (!out) throw std::runtime_error("cannot write " + path);
+  const uint32_t zero = 0, slots = 1;
+  const uint8_t compressed = 1;
+  out.write("kmtricks", 8); out.write((const char*)&zero, 4); out.write((const char*)&compressed, 1);
+  out.write("matrix\0\0", 8);
+  out.write((const char*)&m.kmer_size, 4); out.write((const char*)&slots, 4); out.write((const char*)&m.count_bytes, 4);
+  out.write((const char*)&m.nb_counts, 4); out.write((const char*)&zero, 4); out.write((const char*)&m.partition, 4);
+  const size_t rec = 8 + (size_t)m.count_bytes * m.nb_counts, n = m.kmers.size();
+  std::vector<char> raw(n * rec);
+  for (size_t i = 0; i < n; ++i)
+  {
+    char* r = raw.data() + i * rec;
+    std::memcpy(r, &m.kmers[i], 8);
+    for (uint32_t s = 0; s < m.nb_counts; ++s) std::memcpy(r + 8 + (size_t)s * m.count_bytes, &m.counts[i * m.nb_counts + s], m.count_bytes);
+  }
+  lz4_frame_encode(out, raw.data(), raw.size());
+}
+
+// ---------------------------------------------------------------------------------------------
+void write_survivor_file(const std::string& path, const survivor_set& s, size_t first, size_t count)
+{
+  std::ofstream out(path, std::ios::binary);
+  if (!out) throw std::runtime_error("cannot write " + path);
+  const uint16_t nc = (uint16_t)s.n_counts;
+  const size_t rec = 8 + 8 + 4 + 8 + 8 + 2 + 8 * (size_t)nc;
+  std::vector<char> raw(count * rec);
+  for (size_t i = 0; i < count; ++i)
+  {
+    char* r = raw.data() + i * rec;
+    const size_t j = first + i;
+    std::memcpy(r, &s.kmer[j], 8); std::memcpy(r + 8, &s.p[j], 8); std::memcpy(r + 16, &s.sign[j], 4);
+    std::memcpy(r + 20, &s.mean_control[j], 8); std::memcpy(r + 28, &s.mean_case[j], 8); std::memcpy(r + 36, &nc, 2);
+    if (nc) std::memcpy(r + 38, &s.counts[j * nc], 8 * (size_t)nc);
+  }
+  lz4_frame_encode(out, raw.data(), raw.size());
+}
+
+size_t read_survivor_file(const std::string& path, survivor_set& s)
+{
+  auto d = slurp(path);
+  const std::vector<char> raw = d.empty() ? std::vector<char>() : lz4_frame_decode(d, 0, path);
+  size_t pos = 0, n = 0;
+  while (pos + 38 <= raw.size())
+  {
+    uint64_t km; double p, mc, mk; int32_t sg; uint16_t nc;
+    std::memcpy(&km, &raw[pos], 8); std::memcpy(&p, &raw[pos + 8], 8); std::memcpy(&sg, &raw[pos + 16], 4);
+    std::memcpy(&mc, &raw[pos + 20], 8); std::memcpy(&mk, &raw[pos + 28], 8); std::memcpy(&nc, &raw[pos + 36], 2);
+    if (s.size() == 0) s.n_counts = nc;
+    if (nc != s.n_counts || pos + 38 + 8 * (size_t)nc > raw.size()) throw std::runtime_error(path + ": malformed survivor record");
+    s.kmer.push_back(km); s.p.push_back(p); s.sign.push_back(sg); s.mean_control.push_back(mc); s.mean_case.push_back(mk);
+    s.counts.resize(s.counts.size() + nc);
+    if (nc) std::memcpy(&s.counts[s.counts.size() - nc], &raw[pos + 38], 8 * (size_t)nc);
+    pos += 38 + 8 * (size_t)nc; ++n;
+  }
+  if (pos != raw.size()) throw std::runtime_error(path + ": trailing bytes");
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+void dump_opt(const resume_options& o, const std::string& path)
+{
+  std::ofstream out(path, std::ios::binary);
+  const uint8_t pc = o.pop_correction ? 1 : 0;
+  out.write((const char*)&o.threshold, 8); out.write((const char*)&o.cutoff, 8); out.write((const char*)&o.correction, 4);
+  out.write((const char*)&pc, 1); out.write((const char*)&o.kmer_pca, 8); out.write((const char*)&o.npc, 8);
+}
+
+bool load_opt(const std::string& path, resume_options& o)
+{
+  std::ifstream in(path, std::ios::binary);
+  char b[37];
+  if (!in.read(b, 37)) return false;
+  uint8_t pc;
+  std::memcpy(&o.threshold, b, 8); std::memcpy(&o.cutoff, b + 8, 8); std::memcpy(&o.correction, b + 16, 4);
+  std::memcpy(&pc, b + 20, 1); std::memcpy(&o.kmer_pca, b + 21, 8); std::memcpy(&o.npc, b + 29, 8);
+  o.pop_correction = pc != 0;
+  return true;
+}
+
+unsigned compare_opt(const resume_options& opt, const resume_options& prev)      // cmd/diff_opt.hpp:106-133
+{
+  unsigned r = 0;
+  if (opt.threshold != prev.threshold || opt.cutoff != prev.cutoff) r |= 0b1;
+  if (prev.pop_correction && opt.pop_correction)
+  {
+    if (opt.kmer_pca != prev.kmer_pca) r |= 0b11;
+    if (opt.npc != prev.npc) r |= 0b10;
+  }
+  if (!prev.pop_correction && opt.pop_correction) r |= 0b11;
+  if (opt.correction != prev.correction) r |= 0b100;
+  if (prev.pop_correction && !opt.pop_correction) r |= 0b100;
+  return r;
 }
 
 std::string kmer_to_string(uint64_t kmer, size_t k)

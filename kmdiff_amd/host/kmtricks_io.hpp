@@ -38,4 +38,52 @@ std::string kmer_file_path(const std::string& run_dir, size_t partition, const s
 // 2-bit code A=0 C=1 T=2 G=3, first base most significant (km::Kmer::to_string)
 std::string kmer_to_string(uint64_t kmer, size_t k);
 
+// ---- matrix files: <run>/matrices/* (the alternate feed, matrix_proxy::merge, merge.hpp:194-203)
+// and positive_kmer_matrix/matrices/matrix_<p>.count.lz4 (--save-sk, merge.hpp:272-278).
+// kmtricks source is absent and the reference holds no matrix fixture: the header is written BY
+// ANALOGY with the k-mer file header the fixture pins (same 13-byte base header, then
+// "matrix\0\0", u32 k, u32 kmer_slots, u32 count_bytes, u32 nb_counts, u32 id, u32 partition =
+// 45 bytes) followed by one LZ4 frame of rows [u64 kmer x slots][count x nb_counts].  Unpinned.
+struct matrix_rows
+{
+  uint32_t kmer_size = 0, count_bytes = 0, nb_counts = 0, partition = 0;
+  std::vector<uint64_t> kmers;                 // one limb per row (k <= 32)
+  std::vector<uint32_t> counts;                // [row][sample], widened
+};
+matrix_rows read_matrix_file(const std::string& path);
+void write_matrix_file(const std::string& path, const matrix_rows& m);
+std::vector<std::string> matrix_paths(const std::string& run_dir);    // sorted; empty when there is no matrices/ content
+
+// ---- survivor files: <out>/partitions/p<i>_uncorrected and p<i>_popstrat_uncorrected
+// (FileAccumulator<KmerSign<KSIZE>>, accumulator.hpp:156-285): one LZ4 frame (lz4_stream) of
+// records [kmer 8 B][p f64][sign i32][mean_control f64][mean_case f64][n u16][n x f64 counts]
+// (KmerSign::dump, kmer.hpp:113-127; the count block is there because WITH_POPSTRAT is ON by
+// default, CMakeLists.txt:8).
+struct survivor_set
+{
+  std::vector<uint64_t> kmer;
+  std::vector<double> p, mean_control, mean_case;
+  std::vector<int32_t> sign;
+  std::vector<double> counts;                  // [record][n_counts]
+  size_t n_counts = 0;
+  size_t size() const { return p.size(); }
+};
+void write_survivor_file(const std::string& path, const survivor_set& s, size_t first, size_t count);
+// appends the file's records to s (s.n_counts is set by the first record read)
+size_t read_survivor_file(const std::string& path, survivor_set& s);
+
+// ---- options.bin (dump_opt / load_opt / compare_opt, cmd/diff_opt.hpp:78-133): 37 bytes
+struct resume_options
+{
+  double threshold = 0, cutoff = 0;
+  int32_t correction = 0;
+  bool pop_correction = false;
+  double kmer_pca = 0;
+  uint64_t npc = 0;
+};
+void dump_opt(const resume_options& o, const std::string& path);
+bool load_opt(const std::string& path, resume_options& o);
+// bit 0: redo stage 1, bit 1: redo the pop-strat stage, bit 2: redo the correction
+unsigned compare_opt(const resume_options& opt, const resume_options& prev);
+
 } // namespace kmd_host

@@ -8,9 +8,13 @@
 // bytes (kmtricks files -> HBM, survivors -> FASTA) and parses flags.  No CPU compute path:
 // without a device the command fails.
 //
-// Not carried over (out of scope): `count`/`infos` sub-commands, --cmodel plugins,
-// KFF output, --save-sk, resume files, the smartpca front end (give --pcs FILE with the
-// principal components instead), progress bars.
+// Also kept: the alternate feed from <run>/matrices (matrix_proxy, merge.hpp:194-203), the
+// survivor files partitions/p<i>_uncorrected / p<i>_popstrat_uncorrected with options.bin and
+// the stage-skip logic of main_diff (--keep-tmp; cmd/diff.hpp:278-370), --save-sk.
+//
+// Not carried over (out of scope): `count`/`infos` sub-commands, --cmodel plugins
+// (the IModel plugin of this build is libkmdiff_hip_model.so), KFF output, the smartpca front
+// end (give --pcs FILE with the principal components instead), progress bars.
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
@@ -36,7 +40,8 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   std::string kmtricks_dir, output_directory = "./kmdiff_output", correction = "bonferroni", pcs;
   size_t nb_controls = 0, nb_cases = 0, cutoff = 100000, log_size = 10000, npc = 2, max_iteration = 0;
   double threshold = 0.05;
-  bool pop_correction = false, stand = true, keep_tmp = false;
+  bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false;
+  double kmer_pca = 0.001;                  // only recorded in options.bin (cli.cpp default)
   int device = 0, verbose = 1;
 };
 
@@ -67,7 +72,9 @@ void usage()
             "  --pcs FILE         principal components (pcs.evec: one row per sample, 10 columns)\n"
             "  --n-pc             number of principal components in [2, 10] {2}\n"
             "  --device           GPU index {0}\n"
-            "  -t/--threads, -f, -m, -r, --keep-tmp, --save-sk: accepted for compatibility, ignored");
+            "  --keep-tmp         keep partitions/p<i>_uncorrected (+ options.bin): a later run resumes from them\n"
+            "  --save-sk          write the significant rows to positive_kmer_matrix/matrices/matrix_<p>.count.lz4\n"
+            "  -t/--threads, -f, -m, -r: accepted for compatibility, ignored");
 }
 
 diff_options parse(int argc, char** argv)
@@ -91,10 +98,13 @@ diff_options parse(int argc, char** argv)
     else if (a == "--n-pc") o.npc = std::stoull(need(i));
     else if (a == "--max-iteration") o.max_iteration = std::stoull(need(i));
     else if (a == "--device") o.device = std::stoi(need(i));
-    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" || a == "--kmer-pca" || a == "--ploidy" ||
+    else if (a == "--keep-tmp") o.keep_tmp = true;
+    else if (a == "--save-sk") o.save_sk = true;
+    else if (a == "--kmer-pca") o.kmer_pca = std::stod(need(i));
+    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" || a == "--ploidy" ||
              a == "--gender" || a == "--random-seed" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
     else if (a == "-f" || a == "--kff-output" || a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
-             a == "--keep-tmp" || a == "--save-sk" || a == "--stand" || a == "--irls") {}
+             a == "--stand" || a == "--irls") {}
     else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
     else die("unknown option " + a);
   }
@@ -161,71 +171,181 @@ int main(int argc, char** argv)
        "kmd_model_create");
     const double first_threshold = opt.threshold / (double)opt.cutoff;                       // cmd/diff.hpp:147
 
-    // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
-    std::fprintf(stderr, "[kmdiff-hip] Process partitions\n");
-    std::vector<uint64_t> s_kmer; std::vector<double> s_p, s_mc, s_mk; std::vector<int32_t> s_sign;
-    std::vector<double> s_counts;                // [n][S] when --pop-correction
-    uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
-    dev_buf d_kmers, d_counts, d_matrix, d_kmer_col, d_cnt, d_srow, d_skmer, d_sp, d_ssign, d_smc, d_smk, d_sc;
-    const size_t T = 4096;
-    for (size_t p = 0; p < cfg.nb_partitions; ++p)
+    // ---- what a previous run left behind (cmd/diff.hpp:278-303)
+    const std::string part_dir = opt.output_directory + "/partitions";
+    fs::create_directories(part_dir);
+    resume_options ropt; ropt.threshold = opt.threshold; ropt.cutoff = (double)opt.cutoff;
+    ropt.correction = correction_type(opt.correction); ropt.pop_correction = opt.pop_correction;
+    ropt.kmer_pca = opt.kmer_pca; ropt.npc = opt.npc;
+    resume_options prev;
+    const bool prev_run = load_opt(opt.output_directory + "/options.bin", prev);
+    auto all_exist = [&](const char* suffix)
     {
-      std::vector<uint64_t> kmers; std::vector<uint32_t> counts; std::vector<uint64_t> offs(S + 1, 0);
-      for (size_t s = 0; s < S; ++s)                                                          // KmDir::get_files_to_merge
+      for (size_t p = 0; p < cfg.nb_partitions; ++p)
+        if (!fs::exists(part_dir + "/p" + std::to_string(p) + suffix)) return false;
+      return true;
+    };
+    const unsigned action = prev_run ? compare_opt(ropt, prev) : 0;
+    const bool prev_1 = prev_run && all_exist("_uncorrected");
+    const bool prev_2 = prev_run && all_exist("_popstrat_uncorrected");
+    const bool want_counts = opt.pop_correction || opt.keep_tmp || opt.save_sk;
+
+    survivor_set sv_all;                           // survivors of all partitions, partition after partition
+    sv_all.n_counts = want_counts ? S : 0;
+    std::vector<size_t> part_begin(cfg.nb_partitions + 1, 0);
+    uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+    const bool run_stage1 = !prev_1 || (action & 0b1);
+    if (run_stage1)
+    {
+      // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
+      std::fprintf(stderr, "[kmdiff-hip] Process partitions\n");
+      const auto mpaths = matrix_paths(opt.kmtricks_dir);                                     // cmd/diff.hpp:80-101
+      const bool from_matrix = !mpaths.empty();
+      if (opt.save_sk)                                                                        // cmd/diff.hpp:52-64,137-143
       {
-        read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s].id), cfg.kmer_size, kmers, counts);
-        offs[s + 1] = kmers.size();
+        const std::string sk = opt.output_directory + "/positive_kmer_matrix";
+        fs::create_directories(sk + "/matrices");
+        for (const char* f : { "/options.txt", "/kmtricks.fof" })
+          if (fs::exists(opt.kmtricks_dir + f)) fs::copy(opt.kmtricks_dir + f, sk, fs::copy_options::overwrite_existing);
+        for (const char* dname : { "/config_gatb", "/repartition_gatb" })
+          if (fs::exists(opt.kmtricks_dir + dname))
+            fs::copy(opt.kmtricks_dir + dname, sk + dname, fs::copy_options::recursive | fs::copy_options::overwrite_existing);
       }
-      const size_t n = kmers.size();
-      if (n == 0) continue;
-      d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
-      ck(kmd_memcpy_h2d(d_kmers.p, kmers.data(), n * 8, nullptr), "h2d");
-      ck(kmd_memcpy_h2d(d_counts.p, counts.data(), n * 4, nullptr), "h2d");
-      d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
-      uint64_t n_rows = 0;
-      ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, nullptr, (const uint32_t*)d_counts.p, offs.data(), 4,
-                             KMD_LAYOUT_TILED, T, n, d_matrix.p, (uint64_t*)d_kmer_col.p, nullptr, &n_rows, nullptr),
-         "kmd_merge_partition");
-      // survivor sink sized for the worst case of this partition (every row)
-      d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
-      d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
-      ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
-      kmd_tile tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p, nullptr, (size_t)n_rows, 0 };
-      kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
-                         (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
-      ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
-      uint64_t c[KMD_NCOUNTERS];
-      ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
-      const size_t ns = (size_t)c[KMD_CNT_SIG];
-      ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                         // reference push order
-      const size_t base = s_p.size();
-      s_kmer.resize(base + ns); s_p.resize(base + ns); s_sign.resize(base + ns); s_mc.resize(base + ns); s_mk.resize(base + ns);
-      if (ns)
+      dev_buf d_kmers, d_counts, d_matrix, d_kmer_col, d_cnt, d_srow, d_skmer, d_sp, d_ssign, d_smc, d_smk, d_sc;
+      const size_t T = 4096;
+      // one accumulator per entry of counts/ (cmd/diff.hpp:103-107); matrix files map onto them in order
+      const size_t n_units = from_matrix ? std::min(mpaths.size(), cfg.nb_partitions) : cfg.nb_partitions;
+      if (from_matrix && mpaths.size() > cfg.nb_partitions) die("more files in matrices/ than partitions in counts/");
+      for (size_t p = 0; p < n_units; ++p)
       {
-        ck(kmd_memcpy_d2h(s_kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(s_p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(s_sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(s_mc.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(s_mk.data() + base, d_smk.p, ns * 8, nullptr), "d2h");
-        if (opt.pop_correction)                                                               // merge.hpp:91-92
+        kmd_tile tile {};
+        uint64_t n_rows = 0;
+        if (from_matrix)
         {
-          d_sc.reserve(ns * S * 8);
-          ck(kmd_survivors_gather_counts(&tile, (int)S, (const uint64_t*)d_srow.p, ns, (double*)d_sc.p, nullptr), "gather_counts");
-          s_counts.resize((base + ns) * S);
-          ck(kmd_memcpy_d2h(s_counts.data() + base * S, d_sc.p, ns * S * 8, nullptr), "d2h");
+          // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
+          const matrix_rows m = read_matrix_file(mpaths[p]);
+          if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
+          n_rows = m.kmers.size();
+          if (n_rows)
+          {
+            d_matrix.reserve(n_rows * S * 4); d_kmer_col.reserve(n_rows * 8);
+            ck(kmd_memcpy_h2d(d_matrix.p, m.counts.data(), n_rows * S * 4, nullptr), "h2d");
+            ck(kmd_memcpy_h2d(d_kmer_col.p, m.kmers.data(), n_rows * 8, nullptr), "h2d");
+          }
+          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p, nullptr, (size_t)n_rows, 0 };
+        }
+        else
+        {
+          std::vector<uint64_t> kmers; std::vector<uint32_t> counts; std::vector<uint64_t> offs(S + 1, 0);
+          for (size_t s = 0; s < S; ++s)                                                      // KmDir::get_files_to_merge
+          {
+            read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s].id), cfg.kmer_size, kmers, counts);
+            offs[s + 1] = kmers.size();
+          }
+          const size_t n = kmers.size();
+          if (n)
+          {
+            d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
+            ck(kmd_memcpy_h2d(d_kmers.p, kmers.data(), n * 8, nullptr), "h2d");
+            ck(kmd_memcpy_h2d(d_counts.p, counts.data(), n * 4, nullptr), "h2d");
+            d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
+            ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, nullptr, (const uint32_t*)d_counts.p, offs.data(), 4,
+                                   KMD_LAYOUT_TILED, T, n, d_matrix.p, (uint64_t*)d_kmer_col.p, nullptr, &n_rows, nullptr),
+               "kmd_merge_partition");
+          }
+          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p, nullptr, (size_t)n_rows, 0 };
+        }
+        size_t ns = 0;
+        const size_t base = sv_all.size();
+        if (n_rows)
+        {
+          // survivor sink sized for the worst case of this partition (every row)
+          d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
+          d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
+          ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
+          kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
+                             (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
+          ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
+          uint64_t c[KMD_NCOUNTERS];
+          ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+          ns = (size_t)c[KMD_CNT_SIG];
+          ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                     // reference push order
+          sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
+          sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);
+          if (ns)
+          {
+            ck(kmd_memcpy_d2h(sv_all.kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
+            ck(kmd_memcpy_d2h(sv_all.p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
+            ck(kmd_memcpy_d2h(sv_all.sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
+            ck(kmd_memcpy_d2h(sv_all.mean_control.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
+            ck(kmd_memcpy_d2h(sv_all.mean_case.data() + base, d_smk.p, ns * 8, nullptr), "d2h");
+            if (want_counts)                                                                  // merge.hpp:91-92
+            {
+              d_sc.reserve(ns * S * 8);
+              ck(kmd_survivors_gather_counts(&tile, (int)S, (const uint64_t*)d_srow.p, ns, (double*)d_sc.p, nullptr), "gather_counts");
+              sv_all.counts.resize((base + ns) * S);
+              ck(kmd_memcpy_d2h(sv_all.counts.data() + base * S, d_sc.p, ns * S * 8, nullptr), "d2h");
+            }
+          }
+          total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
+        }
+        part_begin[p + 1] = base + ns;
+        if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
+        {
+          matrix_rows sk; sk.kmer_size = (uint32_t)cfg.kmer_size; sk.count_bytes = 4; sk.nb_counts = (uint32_t)S; sk.partition = (uint32_t)p;
+          sk.kmers.assign(sv_all.kmer.begin() + base, sv_all.kmer.end());
+          sk.counts.resize(ns * S);
+          for (size_t i = 0; i < ns * S; ++i) sk.counts[i] = (uint32_t)sv_all.counts[base * S + i];
+          write_matrix_file(opt.output_directory + "/positive_kmer_matrix/matrices/matrix_" + std::to_string(p) + ".count.lz4", sk);
         }
       }
-      total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
+      for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
+      if (opt.keep_tmp)                                                                       // FileAccumulator, del = !keep_tmp
+        for (size_t p = 0; p < cfg.nb_partitions; ++p)
+          write_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
+      std::fprintf(stderr, "[kmdiff-hip] %" PRIu64 "/%" PRIu64 " significant k-mers.\n", n_sig, total_kmers);      // cmd/diff.hpp:160
+      std::fprintf(stderr, "[kmdiff-hip] Before correction: %" PRIu64 " (control), %" PRIu64 " (case).\n", n_sig_control, n_sig_case);
     }
-    std::fprintf(stderr, "[kmdiff-hip] %" PRIu64 "/%" PRIu64 " significant k-mers.\n", n_sig, total_kmers);      // cmd/diff.hpp:160
-    std::fprintf(stderr, "[kmdiff-hip] Before correction: %" PRIu64 " (control), %" PRIu64 " (case).\n", n_sig_control, n_sig_case);
+    else
+    {
+      // ---- stage 1 skipped: the survivors of the previous run (cmd/diff.hpp:329-337).  The
+      // reference takes total_kmers from the loaded options, which options.bin does not hold
+      // (diff_opt.hpp:78-88); here it is kept in resume.txt next to options.bin.
+      std::fprintf(stderr, "[kmdiff-hip] Resume: partitions/p*_uncorrected of the previous run\n");
+      for (size_t p = 0; p < cfg.nb_partitions; ++p)
+      {
+        read_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all);
+        part_begin[p + 1] = sv_all.size();
+      }
+      std::ifstream rs(opt.output_directory + "/resume.txt");
+      if (!(rs >> total_kmers >> n_sig >> n_sig_control >> n_sig_case)) die("resume.txt of the previous run is missing");
+      if (want_counts && sv_all.size() && sv_all.n_counts != S) die("previous run's survivor files hold another sample count");
+    }
+    dump_opt(ropt, opt.output_directory + "/options.bin");
+    {
+      std::ofstream rs(opt.output_directory + "/resume.txt");
+      rs << total_kmers << ' ' << n_sig << ' ' << n_sig_control << ' ' << n_sig_case << '\n';
+    }
+    std::vector<uint64_t>& s_kmer = sv_all.kmer;
+    std::vector<double>& s_p = sv_all.p; std::vector<double>& s_mc = sv_all.mean_control; std::vector<double>& s_mk = sv_all.mean_case;
+    std::vector<int32_t>& s_sign = sv_all.sign;
+    std::vector<double>& s_counts = sv_all.counts;
 
     const size_t n = s_p.size();
     dev_buf d_p, d_sign, d_keep;
     d_p.reserve(std::max<size_t>(n, 1) * 8); d_sign.reserve(std::max<size_t>(n, 1) * 4); d_keep.reserve(std::max<size_t>(n, 1));
 
     // ---- stage 2: do_pop (cmd/diff.hpp:167-224) with externally computed principal components
-    if (opt.pop_correction && n)
+    const bool run_stage2 = opt.pop_correction && ((!prev_2 || (action & 0b10)) || run_stage1);            // cmd/diff.hpp:349
+    if (opt.pop_correction && !run_stage2)
+    {
+      std::fprintf(stderr, "[kmdiff-hip] Resume: partitions/p*_popstrat_uncorrected of the previous run\n");
+      survivor_set ps;
+      for (size_t p = 0; p < cfg.nb_partitions; ++p) read_survivor_file(part_dir + "/p" + std::to_string(p) + "_popstrat_uncorrected", ps);
+      if (ps.size() != n) die("previous run's pop-strat survivor files do not match");
+      s_p = ps.p;
+    }
+    if (run_stage2 && n)
     {
       std::ifstream zin(opt.pcs);
       if (!zin) die("cannot open " + opt.pcs);
@@ -242,6 +362,9 @@ int main(int argc, char** argv)
       kmd_popstrat_destroy(ps);
       std::fprintf(stderr, "[kmdiff-hip] Population correction done.\n");
     }
+    if (run_stage2 && opt.keep_tmp)
+      for (size_t p = 0; p < cfg.nb_partitions; ++p)
+        write_survivor_file(part_dir + "/p" + std::to_string(p) + "_popstrat_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
 
     // ---- stage 3: do_correction (cmd/diff.hpp:227-260)
     uint64_t kept = 0, c_controls = 0, c_cases = 0;

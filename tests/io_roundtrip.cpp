@@ -1,0 +1,45 @@
+// Test harness (no GPU): reads a file with the host readers of kmdiff_amd/host/kmtricks_io.cpp and
+// writes it back with the host writers, so that tests/test_host_io.py can compare both directions
+// with the independent Python reader/writer of tests/kmtricks_files.py.
+//   io_roundtrip matrix <in> <out> | survivors <in> <out> | options <in> <out>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../kmdiff_amd/host/kmtricks_io.hpp"
+
+int main(int argc, char** argv)
+{
+  if (argc != 4) { std::fprintf(stderr, "usage: io_roundtrip matrix|survivors|options <in> <out>\n"); return 2; }
+  const std::string what = argv[1], in = argv[2], out = argv[3];
+  try
+  {
+    if (what == "matrix")
+    {
+      const kmd_host::matrix_rows m = kmd_host::read_matrix_file(in);
+      std::printf("rows=%zu k=%u count_bytes=%u nb_counts=%u partition=%u\n", m.kmers.size(), m.kmer_size, m.count_bytes,
+                  m.nb_counts, m.partition);
+      kmd_host::write_matrix_file(out, m);
+    }
+    else if (what == "survivors")
+    {
+      kmd_host::survivor_set s;
+      const size_t n = kmd_host::read_survivor_file(in, s);
+      std::printf("records=%zu n_counts=%zu\n", n, s.n_counts);
+      kmd_host::write_survivor_file(out, s, 0, n);
+    }
+    else if (what == "options")
+    {
+      kmd_host::resume_options o, same;
+      if (!kmd_host::load_opt(in, o)) { std::fprintf(stderr, "short options.bin\n"); return 1; }
+      same = o;
+      std::printf("threshold=%.17g cutoff=%.17g correction=%d pop=%d kmer_pca=%.17g npc=%llu action_same=%u\n", o.threshold, o.cutoff,
+                  o.correction, (int)o.pop_correction, o.kmer_pca, (unsigned long long)o.npc, kmd_host::compare_opt(o, same));
+      kmd_host::dump_opt(o, out);
+    }
+    else return 2;
+  }
+  catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+  return 0;
+}

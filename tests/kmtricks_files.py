@@ -158,5 +158,51 @@ def write_run_dir(root, k, sample_ids, partitions, abundance_min=1):
     os.makedirs(os.path.join(root, "matrices"), exist_ok=True)
 
 
+def write_matrix_file(path, k, partition, kmers, counts, count_bytes=4):
+    """<run>/matrices/*: header BY ANALOGY with the k-mer file header (no fixture, kmtricks absent):
+    13-byte base header, "matrix\\0\\0", u32 k, u32 slots, u32 count_bytes, u32 nb_counts, u32 id,
+    u32 partition; then one LZ4 frame of rows [u64 kmer][count x nb_counts]."""
+    kmers = np.asarray(kmers, dtype="<u8")
+    counts = np.asarray(counts).astype({1: "<u1", 2: "<u2", 4: "<u4"}[count_bytes])
+    n, S = counts.shape
+    rec = np.zeros((n, 8 + S * count_bytes), dtype=np.uint8)
+    rec[:, :8] = kmers.view(np.uint8).reshape(n, 8)
+    rec[:, 8:] = np.ascontiguousarray(counts).view(np.uint8).reshape(n, S * count_bytes)
+    hdr = struct.pack("<8sIB8sIIIIII", b"kmtricks", 0, 1, b"matrix\0\0", k, 1, count_bytes, S, 0, partition)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(hdr + lz4_frame_encode(rec.tobytes()))
+
+
+def read_matrix_file(path):
+    d = open(path, "rb").read()
+    magic, _, comp, kind, k, slots, cbytes, S, sid, part = struct.unpack("<8sIB8sIIIIII", d[:45])
+    assert magic == b"kmtricks" and kind.rstrip(b"\0") == b"matrix" and slots == 1
+    raw = lz4_frame_decode(d[45:]) if comp else d[45:]
+    rec = 8 + S * cbytes
+    n = len(raw) // rec
+    a = np.frombuffer(raw, dtype=np.uint8, count=n * rec).reshape(n, rec)
+    kmers = a[:, :8].copy().view("<u8").reshape(n)
+    counts = a[:, 8:].copy().view({1: "<u1", 2: "<u2", 4: "<u4"}[cbytes]).reshape(n, S).astype(np.uint32)
+    return {"k": k, "count_bytes": cbytes, "nb_counts": S, "partition": part}, kmers, counts
+
+
+def read_survivor_file(path):
+    """partitions/p<i>_uncorrected (FileAccumulator<KmerSign<32>>, WITH_POPSTRAT): one LZ4 frame of
+    [kmer u64][p f64][sign i32][mean_control f64][mean_case f64][n u16][n x f64]."""
+    d = open(path, "rb").read()
+    raw = lz4_frame_decode(d) if d else b""
+    out = {"kmer": [], "p": [], "sign": [], "mc": [], "mk": [], "counts": []}
+    pos = 0
+    while pos < len(raw):
+        km, p, sg, mc, mk, n = struct.unpack_from("<QdiddH", raw, pos)
+        pos += 38
+        out["kmer"].append(km); out["p"].append(p); out["sign"].append(sg); out["mc"].append(mc); out["mk"].append(mk)
+        out["counts"].append(np.frombuffer(raw, dtype="<f8", count=n, offset=pos).copy())
+        pos += 8 * n
+    assert pos == len(raw)
+    return out
+
+
 def kmer_to_string(v, k):
     return "".join("ACTG"[(int(v) >> (2 * (k - 1 - i))) & 3] for i in range(k))

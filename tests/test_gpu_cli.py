@@ -106,6 +106,67 @@ def test_cli_matches_oracle_pipeline(synth_run, tmp_path, correction):
             assert abs(pv - surv["p"][i]) <= 1e-5 * surv["p"][i] + 1e-300          # %g keeps 6 digits
 
 
+def test_cli_matrix_feed_equals_kmer_file_feed(synth_run, tmp_path):
+    """cmd/diff.hpp:80-101,151-152: a non-empty matrices/ switches do_diff to matrix_proxy
+    (merge.hpp:194-203, pre-merged rows): same survivors and decisions as the k-way merge feed."""
+    import shutil
+    run_dir, nc, nk, k, mats, kms = synth_run
+    a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000], tmp_path / "a")
+    mrun = tmp_path / "km_matrix"
+    shutil.copytree(run_dir, mrun)
+    for p, (m, km) in enumerate(zip(mats, kms)):
+        KF.write_matrix_file(str(mrun / "matrices" / ("matrix_%d.count.lz4" % p)), k, p, km, m)
+    b, _ = run_cli(["-d", mrun, "-1", nc, "-2", nk, "-u", 1000], tmp_path / "b")
+    assert a == b and a["n_sig"] > 10
+    for name in ("control_kmers.fasta", "case_kmers.fasta"):
+        assert open(tmp_path / "a" / name).read() == open(tmp_path / "b" / name).read()
+
+
+def test_cli_keep_tmp_files_resume_and_save_sk(synth_run, tmp_path):
+    """--keep-tmp leaves partitions/p<i>_uncorrected in the reference's record format
+    (kmer.hpp:113-127 through lz4_stream) and options.bin (diff_opt.hpp:78-88); a second run that
+    only changes the corrector skips stage 1 (cmd/diff.hpp:310-337) and must equal a fresh run;
+    --save-sk writes the significant rows (merge.hpp:83-86)."""
+    import struct
+    run_dir, nc, nk, k, mats, kms = synth_run
+    o = OL.load()
+    out = tmp_path / "o"
+    s1, err1 = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "--keep-tmp", "--save-sk"], out)
+    assert "Resume" not in err1
+    surv, _, total = oracle_pipeline(o, nc, nk, mats, kms, 0.05 / 1000, "bonferroni", 0.05)
+    got = {"kmer": [], "p": [], "sign": [], "mc": [], "mk": [], "counts": []}
+    sk_rows = []
+    for p in range(3):
+        f = KF.read_survivor_file(str(out / "partitions" / ("p%d_uncorrected" % p)))
+        for key in got:
+            got[key] += f[key]
+        hdr, km, cnt = KF.read_matrix_file(str(out / "positive_kmer_matrix" / "matrices" / ("matrix_%d.count.lz4" % p)))
+        assert (hdr["k"], hdr["count_bytes"], hdr["nb_counts"], hdr["partition"]) == (k, 4, nc + nk, p)
+        assert km.tolist() == f["kmer"]
+        sk_rows.append(cnt)
+    assert got["kmer"] == surv["kmer"] and got["sign"] == surv["sign"]
+    assert got["mc"] == surv["mc"] and got["mk"] == surv["mk"]
+    assert np.allclose(got["p"], surv["p"], rtol=0, atol=1e-10)
+    lut = [{int(v): i for i, v in enumerate(km)} for km in kms]
+    want_rows = np.array([next(m[l[kv]] for m, l in zip(mats, lut) if kv in l) for kv in surv["kmer"]])
+    assert (np.array(got["counts"]) == want_rows).all() and (np.concatenate(sk_rows) == want_rows).all()
+    ob = open(out / "options.bin", "rb").read()
+    assert len(ob) == 37
+    thr, cutoff, corr, pop, kpca, npc = struct.unpack("<ddi?dQ", ob)
+    assert (thr, cutoff, corr, pop, npc) == (0.05, 1000.0, 1, False, 2)
+    assert os.path.exists(os.path.join(str(out), "positive_kmer_matrix", "kmtricks.fof"))
+    # second run, other corrector: stage 1 is not redone
+    s2, err2 = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "--keep-tmp", "-c", "benjamini"], out)
+    assert "Resume" in err2 and "Process partitions" not in err2
+    fresh, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-c", "benjamini"], tmp_path / "fresh")
+    assert s2 == fresh
+    for name in ("control_kmers.fasta", "case_kmers.fasta"):
+        assert open(out / name).read() == open(tmp_path / "fresh" / name).read()
+    # third run, other first-pass threshold: stage 1 IS redone (compare_opt bit 0)
+    s3, err3 = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 100, "--keep-tmp", "-c", "benjamini"], out)
+    assert "Process partitions" in err3 and s3["n_sig"] > s2["n_sig"]
+
+
 def test_cli_pop_correction(synth_run, tmp_path):
     run_dir, nc, nk, k, mats, kms = synth_run
     o = OL.load()

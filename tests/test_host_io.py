@@ -1,0 +1,91 @@
+"""Host-side file formats (kmdiff_amd/host/kmtricks_io.cpp) against the independent Python
+reader/writer of tests/kmtricks_files.py, both directions, no GPU:
+  matrices/*                      the alternate feed (matrix_proxy, merge.hpp:194-203) and --save-sk
+  partitions/p<i>_uncorrected     FileAccumulator<KmerSign> records (kmer.hpp:113-127)
+  options.bin                     dump_opt / load_opt / compare_opt (cmd/diff_opt.hpp:78-133)
+The matrix header is by analogy with the k-mer file header (no fixture, kmtricks absent): these
+tests pin the C++ and Python sides to each other, not to kmtricks."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import kmtricks_files as KF
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "kmdiff_amd", "bin", "io_roundtrip")
+
+
+def tool(*args):
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kmdiff_amd", "host"), "../bin/io_roundtrip"], check=True,
+                       capture_output=True)
+    r = subprocess.run([TOOL] + [str(a) for a in args], capture_output=True, text=True, timeout=120)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("count_bytes", [1, 2, 4])
+def test_matrix_file_both_directions(tmp_path, count_bytes):
+    rng = np.random.default_rng(3)
+    n, S = 70_000, 7                                    # several 64 KB LZ4 blocks
+    km = np.sort(rng.integers(0, 1 << 62, n, dtype=np.uint64))
+    cnt = rng.integers(0, 1 << (8 * count_bytes), (n, S), dtype=np.uint64).astype(np.uint32)
+    KF.write_matrix_file(str(tmp_path / "in.lz4"), 31, 5, km, cnt, count_bytes)
+    rc, out, err = tool("matrix", tmp_path / "in.lz4", tmp_path / "out.lz4")
+    assert rc == 0, err
+    assert out.split() == ["rows=%d" % n, "k=31", "count_bytes=%d" % count_bytes, "nb_counts=%d" % S, "partition=5"]
+    hdr, km2, cnt2 = KF.read_matrix_file(str(tmp_path / "out.lz4"))
+    assert hdr == {"k": 31, "count_bytes": count_bytes, "nb_counts": S, "partition": 5}
+    assert (km2 == km).all() and (cnt2 == cnt).all()
+
+
+def test_matrix_file_rejects_other_kmtricks_files(tmp_path):
+    KF.write_kmer_file(str(tmp_path / "x.kmer.lz4"), 31, 0, 0, [1, 2, 3], [1, 1, 1])
+    rc, _, err = tool("matrix", tmp_path / "x.kmer.lz4", tmp_path / "o")
+    assert rc == 1 and "not a kmtricks count matrix" in err
+
+
+@pytest.mark.parametrize("n,S", [(0, 9), (1, 0), (5000, 40)])
+def test_survivor_file_both_directions(tmp_path, n, S):
+    rng = np.random.default_rng(4)
+    raw = b""
+    recs = []
+    for i in range(n):
+        rec = (int(rng.integers(0, 1 << 62)), float(rng.random() * 1e-7), int(rng.integers(0, 3)), float(rng.integers(0, 500)),
+               float(rng.integers(0, 500)))
+        counts = rng.integers(0, 300, S).astype("<f8")
+        raw += struct.pack("<QdiddH", *rec, S) + counts.tobytes()
+        recs.append((rec, counts))
+    with open(tmp_path / "p0_uncorrected", "wb") as f:
+        f.write(KF.lz4_frame_encode(raw))
+    rc, out, err = tool("survivors", tmp_path / "p0_uncorrected", tmp_path / "back")
+    assert rc == 0, err
+    assert out.split()[0] == "records=%d" % n
+    got = KF.read_survivor_file(str(tmp_path / "back"))
+    assert len(got["p"]) == n
+    for i, (rec, counts) in enumerate(recs):
+        assert (got["kmer"][i], got["p"][i], got["sign"][i], got["mc"][i], got["mk"][i]) == rec
+        assert (got["counts"][i] == counts).all()
+
+
+def test_survivor_file_truncated_record_is_an_error(tmp_path):
+    raw = struct.pack("<QdiddH", 5, 1e-9, 1, 2.0, 3.0, 4) + b"\0" * 8       # says 4 counts, holds 1
+    with open(tmp_path / "bad", "wb") as f:
+        f.write(KF.lz4_frame_encode(raw))
+    rc, _, err = tool("survivors", tmp_path / "bad", tmp_path / "o")
+    assert rc == 1 and "malformed" in err
+
+
+def test_options_bin_layout(tmp_path):
+    """threshold f64, cutoff f64, correction i32, pop_correction u8, kmer_pca f64, npc u64 = 37 bytes."""
+    blob = struct.pack("<ddi?dQ", 0.05, 100000.0, 2, True, 0.001, 3)
+    assert len(blob) == 37
+    open(tmp_path / "options.bin", "wb").write(blob)
+    rc, out, err = tool("options", tmp_path / "options.bin", tmp_path / "back.bin")
+    assert rc == 0, err
+    assert "correction=2 pop=1" in out and "npc=3" in out and "action_same=0" in out
+    assert open(tmp_path / "back.bin", "rb").read() == blob
+    open(tmp_path / "short.bin", "wb").write(blob[:20])
+    assert tool("options", tmp_path / "short.bin", tmp_path / "x")[0] == 1
