@@ -105,9 +105,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # dev switches (not used by the driver): KMD_BENCH_OVERSUBSCRIBE=1 folds the ranks onto the GPUs
+    # there are, KMD_BENCH_BACKEND=gloo swaps RCCL out -- together they run the N>1 code on a 1-GPU box
+    if os.environ.get("KMD_BENCH_OVERSUBSCRIBE") == "1":
+        local_rank %= torch.cuda.device_count()
+    backend = os.environ.get("KMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
 
     import kmdiff_amd as K

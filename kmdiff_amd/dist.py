@@ -57,21 +57,27 @@ def allreduce_totals(totals):
     return allreduce_counters(totals)
 
 
+def all_gather(t):
+    """dist.all_gather of equally shaped tensors; the result lives where `t` lives.  Under gloo
+    (tests, 1-GPU dry runs of the N>1 code) device tensors travel through host memory."""
+    world = dist.get_world_size()
+    wire = t if (dist.get_backend() == "nccl" or t.device.type == "cpu") else t.cpu()
+    out = [torch.empty_like(wire) for _ in range(world)]
+    dist.all_gather(out, wire.contiguous())
+    return [o.to(t.device) for o in out]
+
+
 def allgather_varlen(t):
     """All-gather of 1-D tensors of different lengths.  Returns (concatenation in rank
     order, offsets[world+1])."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return t, [0, int(t.numel())]
-    world = dist.get_world_size()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [int(s.item()) for s in all_gather(n)]
     m = max(max(sizes), 1)
     pad = torch.zeros(m, dtype=t.dtype, device=t.device)
     pad[:t.numel()] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
+    out = all_gather(pad)
     cat = torch.cat([o[:s] for o, s in zip(out, sizes)])
     offs = [0]
     for s in sizes:
@@ -151,9 +157,9 @@ def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_b
     if world == 1 or correction not in (K.CORR_BENJAMINI, K.CORR_HOLM):
         keep, n_ctrl, n_case = K.aggregate(correction, threshold, total_kmers, pvalue_buf, sign_buf, n_local)
         return keep, g, (n_ctrl, n_case)
-    dev = _dev()
-    if dev.type != "cuda":
+    if not torch.cuda.is_available():
         raise RuntimeError("correct_sharded(BH/Holm) needs the HIP library: no CPU decision path")
+    dev = torch.device("cuda", torch.cuda.current_device())      # compute device (the wire may be gloo)
     if n_local:
         p_local = torch.as_tensor(_CudaView(pvalue_buf.ptr, n_local, "<f8"), device=dev)
         s_local = torch.as_tensor(_CudaView(sign_buf.ptr, n_local, "<i4"), device=dev)
@@ -161,8 +167,7 @@ def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_b
         p_local = torch.empty(0, dtype=torch.float64, device=dev)
         s_local = torch.empty(0, dtype=torch.int32, device=dev)
     hist = pvalue_histogram(K, p_local)
-    hists = [torch.empty_like(hist) for _ in range(world)]
-    dist.all_gather(hists, hist)                                   # per-rank histograms over xGMI
+    hists = all_gather(hist)                                       # per-rank histograms over xGMI
     hist_global = torch.stack(hists).sum(dim=0).contiguous()
     first_bin, before = critical_bin(K, correction, threshold, total_kmers, hist_global)
     idx = tail_of(p_local, first_bin)

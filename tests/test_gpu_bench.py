@@ -1,0 +1,52 @@
+"""bench.py's contract (one JSON line, the keys the driver reads) at N=1, and the N=2 code path --
+partition sharding, counter all-reduce, sharded BH/Holm -- run as two ranks folded onto the one
+GPU of the test box with gloo as the wire (KMD_BENCH_OVERSUBSCRIBE / KMD_BENCH_BACKEND; RCCL itself
+is exercised by the driver's multi-GPU run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROWS = 2_000_000
+
+
+def last_json(out):
+    lines = [l for l in out.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", str(ROWS), "--steps", "4", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["unit"] == "k-mers/s" and "workload" in d["config"]
+    assert d["config"]["counters"]["total"] == ROWS * 4
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+@pytest.mark.parametrize("correction", ["bonferroni", "benjamini", "holm"])
+def test_bench_two_ranks_on_one_gpu(correction):
+    env = dict(os.environ, KMD_BENCH_OVERSUBSCRIBE="1", KMD_BENCH_BACKEND="gloo")
+    port = {"bonferroni": 29521, "benjamini": 29522, "holm": 29523}[correction]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows",
+                        str(ROWS), "--steps", "4", "--warmup", "1", "--correction", correction],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    c = d["config"]["counters"]
+    assert c["total"] == ROWS * 4 * 2 and c["n_sig"] == c["n_sig_control"] + c["n_sig_case"]
+    assert 0 < c["kept_after_correction"] <= c["n_sig"]
