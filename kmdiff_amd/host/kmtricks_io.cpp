@@ -162,7 +162,7 @@ std::string kmer_file_path(const std::string& run_dir, size_t partition, const s
 }
 
 size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<uint64_t>& kmers,
-                      std::vector<uint32_t>& counts)
+                      std::vector<uint32_t>& counts, std::vector<uint64_t>* kmers_hi)
 {
   auto d = slurp(path);
   if (d.size() < 41 || std::memcmp(d.data(), "kmtricks", 8) != 0 || std::memcmp(d.data() + 13, "kmer", 4) != 0)
@@ -170,7 +170,8 @@ size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<ui
   const uint8_t compressed = rd<uint8_t>(d, 12);
   const uint32_t k = rd<uint32_t>(d, 21), slots = rd<uint32_t>(d, 25), cbytes = rd<uint32_t>(d, 29);
   if (expected_k && k != expected_k) throw std::runtime_error(path + ": k-mer size differs from the run's");
-  if (slots != 1) throw std::runtime_error(path + ": k > 32 is not supported by this reader yet");
+  if (slots != 1 && slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
+  if (slots == 2 && !kmers_hi) throw std::runtime_error(path + ": two-limb k-mers need a high-limb sink");
   if (cbytes != 1 && cbytes != 2 && cbytes != 4) throw std::runtime_error(path + ": bad count width");
   std::vector<char> raw;
   if (compressed) raw = lz4_frame_decode(d, 41, path);
@@ -180,8 +181,10 @@ size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<ui
   for (size_t i = 0; i < n; ++i)
   {
     uint64_t km; std::memcpy(&km, raw.data() + i * rec, 8);
-    uint32_t c = 0; std::memcpy(&c, raw.data() + i * rec + 8, cbytes);
+    uint32_t c = 0; std::memcpy(&c, raw.data() + i * rec + 8 * slots, cbytes);
     kmers.push_back(km); counts.push_back(c);
+    if (slots == 2) { uint64_t h; std::memcpy(&h, raw.data() + i * rec + 8, 8); kmers_hi->push_back(h); }
+    else if (kmers_hi) kmers_hi->push_back(0);
   }
   return n;
 }
@@ -209,18 +212,20 @@ matrix_rows read_matrix_file(const std::string& path)
   m.count_bytes = rd<uint32_t>(d, 29);
   m.nb_counts = rd<uint32_t>(d, 33);
   m.partition = rd<uint32_t>(d, 41);
-  if (slots != 1) throw std::runtime_error(path + ": k > 32 is not supported by this reader yet");
+  if (slots != 1 && slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
   if (m.count_bytes != 1 && m.count_bytes != 2 && m.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
   std::vector<char> raw;
   if (compressed) raw = lz4_frame_decode(d, 45, path); else raw.assign(d.begin() + 45, d.end());
-  const size_t rec = 8 + (size_t)m.count_bytes * m.nb_counts, n = raw.size() / rec;
+  const size_t kb = 8 * (size_t)slots, rec = kb + (size_t)m.count_bytes * m.nb_counts, n = raw.size() / rec;
   if (n * rec != raw.size()) throw std::runtime_error(path + ": truncated row");
   m.kmers.resize(n); m.counts.assign(n * m.nb_counts, 0);
+  if (slots == 2) m.kmers_hi.resize(n);
   for (size_t i = 0; i < n; ++i)
   {
     const char* r = raw.data() + i * rec;
     std::memcpy(&m.kmers[i], r, 8);
-    for (uint32_t s = 0; s < m.nb_counts; ++s) std::memcpy(&m.counts[i * m.nb_counts + s], r + 8 + (size_t)s * m.count_bytes, m.count_bytes);
+    if (slots == 2) std::memcpy(&m.kmers_hi[i], r + 8, 8);
+    for (uint32_t s = 0; s < m.nb_counts; ++s) std::memcpy(&m.counts[i * m.nb_counts + s], r + kb + (size_t)s * m.count_bytes, m.count_bytes);
   }
   return m;
 }
@@ -229,19 +234,20 @@ void write_matrix_file(const std::string& path, const matrix_rows& m)
 {
   std::ofstream out(path, std::ios::binary);
   if (!out) throw std::runtime_error("cannot write " + path);
-  const uint32_t zero = 0, slots = 1;
+  const uint32_t zero = 0, slots = m.kmers_hi.empty() ? 1 : 2;
   const uint8_t compressed = 1;
   out.write("kmtricks", 8); out.write((const char*)&zero, 4); out.write((const char*)&compressed, 1);
   out.write("matrix\0\0", 8);
   out.write((const char*)&m.kmer_size, 4); out.write((const char*)&slots, 4); out.write((const char*)&m.count_bytes, 4);
   out.write((const char*)&m.nb_counts, 4); out.write((const char*)&zero, 4); out.write((const char*)&m.partition, 4);
-  const size_t rec = 8 + (size_t)m.count_bytes * m.nb_counts, n = m.kmers.size();
+  const size_t kb = 8 * (size_t)slots, rec = kb + (size_t)m.count_bytes * m.nb_counts, n = m.kmers.size();
   std::vector<char> raw(n * rec);
   for (size_t i = 0; i < n; ++i)
   {
     char* r = raw.data() + i * rec;
     std::memcpy(r, &m.kmers[i], 8);
-    for (uint32_t s = 0; s < m.nb_counts; ++s) std::memcpy(r + 8 + (size_t)s * m.count_bytes, &m.counts[i * m.nb_counts + s], m.count_bytes);
+    if (slots == 2) std::memcpy(r + 8, &m.kmers_hi[i], 8);
+    for (uint32_t s = 0; s < m.nb_counts; ++s) std::memcpy(r + kb + (size_t)s * m.count_bytes, &m.counts[i * m.nb_counts + s], m.count_bytes);
   }
   lz4_frame_encode(out, raw.data(), raw.size());
 }
@@ -252,15 +258,18 @@ void write_survivor_file(const std::string& path, const survivor_set& s, size_t 
   std::ofstream out(path, std::ios::binary);
   if (!out) throw std::runtime_error("cannot write " + path);
   const uint16_t nc = (uint16_t)s.n_counts;
-  const size_t rec = 8 + 8 + 4 + 8 + 8 + 2 + 8 * (size_t)nc;
+  const size_t kb = s.kmer_bytes, rec = kb + 8 + 4 + 8 + 8 + 2 + 8 * (size_t)nc;
   std::vector<char> raw(count * rec);
   for (size_t i = 0; i < count; ++i)
   {
     char* r = raw.data() + i * rec;
     const size_t j = first + i;
-    std::memcpy(r, &s.kmer[j], 8); std::memcpy(r + 8, &s.p[j], 8); std::memcpy(r + 16, &s.sign[j], 4);
-    std::memcpy(r + 20, &s.mean_control[j], 8); std::memcpy(r + 28, &s.mean_case[j], 8); std::memcpy(r + 36, &nc, 2);
-    if (nc) std::memcpy(r + 38, &s.counts[j * nc], 8 * (size_t)nc);
+    std::memcpy(r, &s.kmer[j], 8);
+    if (kb == 16) std::memcpy(r + 8, &s.kmer_hi[j], 8);
+    r += kb;
+    std::memcpy(r, &s.p[j], 8); std::memcpy(r + 8, &s.sign[j], 4);
+    std::memcpy(r + 12, &s.mean_control[j], 8); std::memcpy(r + 20, &s.mean_case[j], 8); std::memcpy(r + 28, &nc, 2);
+    if (nc) std::memcpy(r + 30, &s.counts[j * nc], 8 * (size_t)nc);
   }
   lz4_frame_encode(out, raw.data(), raw.size());
 }
@@ -270,17 +279,22 @@ size_t read_survivor_file(const std::string& path, survivor_set& s)
   auto d = slurp(path);
   const std::vector<char> raw = d.empty() ? std::vector<char>() : lz4_frame_decode(d, 0, path);
   size_t pos = 0, n = 0;
-  while (pos + 38 <= raw.size())
+  const size_t kb = s.kmer_bytes, fixed = kb + 30;
+  while (pos + fixed <= raw.size())
   {
-    uint64_t km; double p, mc, mk; int32_t sg; uint16_t nc;
-    std::memcpy(&km, &raw[pos], 8); std::memcpy(&p, &raw[pos + 8], 8); std::memcpy(&sg, &raw[pos + 16], 4);
-    std::memcpy(&mc, &raw[pos + 20], 8); std::memcpy(&mk, &raw[pos + 28], 8); std::memcpy(&nc, &raw[pos + 36], 2);
+    uint64_t km, kh = 0; double p, mc, mk; int32_t sg; uint16_t nc;
+    std::memcpy(&km, &raw[pos], 8);
+    if (kb == 16) std::memcpy(&kh, &raw[pos + 8], 8);
+    const char* r = &raw[pos + kb];
+    std::memcpy(&p, r, 8); std::memcpy(&sg, r + 8, 4);
+    std::memcpy(&mc, r + 12, 8); std::memcpy(&mk, r + 20, 8); std::memcpy(&nc, r + 28, 2);
     if (s.size() == 0) s.n_counts = nc;
-    if (nc != s.n_counts || pos + 38 + 8 * (size_t)nc > raw.size()) throw std::runtime_error(path + ": malformed survivor record");
+    if (nc != s.n_counts || pos + fixed + 8 * (size_t)nc > raw.size()) throw std::runtime_error(path + ": malformed survivor record");
     s.kmer.push_back(km); s.p.push_back(p); s.sign.push_back(sg); s.mean_control.push_back(mc); s.mean_case.push_back(mk);
+    if (kb == 16) s.kmer_hi.push_back(kh);
     s.counts.resize(s.counts.size() + nc);
-    if (nc) std::memcpy(&s.counts[s.counts.size() - nc], &raw[pos + 38], 8 * (size_t)nc);
-    pos += 38 + 8 * (size_t)nc; ++n;
+    if (nc) std::memcpy(&s.counts[s.counts.size() - nc], r + 30, 8 * (size_t)nc);
+    pos += fixed + 8 * (size_t)nc; ++n;
   }
   if (pos != raw.size()) throw std::runtime_error(path + ": trailing bytes");
   return n;
@@ -320,6 +334,18 @@ unsigned compare_opt(const resume_options& opt, const resume_options& prev)     
   if (opt.correction != prev.correction) r |= 0b100;
   if (prev.pop_correction && !opt.pop_correction) r |= 0b100;
   return r;
+}
+
+std::string kmer_to_string(uint64_t hi, uint64_t lo, size_t k)
+{
+  static const char code[4] = { 'A', 'C', 'T', 'G' };
+  std::string s(k, 'A');
+  for (size_t i = 0; i < k; ++i)
+  {
+    const size_t bit = 2 * (k - 1 - i);                  // position of the base in the 128-bit value
+    s[i] = code[(bit >= 64 ? (hi >> (bit - 64)) : (lo >> bit)) & 3];
+  }
+  return s;
 }
 
 std::string kmer_to_string(uint64_t kmer, size_t k)

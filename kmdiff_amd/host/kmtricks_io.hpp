@@ -28,15 +28,18 @@ std::vector<fof_entry> read_fof(const std::string& run_dir);
 // <run>/histograms/<id>.hist -> total k-mer abundance minus the abundances below ab_min
 uint64_t sample_total(const std::string& run_dir, const fof_entry& sample, size_t abundance_min);
 
-// <run>/counts/partition_<p>/<id>.kmer.lz4 -> records appended to kmers / counts
-// (k <= 32: one 64-bit limb).  Returns the number of records read.
+// <run>/counts/partition_<p>/<id>.kmer.lz4 -> records appended to kmers / counts.  k <= 32: one
+// 64-bit limb; 32 < k <= 64: two limbs, low limb first in the file (km::Kmer<64> holds one
+// 128-bit integer and dumps its bytes; no fixture with k > 32 exists: unpinned), the high limbs
+// go to kmers_hi (required then).  Returns the number of records read.
 size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<uint64_t>& kmers,
-                      std::vector<uint32_t>& counts);
+                      std::vector<uint32_t>& counts, std::vector<uint64_t>* kmers_hi = nullptr);
 
 std::string kmer_file_path(const std::string& run_dir, size_t partition, const std::string& id);
 
 // 2-bit code A=0 C=1 T=2 G=3, first base most significant (km::Kmer::to_string)
 std::string kmer_to_string(uint64_t kmer, size_t k);
+std::string kmer_to_string(uint64_t hi, uint64_t lo, size_t k);       // 32 < k <= 64
 
 // ---- matrix files: <run>/matrices/* (the alternate feed, matrix_proxy::merge, merge.hpp:194-203)
 // and positive_kmer_matrix/matrices/matrix_<p>.count.lz4 (--save-sk, merge.hpp:272-278).
@@ -47,7 +50,8 @@ std::string kmer_to_string(uint64_t kmer, size_t k);
 struct matrix_rows
 {
   uint32_t kmer_size = 0, count_bytes = 0, nb_counts = 0, partition = 0;
-  std::vector<uint64_t> kmers;                 // one limb per row (k <= 32)
+  std::vector<uint64_t> kmers;                 // low limb per row
+  std::vector<uint64_t> kmers_hi;              // high limb per row when 32 < k <= 64, else empty
   std::vector<uint32_t> counts;                // [row][sample], widened
 };
 matrix_rows read_matrix_file(const std::string& path);
@@ -56,12 +60,14 @@ std::vector<std::string> matrix_paths(const std::string& run_dir);    // sorted;
 
 // ---- survivor files: <out>/partitions/p<i>_uncorrected and p<i>_popstrat_uncorrected
 // (FileAccumulator<KmerSign<KSIZE>>, accumulator.hpp:156-285): one LZ4 frame (lz4_stream) of
-// records [kmer 8 B][p f64][sign i32][mean_control f64][mean_case f64][n u16][n x f64 counts]
+// records [kmer 8 B (16 B, low limb first, when 32 < k <= 64)][p f64][sign i32][mean_control f64][mean_case f64][n u16][n x f64 counts]
 // (KmerSign::dump, kmer.hpp:113-127; the count block is there because WITH_POPSTRAT is ON by
 // default, CMakeLists.txt:8).
 struct survivor_set
 {
   std::vector<uint64_t> kmer;
+  std::vector<uint64_t> kmer_hi;               // filled when kmer_bytes == 16
+  size_t kmer_bytes = 8;                       // 8 * ceil(KSIZE / 32): set before reading / writing
   std::vector<double> p, mean_control, mean_case;
   std::vector<int32_t> sign;
   std::vector<double> counts;                  // [record][n_counts]

@@ -158,7 +158,8 @@ int main(int argc, char** argv)
     std::fprintf(stderr, "[kmdiff-hip] device %d: %s\n", opt.device % ndev, dn);
 
     const kmtricks_config cfg = get_kmtricks_config(opt.kmtricks_dir);                       // src/main.cc:74
-    if (cfg.kmer_size > 32) die("k > 32 is not supported by the file reader yet");
+    if (cfg.kmer_size > 64) die("k > 64 is not supported");
+    const bool two_limbs = cfg.kmer_size > 32;                                                // KSIZE 32 / 64, src/main.cc:75
     const auto fof = read_fof(opt.kmtricks_dir);
     const size_t S = opt.nb_controls + opt.nb_cases;
     if (fof.size() < S) die("kmtricks.fof has fewer samples than -1 + -2");
@@ -192,6 +193,7 @@ int main(int argc, char** argv)
 
     survivor_set sv_all;                           // survivors of all partitions, partition after partition
     sv_all.n_counts = want_counts ? S : 0;
+    sv_all.kmer_bytes = two_limbs ? 16 : 8;
     std::vector<size_t> part_begin(cfg.nb_partitions + 1, 0);
     uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
     const bool run_stage1 = !prev_1 || (action & 0b1);
@@ -211,7 +213,8 @@ int main(int argc, char** argv)
           if (fs::exists(opt.kmtricks_dir + dname))
             fs::copy(opt.kmtricks_dir + dname, sk + dname, fs::copy_options::recursive | fs::copy_options::overwrite_existing);
       }
-      dev_buf d_kmers, d_counts, d_matrix, d_kmer_col, d_cnt, d_srow, d_skmer, d_sp, d_ssign, d_smc, d_smk, d_sc;
+      dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
+              d_smk, d_sc;
       const size_t T = 4096;
       // one accumulator per entry of counts/ (cmd/diff.hpp:103-107); matrix files map onto them in order
       const size_t n_units = from_matrix ? std::min(mpaths.size(), cfg.nb_partitions) : cfg.nb_partitions;
@@ -225,21 +228,28 @@ int main(int argc, char** argv)
           // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
           const matrix_rows m = read_matrix_file(mpaths[p]);
           if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
+          if (two_limbs != !m.kmers_hi.empty()) die(mpaths[p] + ": k-mer width differs from the run's");
           n_rows = m.kmers.size();
           if (n_rows)
           {
             d_matrix.reserve(n_rows * S * 4); d_kmer_col.reserve(n_rows * 8);
             ck(kmd_memcpy_h2d(d_matrix.p, m.counts.data(), n_rows * S * 4, nullptr), "h2d");
             ck(kmd_memcpy_h2d(d_kmer_col.p, m.kmers.data(), n_rows * 8, nullptr), "h2d");
+            if (two_limbs)
+            {
+              d_kmer_col_hi.reserve(n_rows * 8);
+              ck(kmd_memcpy_h2d(d_kmer_col_hi.p, m.kmers_hi.data(), n_rows * 8, nullptr), "h2d");
+            }
           }
-          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p, nullptr, (size_t)n_rows, 0 };
+          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p,
+                            two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
         }
         else
         {
-          std::vector<uint64_t> kmers; std::vector<uint32_t> counts; std::vector<uint64_t> offs(S + 1, 0);
+          std::vector<uint64_t> kmers, kmers_hi; std::vector<uint32_t> counts; std::vector<uint64_t> offs(S + 1, 0);
           for (size_t s = 0; s < S; ++s)                                                      // KmDir::get_files_to_merge
           {
-            read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s].id), cfg.kmer_size, kmers, counts);
+            read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s].id), cfg.kmer_size, kmers, counts, two_limbs ? &kmers_hi : nullptr);
             offs[s + 1] = kmers.size();
           }
           const size_t n = kmers.size();
@@ -249,11 +259,18 @@ int main(int argc, char** argv)
             ck(kmd_memcpy_h2d(d_kmers.p, kmers.data(), n * 8, nullptr), "h2d");
             ck(kmd_memcpy_h2d(d_counts.p, counts.data(), n * 4, nullptr), "h2d");
             d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
-            ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, nullptr, (const uint32_t*)d_counts.p, offs.data(), 4,
-                                   KMD_LAYOUT_TILED, T, n, d_matrix.p, (uint64_t*)d_kmer_col.p, nullptr, &n_rows, nullptr),
+            if (two_limbs)
+            {
+              d_kmers_hi.reserve(n * 8); d_kmer_col_hi.reserve(n * 8);
+              ck(kmd_memcpy_h2d(d_kmers_hi.p, kmers_hi.data(), n * 8, nullptr), "h2d");
+            }
+            ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
+                                   (const uint32_t*)d_counts.p, offs.data(), 4, KMD_LAYOUT_TILED, T, n, d_matrix.p,
+                                   (uint64_t*)d_kmer_col.p, two_limbs ? (uint64_t*)d_kmer_col_hi.p : nullptr, &n_rows, nullptr),
                "kmd_merge_partition");
           }
-          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p, nullptr, (size_t)n_rows, 0 };
+          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p,
+                            two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
         }
         size_t ns = 0;
         const size_t base = sv_all.size();
@@ -262,8 +279,9 @@ int main(int argc, char** argv)
           // survivor sink sized for the worst case of this partition (every row)
           d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
           d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
+          if (two_limbs) d_skmer_hi.reserve(n_rows * 8);
           ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
-          kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
+          kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, two_limbs ? (uint64_t*)d_skmer_hi.p : nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
                              (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
           ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
           uint64_t c[KMD_NCOUNTERS];
@@ -272,9 +290,11 @@ int main(int argc, char** argv)
           ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                     // reference push order
           sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
           sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);
+          if (two_limbs) sv_all.kmer_hi.resize(base + ns);
           if (ns)
           {
             ck(kmd_memcpy_d2h(sv_all.kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
+            if (two_limbs) ck(kmd_memcpy_d2h(sv_all.kmer_hi.data() + base, d_skmer_hi.p, ns * 8, nullptr), "d2h");
             ck(kmd_memcpy_d2h(sv_all.p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
             ck(kmd_memcpy_d2h(sv_all.sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
             ck(kmd_memcpy_d2h(sv_all.mean_control.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
@@ -294,6 +314,7 @@ int main(int argc, char** argv)
         {
           matrix_rows sk; sk.kmer_size = (uint32_t)cfg.kmer_size; sk.count_bytes = 4; sk.nb_counts = (uint32_t)S; sk.partition = (uint32_t)p;
           sk.kmers.assign(sv_all.kmer.begin() + base, sv_all.kmer.end());
+          if (two_limbs) sk.kmers_hi.assign(sv_all.kmer_hi.begin() + base, sv_all.kmer_hi.end());
           sk.counts.resize(ns * S);
           for (size_t i = 0; i < ns * S; ++i) sk.counts[i] = (uint32_t)sv_all.counts[base * S + i];
           write_matrix_file(opt.output_directory + "/positive_kmer_matrix/matrices/matrix_" + std::to_string(p) + ".count.lz4", sk);
@@ -394,7 +415,7 @@ int main(int argc, char** argv)
       size_t& idx = control ? ic : ik;
       char pv[64]; std::snprintf(pv, sizeof pv, "%g", s_p[i]);                               // {:g}
       f << '>' << idx << "_pval=" << pv << "_control=" << (uint64_t)s_mc[i] << "_case=" << shortest(s_mk[i]) << '\n'
-        << kmer_to_string(s_kmer[i], cfg.kmer_size) << '\n';
+        << (two_limbs ? kmer_to_string(sv_all.kmer_hi[i], s_kmer[i], cfg.kmer_size) : kmer_to_string(s_kmer[i], cfg.kmer_size)) << '\n';
       ++idx;
     }
     std::fprintf(stderr, "[kmdiff-hip] Significant k-mers: %" PRIu64 " (control), %" PRIu64 " (case).\n", c_controls, c_cases);   // cmd/diff.hpp:259

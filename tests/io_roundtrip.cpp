@@ -1,7 +1,7 @@
 // Test harness (no GPU): reads a file with the host readers of kmdiff_amd/host/kmtricks_io.cpp and
 // writes it back with the host writers, so that tests/test_host_io.py can compare both directions
 // with the independent Python reader/writer of tests/kmtricks_files.py.
-//   io_roundtrip matrix <in> <out> | survivors <in> <out> | options <in> <out>
+//   io_roundtrip matrix <in> <out> | survivors <in> <out> | survivors16 <in> <out> | options <in> <out>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -18,13 +18,15 @@ int main(int argc, char** argv)
     if (what == "matrix")
     {
       const kmd_host::matrix_rows m = kmd_host::read_matrix_file(in);
+      if (!m.kmers_hi.empty()) std::printf("two-limb ");
       std::printf("rows=%zu k=%u count_bytes=%u nb_counts=%u partition=%u\n", m.kmers.size(), m.kmer_size, m.count_bytes,
                   m.nb_counts, m.partition);
       kmd_host::write_matrix_file(out, m);
     }
-    else if (what == "survivors")
+    else if (what == "survivors" || what == "survivors16")
     {
       kmd_host::survivor_set s;
+      s.kmer_bytes = what == "survivors16" ? 16 : 8;
       const size_t n = kmd_host::read_survivor_file(in, s);
       std::printf("records=%zu n_counts=%zu\n", n, s.n_counts);
       kmd_host::write_survivor_file(out, s, 0, n);

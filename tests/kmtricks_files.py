@@ -82,15 +82,19 @@ def read_kmer_file(path):
     return {"k": k, "slots": slots, "count_bytes": cbytes, "sample_id": sid, "partition": part}, kmers, counts
 
 
-def write_kmer_file(path, k, sample_id, partition, kmers, counts, count_bytes=4, compressed=True):
-    kmers = np.asarray(kmers, dtype="<u8")
-    counts = np.asarray(counts).astype({1: "<u1", 2: "<u2", 4: "<u4"}[count_bytes])
+def write_kmer_file(path, k, sample_id, partition, kmers, counts, count_bytes=4, compressed=True, kmers_hi=None):
+    """kmers_hi: high limbs for 32 < k <= 64 (two slots, low limb first -- unpinned, see kmtricks_io.hpp)."""
+    kmers = np.ascontiguousarray(kmers, dtype="<u8")
+    counts = np.ascontiguousarray(np.asarray(counts).astype({1: "<u1", 2: "<u2", 4: "<u4"}[count_bytes]))
     n = len(kmers)
-    rec = np.zeros((n, 8 + count_bytes), dtype=np.uint8)
+    slots = 1 if kmers_hi is None else 2
+    rec = np.zeros((n, 8 * slots + count_bytes), dtype=np.uint8)
     rec[:, :8] = kmers.view(np.uint8).reshape(n, 8)
-    rec[:, 8:] = counts.view(np.uint8).reshape(n, count_bytes)
+    if kmers_hi is not None:
+        rec[:, 8:16] = np.ascontiguousarray(kmers_hi, dtype="<u8").view(np.uint8).reshape(n, 8)
+    rec[:, 8 * slots:] = counts.view(np.uint8).reshape(n, count_bytes)
     raw = rec.tobytes()
-    hdr = struct.pack("<8sIB8sIIIII", b"kmtricks", 0, 1 if compressed else 0, b"kmer\0\0\0\0", k, 1,
+    hdr = struct.pack("<8sIB8sIIIII", b"kmtricks", 0, 1 if compressed else 0, b"kmer\0\0\0\0", k, slots,
                       count_bytes, sample_id, partition)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "wb") as f:
@@ -137,7 +141,7 @@ def read_fof(path):
 
 
 def write_run_dir(root, k, sample_ids, partitions, abundance_min=1):
-    """partitions: list over partitions of a list over samples of (kmers, counts)."""
+    """partitions: list over partitions of a list over samples of (kmers, counts[, kmers_hi])."""
     os.makedirs(root, exist_ok=True)
     with open(os.path.join(root, "kmtricks.fof"), "w") as f:
         for s in sample_ids:
@@ -148,9 +152,10 @@ def write_run_dir(root, k, sample_ids, partitions, abundance_min=1):
                 "nb_partitions=0,\n" % (root, k, abundance_min))
     per_sample = [[] for _ in sample_ids]
     for p, streams in enumerate(partitions):
-        for s, (km, ct) in enumerate(streams):
+        for s, stream in enumerate(streams):
+            km, ct = stream[0], stream[1]
             write_kmer_file(os.path.join(root, "counts", "partition_%d" % p, "%s.kmer.lz4" % sample_ids[s]),
-                            k, s, p, km, ct)
+                            k, s, p, km, ct, kmers_hi=stream[2] if len(stream) > 2 else None)
             per_sample[s].append(np.asarray(ct, dtype=np.uint64))
     for s, name in enumerate(sample_ids):
         allc = np.concatenate(per_sample[s]) if per_sample[s] else np.zeros(0, np.uint64)
@@ -187,21 +192,29 @@ def read_matrix_file(path):
     return {"k": k, "count_bytes": cbytes, "nb_counts": S, "partition": part}, kmers, counts
 
 
-def read_survivor_file(path):
+def read_survivor_file(path, kmer_bytes=8):
     """partitions/p<i>_uncorrected (FileAccumulator<KmerSign<32>>, WITH_POPSTRAT): one LZ4 frame of
     [kmer u64][p f64][sign i32][mean_control f64][mean_case f64][n u16][n x f64]."""
     d = open(path, "rb").read()
     raw = lz4_frame_decode(d) if d else b""
-    out = {"kmer": [], "p": [], "sign": [], "mc": [], "mk": [], "counts": []}
+    out = {"kmer": [], "kmer_hi": [], "p": [], "sign": [], "mc": [], "mk": [], "counts": []}
     pos = 0
     while pos < len(raw):
-        km, p, sg, mc, mk, n = struct.unpack_from("<QdiddH", raw, pos)
-        pos += 38
+        if kmer_bytes == 16:
+            out["kmer_hi"].append(struct.unpack_from("<Q", raw, pos + 8)[0])
+        km = struct.unpack_from("<Q", raw, pos)[0]
+        p, sg, mc, mk, n = struct.unpack_from("<diddH", raw, pos + kmer_bytes)
+        pos += kmer_bytes + 30
         out["kmer"].append(km); out["p"].append(p); out["sign"].append(sg); out["mc"].append(mc); out["mk"].append(mk)
         out["counts"].append(np.frombuffer(raw, dtype="<f8", count=n, offset=pos).copy())
         pos += 8 * n
     assert pos == len(raw)
     return out
+
+
+def kmer_to_string2(hi, lo, k):
+    v = (int(hi) << 64) | int(lo)
+    return "".join("ACTG"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
 
 
 def kmer_to_string(v, k):

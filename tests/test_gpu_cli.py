@@ -167,6 +167,39 @@ def test_cli_keep_tmp_files_resume_and_save_sk(synth_run, tmp_path):
     assert "Process partitions" in err3 and s3["n_sig"] > s2["n_sig"]
 
 
+def test_cli_two_limb_kmers_k63(tmp_path):
+    """configs[3]: 32 < k <= 64, the (hi, lo) 128-bit k-mer through file reader, two-limb merge,
+    filter, survivor files and FASTA."""
+    o = OL.load()
+    nc, nk, n, k = 3, 3, 20_000, 63
+    parts, mats, los, his = [], [], [], []
+    for p in range(2):
+        host, lo, hi = o.synth_rows(SEED, p, 0, n, nc, nk, 4, kmer_limbs=2)
+        parts.append([(lo[host[:, s] > 0], host[host[:, s] > 0, s], hi[host[:, s] > 0]) for s in range(nc + nk)])
+        mats.append(host); los.append(lo); his.append(hi)
+    ids = ["C%d" % i for i in range(nc)] + ["K%d" % i for i in range(nk)]
+    KF.write_run_dir(str(tmp_path / "km"), k, ids, parts)
+    s, _ = run_cli(["-d", tmp_path / "km", "-1", nc, "-2", nk, "-c", "disabled", "-s", 0.05, "-u", 1000, "--keep-tmp"], tmp_path / "o")
+    totals = np.sum([m.sum(axis=0, dtype=np.uint64) for m in mats], axis=0)
+    lf = o.lf_table(10000)
+    want = {"control": [], "case": []}
+    n_sig = 0
+    for p, m in enumerate(mats):
+        out = o.diff_partition(m, OL.LAYOUT_ROWS, nc, nk, int(totals[:nc].sum()), int(totals[nc:].sum()), lf, 0.05 / 1000)
+        idx = out["row"].astype(np.int64)
+        n_sig += len(idx)
+        f = KF.read_survivor_file(str(tmp_path / "o" / "partitions" / ("p%d_uncorrected" % p)), kmer_bytes=16)
+        assert f["kmer"] == los[p][idx].tolist() and f["kmer_hi"] == his[p][idx].tolist()
+        assert np.allclose(f["p"], out["pvalue"], rtol=0, atol=1e-10)
+        for i, sg, pv in zip(idx, out["sign"], out["pvalue"]):
+            if pv < 0.05:                                                    # "disabled" = threshold corrector
+                want["control" if sg == 0 else "case"].append(KF.kmer_to_string2(his[p][i], los[p][i], k))
+    assert s["n_sig"] == n_sig and n_sig > 5 and s["total_kmers"] == 2 * n and s["kmer_size"] == 63
+    for name in ("control", "case"):
+        got = [seq for _, seq in read_fasta(tmp_path / "o" / ("%s_kmers.fasta" % name))]
+        assert got == want[name] and all(len(q) == 63 for q in got)
+
+
 def test_cli_pop_correction(synth_run, tmp_path):
     run_dir, nc, nk, k, mats, kms = synth_run
     o = OL.load()

@@ -70,6 +70,30 @@ def test_survivor_file_both_directions(tmp_path, n, S):
         assert (got["counts"][i] == counts).all()
 
 
+def test_two_limb_kmers_in_kmer_matrix_and_survivor_files(tmp_path):
+    """32 < k <= 64: two 64-bit slots per k-mer, low limb first (unpinned: no fixture with k > 32)."""
+    rng = np.random.default_rng(6)
+    n, S = 1000, 3
+    lo = rng.integers(0, 1 << 63, n, dtype=np.uint64); hi = np.sort(rng.integers(0, 1 << 30, n, dtype=np.uint64))
+    cnt = rng.integers(0, 1000, (n, S)).astype(np.uint32)
+    rec = np.zeros((n, 16 + 4 * S), dtype=np.uint8)
+    rec[:, :8] = lo.view(np.uint8).reshape(n, 8); rec[:, 8:16] = hi.view(np.uint8).reshape(n, 8)
+    rec[:, 16:] = cnt.view(np.uint8).reshape(n, 4 * S)
+    hdr = struct.pack("<8sIB8sIIIIII", b"kmtricks", 0, 1, b"matrix\0\0", 63, 2, 4, S, 0, 1)
+    open(tmp_path / "m.lz4", "wb").write(hdr + KF.lz4_frame_encode(rec.tobytes()))
+    rc, out, err = tool("matrix", tmp_path / "m.lz4", tmp_path / "m2.lz4")
+    assert rc == 0 and out.startswith("two-limb rows=%d k=63" % n), err
+    d = open(tmp_path / "m2.lz4", "rb").read()
+    assert d[:45] == hdr and KF.lz4_frame_decode(d[45:]) == rec.tobytes()
+    raw = b"".join(struct.pack("<QQdiddH", int(lo[i]), int(hi[i]), 1e-9 * i, i % 3, 1.0, 2.0, 2) + struct.pack("<dd", 3.0, 4.0)
+                   for i in range(50))
+    open(tmp_path / "s16", "wb").write(KF.lz4_frame_encode(raw))
+    rc, out, err = tool("survivors16", tmp_path / "s16", tmp_path / "s16b")
+    assert rc == 0 and out.split()[0] == "records=50", err
+    got = KF.read_survivor_file(str(tmp_path / "s16b"), kmer_bytes=16)
+    assert got["kmer"] == lo[:50].tolist() and got["kmer_hi"] == hi[:50].tolist() and got["sign"] == [i % 3 for i in range(50)]
+
+
 def test_survivor_file_truncated_record_is_an_error(tmp_path):
     raw = struct.pack("<QdiddH", 5, 1e-9, 1, 2.0, 3.0, 4) + b"\0" * 8       # says 4 counts, holds 1
     with open(tmp_path / "bad", "wb") as f:
