@@ -92,6 +92,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise KmdError("libkmdiff_hip.so is not built (%s); run `python -c 'import "
                            "__graft_entry__ as g; g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64
+        # (soname libamdhip64.so.7, requested by libtorch_hip as "libamdhip64.so"): if this
+        # library pulled in /opt/rocm's copy first, the loader would not recognise it under
+        # torch's name, a second runtime would come up and find "No HIP GPUs".  Loading torch
+        # first makes its copy the one this library binds to (same soname), whatever the
+        # caller's import order.  Without torch (plain C / C++ hosts) there is nothing to share.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             L = C.CDLL(LIB_PATH)
         except OSError as e:

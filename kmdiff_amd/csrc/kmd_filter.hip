@@ -241,6 +241,32 @@ __device__ __forceinline__ void stage_table(const filter_params& P, double2* s_t
 // current one, so a wave always has kBatch..2*kBatch KiB-sized loads outstanding.
 constexpr int kBatch = KMD_BATCH;
 
+// Every count is read exactly once: with KMD_NT_LOADS the column loads carry the non-temporal
+// hint (no reuse to protect in L2 / MALL).
+#ifndef KMD_NT_LOADS
+#define KMD_NT_LOADS 1
+#endif
+template <typename V> __device__ __forceinline__ V stream_load(const V* p)
+{
+#if KMD_NT_LOADS
+  if constexpr (sizeof(V) == 16)
+  {
+    typedef uint32_t n4 __attribute__((ext_vector_type(4)));
+    const n4 t = __builtin_nontemporal_load(reinterpret_cast<const n4*>(p));
+    V r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r;
+  }
+  else if constexpr (sizeof(V) == 8)
+  {
+    typedef uint32_t n2 __attribute__((ext_vector_type(2)));
+    const n2 t = __builtin_nontemporal_load(reinterpret_cast<const n2*>(p));
+    V r; r.x = t.x; r.y = t.y; return r;
+  }
+  else return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <typename CT, int RPL>
 struct soa_batch
 {
@@ -255,7 +281,7 @@ struct soa_batch
     for (int j = 0; j < kBatch; ++j)
     {
       const int s = (s0 + j < S) ? (s0 + j) : (S - 1);
-      v[j] = *reinterpret_cast<const V*>(rows0 + (size_t)s * ld);
+      v[j] = stream_load(reinterpret_cast<const V*>(rows0 + (size_t)s * ld));
     }
   }
 
