@@ -246,7 +246,8 @@ int kmd_column_sums(const void* d_counts, int count_bytes, int layout, size_t ld
                     size_t n_rows, int n_samples, uint64_t* d_totals, void* stream);
 /* Streaming-copy bandwidth probe (float4 copy of `bytes`), for the measured roofline. */
 int kmd_copy_probe(void* d_dst, const void* d_src, size_t bytes, void* stream);
-/* Streaming read of `bytes` with 4-, 8- or 16-byte loads per lane: a known byte count that
+/* Streaming read of `bytes` with 4-, 8- or 16-byte loads per lane (width_bytes + 64: the same
+ * with the non-temporal hint the filter kernel's column loads carry): a known byte count that
  * calibrates the FETCH_SIZE counter for the filter kernel's access width. */
 int kmd_read_probe(const void* d_src, size_t bytes, int width_bytes, uint64_t* d_sink, void* stream);
 

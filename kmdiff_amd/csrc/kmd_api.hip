@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) k_copy_probe(const float4* __restrict__ s
 
 // streaming-read probes of a known byte count, one per load width: calibrates the FETCH_SIZE
 // PMC counter for the access pattern of the filter kernel (MI355X_MICROARCH.md, HBM section)
-template <typename V>
+template <typename V, bool NT>
 __global__ void __launch_bounds__(256) k_read_probe(const V* __restrict__ src, size_t n,
                                                     unsigned long long* __restrict__ sink)
 {
@@ -443,10 +443,22 @@ __global__ void __launch_bounds__(256) k_read_probe(const V* __restrict__ src, s
   unsigned int acc = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
   {
-    const V v = src[i];
-    if constexpr (sizeof(V) == 4) acc += v;
-    else if constexpr (sizeof(V) == 8) acc += v.x ^ v.y;
-    else acc += v.x ^ v.y ^ v.z ^ v.w;
+    if constexpr (sizeof(V) == 4)
+    {
+      acc += NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+    else if constexpr (sizeof(V) == 8)
+    {
+      typedef uint32_t n2 __attribute__((ext_vector_type(2)));
+      const n2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const n2*>(src + i)) : *reinterpret_cast<const n2*>(src + i);
+      acc += v.x ^ v.y;
+    }
+    else
+    {
+      typedef uint32_t n4 __attribute__((ext_vector_type(4)));
+      const n4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const n4*>(src + i)) : *reinterpret_cast<const n4*>(src + i);
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
   }
   if (acc == 0x9E3779B9u) atomicAdd(sink, 1ull);     // keeps the loads alive
 }
@@ -458,6 +470,8 @@ extern "C" {
 int kmd_read_probe(const void* d_src, size_t bytes, int width_bytes, uint64_t* d_sink, void* stream)
 {
   KMD_REQUIRE(d_src && d_sink, "kmd_read_probe: NULL");
+  const bool nt = (width_bytes & 64) != 0;                // + 64: non-temporal loads (the filter kernel's)
+  width_bytes &= ~64;
   KMD_REQUIRE(width_bytes == 4 || width_bytes == 8 || width_bytes == 16, "kmd_read_probe: width");
   KMD_REQUIRE(bytes % 16 == 0, "kmd_read_probe: bytes % 16");
   const size_t n = bytes / (size_t)width_bytes;
@@ -465,9 +479,12 @@ int kmd_read_probe(const void* d_src, size_t bytes, int width_bytes, uint64_t* d
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned long long* sink = reinterpret_cast<unsigned long long*>(d_sink);
   const dim3 grid(256 * 8), block(256);
-  if (width_bytes == 4) hipLaunchKernelGGL((k_read_probe<uint32_t>), grid, block, 0, st, static_cast<const uint32_t*>(d_src), n, sink);
-  else if (width_bytes == 8) hipLaunchKernelGGL((k_read_probe<uint2>), grid, block, 0, st, static_cast<const uint2*>(d_src), n, sink);
-  else hipLaunchKernelGGL((k_read_probe<uint4>), grid, block, 0, st, static_cast<const uint4*>(d_src), n, sink);
+  if (width_bytes == 4 && !nt) hipLaunchKernelGGL((k_read_probe<uint32_t, false>), grid, block, 0, st, static_cast<const uint32_t*>(d_src), n, sink);
+  else if (width_bytes == 4) hipLaunchKernelGGL((k_read_probe<uint32_t, true>), grid, block, 0, st, static_cast<const uint32_t*>(d_src), n, sink);
+  else if (width_bytes == 8 && !nt) hipLaunchKernelGGL((k_read_probe<uint2, false>), grid, block, 0, st, static_cast<const uint2*>(d_src), n, sink);
+  else if (width_bytes == 8) hipLaunchKernelGGL((k_read_probe<uint2, true>), grid, block, 0, st, static_cast<const uint2*>(d_src), n, sink);
+  else if (!nt) hipLaunchKernelGGL((k_read_probe<uint4, false>), grid, block, 0, st, static_cast<const uint4*>(d_src), n, sink);
+  else hipLaunchKernelGGL((k_read_probe<uint4, true>), grid, block, 0, st, static_cast<const uint4*>(d_src), n, sink);
   KMD_HIP(hipGetLastError());
   return KMD_OK;
 }

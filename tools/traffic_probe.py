@@ -17,7 +17,7 @@ nbytes = 4 << 30
 buf = K.DeviceBuffer(nbytes)
 lib.kmd_memset(buf.ptr, 1, nbytes, None)
 sink = K.DeviceBuffer(8).zero()
-for w in (4, 8, 16):
+for w in (4, 8, 16, 64 + 8, 64 + 16):          # + 64: non-temporal (what k_filter_soa issues)
     for _ in range(2):
         K._native.check(lib.kmd_read_probe(buf.ptr, nbytes, w, sink.ptr, None))
 lib.kmd_stream_sync(None)
