@@ -329,7 +329,7 @@ struct bucket_state
 {
   uint32_t j, n, d;
   bool work;
-  uint32_t cnt_r[PER_LANE], smp_r[PER_LANE], row_r[PER_LANE];   // count, sample, row within the bucket
+  uint32_t cnt_r[PER_LANE], sr_r[PER_LANE];   // count; sample (low 16 bits) | row within the bucket << 16
 };
 
 // One pass: every wave owns a bucket -- hash set, distinct count, sort (stage A); row number by
@@ -339,8 +339,15 @@ struct bucket_state
 // out for a whole iteration and nobody waits for the slowest wave of the sweep.
 // The grid must be fully resident (persistent): a wave waits on the status words of
 // lower-numbered buckets, which are always being worked on by resident waves.
+#ifndef KMD_MERGE_SLOT_MULT
+#define KMD_MERGE_SLOT_MULT 1        // hash slots per record of capacity (2: ~9 % slower, one wave less per SIMD)
+#endif
+#ifndef KMD_MERGE_WAVES_PER_EU
+#define KMD_MERGE_WAVES_PER_EU 1     // occupancy the register allocator must leave room for
+#endif
 template <typename CT, uint32_t kWaveCap, int kWavesPerBlock>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint64_t* __restrict__ keys,
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(KMD_MERGE_WAVES_PER_EU)))
+k_bucket_merge(const uint64_t* __restrict__ keys,
                                                               const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ start, uint32_t S,
                                                               uint32_t nb, unsigned long long* __restrict__ status,
@@ -350,13 +357,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
                                                               uint64_t* __restrict__ kmer_out,
                                                               uint32_t* __restrict__ overflow)
 {
-  constexpr uint32_t kWaveSlots = 2 * kWaveCap;
+  constexpr uint32_t kWaveSlots = KMD_MERGE_SLOT_MULT * kWaveCap;
   __shared__ unsigned long long s_hash_all[kWavesPerBlock][kWaveSlots];
   __shared__ unsigned long long s_keys_all[kWavesPerBlock][2][kWaveCap];
   // segment tables while the records are loaded; afterwards the same memory holds the unsorted
   // distinct keys and then the slot -> row table
-  __shared__ unsigned long long s_seg_all[kWavesPerBlock][kWaveCap + 2];
-  static_assert(sizeof(unsigned long long) * (kWaveCap + 2) >= sizeof(uint32_t) * (2 * kMaxFastSamples + 1), "segment tables");
+  __shared__ unsigned long long s_seg_all[kWavesPerBlock][kWaveCap];
+  constexpr uint32_t kMaxS = kWaveCap / 4;              // samples this instantiation serves (fast_bucket_cap)
+  constexpr int kSPL = kMaxS / 64;                      // samples per lane in the segment phase
+  static_assert(sizeof(unsigned long long) * kWaveCap >= sizeof(uint32_t) * (2 * kMaxS + 1), "segment tables");
   static_assert(sizeof(unsigned long long) * kWaveCap >= sizeof(uint16_t) * kWaveSlots, "slot -> row table");
   constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
   constexpr int kPerLane = kWaveCap / 64;               // records of a bucket held by one lane
@@ -364,7 +373,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned long long* s_hash = s_hash_all[w];
   uint32_t* s_beg = reinterpret_cast<uint32_t*>(s_seg_all[w]);
-  uint32_t* pref = s_beg + kMaxFastSamples;
+  uint32_t* pref = s_beg + kMaxS;
   unsigned long long* s_tmp = s_seg_all[w];                          // unsorted distinct keys
   uint16_t* s_rank = reinterpret_cast<uint16_t*>(s_seg_all[w]);      // hash slot -> row within the bucket
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
@@ -373,11 +382,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
 
   // segment bounds of the wave's first bucket; those of the next bucket are fetched while the
   // current one is processed (one dependent global round trip less per bucket)
-  uint32_t nb_beg[4] = { 0, 0, 0, 0 }, nb_end[4] = { 0, 0, 0, 0 };
+  uint32_t nb_beg[kSPL], nb_end[kSPL];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < kSPL; ++q)
   {
-    const uint32_t s = lane * 4 + q;
+    const uint32_t s = lane * kSPL + q;
+    nb_beg[q] = 0; nb_end[q] = 0;
     if (s < S) { nb_beg[q] = start[(size_t)j_first * S + s]; nb_end[q] = start[(size_t)(j_first + 1) * S + s]; }
   }
 
@@ -390,12 +400,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
   // ---------------- stage A: records -> registers, hash set, distinct count (published), sorted keys
   auto stage_a = [&](uint32_t j, state_t& st, unsigned long long* s_keys)
   {
-    // the S segments of this bucket; exclusive prefix of their lengths (4 samples per lane)
-    uint32_t len[4], lsum = 0;
+    // the S segments of this bucket; exclusive prefix of their lengths (kSPL samples per lane)
+    uint32_t len[kSPL], lsum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < kSPL; ++q)
     {
-      const uint32_t s = lane * 4 + q;
+      const uint32_t s = lane * kSPL + q;
       len[q] = 0;
       if (s < S)
       {
@@ -409,9 +419,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
       if (jn < nb)
       {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < kSPL; ++q)
         {
-          const uint32_t s = lane * 4 + q;
+          const uint32_t s = lane * kSPL + q;
           if (s < S) { nb_beg[q] = start[(size_t)jn * S + s]; nb_end[q] = start[(size_t)(jn + 1) * S + s]; }
         }
       }
@@ -425,9 +435,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
     }
     uint32_t run = incl - lsum;                         // records before this lane's first sample
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < kSPL; ++q)
     {
-      const uint32_t s = lane * 4 + q;
+      const uint32_t s = lane * kSPL + q;
       if (s < S) pref[s] = run;
       run += len[q];
     }
@@ -446,7 +456,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
     constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
     if (n > 0 && !too_big)
     {
-      while (slots < 2 * n) slots <<= 1;
+      while (slots < 2 * n && slots < kWaveSlots) slots <<= 1;   // distinct keys are ~n / (samples present per row)
       const uint32_t mask = slots - 1;
       for (uint32_t t = lane; t < slots; t += 64) s_hash[t] = kEmpty;
       wave_sync();
@@ -456,13 +466,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
       for (int r = 0; r < kPerLane; ++r)
       {
         const uint32_t f = (uint32_t)r * 64 + lane;
-        key_r[r] = 0; st.cnt_r[r] = 0; st.smp_r[r] = 0; slot_r[r] = kNoSlot;
+        key_r[r] = 0; st.cnt_r[r] = 0; st.sr_r[r] = 0; slot_r[r] = kNoSlot;
         if (f < n)
         {
           uint32_t lo = 0, hi = S;                      // last q with pref[q] <= f
           while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= f) lo = mid; else hi = mid; }
           const uint32_t i = s_beg[lo] + (f - pref[lo]);
-          key_r[r] = keys[i]; st.cnt_r[r] = counts[i]; st.smp_r[r] = lo;
+          key_r[r] = keys[i]; st.cnt_r[r] = counts[i]; st.sr_r[r] = lo;
         }
       }
 #ifdef KMD_MERGE_TIMING
@@ -560,8 +570,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
 #pragma unroll
       for (int r = 0; r < kPerLane; ++r)
       {
-        st.row_r[r] = 0;
-        if ((uint32_t)r * 64 + lane < n) st.row_r[r] = slot_r[r] == kNoSlot ? d - 1 : (uint32_t)s_rank[slot_r[r]];
+        if ((uint32_t)r * 64 + lane < n) st.sr_r[r] |= (slot_r[r] == kNoSlot ? d - 1 : (uint32_t)s_rank[slot_r[r]]) << 16;
       }
       wave_sync();                                      // the segment tables of the next bucket go here
     }
@@ -610,8 +619,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_bucket_merge(const uint
       {
         uint32_t c = st.cnt_r[r];
         if (c > cmax) c = cmax;
-        if (in_lds) tile[st.smp_r[r] * d + st.row_r[r]] = (CT)c;
-        else matrix[kmd::count_index(layout, ld, (int)S, rb + st.row_r[r], (int)st.smp_r[r])] = (CT)c;
+        const uint32_t smp = st.sr_r[r] & 0xFFFFu, row = st.sr_r[r] >> 16;
+        if (in_lds) tile[smp * d + row] = (CT)c;
+        else matrix[kmd::count_index(layout, ld, (int)S, rb + row, (int)smp)] = (CT)c;
       }
     }
     wave_sync();
