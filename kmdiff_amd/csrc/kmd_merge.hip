@@ -20,6 +20,7 @@
 
 #include "kmd_internal.h"
 
+#include <algorithm>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 
@@ -155,23 +156,26 @@ __global__ void __launch_bounds__(256) k_transpose_starts(const uint32_t* __rest
 // cluster inside a wide slice gets a fine grid of its own); repeated by the host until every
 // bucket fits.  split[j] = slices bucket j becomes (1 = kept), klo/kstep[j] = first key and slice
 // width of a cut bucket, counters[0] += buckets over capacity.
+// The table is read as start[j * js + s * ss]: (S, 1) for the bucket-major table, (1, nb + 1)
+// for the stream-major one k_bucket_starts wrote -- one thread per bucket, so the stream-major
+// form (level 0, every bucket) is the coalesced one.
 __global__ void __launch_bounds__(256) k_bucket_split(const uint64_t* __restrict__ keys,
-                                                      const uint32_t* __restrict__ start, uint32_t S, uint32_t nb,
-                                                      uint32_t cap, uint32_t* __restrict__ split,
-                                                      uint64_t* __restrict__ klo, uint64_t* __restrict__ kstep,
-                                                      uint32_t* __restrict__ counters)
+                                                      const uint32_t* __restrict__ start, size_t js, size_t ss,
+                                                      uint32_t S, uint32_t nb, uint32_t cap,
+                                                      uint32_t* __restrict__ split, uint64_t* __restrict__ klo,
+                                                      uint64_t* __restrict__ kstep, uint32_t* __restrict__ counters)
 {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
   uint32_t n = 0;
-  for (uint32_t s = 0; s < S; ++s) n += start[(j + 1) * S + s] - start[j * S + s];
+  for (uint32_t s = 0; s < S; ++s) n += start[(j + 1) * js + s * ss] - start[j * js + s * ss];
   uint32_t m = 1;
   if (n > cap)
   {
     uint64_t lo = ~0ull, hi = 0;
     for (uint32_t s = 0; s < S; ++s)
     {
-      const uint32_t b = start[j * S + s], e = start[(j + 1) * S + s];
+      const uint32_t b = start[j * js + s * ss], e = start[(j + 1) * js + s * ss];
       if (e > b)
       {
         const uint64_t kb = keys[b], ke = keys[e - 1];
@@ -777,7 +781,9 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
     KMD_HIP(sc.take(&p_kstep, nb * 8));
     uint32_t* split = static_cast<uint32_t*>(p_split);
     KMD_HIP(hipMemsetAsync(overflow + 2, 0, 4, st));
-    hipLaunchKernelGGL(k_bucket_split, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_kmers, start, (uint32_t)S,
+    const bool sm_form = level == 0;                          // the stream-major table still describes level 0
+    hipLaunchKernelGGL(k_bucket_split, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_kmers,
+                       sm_form ? start_sm : start, sm_form ? (size_t)1 : (size_t)S, sm_form ? nb + 1 : (size_t)1, (uint32_t)S,
                        (uint32_t)nb, cap, split, static_cast<uint64_t*>(p_klo), static_cast<uint64_t*>(p_kstep),
                        overflow + 2);
     KMD_HIP(hipMemcpyAsync(&n_over, overflow + 2, 4, hipMemcpyDeviceToHost, st));
