@@ -7,12 +7,13 @@
 // itself is not part of the reference tree (empty submodule); the contract restated here is
 // the one SURVEY.md 8a R1 derives from the call site and the fixture bytes.
 //
-// Round-1 form: correct and device-resident, NOT yet a tuned kernel.  The S sorted streams are
-// tagged with their sample id, radix-sorted together (rocPRIM), run heads are flagged and
-// scanned into row numbers, and a scatter kernel writes the matrix in the layout K1 wants.
-// The sort ignores that the inputs are already sorted; the bucketed LDS merge that uses it
-// (sampled splitters -> one workgroup merges one key range in LDS) is the planned
-// replacement and keeps this interface.
+// Two device implementations behind kmd_merge_partition (bottom of the file):
+//   * the bucketed LDS merge (one 64-bit limb, <= 256 samples): uses that the inputs are
+//     sorted -- key-range buckets, one wave per bucket, one pass (second half of the file);
+//   * the sort-based merge (two-limb k-mers, tiny inputs, mostly-clustered keys): records
+//     tagged with their sample id, radix-sorted together (rocPRIM), run heads flagged and
+//     scanned into row numbers, a scatter kernel writes the matrix (first half of the file).
+// Both write the layout K1 wants and the sorted k-mer column.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,19 +82,22 @@ __global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ ke
 
 
 // ---------------------------------------------------------------------------------------------
-// Fast path (one 64-bit limb, enough records): key-range buckets merged in LDS.
+// Bucketed LDS merge (one 64-bit limb, enough records).
 //
-//   pass 1  k_bucket_starts : one streaming pass over the keys; because every stream is sorted,
-//           the first record of bucket j in stream s is where bucket(key) changes: a
-//           [bucket][sample] table of start offsets, no searching.
-//   pass 2  k_bucket_merge : one WAVE per bucket inserts the bucket's keys (S short segments,
-//           <= kWaveCap records, kept in registers) into an LDS hash set -> number of distinct
-//           k-mers; the first row of the bucket comes from a decoupled look-back over the
-//           lower-numbered buckets' status words (single pass, persistent grid); distinct keys
-//           are compacted and bitonic-sorted in LDS, every record binary-searches its row, the
-//           bucket's d x S block of the matrix is assembled in LDS and written out whole.
-// Buckets are equal slices of [min key, max key]; a bucket holding more than kWaveCap records
-// (heavily clustered keys) raises a flag and the caller falls back to the sort-based path.
+//   k_bucket_starts     one streaming pass over the keys; because every stream is sorted, the
+//                       first record of bucket j in stream s is where bucket(key) changes: a
+//                       table of start offsets, no searching (written stream-major, coalesced)
+//   k_transpose_starts  -> [bucket][sample]: the S offsets of a bucket in one contiguous span
+//   k_bucket_split /    buckets holding more records than a wave takes (random keys: Poisson
+//   k_refine_starts     sizes; real partitions cluster) are cut again, level by level, on the
+//                       start table alone
+//   k_bucket_merge      one WAVE per bucket, one pass: records -> registers, LDS hash set ->
+//                       distinct count (published), rank by counting; first row by a two-level
+//                       decoupled look-back; the bucket's d x S block assembled in LDS and
+//                       written whole.  Stage A of the next bucket runs before stage B of the
+//                       current one (software pipeline, see the kernel).
+// Buckets start as equal slices of [min key, max key].  Input that is mostly clusters, or a
+// bucket still over capacity after kMaxLevels cuts, hands over to the sort-based path.
 constexpr uint64_t kEmpty = ~0ull;
 
 // bucket(key) = floor((key - kmin) * nb / (span + 1)) as a 64x64 -> high-64 multiply: equal
@@ -106,7 +110,8 @@ __device__ __forceinline__ uint32_t bucket_of(const bucket_map& B, uint64_t key)
   return (uint32_t)__umul64hi(key - B.kmin, B.mult);
 }
 
-// start[s * (nb + 1) + j] (stream-major: the writes of a stream are consecutive) = index of the first record of stream s whose bucket is >= j   (j in [0, nb]);
+// start[s * (nb + 1) + j] = index of the first record of stream s whose bucket is >= j
+// (j in [0, nb]; stream-major: the writes of a stream are consecutive);
 // one launch for all streams: blockIdx.y = stream, grid-stride over its records
 __global__ void __launch_bounds__(256) k_bucket_starts(const uint64_t* __restrict__ keys,
                                                        const uint64_t* __restrict__ offs, uint32_t S,
