@@ -584,6 +584,139 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params 
   flush_beyond(P, n_beyond);
 }
 
+// ---- row-major rows, 16-byte aligned pitch: wave-private staging -------------------------
+// What a host that hands over kmtricks rows (matrix_proxy, merge.hpp:194-203) delivers.  A wave
+// owns 64 consecutive rows at a time.  Their bytes are fetched with 16-byte loads that are
+// contiguous across the lanes (lane L takes vector k*64+L of the [64 rows x cv vectors] block),
+// parked in a wave-private LDS tile whose row pitch is an ODD number of vectors (16 lanes x
+// 16 B of a row-walk then hit 16 different bank groups), and each lane walks its own row.  No
+// workgroup barrier; the loads of the next block are issued before the current one is summed.
+// CV = vectors of a row handled per pass (bounds the registers of the in-flight block), BLOCK =
+// threads per workgroup (its waves share one copy of the table head); picked by row width in
+// launch_rows: a single pass per row and as many waves as registers and LDS allow.
+template <typename CT, int kRowsCV, int kRowsWaveBlock>
+__global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filter_params P, const uint32_t row_vecs,
+                                                                     const uint32_t n_chunks, const uint32_t cvb)
+{
+  extern __shared__ double2 s_all[];
+  double2* s_lf = s_all;
+  stage_table(P, s_lf);
+  uint32_t n_beyond = 0;
+  typedef uint32_t n4 __attribute__((ext_vector_type(4)));
+  constexpr uint32_t per = 4 / sizeof(CT);              // counts per dword
+  constexpr uint32_t epv = 4 * per;                     // counts per 16-byte vector
+  constexpr uint32_t emask = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  using ACC = typename acc_of<CT>::type;
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t S = (uint32_t)(P.nc + P.nk), nc = (uint32_t)P.nc;
+  const uint32_t pitch_max = cvb | 1u;                  // cvb = vectors per pass (<= kRowsCV)
+  n4* tile = reinterpret_cast<n4*>(s_all + P.lds_n) + (size_t)w * 64 * pitch_max;
+  const size_t ld_vecs = P.ld * sizeof(CT) / 16;        // row pitch in vectors (exact)
+  const n4* __restrict__ base = static_cast<const n4*>(P.counts);
+  const size_t n_tiles = (P.n_rows + 63) / 64;
+  const size_t n_waves = (size_t)gridDim.x * (kRowsWaveBlock / 64);
+
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
+
+  n4 buf[kRowsCV];
+  // loads of chunk `ch` of the 64 rows starting at row0 (rows past the end re-read the last row)
+  auto issue = [&](size_t row0, uint32_t ch)
+  {
+    const uint32_t c0 = ch * cvb;
+    const uint32_t cv = (row_vecs - c0) < cvb ? (row_vecs - c0) : cvb;
+    const uint32_t q = 64u / cv, rem = 64u % cv;        // (row, c) of vector v+64 from those of v
+    uint32_t r = lane / cv, c = lane - r * cv;
+#pragma unroll
+    for (int k = 0; k < kRowsCV; ++k)
+    {
+      if ((uint32_t)k < cv)                             // wave-uniform
+      {
+        size_t row = row0 + r;
+        if (row >= P.n_rows) row = P.n_rows - 1;
+        buf[k] = __builtin_nontemporal_load(base + row * ld_vecs + c0 + c);
+        r += q; c += rem;
+        if (c >= cv) { c -= cv; ++r; }
+      }
+    }
+  };
+
+  size_t t = (size_t)blockIdx.x * (kRowsWaveBlock / 64) + w;
+  if (t < n_tiles) issue(t * 64, 0);
+  for (; t < n_tiles; t += n_waves)
+  {
+    const size_t row0 = t * 64;
+    ACC sc = 0, sk = 0;
+    for (uint32_t ch = 0; ch < n_chunks; ++ch)
+    {
+      const uint32_t c0 = ch * cvb;
+      const uint32_t cv = (row_vecs - c0) < cvb ? (row_vecs - c0) : cvb;
+      const uint32_t pitch = cv | 1u;
+      {
+        const uint32_t q = 64u / cv, rem = 64u % cv;
+        uint32_t r = lane / cv, c = lane - r * cv;
+#pragma unroll
+        for (int k = 0; k < kRowsCV; ++k)
+          if ((uint32_t)k < cv)
+          {
+            tile[r * pitch + c] = buf[k];
+            r += q; c += rem;
+            if (c >= cv) { c -= cv; ++r; }
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // next block of loads in flight while this one is added up
+      if (ch + 1 < n_chunks) issue(row0, ch + 1);
+      else if (t + n_waves < n_tiles) issue((t + n_waves) * 64, 0);
+      const n4* __restrict__ mine = tile + lane * pitch;
+      for (uint32_t c = 0; c < cv; ++c)
+      {
+        const n4 v = mine[c];
+        const uint32_t e0 = (c0 + c) * epv;             // first count of this vector (wave-uniform)
+        if constexpr (per == 1)
+        {
+          if (e0 + 4 <= nc) sc += (ACC)v.x + v.y + v.z + v.w;
+          else if (e0 >= nc && e0 + 4 <= S) sk += (ACC)v.x + v.y + v.z + v.w;
+          else
+          {
+            const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e)
+              if (e0 + e < nc) sc += d[e]; else if (e0 + e < S) sk += d[e];
+          }
+        }
+        else
+        {
+          const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+          const bool all_c = e0 + epv <= nc, all_k = e0 >= nc && e0 + epv <= S;
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+            for (uint32_t e = 0; e < per; ++e)
+            {
+              const uint32_t x = (d[j] >> (8 * sizeof(CT) * e)) & emask;
+              const uint32_t el = e0 + j * per + e;
+              if (all_c) sc += x;
+              else if (all_k) sk += x;
+              else if (el < nc) sc += x;
+              else if (el < S) sk += x;
+            }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // tile consumed before it is overwritten
+      __builtin_amdgcn_wave_barrier();
+    }
+    row_state st;
+    st.row = row0 + lane;
+    st.valid = st.row < P.n_rows;
+    st.sum_c = sc; st.sum_k = sk;
+    finish_row(P, s_lf, st, n_beyond);
+  }
+  flush_beyond(P, n_beyond);
+}
+
 // Row-major rows whose pitch is not a whole number of dwords: each lane walks its own row
 // straight from global memory (correct for any pitch/alignment; not a tuned path).
 template <typename CT>
@@ -781,6 +914,40 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   }
   const uint32_t row_dw = (S + per - 1) / per;
   const size_t ld_dw = P.ld / per;
+  // 16-byte aligned rows: the wave-private kernel (a row's last vector may reach into the
+  // padding up to the pitch, never past it)
+  const bool vec_rows = ((P.ld * sizeof(CT)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);
+  if (vec_rows && std::getenv("KMD_ROWS_KERNEL_OLD") == nullptr)
+  {
+    const uint32_t row_vecs = (uint32_t)(((size_t)S * sizeof(CT) + 15) / 16);
+    auto launch = [&](auto kernel, int cv_max, int block) -> int
+    {
+      const uint32_t n_chunks = (row_vecs + cv_max - 1) / cv_max;
+      // full passes of cv_max vectors (256 B: whole cache lines of a row) and a short last one --
+      // measured better than balanced passes, whose pieces straddle lines (S=68: 1.24 vs 1.57 ms)
+      const uint32_t cvb = (uint32_t)cv_max < row_vecs ? (uint32_t)cv_max : row_vecs;
+      const size_t wpb = (size_t)block / 64;
+      const size_t tiles_bytes = wpb * 64 * (cvb | 1u) * 16;
+      const size_t avail = m->lds_per_block_max - 256 - tiles_bytes;
+      size_t want = (size_t)P.lf_n * sizeof(double2);
+      if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
+      P.lds_n = (uint32_t)(want / sizeof(double2));
+      const size_t lds = want + tiles_bytes;
+      const size_t n_wtiles = (P.n_rows + 63) / 64;
+      size_t grid = (size_t)m->n_cu;
+      if (grid > (n_wtiles + wpb - 1) / wpb) grid = (n_wtiles + wpb - 1) / wpb;
+      int rc = allow_big_lds(kernel, lds);
+      if (rc != KMD_OK) return rc;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), lds, stream, P, row_vecs, n_chunks, cvb);
+      KMD_HIP(hipGetLastError());
+      return KMD_OK;
+    };
+    // one pass per row where the registers allow it, and then as many waves as fit
+    if (row_vecs <= 4) return launch(k_filter_rows_wave<CT, 4, 1024>, 4, 1024);
+    if (row_vecs <= 8) return launch(k_filter_rows_wave<CT, 8, 1024>, 8, 1024);
+    if (row_vecs <= 10) return launch(k_filter_rows_wave<CT, 10, 768>, 10, 768);
+    return launch(k_filter_rows_wave<CT, 16, 512>, 16, 512);
+  }
   const bool vec4 = (row_dw % 4 == 0) && (ld_dw % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);
   // column chunk: whole rows when they fit in ~48 KiB of LDS, else 44-dword chunks
