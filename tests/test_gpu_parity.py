@@ -223,6 +223,36 @@ def test_unaligned_soa_pitch_and_padded_rows(K, oracle):
     assert (acc.get()["row"]).tolist() == want8["row"].tolist()
 
 
+def test_row_major_16_byte_pitch_shapes(K, oracle):
+    """Row-major with a 16-byte aligned pitch takes the wave-private kernel: one pass per row
+    (<= 4 / 8 / 10 / 16 vectors), several passes (wider rows), a last vector that reaches into
+    the padding (garbage there must be ignored), control/case boundary inside a vector, fewer
+    rows than one wave, rows that are not a multiple of 64."""
+    rng = np.random.default_rng(77)
+    lf = oracle.lf_table(10000)
+    shapes = [(1, 1, 4), (3, 4, 4), (4, 4, 4), (7, 9, 4), (9, 7, 2), (16, 16, 4), (20, 20, 4), (20, 20, 2), (20, 20, 1),
+              (17, 30, 4), (33, 35, 4), (100, 100, 4), (100, 100, 1), (5, 6, 1), (31, 33, 2), (40, 41, 4)]
+    for it, (nc, nk, cb) in enumerate(shapes):
+        S = nc + nk
+        n = int(rng.choice([1, 63, 64, 65, 1000, 4099]))
+        host, lo, _ = oracle.synth_rows(SEED + 100 + it, it, 0, n, nc, nk, cb)
+        per16 = 16 // cb
+        ld = (S + per16 - 1) // per16 * per16 + (per16 if it % 3 == 0 else 0)      # sometimes a whole spare vector
+        padded = rng.integers(1, 200, (n, ld)).astype(host.dtype)                   # garbage in the padding
+        padded[:, :S] = host
+        m = K.CountMatrix(n, S, cb, K.LAYOUT_ROWS, ld=ld, with_kmers=False)
+        K._native.check(K._native.lib().kmd_memcpy_h2d(m.counts.ptr, padded.ctypes.data, padded.nbytes, None))
+        tcs, tks = totals_of(host, nc)
+        want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), lf, 0.05)
+        obs, acc, ns = run_filter(K, m, nc, nk, tcs, tks, 10000, 0.05)
+        got = acc.get()
+        assert obs.total() == n, (nc, nk, cb, n)
+        assert got["row"].tolist() == want["row"].tolist(), (nc, nk, cb, n, ld)
+        assert got["sign"].tolist() == want["sign"].tolist()
+        assert np.allclose(got["pvalue"], want["pvalue"], rtol=0, atol=1e-10)
+        assert got["mean_control"].tolist() == want["mean_control"].tolist() and got["mean_case"].tolist() == want["mean_case"].tolist()
+
+
 def test_survivor_capacity_overflow_is_reported(K, oracle):
     n = 5000
     mat = K.synth_matrix(SEED, 1, n, 4, 4, 4, K.LAYOUT_SOA)
