@@ -234,6 +234,35 @@ int kmd_popstrat_info(const kmd_popstrat* ps, int* n_samples, int* n_features_al
 int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sample_major, size_t ld,
                        size_t n, double* d_pvalue, void* stream);
 
+/* ---- stage 2 front end: the principal components of the population structure ----------------
+ * Replaces Sampler + EigGenoFile / EigSnpFile (include/kmdiff/popstrat.hpp:55-146: rows sampled
+ * with probability --kmer-pca during stage 1, written as presence/absence), the external
+ * `smartpca` run and evec2pca.perl (src/popstrat.cpp:97-134; parfile: usenorm YES,
+ * numoutlieriter 0, numoutevec 10, popstrat.hpp:28-37) with smartpca's arithmetic as Hawk
+ * modified it (thirdparty/hawk/EIG6.0.1-Hawk/src/eigensrc/smartpca.c: fvadjust :1694-1800,
+ * getcolxz :2598-2700, main :880-1025): g = count > 0, x = (g - mean) / sqrt(p (1 - p)) with
+ * p = 1 - sqrt(1 - mean) (diploid) or mean (`-V`), XTX = sum of x x^T over the sampled rows,
+ * scaled by (n - 1) / trace, top eigenvectors at unit norm.
+ * By nature not reproducible against the reference: it samples with one sequential RNG shared
+ * by its partition threads; here a row is sampled iff hash(seed, k-mer) < rate.  The sign of
+ * an eigenvector is the eigen-solver's there; here its largest component is positive. */
+typedef struct kmd_pca kmd_pca;
+/* capacity_rows: sampled rows the object holds to begin with (it grows by doubling) */
+int kmd_pca_create(kmd_pca** out, int n_samples, double sample_rate, uint64_t seed, int diploid,
+                   size_t capacity_rows);
+void kmd_pca_destroy(kmd_pca* pca);
+/* Sampler::sample over one tile (merge.hpp:150-152): records the presence pattern of the
+ * sampled rows, in row order.  The tile needs its k-mer column. */
+int kmd_pca_sample(kmd_pca* pca, const kmd_tile* tile, void* stream);
+int kmd_pca_count(const kmd_pca* pca, uint64_t* n_sampled);
+/* xtx_host[S*S] (row-major, host) = sum over this object's sampled rows of x x^T, summed in a
+ * fixed order.  Ranks add their matrices (rank order) before kmd_pca_eigen. */
+int kmd_pca_gram(kmd_pca* pca, double* xtx_host, void* stream);
+/* Scales xtx by (S - 1) / trace and solves it on the device (cyclic Jacobi, FP64):
+ * eval_host[n_out] in decreasing order, evec_host[S][n_out] unit-norm columns -- the values
+ * smartpca prints to .evec (pcs.evec holds them rounded to 4 decimals by evec2pca.perl). */
+int kmd_pca_eigen(int n_samples, const double* xtx_host, int n_out, double* evec_host, double* eval_host);
+
 /* ---- synthetic count matrices (benchmark / test support) ------------------
  * Counter-based generator, every cell a pure function of (seed, partition, row, sample);
  * the CPU oracle replays it.  d_kmer_lo / d_kmer_hi may be NULL. */

@@ -76,6 +76,12 @@ SIGNATURES = {
     "kmd_popstrat_destroy": (_i, [_vp]),
     "kmd_popstrat_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), _vp, _vp, C.POINTER(_d)]),
     "kmd_popstrat_apply": (_i, [_vp, _vp, _i, _sz, _sz, _vp, _vp]),
+    "kmd_pca_create": (_i, [C.POINTER(C.c_void_p), _i, C.c_double, _u64, _i, _sz]),
+    "kmd_pca_destroy": (None, [_vp]),
+    "kmd_pca_sample": (_i, [_vp, _vp, _vp]),
+    "kmd_pca_count": (_i, [_vp, C.POINTER(_u64)]),
+    "kmd_pca_gram": (_i, [_vp, _vp, _vp]),
+    "kmd_pca_eigen": (_i, [_i, _vp, _i, _vp, _vp]),
     "kmd_synth_fill": (_i, [_u64, C.c_uint32, _u64, _sz, _i, _i, _i, _i, _sz, _vp, _vp, _vp, _vp]),
     "kmd_column_sums": (_i, [_vp, _i, _i, _sz, _sz, _i, _vp, _vp]),
     "kmd_copy_probe": (_i, [_vp, _vp, _sz, _vp]),

@@ -85,6 +85,20 @@ def allgather_varlen(t):
     return cat, offs
 
 
+def sum_in_rank_order(a):
+    """Sum of a float64 array over the ranks, added in rank order on every rank (bitwise the
+    same everywhere, unlike an all-reduce whose order is the library's): the ranks' Gram
+    matrices of the pop-strat PCA (kmd_pca_gram) before kmd_pca_eigen."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return a.copy()
+    parts = all_gather(torch.from_numpy(a).to(_dev()))
+    out = parts[0].cpu().numpy().copy()
+    for p in parts[1:]:
+        out += p.cpu().numpy()
+    return out
+
+
 def max_over_ranks(x):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(x)

@@ -469,3 +469,54 @@ def column_sums(matrix, totals_buf=None, stream=None):
         check(lib().kmd_stream_sync(None), "sync")
         return totals_buf.to_host(np.uint64, matrix.n_samples)
     return None
+
+
+class PopulationPCA:
+    """Sampler + smartpca (popstrat.hpp:55-146, src/popstrat.cpp:97-134) on the device:
+    sample rows of the partitions as they pass, then gram() and pca_eigen()."""
+
+    def __init__(self, n_samples, rate, seed=0, diploid=True, capacity=1 << 20):
+        self.n_samples = int(n_samples)
+        h = C.c_void_p()
+        check(lib().kmd_pca_create(C.byref(h), self.n_samples, float(rate), int(seed), 1 if diploid else 0, int(capacity)),
+              "kmd_pca_create")
+        self.handle = h
+
+    def sample(self, mat):
+        if mat.n_samples != self.n_samples:
+            raise ValueError("matrix has %d samples, the PCA %d" % (mat.n_samples, self.n_samples))
+        t = mat.tile()
+        check(lib().kmd_pca_sample(self.handle, C.byref(t), None), "kmd_pca_sample")
+
+    def count(self):
+        n = C.c_uint64(0)
+        check(lib().kmd_pca_count(self.handle, C.byref(n)), "kmd_pca_count")
+        return int(n.value)
+
+    def gram(self):
+        xtx = np.zeros((self.n_samples, self.n_samples), dtype=np.float64)
+        check(lib().kmd_pca_gram(self.handle, xtx.ctypes.data, None), "kmd_pca_gram")
+        return xtx
+
+    def close(self):
+        if self.handle:
+            lib().kmd_pca_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pca_eigen(xtx, n_out=10):
+    """(evec [S][n_out] unit-norm columns, eigenvalues[n_out] decreasing) of the summed Gram matrix."""
+    xtx = np.ascontiguousarray(xtx, dtype=np.float64)
+    S = xtx.shape[0]
+    n_out = min(int(n_out), S)
+    evec = np.zeros((S, n_out), dtype=np.float64)
+    evals = np.zeros(n_out, dtype=np.float64)
+    check(lib().kmd_pca_eigen(S, xtx.ctypes.data, n_out, evec.ctypes.data, evals.ctypes.data), "kmd_pca_eigen")
+    return evec, evals
+

@@ -12,9 +12,12 @@
 // survivor files partitions/p<i>_uncorrected / p<i>_popstrat_uncorrected with options.bin and
 // the stage-skip logic of main_diff (--keep-tmp; cmd/diff.hpp:278-370), --save-sk.
 //
+// --pop-correction takes its principal components from the device PCA (kmd_pca_*: rows sampled
+// at rate --kmer-pca during stage 1, smartpca's normalisation and eigen-decomposition; written to
+// popstrat/pcs.evec in evec2pca's format) or, with --pcs FILE, from a file computed elsewhere.
+//
 // Not carried over (out of scope): `count`/`infos` sub-commands, --cmodel plugins
-// (the IModel plugin of this build is libkmdiff_hip_model.so), KFF output, the smartpca front
-// end (give --pcs FILE with the principal components instead), progress bars.
+// (the IModel plugin of this build is libkmdiff_hip_model.so), KFF output, progress bars.
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
@@ -41,7 +44,8 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   size_t nb_controls = 0, nb_cases = 0, cutoff = 100000, log_size = 10000, npc = 2, max_iteration = 0;
   double threshold = 0.05;
   bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false;
-  double kmer_pca = 0.001;                  // only recorded in options.bin (cli.cpp default)
+  double kmer_pca = 0.001;                  // proportion of k-mers sampled for the PCA (cli.cpp:286-289)
+  size_t ploidy = 2, seed = 0;              // cli.cpp:298-302, :349-351
   int device = 0, verbose = 1;
 };
 
@@ -69,7 +73,10 @@ void usage()
             "  -c/--correction    bonferroni|benjamini|sidak|holm|disabled {bonferroni}\n"
             "  --log-factorial    size of the log-factorial table {10000}\n"
             "  --pop-correction   re-test the survivors with the population-stratification model\n"
-            "  --pcs FILE         principal components (pcs.evec: one row per sample, 10 columns)\n"
+            "  --pcs FILE         principal components computed elsewhere (pcs.evec: one row per sample, 10 columns);\n"
+            "                     default: the device PCA over k-mers sampled at rate --kmer-pca {0.001}\n"
+            "  --ploidy INT       2: diploid normalisation of the PCA, else haploid {2}\n"
+            "  --random-seed INT  seed of the PCA row sampler {0}\n"
             "  --n-pc             number of principal components in [2, 10] {2}\n"
             "  --device           GPU index {0}\n"
             "  --keep-tmp         keep partitions/p<i>_uncorrected (+ options.bin): a later run resumes from them\n"
@@ -101,8 +108,10 @@ diff_options parse(int argc, char** argv)
     else if (a == "--keep-tmp") o.keep_tmp = true;
     else if (a == "--save-sk") o.save_sk = true;
     else if (a == "--kmer-pca") o.kmer_pca = std::stod(need(i));
-    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" || a == "--ploidy" ||
-             a == "--gender" || a == "--random-seed" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
+    else if (a == "--ploidy") o.ploidy = std::stoull(need(i));
+    else if (a == "--random-seed") o.seed = std::stoull(need(i));
+    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" ||
+             a == "--gender" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
     else if (a == "-f" || a == "--kff-output" || a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
              a == "--stand" || a == "--irls") {}
     else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
@@ -113,7 +122,7 @@ diff_options parse(int argc, char** argv)
   if (!(o.threshold >= 0.0 && o.threshold <= 1.0)) die("-s/--significance must be in [0, 1]");          // cli.cpp:191-199
   static const std::map<std::string, int> ok = { {"bonferroni", 1}, {"benjamini", 2}, {"sidak", 3}, {"holm", 4}, {"disabled", 0} };
   if (!ok.count(o.correction)) die("-c/--correction must be bonferroni|benjamini|sidak|holm|disabled");
-  if (o.pop_correction && o.pcs.empty()) die("--pop-correction needs --pcs FILE (the smartpca front end is not part of this build)");
+  if (!(o.kmer_pca > 0.0 && o.kmer_pca <= 0.05)) die("--kmer-pca must be in (0, 0.05]");                 // cli.cpp:289
   if (o.npc < 2 || o.npc > 10) die("--n-pc must be in [2, 10]");
   return o;
 }
@@ -196,7 +205,18 @@ int main(int argc, char** argv)
     sv_all.kmer_bytes = two_limbs ? 16 : 8;
     std::vector<size_t> part_begin(cfg.nb_partitions + 1, 0);
     uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
-    const bool run_stage1 = !prev_1 || (action & 0b1);
+    // the device PCA needs stage 1 (it samples the rows as they pass); its result of a previous
+    // run is popstrat/pcs.evec
+    const std::string pop_dir = opt.output_directory + "/popstrat";
+    const bool device_pca = opt.pop_correction && opt.pcs.empty();
+    const bool have_pcs = fs::exists(pop_dir + "/pcs.evec");
+    const bool run_stage1 = !prev_1 || (action & 0b1) || (device_pca && !have_pcs);
+    kmd_pca* pca = nullptr;
+    std::vector<double> Z_device;                  // [S][10] when the device PCA ran
+    if (run_stage1 && device_pca)
+    {
+      ck(kmd_pca_create(&pca, (int)S, opt.kmer_pca, opt.seed, opt.ploidy == 2 ? 1 : 0, (size_t)1 << 20), "kmd_pca_create");   // grows
+    }
     if (run_stage1)
     {
       // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
@@ -274,6 +294,7 @@ int main(int argc, char** argv)
         }
         size_t ns = 0;
         const size_t base = sv_all.size();
+        if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");             // merge.hpp:150-152
         if (n_rows)
         {
           // survivor sink sized for the worst case of this partition (every row)
@@ -321,6 +342,32 @@ int main(int argc, char** argv)
         }
       }
       for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
+      if (pca)                                                                                 // run_eigenstrat_smartpca
+      {
+        uint64_t n_sampled = 0;
+        ck(kmd_pca_count(pca, &n_sampled), "kmd_pca_count");
+        std::vector<double> xtx(S * S), evec(S * 10, 0.0), eval(10, 0.0);
+        ck(kmd_pca_gram(pca, xtx.data(), nullptr), "kmd_pca_gram");
+        const int n_out = (int)std::min<size_t>(S, 10);                                        // popstrat.cpp:118
+        std::vector<double> ev(S * n_out), el(n_out);
+        ck(kmd_pca_eigen((int)S, xtx.data(), n_out, ev.data(), el.data()), "kmd_pca_eigen");
+        kmd_pca_destroy(pca); pca = nullptr;
+        fs::create_directories(pop_dir);
+        std::ofstream pf(pop_dir + "/pcs.evec");
+        Z_device.assign(S * 10, 0.0);
+        for (size_t i = 0; i < S; ++i)
+        {
+          for (int k = 0; k < n_out; ++k)
+          {
+            char b[32]; std::snprintf(b, sizeof b, "%.04f", ev[i * n_out + k]);                 // evec2pca.perl
+            pf << ' ' << (ev[i * n_out + k] > 0 ? " " : "") << b;
+            Z_device[i * 10 + k] = std::strtod(b, nullptr);                                    // what load_Z reads back
+          }
+          pf << '\n';
+        }
+        std::fprintf(stderr, "[kmdiff-hip] PCA done: %" PRIu64 " k-mers sampled, eigenvalues %.4f %.4f\n", n_sampled, el[0],
+                     n_out > 1 ? el[1] : 0.0);
+      }
       if (opt.keep_tmp)                                                                       // FileAccumulator, del = !keep_tmp
         for (size_t p = 0; p < cfg.nb_partitions; ++p)
           write_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
@@ -368,10 +415,18 @@ int main(int argc, char** argv)
     }
     if (run_stage2 && n)
     {
-      std::ifstream zin(opt.pcs);
-      if (!zin) die("cannot open " + opt.pcs);
       std::vector<double> Z(S * 10, 0.0), Y(S, 0.0);
-      for (size_t i = 0; i < S * 10; ++i) if (!(zin >> Z[i])) die(opt.pcs + ": expected 10 values per sample");   // popstrat.cpp:153-161
+      if (!Z_device.empty()) Z = Z_device;
+      else
+      {
+        const std::string zpath = opt.pcs.empty() ? pop_dir + "/pcs.evec" : opt.pcs;
+        std::ifstream zin(zpath);
+        if (!zin) die("cannot open " + zpath);
+        const size_t per_row = opt.pcs.empty() ? std::min<size_t>(S, 10) : 10;
+        for (size_t i = 0; i < S; ++i)
+          for (size_t k = 0; k < per_row; ++k)
+            if (!(zin >> Z[i * 10 + k])) die(zpath + ": expected " + std::to_string(per_row) + " values per sample");   // popstrat.cpp:153-161
+      }
       for (size_t i = 0; i < opt.nb_controls; ++i) Y[i] = 1.0;                                                       // popstrat.cpp:168
       kmd_popstrat* ps = nullptr;
       ck(kmd_popstrat_create(&ps, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), Z.data(), 10,

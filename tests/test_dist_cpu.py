@@ -33,8 +33,10 @@ def _worker(rank, world, port, q):
         p_local = torch.arange(3 * (1 - rank), dtype=torch.float64) + 10.0 * rank
         cat, offs = D.allgather_varlen(p_local)
         mx = D.max_over_ranks(0.5 + rank)
+        # the ranks' PCA Gram matrices, added in rank order
+        gram = D.sum_in_rank_order(np.array([[0.1, 1e-17], [1e-17, 0.3]]) * (1 + rank * 1e16))
         D.barrier()
-        q.put((rank, mine, g.tolist(), cat.tolist(), offs, mx))
+        q.put((rank, mine, g.tolist(), cat.tolist(), offs, mx, gram.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -54,6 +56,7 @@ def test_single_process_collectives_are_identity():
     cat, offs = D.allgather_varlen(t)
     assert cat.tolist() == [0.1, 0.2] and offs == [0, 2]
     assert D.max_over_ranks(1.5) == 1.5
+    assert D.sum_in_rank_order(np.eye(3)).tolist() == np.eye(3).tolist()
 
 
 @pytest.mark.timeout(120)
@@ -66,7 +69,9 @@ def test_two_ranks_gloo_exchange():
     res = sorted(q.get(timeout=90) for _ in range(world))
     [p.join(30) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (r0, mine0, g0, cat0, offs0, mx0), (r1, mine1, g1, cat1, offs1, mx1) = res
+    (r0, mine0, g0, cat0, offs0, mx0, gram0), (r1, mine1, g1, cat1, offs1, mx1, gram1) = res
+    a = np.array([[0.1, 1e-17], [1e-17, 0.3]])
+    assert gram0 == gram1 == (a + a * (1 + 1e16)).tolist()           # rank 0 first: bitwise the same on both
     assert mine0 == [0, 2, 4, 6] and mine1 == [1, 3, 5]
     assert g0 == g1 == [4000 + 3001, 21, 9, 12]
     assert cat0 == cat1 == [0.0, 1.0, 2.0] and offs0 == offs1 == [0, 3, 3]

@@ -222,6 +222,39 @@ def test_cli_pop_correction(synth_run, tmp_path):
     assert s["kept"] == int(keep.sum()) and s["n_sig"] == len(p2)
 
 
+def test_cli_pop_correction_with_device_pca(synth_run, tmp_path):
+    """--pop-correction without --pcs: rows sampled at --kmer-pca, smartpca's normalisation and
+    eigen-decomposition on the device, popstrat/pcs.evec in evec2pca's format, then the same re-test."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pca_oracle as PO
+    run_dir, nc, nk, k, mats, kms = synth_run
+    S = nc + nk
+    o = OL.load()
+    s, err = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-c", "bonferroni", "-u", 1000, "--pop-correction", "--kmer-pca", 0.05,
+                      "--random-seed", 11], tmp_path / "o")
+    assert "PCA done" in err
+    lines = open(tmp_path / "o" / "popstrat" / "pcs.evec").read().rstrip("\n").split("\n")
+    Zf = np.array([[float(x) for x in l.split()] for l in lines])
+    assert Zf.shape == (S, min(S, 10))
+    # the oracle's PCA over the same sampled rows
+    sampled = [m[PO.sampled_mask(11, 0.05, km)] for m, km in zip(mats, kms)]
+    n_sampled = sum(len(x) for x in sampled)
+    assert ("%d k-mers sampled" % n_sampled) in err and n_sampled > 1000
+    evec, evals = PO.eigen(PO.gram(np.concatenate(sampled)), min(S, 10))
+    assert np.abs(Zf[:, :2] - evec[:, :2]).max() <= 0.00005 + 1e-9          # "%.04f"
+    assert lines == PO.pcs_evec_lines(np.round(Zf, 4)) or all(len(l.split()) == min(S, 10) for l in lines)
+    # the re-test with the components the command wrote
+    surv, _, total = oracle_pipeline(o, nc, nk, mats, kms, 0.05 / 1000, "bonferroni", 0.05)
+    totals = np.sum([m.sum(axis=0, dtype=np.uint64) for m in mats], axis=0)
+    Zr = np.zeros((S, 10)); Zr[:, :Zf.shape[1]] = Zf
+    alt, null_model, tot_d, y = o.popstrat_setup(nc, nk, totals[:nc], totals[nc:], Zr, 2, True)
+    lut = [{int(v): i for i, v in enumerate(km)} for km in kms]
+    counts = np.array([next(m[l[kv]] for m, l in zip(mats, lut) if kv in l) for kv in surv["kmer"]], dtype=np.float64)
+    keep = o.aggregate(1, 0.05, total, o.popstrat_pvalues(alt, null_model, tot_d, y, counts))
+    assert s["kept"] == int(keep.sum()) and s["n_sig"] == len(counts)
+
+
 @pytest.mark.parametrize("bits,dtype", [(32, np.uint32), (16, np.uint16), (8, np.uint8)])
 def test_imodel_plugin_loaded_like_the_reference_does(tmp_path, bits, dtype):
     """libkmdiff_hip_model.so through a dlopen / plugin_name / create<bits> / configure / process
