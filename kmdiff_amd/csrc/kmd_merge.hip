@@ -374,7 +374,8 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
   __shared__ unsigned long long s_seg_all[kWavesPerBlock][kWaveCap];
   constexpr uint32_t kMaxS = kWaveCap / 4;              // samples this instantiation serves (fast_bucket_cap)
   constexpr int kSPL = kMaxS / 64;                      // samples per lane in the segment phase
-  static_assert(sizeof(unsigned long long) * kWaveCap >= sizeof(uint32_t) * (2 * kMaxS + 1), "segment tables");
+  static_assert(sizeof(unsigned long long) * (kWaveCap / 2) >= sizeof(uint32_t) * (2 * kMaxS + 1), "segment tables (lower half)");
+  static_assert(sizeof(unsigned long long) * (kWaveCap / 2) >= sizeof(uint16_t) * kWaveCap, "record -> sample table (upper half)");
   static_assert(sizeof(unsigned long long) * kWaveCap >= sizeof(uint16_t) * kWaveSlots, "slot -> row table");
   constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
   constexpr int kPerLane = kWaveCap / 64;               // records of a bucket held by one lane
@@ -383,6 +384,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
   unsigned long long* s_hash = s_hash_all[w];
   uint32_t* s_beg = reinterpret_cast<uint32_t*>(s_seg_all[w]);
   uint32_t* pref = s_beg + kMaxS;
+  uint16_t* smp_of = reinterpret_cast<uint16_t*>(s_seg_all[w] + kWaveCap / 2);    // [kWaveCap], upper half of the region
   unsigned long long* s_tmp = s_seg_all[w];                          // unsorted distinct keys
   uint16_t* s_rank = reinterpret_cast<uint16_t*>(s_seg_all[w]);      // hash slot -> row within the bucket
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
@@ -443,17 +445,23 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
       if ((int)lane >= o) incl += up;
     }
     uint32_t run = incl - lsum;                         // records before this lane's first sample
+    const uint32_t n = __shfl(incl, 63, 64);
+    const bool too_big = n > kWaveCap;
+    if (too_big && lane == 0) atomicAdd(overflow, 1u);  // the caller falls back to the sort path
 #pragma unroll
     for (int q = 0; q < kSPL; ++q)
     {
       const uint32_t s = lane * kSPL + q;
-      if (s < S) pref[s] = run;
+      if (s < S)
+      {
+        pref[s] = run;
+        // record -> sample table: every record of the bucket looks its stream up with one LDS
+        // read (segments are ~3 records long; a binary search over pref is 6 dependent reads)
+        if (!too_big)
+          for (uint32_t t = 0; t < len[q]; ++t) smp_of[run + t] = (uint16_t)s;
+      }
       run += len[q];
     }
-    if (lane == 63) pref[S] = incl;                     // pref[S] = n
-    const uint32_t n = __shfl(incl, 63, 64);
-    const bool too_big = n > kWaveCap;
-    if (too_big && lane == 0) atomicAdd(overflow, 1u);  // the caller falls back to the sort path
 
     TICK(0);
     // hash set sized to the bucket; every lane keeps its records in registers
@@ -478,8 +486,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
         key_r[r] = 0; st.cnt_r[r] = 0; st.sr_r[r] = 0; slot_r[r] = kNoSlot;
         if (f < n)
         {
-          uint32_t lo = 0, hi = S;                      // last q with pref[q] <= f
-          while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= f) lo = mid; else hi = mid; }
+          const uint32_t lo = smp_of[f];                // the stream this record comes from
           const uint32_t i = s_beg[lo] + (f - pref[lo]);
           key_r[r] = keys[i]; st.cnt_r[r] = counts[i]; st.sr_r[r] = lo;
         }
