@@ -594,11 +594,11 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
   };
 
   // ---------------- stage B: row number by look-back, LDS block, write-out
-  auto stage_b = [&](const state_t& st, const unsigned long long* s_keys)
+  auto stage_b = [&](const state_t& st, const unsigned long long* s_keys, bool have_rb, unsigned long long early_rb)
   {
     const uint32_t j = st.j, n = st.n, d = st.d;
     TICK(3);
-    const unsigned long long rb64 = rows_before(status, group, j, lane);
+    const unsigned long long rb64 = have_rb ? early_rb : rows_before(status, group, j, lane);
     TICK(4);
     if (lane == 0 && j == nb - 1) group[(j >> 6) + 1].base = rb64 + d;          // the partition's row count
     if (!st.work) return;
@@ -674,8 +674,14 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
     const uint32_t jn = cur.j + n_waves;
     const bool have_next = jn < nb;
     state_t nxt;
+    // A group's first bucket resolves the group's base BEFORE its wave turns to the next
+    // bucket: everything it needs (the earlier groups' sums) was published a stage ago, and
+    // the 63 other buckets of the group, which wait for that one word, find it there.
+    const bool leader = (cur.j & 63u) == 0;
+    unsigned long long early_rb = 0;
+    if (leader) early_rb = rows_before(status, group, cur.j, lane);
     if (have_next) stage_a(jn, nxt, s_keys_all[w][buf ^ 1]);
-    stage_b(cur, s_keys_all[w][buf]);
+    stage_b(cur, s_keys_all[w][buf], leader, early_rb);
     if (!have_next) break;
     cur = nxt;
     buf ^= 1;
