@@ -331,6 +331,17 @@ __device__ __forceinline__ unsigned long long rows_before(const unsigned long lo
   return (bs & kStMask) + (unsigned long long)__shfl(own, 0, 64);
 }
 
+// t = q * d + r for t < 2^24, d >= 1, with the wave-uniform rcp = 1.0f / d: one multiply and a
+// one-step fix-up instead of an integer division (or a subtract-until-it-fits loop) per element
+__device__ __forceinline__ void divmod_rcp(uint32_t t, uint32_t d, float rcp, uint32_t& q, uint32_t& r)
+{
+  q = (uint32_t)((float)t * rcp);
+  int rr = (int)t - (int)(q * d);
+  if (rr < 0) { --q; rr += (int)d; }
+  else if (rr >= (int)d) { ++q; rr -= (int)d; }
+  r = (uint32_t)rr;
+}
+
 // What stage A (count) of a bucket hands to its stage B (emit): the records (count, sample, row
 // within the bucket) stay in registers, the sorted distinct keys in one of the wave's two LDS
 // key buffers.
@@ -610,6 +621,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
     // between two stage A's) and written out whole: no zero-fill pass over the matrix, no 4-byte
     // scatter; a block too large for LDS is zero-filled and scattered in place
     const uint32_t cells = d * S;
+    const float rcp_d = 1.0f / (float)d;
     const bool in_lds = (size_t)cells * sizeof(CT) <= sizeof(unsigned long long) * kWaveSlots;
     CT* tile = reinterpret_cast<CT*>(s_hash);                        // [sample][row in bucket]
     if (in_lds)
@@ -619,10 +631,10 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
     }
     else
     {
-      uint32_t row = lane, smp = 0;
-      for (uint32_t t = lane; t < cells; t += 64, row += 64)
+      for (uint32_t t = lane; t < cells; t += 64)
       {
-        while (row >= d) { row -= d; ++smp; }
+        uint32_t smp, row;
+        divmod_rcp(t, d, rcp_d, smp, row);
         matrix[kmd::count_index(layout, ld, (int)S, rb + row, (int)smp)] = (CT)0;
       }
     }
@@ -646,19 +658,20 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
     {
       if (layout == KMD_LAYOUT_ROWS)            // consecutive lanes -> consecutive samples of a row: one contiguous span
       {
-        uint32_t smp = lane, row = 0;
-        for (uint32_t t = lane; t < cells; t += 64, smp += 64)
+        const float rcp_s = 1.0f / (float)S;
+        for (uint32_t t = lane; t < cells; t += 64)
         {
-          while (smp >= S) { smp -= S; ++row; }
+          uint32_t row, smp;
+          divmod_rcp(t, S, rcp_s, row, smp);
           matrix[(rb + row) * ld + smp] = tile[smp * d + row];
         }
       }
       else                                      // consecutive lanes -> consecutive rows of a sample
       {
-        uint32_t row = lane, smp = 0;
-        for (uint32_t t = lane; t < cells; t += 64, row += 64)
+        for (uint32_t t = lane; t < cells; t += 64)
         {
-          while (row >= d) { row -= d; ++smp; }
+          uint32_t smp, row;
+          divmod_rcp(t, d, rcp_d, smp, row);
           matrix[kmd::count_index(layout, ld, (int)S, rb + row, (int)smp)] = tile[t];
         }
       }
