@@ -855,12 +855,30 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
     int per_cu = 0;
     KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 1) per_cu -= 1;                            // margin: the API can over-report by one
-    size_t grid = (size_t)n_cu * (size_t)per_cu;
-    if (grid > (nb + wpb - 1) / wpb) grid = (nb + wpb - 1) / wpb;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers, d_counts, start, (uint32_t)S,
-                       (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out, overflow);
-    KMD_HIP(hipGetLastError());
+    const size_t want = (nb + wpb - 1) / wpb;
+    uint32_t S32 = (uint32_t)S, nb32 = (uint32_t)nb;
+    int lay = layout;
+    size_t ld_ = ld, cap_ = row_capacity;
+    const uint64_t* a_keys = d_kmers; const uint32_t* a_counts = d_counts; const uint32_t* a_start = start;
+    unsigned long long* a_status = status; merge_group* a_group = group;
+    CT* a_matrix = d_matrix; uint64_t* a_kmer_out = d_kmer_out; uint32_t* a_overflow = overflow;
+    void* args[] = { &a_keys, &a_counts, &a_start, &S32, &nb32, &a_status, &a_group, &lay, &ld_, &cap_, &a_matrix,
+                     &a_kmer_out, &a_overflow };
+    // A cooperative launch is the runtime's own guarantee that the whole grid is resident: the
+    // full occupancy can be used.  If it is refused, launch one workgroup per CU less (the
+    // occupancy query may over-report by one).
+    size_t grid = std::min((size_t)n_cu * (size_t)per_cu, want);
+    hipError_t e = std::getenv("KMD_MERGE_NO_COOP") ? hipErrorNotSupported
+                 : hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3((unsigned)grid), dim3(64 * wpb), args, 0, st);
+    if (e != hipSuccess)
+    {
+      (void)hipGetLastError();
+      grid = std::min((size_t)n_cu * (size_t)std::max(per_cu - 1, 1), want);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers, d_counts, start, (uint32_t)S,
+                         (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out, overflow);
+      KMD_HIP(hipGetLastError());
+    }
+    if (dbg) std::fprintf(stderr, "[merge_fast] grid %zu x %d threads (%s)\n", grid, 64 * wpb, e == hipSuccess ? "cooperative" : "plain");
     return KMD_OK;
   };
   int rc_launch;
