@@ -25,3 +25,5 @@ run tools/kbench_popstrat.py
 run tools/kbench_popstrat.py --nc 20 --nk 20 2>/dev/null
 run tools/kbench_pca.py
 run tools/kbench_pca.py --nc 100 --nk 100 --rows 8000000 --rate 0.01
+for k in even random; do run tools/kbench_pipeline.py --keys $k; done
+run tools/kbench_pipeline.py --nc 100 --nk 100 --rows 800000
