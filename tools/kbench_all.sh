@@ -22,6 +22,7 @@ for k in even random; do
 done
 echo "$(KMD_MERGE_PATH=sort run tools/kbench_merge.py --iters 2 --keys random)   [KMD_MERGE_PATH=sort]"
 run tools/kbench_popstrat.py
+run tools/kbench_popstrat.py --thr 0.05
 run tools/kbench_popstrat.py --nc 20 --nk 20 2>/dev/null
 run tools/kbench_pca.py
 run tools/kbench_pca.py --nc 100 --nk 100 --rows 8000000 --rate 0.01
