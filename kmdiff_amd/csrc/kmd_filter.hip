@@ -125,13 +125,9 @@ struct row_state
 
 // One row from its two count sums to the survivor sink.  Must be called by all 64 lanes of
 // the wave together (ballots / cooperative fallback inside).
-__device__ __forceinline__ void finish_row(const filter_params& P, const double2* s_tab,
-                                           const row_state& st, uint32_t& n_beyond)
+// Can this row still reach `p <= threshold`?  (Also counts the rows beyond the table.)
+__device__ __forceinline__ bool row_may_pass(const filter_params& P, const row_state& st, uint32_t& n_beyond)
 {
-#ifdef KMD_ABLATE_MATH   // dev only: memory-side ceiling of the load loop (results are wrong)
-  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
-  return;
-#endif
   if (st.valid && (st.sum_c >= P.lf_n || st.sum_k >= P.lf_n))
     ++n_beyond;        // rows beyond the table; flushed once per wave at kernel end (with many
                        // samples most waves see such rows: a global atomic here serialises the chip)
@@ -144,13 +140,16 @@ __device__ __forceinline__ void finish_row(const filter_params& P, const double2
   // dropped here for ~25 flops instead of a division and two logarithms.  The factor 2 and
   // the host-side enabling conditions (fill_params) cover the rounding of the bound itself;
   // rows that pass are evaluated exactly as before, so every exposed number is unchanged.
-  {
-    const double dsc = (double)st.sum_c, dsk = (double)st.sum_k;
-    const double a = dsc * P.dTk - dsk * P.dTc;
-    const bool maybe = st.valid && !(a * a < P.pf_cut * ((dsc + dsk) * P.dTcTk));
-    if (!__ballot(maybe)) return;
-  }
+  const double dsc = (double)st.sum_c, dsk = (double)st.sum_k;
+  const double a = dsc * P.dTk - dsk * P.dTc;
+  return st.valid && !(a * a < P.pf_cut * ((dsc + dsk) * P.dTcTk));
+}
 
+// The exact evaluation of rows that passed the pre-filter: likelihood ratio, candidate cut, tail
+// function, sign, compaction into the survivor sink.  Must be called by all 64 lanes of the wave
+// together (ballots inside); lanes without a row pass valid = false.
+__device__ __forceinline__ void evaluate_row(const filter_params& P, const double2* s_tab, const row_state& st)
+{
   // table entry of each sum: { lf[k], log(k) }.  k = table_index(sum) (model.hpp:152-156);
   // sums beyond the table (or >= 2^31, where k wraps to 0 but lambda does not) take the
   // logarithm on the device.
@@ -218,6 +217,86 @@ __device__ __forceinline__ void finish_row(const filter_params& P, const double2
       }
     }
   }
+}
+
+// One row from its two count sums to the survivor sink, at once.  Must be called by all 64 lanes
+// of the wave together.
+__device__ __forceinline__ void finish_row(const filter_params& P, const double2* s_tab,
+                                           const row_state& st, uint32_t& n_beyond)
+{
+#ifdef KMD_ABLATE_MATH   // dev only: memory-side ceiling of the load loop (results are wrong)
+  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
+  return;
+#endif
+  row_state e = st;
+  e.valid = row_may_pass(P, st, n_beyond);
+  if (!__ballot(e.valid)) return;
+  evaluate_row(P, s_tab, e);
+}
+
+// Deferred evaluation.  About 1 % of the rows pass the pre-filter, so in half of the 64-row
+// steps of a wave SOME lane does -- and evaluating at once runs the two logarithms, the division
+// and the compaction logic with one or two live lanes out of 64.  Instead the rows that pass are
+// parked in a wave-private LDS queue and evaluated 64 at a time with every lane busy: ~40 x
+// fewer passes through the expensive code.  The survivor order is unspecified either way
+// (kmd_survivors_sort_by_row restores the reference's); every exposed number is unchanged.
+#ifndef KMD_DEFER
+#define KMD_DEFER 1
+#endif
+constexpr uint32_t kQueueCap = 128;                      // >= 63 parked + 64 pushed by one step
+constexpr size_t kQueueBytesPerWave = kQueueCap * 3 * sizeof(unsigned long long);
+struct wave_queue
+{
+  unsigned long long *sc, *sk, *row;                     // [kQueueCap] each, LDS
+  uint32_t n;                                            // parked rows (wave-uniform)
+};
+
+__device__ __forceinline__ void queue_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void defer_row(const filter_params& P, const double2* s_tab, const row_state& st,
+                                          uint32_t& n_beyond, wave_queue& Q)
+{
+#ifdef KMD_ABLATE_MATH
+  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
+  return;
+#endif
+  const bool maybe = row_may_pass(P, st, n_beyond);
+  const unsigned long long m = __ballot(maybe);
+  if (!m) return;
+  const uint32_t lane = (uint32_t)__lane_id();
+  if (maybe)
+  {
+    const uint32_t at = Q.n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    Q.sc[at] = st.sum_c; Q.sk[at] = st.sum_k; Q.row[at] = st.row;
+  }
+  Q.n += (uint32_t)__popcll(m);
+  if (Q.n >= 64)
+  {
+    queue_fence();
+    Q.n -= 64;                                           // the 64 most recent: nothing to move
+    row_state e;
+    e.sum_c = Q.sc[Q.n + lane]; e.sum_k = Q.sk[Q.n + lane]; e.row = Q.row[Q.n + lane];
+    e.valid = true;
+    queue_fence();                                       // read before the next step overwrites
+    evaluate_row(P, s_tab, e);
+  }
+}
+
+__device__ __forceinline__ void drain_queue(const filter_params& P, const double2* s_tab, wave_queue& Q)
+{
+  if (Q.n == 0) return;
+  queue_fence();
+  const uint32_t lane = (uint32_t)__lane_id();
+  row_state e;
+  e.valid = lane < Q.n;
+  e.sum_c = e.valid ? Q.sc[lane] : 0; e.sum_k = e.valid ? Q.sk[lane] : 0; e.row = e.valid ? Q.row[lane] : 0;
+  Q.n = 0;
+  evaluate_row(P, s_tab, e);
 }
 
 // one atomic per wave per launch for the beyond-table row count
@@ -398,6 +477,11 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
   extern __shared__ double2 s_lf[];
   stage_table(P, s_lf);
   uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
+  wave_queue Q;                // rows that passed the pre-filter, evaluated 64 at a time
+  {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s_lf + P.lds_n) + (size_t)(threadIdx.x >> 6) * kQueueCap * 3;
+    Q.sc = q; Q.sk = q + kQueueCap; Q.row = q + 2 * kQueueCap; Q.n = 0;
+  }
 
   using ACC = typename acc_of<CT>::type;
   const CT* __restrict__ base = static_cast<const CT*>(P.counts);
@@ -481,7 +565,11 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
       st.sum_c = sc[0]; st.sum_k = sk[0];
       st.row = r0 + j;
       st.valid = (r0 + j) < P.n_rows;
+#if KMD_DEFER
+      defer_row(P, s_lf, st, n_beyond, Q);
+#else
       finish_row(P, s_lf, st, n_beyond);
+#endif
 #pragma unroll
       for (int i = 0; i + 1 < RPL; ++i) { sc[i] = sc[i + 1]; sk[i] = sk[i + 1]; }
     }
@@ -490,6 +578,7 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
     t_load += t1 - t0; t_math += t2 - t1; ++n_tiles_done;
 #endif
   }
+  drain_queue(P, s_lf, Q);
   flush_beyond(P, n_beyond);
 #ifdef KMD_TIMING
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1016,14 +1105,15 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
     // workgroup of kBlock threads per CU holds it; larger tables keep their head in LDS
     size_t want = m->lf_n * sizeof(double2);
     const int blocks_per_cu = KMD_BLOCKS_PER_CU;
-    const size_t budget = lds_cap / blocks_per_cu - 256;
+    const size_t queues = (size_t)(kBlock / 64) * kQueueBytesPerWave;     // deferred-evaluation queues, one per wave
+    const size_t budget = lds_cap / blocks_per_cu - 256 - queues;
     if (want > budget) want = budget / sizeof(double2) * sizeof(double2);
     P.lds_n = (uint32_t)(want / sizeof(double2));
     switch (tile->count_bytes)
     {
-      case 1: return launch_soa<uint8_t>(P, m, want, blocks_per_cu, tiled, st);
-      case 2: return launch_soa<uint16_t>(P, m, want, blocks_per_cu, tiled, st);
-      default: return launch_soa<uint32_t>(P, m, want, blocks_per_cu, tiled, st);
+      case 1: return launch_soa<uint8_t>(P, m, want + queues, blocks_per_cu, tiled, st);
+      case 2: return launch_soa<uint16_t>(P, m, want + queues, blocks_per_cu, tiled, st);
+      default: return launch_soa<uint32_t>(P, m, want + queues, blocks_per_cu, tiled, st);
     }
   }
   else
