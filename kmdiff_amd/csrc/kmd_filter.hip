@@ -683,7 +683,7 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params 
 // CV = vectors of a row handled per pass (bounds the registers of the in-flight block), BLOCK =
 // threads per workgroup (its waves share one copy of the table head); picked by row width in
 // launch_rows: a single pass per row and as many waves as registers and LDS allow.
-template <typename CT, int kRowsCV, int kRowsWaveBlock>
+template <typename CT, int kRowsCV, int kRowsWaveBlock, bool kDefer>
 __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filter_params P, const uint32_t row_vecs,
                                                                      const uint32_t n_chunks, const uint32_t cvb)
 {
@@ -699,7 +699,14 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t S = (uint32_t)(P.nc + P.nk), nc = (uint32_t)P.nc;
   const uint32_t pitch_max = cvb | 1u;                  // cvb = vectors per pass (<= kRowsCV)
-  n4* tile = reinterpret_cast<n4*>(s_all + P.lds_n) + (size_t)w * 64 * pitch_max;
+  // LDS: table head | (kDefer) one deferred-evaluation queue per wave | one tile per wave
+  wave_queue Q;
+  {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s_all + P.lds_n) + (size_t)w * kQueueCap * 3;
+    Q.sc = q; Q.sk = q + kQueueCap; Q.row = q + 2 * kQueueCap; Q.n = 0;
+  }
+  n4* tile = reinterpret_cast<n4*>(reinterpret_cast<char*>(s_all + P.lds_n) +
+                                   (kDefer ? (size_t)(kRowsWaveBlock / 64) * kQueueBytesPerWave : 0)) + (size_t)w * 64 * pitch_max;
   const size_t ld_vecs = P.ld * sizeof(CT) / 16;        // row pitch in vectors (exact)
   const n4* __restrict__ base = static_cast<const n4*>(P.counts);
   const size_t n_tiles = (P.n_rows + 63) / 64;
@@ -801,8 +808,10 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
     st.row = row0 + lane;
     st.valid = st.row < P.n_rows;
     st.sum_c = sc; st.sum_k = sk;
-    finish_row(P, s_lf, st, n_beyond);
+    if constexpr (kDefer) defer_row(P, s_lf, st, n_beyond, Q);
+    else finish_row(P, s_lf, st, n_beyond);
   }
+  if constexpr (kDefer) drain_queue(P, s_lf, Q);
   flush_beyond(P, n_beyond);
 }
 
@@ -1009,14 +1018,14 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   if (vec_rows && std::getenv("KMD_ROWS_KERNEL_OLD") == nullptr)
   {
     const uint32_t row_vecs = (uint32_t)(((size_t)S * sizeof(CT) + 15) / 16);
-    auto launch = [&](auto kernel, int cv_max, int block) -> int
+    auto launch = [&](auto kernel, int cv_max, int block, bool defer) -> int
     {
       const uint32_t n_chunks = (row_vecs + cv_max - 1) / cv_max;
       // full passes of cv_max vectors (256 B: whole cache lines of a row) and a short last one --
       // measured better than balanced passes, whose pieces straddle lines (S=68: 1.24 vs 1.57 ms)
       const uint32_t cvb = (uint32_t)cv_max < row_vecs ? (uint32_t)cv_max : row_vecs;
       const size_t wpb = (size_t)block / 64;
-      const size_t tiles_bytes = wpb * 64 * (cvb | 1u) * 16;
+      const size_t tiles_bytes = wpb * 64 * (cvb | 1u) * 16 + (defer ? wpb * kQueueBytesPerWave : 0);    // + the waves' queues
       const size_t avail = m->lds_per_block_max - 256 - tiles_bytes;
       size_t want = (size_t)P.lf_n * sizeof(double2);
       if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
@@ -1032,10 +1041,13 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
       return KMD_OK;
     };
     // one pass per row where the registers allow it, and then as many waves as fit
-    if (row_vecs <= 4) return launch(k_filter_rows_wave<CT, 4, 1024>, 4, 1024);
-    if (row_vecs <= 8) return launch(k_filter_rows_wave<CT, 8, 1024>, 8, 1024);
-    if (row_vecs <= 10) return launch(k_filter_rows_wave<CT, 10, 768>, 10, 768);
-    return launch(k_filter_rows_wave<CT, 16, 512>, 16, 512);
+    // measured: narrow rows are instruction-bound and gain from the deferred-evaluation queue
+    // (S=8: 1.08 -> 0.67 ms; u16 S=40: 0.90 -> 0.80 ms even with 12 instead of 16 waves); from 10
+    // vectors on the queues' LDS would cost resident waves and the kernel is HBM-bound anyway
+    if (row_vecs <= 4) return launch(k_filter_rows_wave<CT, 4, 1024, true>, 4, 1024, true);
+    if (row_vecs <= 8) return launch(k_filter_rows_wave<CT, 8, 768, true>, 8, 768, true);
+    if (row_vecs <= 10) return launch(k_filter_rows_wave<CT, 10, 768, false>, 10, 768, false);
+    return launch(k_filter_rows_wave<CT, 16, 512, false>, 16, 512, false);
   }
   const bool vec4 = (row_dw % 4 == 0) && (ld_dw % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);
