@@ -23,7 +23,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <filesystem>
+#include <future>
+#include <mutex>
+#include <thread>
 #include <fstream>
 #include <map>
 #include <stdexcept>
@@ -46,6 +50,7 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false;
   double kmer_pca = 0.001;                  // proportion of k-mers sampled for the PCA (cli.cpp:286-289)
   size_t ploidy = 2, seed = 0;              // cli.cpp:298-302, :349-351
+  size_t threads = std::max(1u, std::thread::hardware_concurrency());   // -t: host threads decoding the k-mer files (cli.cpp:72-76)
   int device = 0, verbose = 1;
 };
 
@@ -81,7 +86,8 @@ void usage()
             "  --device           GPU index {0}\n"
             "  --keep-tmp         keep partitions/p<i>_uncorrected (+ options.bin): a later run resumes from them\n"
             "  --save-sk          write the significant rows to positive_kmer_matrix/matrices/matrix_<p>.count.lz4\n"
-            "  -t/--threads, -f, -m, -r: accepted for compatibility, ignored");
+            "  -t/--threads INT   host threads decoding the per-sample k-mer files {all}\n"
+            "  -f, -m, -r: accepted for compatibility, ignored");
 }
 
 diff_options parse(int argc, char** argv)
@@ -110,7 +116,8 @@ diff_options parse(int argc, char** argv)
     else if (a == "--kmer-pca") o.kmer_pca = std::stod(need(i));
     else if (a == "--ploidy") o.ploidy = std::stoull(need(i));
     else if (a == "--random-seed") o.seed = std::stoull(need(i));
-    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" ||
+    else if (a == "-t" || a == "--threads") o.threads = std::max<size_t>(1, std::stoull(need(i)));
+    else if (a == "-v" || a == "--verbose" ||
              a == "--gender" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
     else if (a == "-f" || a == "--kff-output" || a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
              a == "--stand" || a == "--irls") {}
@@ -239,14 +246,62 @@ int main(int argc, char** argv)
       // one accumulator per entry of counts/ (cmd/diff.hpp:103-107); matrix files map onto them in order
       const size_t n_units = from_matrix ? std::min(mpaths.size(), cfg.nb_partitions) : cfg.nb_partitions;
       if (from_matrix && mpaths.size() > cfg.nb_partitions) die("more files in matrices/ than partitions in counts/");
+      // Host side of a partition: its S files are LZ4-decoded by up to -t threads (the reference
+      // spends -t on whole partitions, merge.hpp:239-307; here the device takes the partitions one
+      // after the other and the threads take the files), and partition p + 1 is decoded while the
+      // device works on partition p.
+      struct partition_input
+      {
+        matrix_rows m;
+        std::vector<uint64_t> kmers, kmers_hi, offs;
+        std::vector<uint32_t> counts;
+      };
+      auto load_partition = [&](size_t p) -> partition_input
+      {
+        partition_input in;
+        if (from_matrix) { in.m = read_matrix_file(mpaths[p]); return in; }
+        std::vector<std::vector<uint64_t>> k(S), kh(S);
+        std::vector<std::vector<uint32_t>> c(S);
+        std::atomic<size_t> next { 0 };
+        std::mutex mu;
+        std::exception_ptr err;
+        auto work = [&]()
+        {
+          for (size_t s2; (s2 = next++) < S;)
+          {
+            try { read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s2].id), cfg.kmer_size, k[s2], c[s2], two_limbs ? &kh[s2] : nullptr); }
+            catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+          }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < std::min(opt.threads, S); ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        if (err) std::rethrow_exception(err);
+        in.offs.assign(S + 1, 0);
+        for (size_t s2 = 0; s2 < S; ++s2) in.offs[s2 + 1] = in.offs[s2] + k[s2].size();             // KmDir::get_files_to_merge order
+        in.kmers.reserve(in.offs[S]); in.counts.reserve(in.offs[S]);
+        if (two_limbs) in.kmers_hi.reserve(in.offs[S]);
+        for (size_t s2 = 0; s2 < S; ++s2)
+        {
+          in.kmers.insert(in.kmers.end(), k[s2].begin(), k[s2].end());
+          in.counts.insert(in.counts.end(), c[s2].begin(), c[s2].end());
+          if (two_limbs) in.kmers_hi.insert(in.kmers_hi.end(), kh[s2].begin(), kh[s2].end());
+        }
+        return in;
+      };
+      std::future<partition_input> ahead;
+      if (n_units) ahead = std::async(std::launch::async, load_partition, (size_t)0);
       for (size_t p = 0; p < n_units; ++p)
       {
         kmd_tile tile {};
         uint64_t n_rows = 0;
+        partition_input in = ahead.get();
+        if (p + 1 < n_units) ahead = std::async(std::launch::async, load_partition, p + 1);
         if (from_matrix)
         {
           // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
-          const matrix_rows m = read_matrix_file(mpaths[p]);
+          const matrix_rows& m = in.m;
           if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
           if (two_limbs != !m.kmers_hi.empty()) die(mpaths[p] + ": k-mer width differs from the run's");
           n_rows = m.kmers.size();
@@ -266,12 +321,8 @@ int main(int argc, char** argv)
         }
         else
         {
-          std::vector<uint64_t> kmers, kmers_hi; std::vector<uint32_t> counts; std::vector<uint64_t> offs(S + 1, 0);
-          for (size_t s = 0; s < S; ++s)                                                      // KmDir::get_files_to_merge
-          {
-            read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s].id), cfg.kmer_size, kmers, counts, two_limbs ? &kmers_hi : nullptr);
-            offs[s + 1] = kmers.size();
-          }
+          const std::vector<uint64_t>&kmers = in.kmers, &kmers_hi = in.kmers_hi, &offs = in.offs;
+          const std::vector<uint32_t>& counts = in.counts;
           const size_t n = kmers.size();
           if (n)
           {

@@ -111,7 +111,7 @@ def test_cli_matrix_feed_equals_kmer_file_feed(synth_run, tmp_path):
     (merge.hpp:194-203, pre-merged rows): same survivors and decisions as the k-way merge feed."""
     import shutil
     run_dir, nc, nk, k, mats, kms = synth_run
-    a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000], tmp_path / "a")
+    a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3], tmp_path / "a")
     mrun = tmp_path / "km_matrix"
     shutil.copytree(run_dir, mrun)
     for p, (m, km) in enumerate(zip(mats, kms)):
