@@ -8,9 +8,9 @@
 // the one SURVEY.md 8a R1 derives from the call site and the fixture bytes.
 //
 // Two device implementations behind kmd_merge_partition (bottom of the file):
-//   * the bucketed LDS merge (one 64-bit limb, <= 256 samples): uses that the inputs are
-//     sorted -- key-range buckets, one wave per bucket, one pass (second half of the file);
-//   * the sort-based merge (two-limb k-mers, tiny inputs, mostly-clustered keys): records
+//   * the bucketed LDS merge (<= 256 samples, one or two 64-bit limbs): uses that the inputs
+//     are sorted -- key-range buckets, one wave per bucket, one pass (second half of the file);
+//   * the sort-based merge (tiny inputs, mostly-clustered keys, > 256 samples): records
 //     tagged with their sample id, radix-sorted together (rocPRIM), run heads flagged and
 //     scanned into row numbers, a scatter kernel writes the matrix (first half of the file).
 // Both write the layout K1 wants and the sorted k-mer column.
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ ke
 
 
 // ---------------------------------------------------------------------------------------------
-// Bucketed LDS merge (one 64-bit limb, enough records).
+// Bucketed LDS merge (enough records).
 //
 //   k_bucket_starts     one streaming pass over the keys; because every stream is sorted, the
 //                       first record of bucket j in stream s is where bucket(key) changes: a
@@ -366,9 +366,13 @@ struct bucket_state
 #ifndef KMD_MERGE_WAVES_PER_EU
 #define KMD_MERGE_WAVES_PER_EU 1     // occupancy the register allocator must leave room for
 #endif
-template <typename CT, uint32_t kWaveCap, int kWavesPerBlock>
+// kTwo: k-mers of two 64-bit limbs (32 < k <= 64).  A 128-bit key cannot be claimed with one LDS
+// compare-and-swap, so the hash set then holds record indices (a 32-bit CAS claims a slot for
+// the first record that reaches it) and keys are compared through the bucket's records, parked
+// in LDS; the buckets themselves are cut on the top 64 bits of the keys (merge_fast).
+template <typename CT, uint32_t kWaveCap, int kWavesPerBlock, bool kTwo>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(KMD_MERGE_WAVES_PER_EU)))
-k_bucket_merge(const uint64_t* __restrict__ keys,
+k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                               const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ start, uint32_t S,
                                                               uint32_t nb, unsigned long long* __restrict__ status,
@@ -376,14 +380,18 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
                                                               int layout, size_t ld, size_t row_capacity,
                                                               CT* __restrict__ matrix,
                                                               uint64_t* __restrict__ kmer_out,
+                                                              uint64_t* __restrict__ kmer_hi_out,
                                                               uint32_t* __restrict__ overflow)
 {
   constexpr uint32_t kWaveSlots = KMD_MERGE_SLOT_MULT * kWaveCap;
+  constexpr uint32_t kL = kTwo ? 2 : 1;                 // limbs: [low limbs | high limbs] in every key array
+  constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
   __shared__ unsigned long long s_hash_all[kWavesPerBlock][kWaveSlots];
-  __shared__ unsigned long long s_keys_all[kWavesPerBlock][2][kWaveCap];
+  __shared__ unsigned long long s_keys_all[kWavesPerBlock][2][kL * kWaveCap];
   // segment tables while the records are loaded; afterwards the same memory holds the unsorted
   // distinct keys and then the slot -> row table
-  __shared__ unsigned long long s_seg_all[kWavesPerBlock][kWaveCap];
+  __shared__ unsigned long long s_seg_all[kWavesPerBlock][kL * kWaveCap];
+  __shared__ unsigned long long s_rk_all[kWavesPerBlock][kTwo ? 2 * kWaveCap : 1];   // kTwo: the records' keys
   constexpr uint32_t kMaxS = kWaveCap / 4;              // samples this instantiation serves (fast_bucket_cap)
   constexpr int kSPL = kMaxS / 64;                      // samples per lane in the segment phase
   static_assert(sizeof(unsigned long long) * (kWaveCap / 2) >= sizeof(uint32_t) * (2 * kMaxS + 1), "segment tables (lower half)");
@@ -398,6 +406,8 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
   uint32_t* pref = s_beg + kMaxS;
   uint16_t* smp_of = reinterpret_cast<uint16_t*>(s_seg_all[w] + kWaveCap / 2);    // [kWaveCap], upper half of the region
   unsigned long long* s_tmp = s_seg_all[w];                          // unsorted distinct keys
+  unsigned long long* s_rk = s_rk_all[w];
+  uint32_t* s_own = reinterpret_cast<uint32_t*>(s_hash_all[w]);      // kTwo: slot -> record that claimed it
   uint16_t* s_rank = reinterpret_cast<uint16_t*>(s_seg_all[w]);      // hash slot -> row within the bucket
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   const uint32_t j_first = blockIdx.x * kWavesPerBlock + w;
@@ -481,13 +491,15 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
     bool any_max = false;
     uint32_t slots = 64;
     uint64_t key_r[kPerLane];
+    uint64_t keyh_r[kTwo ? kPerLane : 1];
     uint32_t slot_r[kPerLane];                          // hash slot of the record's key (kNoSlot: the empty-marker key)
     constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
     if (n > 0 && !too_big)
     {
       while (slots < 2 * n && slots < kWaveSlots) slots <<= 1;   // distinct keys are ~n / (samples present per row)
       const uint32_t mask = slots - 1;
-      for (uint32_t t = lane; t < slots; t += 64) s_hash[t] = kEmpty;
+      if constexpr (kTwo) { for (uint32_t t = lane; t < slots; t += 64) s_own[t] = kEmpty32; }
+      else { for (uint32_t t = lane; t < slots; t += 64) s_hash[t] = kEmpty; }
       wave_sync();
       bool has_max_key = false;                         // the key equal to the empty marker, if present
       // all loads of the bucket first (independent: one memory round trip), then the inserts
@@ -501,7 +513,19 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
           const uint32_t lo = smp_of[f];                // the stream this record comes from
           const uint32_t i = s_beg[lo] + (f - pref[lo]);
           key_r[r] = keys[i]; st.cnt_r[r] = counts[i]; st.sr_r[r] = lo;
+          if constexpr (kTwo) keyh_r[r] = keys_hi[i];
         }
+      }
+      if constexpr (kTwo)
+      {
+        // the bucket's keys where every lane can compare against them
+#pragma unroll
+        for (int r = 0; r < kPerLane; ++r)
+        {
+          const uint32_t f = (uint32_t)r * 64 + lane;
+          if (f < n) { s_rk[f] = key_r[r]; s_rk[kWaveCap + f] = keyh_r[r]; }
+        }
+        wave_sync();
       }
 #ifdef KMD_MERGE_TIMING
       if (key_r[0] == 12345 && st.cnt_r[0] == 77) T[7]++;   // forces the loads to complete here
@@ -512,7 +536,23 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
       {
         const uint32_t f = (uint32_t)r * 64 + lane;
         bool fresh = false;
-        if (f < n)
+        if constexpr (kTwo)
+        {
+          if (f < n)
+          {
+            const uint64_t k = key_r[r], kh = keyh_r[r];
+            uint32_t h = (hash_slot(k ^ (kh * 0x9E3779B97F4A7C15ull)) >> 16) & mask;
+            for (;;)
+            {
+              const uint32_t old = atomicCAS(&s_own[h], kEmpty32, f);
+              if (old == kEmpty32) { fresh = true; break; }
+              if (s_rk[old] == k && s_rk[kWaveCap + old] == kh) break;
+              h = (h + 1) & mask;
+            }
+            slot_r[r] = h;
+          }
+        }
+        else if (f < n)
         {
           const uint64_t k = key_r[r];
           if (k == kEmpty) has_max_key = true;
@@ -555,25 +595,34 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
       uint32_t filled = 0;
       for (uint32_t t0 = 0; t0 < slots; t0 += 64)
       {
-        const unsigned long long k = s_hash[t0 + lane];
-        const bool occ = k != kEmpty;
+        unsigned long long k = 0, kh = 0;
+        bool occ;
+        if constexpr (kTwo)
+        {
+          const uint32_t own = s_own[t0 + lane];
+          occ = own != kEmpty32;
+          if (occ) { k = s_rk[own]; kh = s_rk[kWaveCap + own]; }
+        }
+        else { k = s_hash[t0 + lane]; occ = k != kEmpty; }
         const unsigned long long m = __ballot(occ);
         if (occ)
         {
           const uint32_t e = filled + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
           s_tmp[e] = k;
+          if constexpr (kTwo) s_tmp[kWaveCap + e] = kh;
           s_tslot[e] = (uint16_t)(t0 + lane);
         }
         filled += (uint32_t)__popcll(m);
       }
       wave_sync();
-      unsigned long long mk[kPerLane];
+      unsigned long long mk[kPerLane], mkh[kTwo ? kPerLane : 1];
       uint32_t ms[kPerLane], below[kPerLane];
 #pragma unroll
       for (int q = 0; q < kPerLane; ++q)
       {
         const uint32_t e = (uint32_t)q * 64 + lane;
         mk[q] = e < filled ? s_tmp[e] : 0ull;
+        if constexpr (kTwo) mkh[q] = e < filled ? s_tmp[kWaveCap + e] : 0ull;
         ms[q] = e < filled ? (uint32_t)s_tslot[e] : 0u;
         below[q] = 0;
       }
@@ -582,16 +631,31 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
       for (uint32_t e = 0; e < filled; ++e)
       {
         const unsigned long long v = s_tmp[e];
+        if constexpr (kTwo)
+        {
+          const unsigned long long vh = s_tmp[kWaveCap + e];
 #pragma unroll
-        for (int q = 0; q < kPerLane; ++q)
-          if ((uint32_t)q < nq) below[q] += v < mk[q] ? 1u : 0u;
+          for (int q = 0; q < kPerLane; ++q)
+            if ((uint32_t)q < nq) below[q] += (vh < mkh[q] || (vh == mkh[q] && v < mk[q])) ? 1u : 0u;
+        }
+        else
+        {
+#pragma unroll
+          for (int q = 0; q < kPerLane; ++q)
+            if ((uint32_t)q < nq) below[q] += v < mk[q] ? 1u : 0u;
+        }
       }
       wave_sync();
 #pragma unroll
       for (int q = 0; q < kPerLane; ++q)
       {
         const uint32_t e = (uint32_t)q * 64 + lane;
-        if (e < filled) { s_keys[below[q]] = mk[q]; s_rank[ms[q]] = (uint16_t)below[q]; }
+        if (e < filled)
+        {
+          s_keys[below[q]] = mk[q];
+          if constexpr (kTwo) s_keys[kWaveCap + below[q]] = mkh[q];
+          s_rank[ms[q]] = (uint16_t)below[q];
+        }
       }
       if (any_max && lane == 0) s_keys[d - 1] = kEmpty;               // the largest key there is
       wave_sync();
@@ -617,6 +681,9 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
     const size_t rb = (size_t)rb64;
     if (kmer_out)
       for (uint32_t t = lane; t < d; t += 64) kmer_out[rb + t] = s_keys[t];
+    if constexpr (kTwo)
+      if (kmer_hi_out)
+        for (uint32_t t = lane; t < d; t += 64) kmer_hi_out[rb + t] = s_keys[kWaveCap + t];
     // the bucket's d x S block of the matrix is assembled in LDS (the hash set's memory, free
     // between two stage A's) and written out whole: no zero-fill pass over the matrix, no 4-byte
     // scatter; a block too large for LDS is zero-filled and scattered in place
@@ -707,6 +774,16 @@ k_bucket_merge(const uint64_t* __restrict__ keys,
 }
 
 // min of the first keys / max of the last keys of the non-empty streams
+// top[i] = the 64 most significant bits of the two-limb key (hi[i], lo[i]) when the high limbs use
+// `bits` bits: what the buckets of two-limb k-mers are cut on (monotone in the full key)
+__global__ void __launch_bounds__(256) k_top64(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, size_t n,
+                                               int bits, uint64_t* __restrict__ top)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  top[i] = bits >= 64 ? hi[i] : bits == 0 ? lo[i] : ((hi[i] << (64 - bits)) | (lo[i] >> bits));
+}
+
 __global__ void k_key_range(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ offs, uint32_t S,
                             uint64_t* __restrict__ out)
 {
@@ -745,9 +822,10 @@ inline uint32_t fast_bucket_cap(int S) { return S <= 64 ? 256u : S <= 128 ? 512u
 // The bucketed LDS merge.  *used = false (and nothing written) when the input does not suit
 // it (clustered keys overflow a bucket): the caller then takes the sort-based path.
 template <typename CT>
-int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const uint64_t* offsets,
-               int layout, size_t ld, size_t row_capacity, CT* d_matrix, uint64_t* d_kmer_out,
-               uint64_t* n_rows_out, int n_cu, hipStream_t st, bool* used)
+int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, const uint32_t* d_counts,
+               const uint64_t* offsets, int layout, size_t ld, size_t row_capacity, CT* d_matrix,
+               uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out, int n_cu, hipStream_t st,
+               bool* used)
 {
   *used = false;
   const size_t n = (size_t)offsets[S];
@@ -758,6 +836,26 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
   uint64_t* d_offs = static_cast<uint64_t*>(sc.p[0]);
   uint64_t* d_range = d_offs + S + 1;
   KMD_HIP(hipMemcpyAsync(d_offs, offsets, ((size_t)S + 1) * 8, hipMemcpyHostToDevice, st));
+  // d_kmers: the 64-bit keys the buckets are cut on -- the k-mers themselves, or for two-limb
+  // k-mers their top 64 bits (the width of the high limbs is taken from the largest one)
+  const uint64_t* d_kmers = d_kmers_lo;
+  const bool two = d_kmers_hi != nullptr;
+  if (two)
+  {
+    uint64_t hr[2];
+    hipLaunchKernelGGL(k_key_range, dim3(1), dim3(64), 0, st, d_kmers_hi, d_offs, (uint32_t)S, d_range);
+    KMD_HIP(hipMemcpyAsync(hr, d_range, 16, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    int bits = 0;
+    while (bits < 64 && (hr[1] >> bits) != 0) ++bits;
+    void* p_top = nullptr;
+    KMD_HIP(sc.take(&p_top, n * 8));
+    hipLaunchKernelGGL(k_top64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_kmers_lo, d_kmers_hi, n, bits,
+                       static_cast<uint64_t*>(p_top));
+    KMD_HIP(hipGetLastError());
+    d_kmers = static_cast<const uint64_t*>(p_top);
+    if (dbg) std::fprintf(stderr, "[merge_fast] two-limb keys, high limbs of %d bits\n", bits);
+  }
   hipLaunchKernelGGL(k_key_range, dim3(1), dim3(64), 0, st, d_kmers, d_offs, (uint32_t)S, d_range);
   uint64_t range[2];
   KMD_HIP(hipMemcpyAsync(range, d_range, 16, hipMemcpyDeviceToHost, st));
@@ -859,11 +957,13 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
     uint32_t S32 = (uint32_t)S, nb32 = (uint32_t)nb;
     int lay = layout;
     size_t ld_ = ld, cap_ = row_capacity;
-    const uint64_t* a_keys = d_kmers; const uint32_t* a_counts = d_counts; const uint32_t* a_start = start;
+    const uint64_t* a_keys = d_kmers_lo; const uint64_t* a_keys_hi = d_kmers_hi;
+    const uint32_t* a_counts = d_counts; const uint32_t* a_start = start;
     unsigned long long* a_status = status; merge_group* a_group = group;
-    CT* a_matrix = d_matrix; uint64_t* a_kmer_out = d_kmer_out; uint32_t* a_overflow = overflow;
-    void* args[] = { &a_keys, &a_counts, &a_start, &S32, &nb32, &a_status, &a_group, &lay, &ld_, &cap_, &a_matrix,
-                     &a_kmer_out, &a_overflow };
+    CT* a_matrix = d_matrix; uint64_t* a_kmer_out = d_kmer_out; uint64_t* a_kmer_hi_out = d_kmer_hi_out;
+    uint32_t* a_overflow = overflow;
+    void* args[] = { &a_keys, &a_keys_hi, &a_counts, &a_start, &S32, &nb32, &a_status, &a_group, &lay, &ld_, &cap_, &a_matrix,
+                     &a_kmer_out, &a_kmer_hi_out, &a_overflow };
     // A cooperative launch is the runtime's own guarantee that the whole grid is resident: the
     // full occupancy can be used.  If it is refused, launch one workgroup per CU less (the
     // occupancy query may over-report by one).
@@ -874,17 +974,27 @@ int merge_fast(int S, const uint64_t* d_kmers, const uint32_t* d_counts, const u
     {
       (void)hipGetLastError();
       grid = std::min((size_t)n_cu * (size_t)std::max(per_cu - 1, 1), want);
-      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers, d_counts, start, (uint32_t)S,
-                         (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out, overflow);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers_lo, d_kmers_hi, d_counts, start,
+                         (uint32_t)S, (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out,
+                         d_kmer_hi_out, overflow);
       KMD_HIP(hipGetLastError());
     }
     if (dbg) std::fprintf(stderr, "[merge_fast] grid %zu x %d threads (%s)\n", grid, 64 * wpb, e == hipSuccess ? "cooperative" : "plain");
     return KMD_OK;
   };
   int rc_launch;
-  if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2>, 2);
-  else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 2>, 2);
-  else rc_launch = launch(k_bucket_merge<CT, 1024, 1>, 1);
+  if (!two)
+  {
+    if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2, false>, 2);
+    else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 2, false>, 2);
+    else rc_launch = launch(k_bucket_merge<CT, 1024, 1, false>, 1);
+  }
+  else
+  {
+    if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2, true>, 2);
+    else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 1, true>, 1);
+    else rc_launch = launch(k_bucket_merge<CT, 1024, 1, true>, 1);
+  }
   if (rc_launch != KMD_OK) return rc_launch;
   uint32_t h_over[2] = { 0, 0 };
   unsigned long long h_last = 0;
@@ -936,7 +1046,7 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
 
   // bucketed LDS merge when it applies (one limb, enough records); else / on overflow: sort
   const char* force = std::getenv("KMD_MERGE_PATH");            // "sort" | "fast" | "fast-only" (tests, benchmarks)
-  const bool want_fast = !d_kmers_hi && (uint32_t)n_samples <= kMaxFastSamples &&
+  const bool want_fast = (uint32_t)n_samples <= kMaxFastSamples &&
                          (force ? std::strcmp(force, "sort") != 0 : n >= (1u << 16));
   if (want_fast)
   {
@@ -947,9 +1057,9 @@ extern "C" int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const
     int rc;
     switch (count_bytes)
     {
-      case 1: rc = merge_fast<uint8_t>(n_samples, d_kmers, d_counts, offsets, layout, ld, row_capacity, static_cast<uint8_t*>(d_matrix), d_kmer_out, n_rows_out, n_cu, st, &used); break;
-      case 2: rc = merge_fast<uint16_t>(n_samples, d_kmers, d_counts, offsets, layout, ld, row_capacity, static_cast<uint16_t*>(d_matrix), d_kmer_out, n_rows_out, n_cu, st, &used); break;
-      default: rc = merge_fast<uint32_t>(n_samples, d_kmers, d_counts, offsets, layout, ld, row_capacity, static_cast<uint32_t*>(d_matrix), d_kmer_out, n_rows_out, n_cu, st, &used); break;
+      case 1: rc = merge_fast<uint8_t>(n_samples, d_kmers, d_kmers_hi, d_counts, offsets, layout, ld, row_capacity, static_cast<uint8_t*>(d_matrix), d_kmer_out, d_kmer_hi_out, n_rows_out, n_cu, st, &used); break;
+      case 2: rc = merge_fast<uint16_t>(n_samples, d_kmers, d_kmers_hi, d_counts, offsets, layout, ld, row_capacity, static_cast<uint16_t*>(d_matrix), d_kmer_out, d_kmer_hi_out, n_rows_out, n_cu, st, &used); break;
+      default: rc = merge_fast<uint32_t>(n_samples, d_kmers, d_kmers_hi, d_counts, offsets, layout, ld, row_capacity, static_cast<uint32_t*>(d_matrix), d_kmer_out, d_kmer_hi_out, n_rows_out, n_cu, st, &used); break;
     }
     if (rc != KMD_OK || used) return rc;
     // "fast-only" (tests): report instead of quietly sorting

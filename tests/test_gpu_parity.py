@@ -533,6 +533,37 @@ def test_merge_partition_two_limb_kmers(K, oracle):
     assert ((np.diff(whi.astype(np.int64)) > 0) | ((np.diff(whi.astype(np.int64)) == 0) & (wlo[1:] > wlo[:-1]))).all()
 
 
+@pytest.mark.parametrize("S,hi_bits", [(6, 6), (40, 62), (70, 30)])
+def test_merge_two_limb_bucketed_path(K, oracle, S, hi_bits, monkeypatch):
+    """32 < k <= 64 through the bucketed LDS merge ("fast-only": no quiet sorting): buckets are cut
+    on the top 64 bits of the (hi, lo) keys, the hash set compares full 128-bit keys -- including
+    keys that share their top 64 bits and differ only below."""
+    monkeypatch.setenv("KMD_MERGE_PATH", "fast-only")
+    rng = np.random.default_rng(S)
+    n = 120_000
+    hi = rng.integers(0, 1 << hi_bits, n, dtype=np.uint64)
+    lo = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    # families of keys equal in their top 64 bits: same hi, lo differing in the lowest bits only
+    hi[:3000] = hi[3000:6000]
+    lo[:3000] = lo[3000:6000] ^ rng.integers(1, 1 << min(hi_bits, 20), 3000, dtype=np.uint64)
+    order = np.lexsort((lo, hi))
+    hi, lo = hi[order], lo[order]
+    keep = np.ones(n, dtype=bool)
+    keep[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+    hi, lo = hi[keep], lo[keep]
+    streams = []
+    for s in range(S):
+        pick = rng.random(len(lo)) < 0.5
+        streams.append((lo[pick], rng.integers(1, 70000, pick.sum()).astype(np.uint32), hi[pick]))
+    streams[1] = (np.zeros(0, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint64))
+    want, wlo, whi = oracle.merge_partition2(streams)
+    m = K.merge_partition(streams, count_bytes=2, layout=K.LAYOUT_TILED)
+    assert m.n_rows == want.shape[0]
+    glo, ghi = m.kmers_to_host()
+    assert (glo == wlo).all() and (ghi == whi).all()
+    assert (m.to_host() == np.minimum(want, 65535)).all()
+
+
 def test_reference_fixture_end_to_end(K, oracle):
     """tests/merge_test.cpp:12-46 on the device: the reference's 4-partition fixture through
     merge + Poisson filter: totals 160/160, 320 rows, 0 significant at 0.05/10000."""

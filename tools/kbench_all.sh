@@ -21,6 +21,9 @@ for k in even random; do
   done
 done
 echo "$(KMD_MERGE_PATH=sort run tools/kbench_merge.py --iters 2 --keys random)   [KMD_MERGE_PATH=sort]"
+KMD_MERGE_PATH=fast-only run tools/kbench_merge.py --limbs 2 --nc 20 --nk 20 --rows 4000000 --iters 3 --keys random
+KMD_MERGE_PATH=fast-only run tools/kbench_merge.py --limbs 2 --nc 50 --nk 50 --rows 1600000 --iters 3 --keys random
+echo "$(KMD_MERGE_PATH=sort run tools/kbench_merge.py --limbs 2 --nc 50 --nk 50 --rows 1600000 --iters 2 --keys random)   [KMD_MERGE_PATH=sort]"
 run tools/kbench_popstrat.py
 run tools/kbench_popstrat.py --thr 0.05
 run tools/kbench_popstrat.py --nc 20 --nk 20 2>/dev/null
