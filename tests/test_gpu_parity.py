@@ -564,6 +564,19 @@ def test_merge_two_limb_bucketed_path(K, oracle, S, hi_bits, monkeypatch):
     assert (m.to_host() == np.minimum(want, 65535)).all()
 
 
+def test_merge_more_samples_than_the_bucketed_path_serves(K, oracle):
+    """> 256 samples: the sort-based merge takes over (kMaxFastSamples); 300 streams, some empty."""
+    rng = np.random.default_rng(300)
+    universe = np.unique(rng.integers(0, 1 << 62, 20_000, dtype=np.uint64))
+    streams = []
+    for s in range(300):
+        pick = rng.random(len(universe)) < (0.0 if s % 50 == 7 else 0.3)
+        streams.append((universe[pick], rng.integers(1, 1000, pick.sum()).astype(np.uint32)))
+    want, kmers = oracle.merge_partition(streams)
+    m = K.merge_partition(streams, count_bytes=4, layout=K.LAYOUT_TILED)
+    assert m.n_rows == want.shape[0] and (m.kmers_to_host()[0] == kmers).all() and (m.to_host() == want).all()
+
+
 def test_reference_fixture_end_to_end(K, oracle):
     """tests/merge_test.cpp:12-46 on the device: the reference's 4-partition fixture through
     merge + Poisson filter: totals 160/160, 320 rows, 0 significant at 0.05/10000."""
