@@ -168,14 +168,24 @@ __global__ void __launch_bounds__(256) k_bucket_split(const uint64_t* __restrict
                                                       const uint32_t* __restrict__ start, size_t js, size_t ss,
                                                       uint32_t S, uint32_t nb, uint32_t cap,
                                                       uint32_t* __restrict__ split, uint64_t* __restrict__ klo,
-                                                      uint64_t* __restrict__ kstep, uint32_t* __restrict__ counters)
+                                                      uint64_t* __restrict__ kstep, uint32_t* __restrict__ counters,
+                                                      int arith, bucket_map B, uint64_t wq, uint64_t wr)
 {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
   uint32_t n = 0;
   for (uint32_t s = 0; s < S; ++s) n += start[(j + 1) * js + s * ss] - start[j * js + s * ss];
   uint32_t m = 1;
-  if (n > cap)
+  if (n > cap && arith)
+  {
+    // level 0: the bucket IS an equal slice of the key range -- cut that slice (no key reads).
+    // bucket_of puts the keys from kmin + j 2^64 / mult on into bucket j; 2^64 = wq mult + wr.
+    m = (n + cap / 4 - 1) / (cap / 4);
+    klo[j] = B.kmin + (uint64_t)j * wq + ((uint64_t)j * wr) / B.mult;
+    kstep[j] = wq / m + 1;
+    atomicAdd(counters, 1u);
+  }
+  else if (n > cap)
   {
     uint64_t lo = ~0ull, hi = 0;
     for (uint32_t s = 0; s < S; ++s)
@@ -898,11 +908,17 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   }
   KMD_HIP(hipGetLastError());
   KMD_DBG("starts");
-  // buckets over capacity are cut into finer slices, level by level (clustered keys); input that
-  // is mostly clusters, or still over capacity after kMaxLevels, goes to the sort path
+  // Buckets over capacity are cut into finer slices on the start table.  Level 0 cuts the
+  // bucket's own slice of the key range (no key reads: random keys put a few % of the buckets
+  // over, Poisson tails); what is still over after that (clusters, the odd tail of a tail) is cut
+  // by the key range its records REALLY span.  Mostly-clustered input, or buckets over capacity
+  // after kMaxLevels, go to the sort path.
   size_t nb = nb0;
   constexpr int kMaxLevels = 6;
-  for (int level = 0;; ++level)
+  const uint64_t wq = (uint64_t)((((unsigned __int128)1) << 64) / B.mult);          // 2^64 = wq mult + wr
+  const uint64_t wr = (uint64_t)((((unsigned __int128)1) << 64) % B.mult);
+  // returns buckets over capacity before the cut (0: table unchanged), -1: give up (sort path), -2: error
+  auto refine_level = [&](int level, bool arith, int* n_over_out) -> int
   {
     uint32_t n_over = 0;
     void *p_split = nullptr, *p_klo = nullptr, *p_kstep = nullptr;
@@ -915,12 +931,13 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     hipLaunchKernelGGL(k_bucket_split, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_kmers,
                        sm_form ? start_sm : start, sm_form ? (size_t)1 : (size_t)S, sm_form ? nb + 1 : (size_t)1, (uint32_t)S,
                        (uint32_t)nb, cap, split, static_cast<uint64_t*>(p_klo), static_cast<uint64_t*>(p_kstep),
-                       overflow + 2);
+                       overflow + 2, arith ? 1 : 0, B, wq, wr);
     KMD_HIP(hipMemcpyAsync(&n_over, overflow + 2, 4, hipMemcpyDeviceToHost, st));
     KMD_HIP(hipStreamSynchronize(st));
     if (dbg) std::fprintf(stderr, "[merge_fast] level %d: %u of %zu buckets over capacity\n", level, n_over, nb);
-    if (n_over == 0) break;
-    if (level == kMaxLevels || n_over > nb / 8) return KMD_OK;
+    *n_over_out = (int)n_over;
+    if (n_over == 0) return KMD_OK;
+    if (n_over > nb / 8) { *n_over_out = -1; return KMD_OK; }
     void *p_first = nullptr, *p_tmp = nullptr, *p_refined = nullptr;
     KMD_HIP(sc.take(&p_first, (nb + 1) * 4));
     uint32_t* first = static_cast<uint32_t*>(p_first);
@@ -931,7 +948,7 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     uint32_t nb_new = 0;
     KMD_HIP(hipMemcpyAsync(&nb_new, first + nb, 4, hipMemcpyDeviceToHost, st));
     KMD_HIP(hipStreamSynchronize(st));
-    if ((uint64_t)nb_new > table_cap) return KMD_OK;
+    if ((uint64_t)nb_new > table_cap) { *n_over_out = -1; return KMD_OK; }
     KMD_HIP(sc.take(&p_refined, ((size_t)nb_new + 1) * (size_t)S * 4));
     const size_t cells = (nb + 1) * (size_t)S;
     hipLaunchKernelGGL(k_refine_starts, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_kmers, start,
@@ -940,67 +957,91 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     KMD_HIP(hipGetLastError());
     start = static_cast<uint32_t*>(p_refined);
     nb = nb_new;
-  }
-  const size_t ng = (nb + 63) / 64;                         // look-back groups
-  const size_t status_bytes = ((nb * 8 + 127) / 128) * 128;
-  KMD_HIP(kmd::scratch_alloc(&sc.p[2], status_bytes + (ng + 1) * sizeof(merge_group)));
-  unsigned long long* status = static_cast<unsigned long long*>(sc.p[2]);
-  merge_group* group = reinterpret_cast<merge_group*>(reinterpret_cast<char*>(sc.p[2]) + status_bytes);
-  KMD_HIP(hipMemsetAsync(status, 0, status_bytes + (ng + 1) * sizeof(merge_group), st));
-  // persistent grid: every wave must be resident (look-back waits on lower-numbered buckets)
-  auto launch = [&](auto kernel, int wpb) -> int
-  {
-    int per_cu = 0;
-    KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
-    if (per_cu < 1) per_cu = 1;
-    const size_t want = (nb + wpb - 1) / wpb;
-    uint32_t S32 = (uint32_t)S, nb32 = (uint32_t)nb;
-    int lay = layout;
-    size_t ld_ = ld, cap_ = row_capacity;
-    const uint64_t* a_keys = d_kmers_lo; const uint64_t* a_keys_hi = d_kmers_hi;
-    const uint32_t* a_counts = d_counts; const uint32_t* a_start = start;
-    unsigned long long* a_status = status; merge_group* a_group = group;
-    CT* a_matrix = d_matrix; uint64_t* a_kmer_out = d_kmer_out; uint64_t* a_kmer_hi_out = d_kmer_hi_out;
-    uint32_t* a_overflow = overflow;
-    void* args[] = { &a_keys, &a_keys_hi, &a_counts, &a_start, &S32, &nb32, &a_status, &a_group, &lay, &ld_, &cap_, &a_matrix,
-                     &a_kmer_out, &a_kmer_hi_out, &a_overflow };
-    // A cooperative launch is the runtime's own guarantee that the whole grid is resident: the
-    // full occupancy can be used.  If it is refused, launch one workgroup per CU less (the
-    // occupancy query may over-report by one).
-    size_t grid = std::min((size_t)n_cu * (size_t)per_cu, want);
-    hipError_t e = std::getenv("KMD_MERGE_NO_COOP") ? hipErrorNotSupported
-                 : hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3((unsigned)grid), dim3(64 * wpb), args, 0, st);
-    if (e != hipSuccess)
-    {
-      (void)hipGetLastError();
-      grid = std::min((size_t)n_cu * (size_t)std::max(per_cu - 1, 1), want);
-      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers_lo, d_kmers_hi, d_counts, start,
-                         (uint32_t)S, (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out,
-                         d_kmer_hi_out, overflow);
-      KMD_HIP(hipGetLastError());
-    }
-    if (dbg) std::fprintf(stderr, "[merge_fast] grid %zu x %d threads (%s)\n", grid, 64 * wpb, e == hipSuccess ? "cooperative" : "plain");
     return KMD_OK;
   };
-  int rc_launch;
-  if (!two)
-  {
-    if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2, false>, 2);
-    else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 2, false>, 2);
-    else rc_launch = launch(k_bucket_merge<CT, 1024, 1, false>, 1);
-  }
-  else
-  {
-    if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2, true>, 2);
-    else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 1, true>, 1);
-    else rc_launch = launch(k_bucket_merge<CT, 1024, 1, true>, 1);
-  }
-  if (rc_launch != KMD_OK) return rc_launch;
+
   uint32_t h_over[2] = { 0, 0 };
   unsigned long long h_last = 0;
-  KMD_HIP(hipMemcpyAsync(h_over, overflow, 8, hipMemcpyDeviceToHost, st));
-  KMD_HIP(hipMemcpyAsync(&h_last, &group[ng].base, 8, hipMemcpyDeviceToHost, st));
-  KMD_HIP(hipStreamSynchronize(st));
+  size_t ng = 0;
+  // one run of the merge kernel over the current table; h_over / h_last are its verdict
+  auto run_merge = [&]() -> int
+  {
+    ng = (nb + 63) / 64;                                     // look-back groups
+    const size_t status_bytes = ((nb * 8 + 127) / 128) * 128;
+    void* p_status = nullptr;
+    KMD_HIP(sc.take(&p_status, status_bytes + (ng + 1) * sizeof(merge_group)));
+    unsigned long long* status = static_cast<unsigned long long*>(p_status);
+    merge_group* group = reinterpret_cast<merge_group*>(reinterpret_cast<char*>(p_status) + status_bytes);
+    KMD_HIP(hipMemsetAsync(status, 0, status_bytes + (ng + 1) * sizeof(merge_group), st));
+    KMD_HIP(hipMemsetAsync(overflow, 0, 8, st));
+    // persistent grid: every wave must be resident (look-back waits on lower-numbered buckets)
+    auto launch = [&](auto kernel, int wpb) -> int
+    {
+      int per_cu = 0;
+      KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
+      if (per_cu < 1) per_cu = 1;
+      const size_t want = (nb + wpb - 1) / wpb;
+      uint32_t S32 = (uint32_t)S, nb32 = (uint32_t)nb;
+      int lay = layout;
+      size_t ld_ = ld, cap_ = row_capacity;
+      const uint64_t* a_keys = d_kmers_lo; const uint64_t* a_keys_hi = d_kmers_hi;
+      const uint32_t* a_counts = d_counts; const uint32_t* a_start = start;
+      unsigned long long* a_status = status; merge_group* a_group = group;
+      CT* a_matrix = d_matrix; uint64_t* a_kmer_out = d_kmer_out; uint64_t* a_kmer_hi_out = d_kmer_hi_out;
+      uint32_t* a_overflow = overflow;
+      void* args[] = { &a_keys, &a_keys_hi, &a_counts, &a_start, &S32, &nb32, &a_status, &a_group, &lay, &ld_, &cap_, &a_matrix,
+                       &a_kmer_out, &a_kmer_hi_out, &a_overflow };
+      // A cooperative launch is the runtime's own guarantee that the whole grid is resident: the
+      // full occupancy can be used.  If it is refused, launch one workgroup per CU less (the
+      // occupancy query may over-report by one).
+      size_t grid = std::min((size_t)n_cu * (size_t)per_cu, want);
+      hipError_t e = std::getenv("KMD_MERGE_NO_COOP") ? hipErrorNotSupported
+                   : hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3((unsigned)grid), dim3(64 * wpb), args, 0, st);
+      if (e != hipSuccess)
+      {
+        (void)hipGetLastError();
+        grid = std::min((size_t)n_cu * (size_t)std::max(per_cu - 1, 1), want);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers_lo, d_kmers_hi, d_counts, start,
+                           (uint32_t)S, (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out,
+                           d_kmer_hi_out, overflow);
+        KMD_HIP(hipGetLastError());
+      }
+      if (dbg) std::fprintf(stderr, "[merge_fast] grid %zu x %d threads (%s)\n", grid, 64 * wpb, e == hipSuccess ? "cooperative" : "plain");
+      return KMD_OK;
+    };
+    int rc_launch;
+    if (!two)
+    {
+      if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2, false>, 2);
+      else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 2, false>, 2);
+      else rc_launch = launch(k_bucket_merge<CT, 1024, 1, false>, 1);
+    }
+    else
+    {
+      if (cap == 256) rc_launch = launch(k_bucket_merge<CT, 256, 2, true>, 2);
+      else if (cap == 512) rc_launch = launch(k_bucket_merge<CT, 512, 1, true>, 1);
+      else rc_launch = launch(k_bucket_merge<CT, 1024, 1, true>, 1);
+    }
+    if (rc_launch != KMD_OK) return rc_launch;
+    KMD_HIP(hipMemcpyAsync(h_over, overflow, 8, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipMemcpyAsync(&h_last, &group[ng].base, 8, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    return KMD_OK;
+  };
+
+  // cut until every bucket fits (a level that finds nothing over capacity is the check), then merge
+  for (int level = 0;; ++level)
+  {
+    int n_over = 0;
+    const int rc_l = refine_level(level, level == 0, &n_over);
+    if (rc_l != KMD_OK) return rc_l;
+    if (n_over == 0) break;
+    if (n_over < 0 || level == kMaxLevels) return KMD_OK;    // mostly clusters / cannot be cut: sort path
+  }
+  {
+    const int rc_m = run_merge();
+    if (rc_m != KMD_OK) return rc_m;
+  }
 #ifdef KMD_MERGE_TIMING
   if (dbg)
   {
@@ -1011,7 +1052,7 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   }
 #endif
   KMD_DBG("merge");
-  if (h_over[0]) return KMD_OK;                              // a bucket overflowed: not used, caller sorts
+  if (h_over[0]) return KMD_OK;                              // still a bucket over capacity: not used, caller sorts
   const size_t n_rows = (size_t)(h_last & kStMask);
   *used = true;
   *n_rows_out = n_rows;
