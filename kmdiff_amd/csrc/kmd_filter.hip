@@ -815,6 +815,153 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
   flush_beyond(P, n_beyond);
 }
 
+// ---- row-major WIDE rows (more than 10 vectors = 160 B): 16 lanes per row --------------------
+// A row of hundreds of bytes needs no transposition through LDS: 16 consecutive lanes read 256
+// consecutive bytes of ONE row per load (two whole cache lines), four rows per wave instruction,
+// and add up what they read; a 16-lane butterfly then yields the row's two sums.  Sixteen such
+// steps fill a 64-entry LDS strip with the sums of 64 rows, which go through the pre-filter and
+// the deferred-evaluation queue with every lane busy.  No tile, 16 waves per CU, many independent
+// loads in flight per wave (kWideU steps are issued at once).
+#ifndef KMD_WIDE_BLOCK
+#define KMD_WIDE_BLOCK 1024
+#endif
+#ifndef KMD_WIDE_U
+#define KMD_WIDE_U 2
+#endif
+constexpr int kWideBlock = KMD_WIDE_BLOCK;
+constexpr int kWideU = KMD_WIDE_U;            // steps (of 4 rows) whose loads are issued together
+constexpr int kWideP = 4;                     // passes (of 16 vectors) of a row per chunk
+
+template <typename CT>
+__global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_params P, const uint32_t row_vecs)
+{
+  extern __shared__ double2 s_all[];
+  double2* s_lf = s_all;
+  stage_table(P, s_lf);
+  uint32_t n_beyond = 0;
+  typedef uint32_t n4 __attribute__((ext_vector_type(4)));
+  constexpr uint32_t per = 4 / sizeof(CT), epv = 4 * per;
+  constexpr uint32_t emask = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  using ACC = typename acc_of<CT>::type;
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t g = lane >> 4, q = lane & 15;           // row within a step, vector within a pass
+  const uint32_t S = (uint32_t)(P.nc + P.nk), nc = (uint32_t)P.nc;
+  wave_queue Q;
+  {
+    unsigned long long* qb = reinterpret_cast<unsigned long long*>(s_all + P.lds_n) + (size_t)w * kQueueCap * 3;
+    Q.sc = qb; Q.sk = qb + kQueueCap; Q.row = qb + 2 * kQueueCap; Q.n = 0;
+  }
+  // the 64 rows' sums of one wave iteration: [64] x {sum_c, sum_k}
+  unsigned long long* strip = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(s_all + P.lds_n) +
+                                                                     (size_t)(kWideBlock / 64) * kQueueBytesPerWave) + (size_t)w * 128;
+  const size_t ld_vecs = P.ld * sizeof(CT) / 16;
+  const n4* __restrict__ base = static_cast<const n4*>(P.counts);
+  const size_t n_tiles = (P.n_rows + 63) / 64;
+  const size_t n_waves = (size_t)gridDim.x * (kWideBlock / 64);
+  const uint32_t n_pass = (row_vecs + 15) / 16;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
+
+  for (size_t t = (size_t)blockIdx.x * (kWideBlock / 64) + w; t < n_tiles; t += n_waves)
+  {
+    const size_t row0 = t * 64;
+    for (uint32_t step0 = 0; step0 < 16; step0 += kWideU)
+    {
+      ACC sc[kWideU], sk[kWideU];
+#pragma unroll
+      for (int u = 0; u < kWideU; ++u) { sc[u] = 0; sk[u] = 0; }
+      for (uint32_t p0 = 0; p0 < n_pass; p0 += kWideP)
+      {
+        n4 buf[kWideU][kWideP];
+#pragma unroll
+        for (int u = 0; u < kWideU; ++u)
+        {
+          size_t row = row0 + (size_t)(step0 + u) * 4 + g;
+          if (row >= P.n_rows) row = P.n_rows - 1;       // re-read the last row (never used)
+          const n4* __restrict__ rp = base + row * ld_vecs;
+#pragma unroll
+          for (int p = 0; p < kWideP; ++p)
+          {
+            const uint32_t c = (p0 + p) * 16 + q;
+            buf[u][p] = n4{ 0, 0, 0, 0 };
+            if (c < row_vecs) buf[u][p] = __builtin_nontemporal_load(rp + c);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < kWideP; ++p)
+        {
+          const uint32_t c = (p0 + p) * 16 + q;
+          const uint32_t e0 = c * epv;                   // first count of this lane's vector
+          // whole pass on one side of the control / case boundary: wave-uniform fast path
+          const uint32_t pe0 = (p0 + p) * 16 * epv, pe1 = pe0 + 16 * epv;
+          const bool all_c = pe1 <= nc, all_k = pe0 >= nc && pe1 <= S;
+#pragma unroll
+          for (int u = 0; u < kWideU; ++u)
+          {
+            const uint32_t d[4] = { buf[u][p].x, buf[u][p].y, buf[u][p].z, buf[u][p].w };
+            if constexpr (per == 1)
+            {
+              if (all_c) sc[u] += (ACC)d[0] + d[1] + d[2] + d[3];
+              else if (all_k) sk[u] += (ACC)d[0] + d[1] + d[2] + d[3];
+              else
+              {
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e)
+                {
+                  const uint32_t el = e0 + e;
+                  sc[u] += el < nc ? d[e] : 0u;
+                  sk[u] += (el >= nc && el < S) ? d[e] : 0u;
+                }
+              }
+            }
+            else
+            {
+#pragma unroll
+              for (uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+                for (uint32_t e = 0; e < per; ++e)
+                {
+                  const uint32_t x = (d[j] >> (8 * sizeof(CT) * e)) & emask;
+                  const uint32_t el = e0 + j * per + e;
+                  if (all_c) sc[u] += x;
+                  else if (all_k) sk[u] += x;
+                  else { sc[u] += el < nc ? x : 0u; sk[u] += (el >= nc && el < S) ? x : 0u; }
+                }
+            }
+          }
+        }
+      }
+      // 16-lane butterflies: every lane of a row's group ends with the row's sums
+#pragma unroll
+      for (int u = 0; u < kWideU; ++u)
+      {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+        {
+          sc[u] += (ACC)__shfl_xor((unsigned long long)sc[u], o, 64);
+          sk[u] += (ACC)__shfl_xor((unsigned long long)sk[u], o, 64);
+        }
+        if (q == 0)
+        {
+          const uint32_t slot = (step0 + (uint32_t)u) * 4 + g;
+          strip[2 * slot] = (unsigned long long)sc[u];
+          strip[2 * slot + 1] = (unsigned long long)sk[u];
+        }
+      }
+    }
+    queue_fence();
+    row_state st;
+    st.row = row0 + lane;
+    st.valid = st.row < P.n_rows;
+    st.sum_c = strip[2 * lane]; st.sum_k = strip[2 * lane + 1];
+    queue_fence();                                       // read before the next iteration's writes
+    defer_row(P, s_lf, st, n_beyond, Q);
+  }
+  drain_queue(P, s_lf, Q);
+  flush_beyond(P, n_beyond);
+}
+
 // Row-major rows whose pitch is not a whole number of dwords: each lane walks its own row
 // straight from global memory (correct for any pitch/alignment; not a tuned path).
 template <typename CT>
@@ -1047,7 +1194,26 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
     if (row_vecs <= 4) return launch(k_filter_rows_wave<CT, 4, 1024, true>, 4, 1024, true);
     if (row_vecs <= 8) return launch(k_filter_rows_wave<CT, 8, 768, true>, 8, 768, true);
     if (row_vecs <= 10) return launch(k_filter_rows_wave<CT, 10, 768, false>, 10, 768, false);
-    return launch(k_filter_rows_wave<CT, 16, 512, false>, 16, 512, false);
+    // the 16-lanes-per-row kernel is bound at ~9.5e9 rows/s by its per-step work; it wins from ~32
+    // vectors (512 B) per row on (S=200 u32: 6.4 vs 4.4 TB/s; S=100: 3.7 vs 4.0; S=48: 1.9 vs 5.2)
+    if (row_vecs < 32 || std::getenv("KMD_ROWS_WIDE_OFF")) return launch(k_filter_rows_wave<CT, 16, 512, false>, 16, 512, false);
+    {
+      // wide rows: 16 lanes per row, no LDS tile
+      const size_t wpb = kWideBlock / 64;
+      const size_t extra = wpb * kQueueBytesPerWave + wpb * 128 * sizeof(unsigned long long);
+      const size_t avail = m->lds_per_block_max - 256 - extra;
+      size_t want = (size_t)P.lf_n * sizeof(double2);
+      if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
+      P.lds_n = (uint32_t)(want / sizeof(double2));
+      const size_t n_wtiles = (P.n_rows + 63) / 64;
+      size_t grid = (size_t)m->n_cu;
+      if (grid > (n_wtiles + wpb - 1) / wpb) grid = (n_wtiles + wpb - 1) / wpb;
+      int rc = allow_big_lds(k_filter_rows_wide<CT>, want + extra);
+      if (rc != KMD_OK) return rc;
+      hipLaunchKernelGGL((k_filter_rows_wide<CT>), dim3((unsigned)grid), dim3(kWideBlock), want + extra, stream, P, row_vecs);
+      KMD_HIP(hipGetLastError());
+      return KMD_OK;
+    }
   }
   const bool vec4 = (row_dw % 4 == 0) && (ld_dw % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);

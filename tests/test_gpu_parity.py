@@ -231,7 +231,8 @@ def test_row_major_16_byte_pitch_shapes(K, oracle):
     rng = np.random.default_rng(77)
     lf = oracle.lf_table(10000)
     shapes = [(1, 1, 4), (3, 4, 4), (4, 4, 4), (7, 9, 4), (9, 7, 2), (16, 16, 4), (20, 20, 4), (20, 20, 2), (20, 20, 1),
-              (17, 30, 4), (33, 35, 4), (100, 100, 4), (100, 100, 1), (5, 6, 1), (31, 33, 2), (40, 41, 4)]
+              (17, 30, 4), (33, 35, 4), (100, 100, 4), (100, 100, 1), (5, 6, 1), (31, 33, 2), (40, 41, 4),
+              (61, 70, 4), (130, 131, 4), (300, 260, 2), (700, 500, 1), (129, 1, 4)]       # >= 32 vectors: 16 lanes per row
     for it, (nc, nk, cb) in enumerate(shapes):
         S = nc + nk
         n = int(rng.choice([1, 63, 64, 65, 1000, 4099]))
