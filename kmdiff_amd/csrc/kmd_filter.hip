@@ -815,15 +815,18 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
   flush_beyond(P, n_beyond);
 }
 
-// ---- row-major WIDE rows (more than 10 vectors = 160 B): 16 lanes per row --------------------
-// A row of hundreds of bytes needs no transposition through LDS: 16 consecutive lanes read 256
-// consecutive bytes of ONE row per load (two whole cache lines), four rows per wave instruction,
-// and add up what they read; a 16-lane butterfly then yields the row's two sums.  Sixteen such
-// steps fill a 64-entry LDS strip with the sums of 64 rows, which go through the pre-filter and
+// ---- row-major WIDE rows: G = 8 or 16 lanes per row -------------------------------------------
+// A row of hundreds of bytes needs no transposition through LDS: G consecutive lanes read 16 G
+// consecutive bytes of ONE row per load (one or two whole cache lines), 64 / G rows per wave
+// instruction, and add up what they read; a G-lane butterfly then yields the row's two sums.  G
+// such steps fill a 64-entry LDS strip with the sums of 64 rows, which go through the pre-filter and
 // the deferred-evaluation queue with every lane busy.  No tile, 16 waves per CU, many independent
 // loads in flight per wave (kWideU steps are issued at once).
 #ifndef KMD_WIDE_BLOCK
 #define KMD_WIDE_BLOCK 1024
+#endif
+#ifndef KMD_WIDE8_MIN
+#define KMD_WIDE8_MIN 16        // rows of at least this many vectors take 8 lanes per row
 #endif
 #ifndef KMD_WIDE_U
 #define KMD_WIDE_U 2
@@ -832,7 +835,7 @@ constexpr int kWideBlock = KMD_WIDE_BLOCK;
 constexpr int kWideU = KMD_WIDE_U;            // steps (of 4 rows) whose loads are issued together
 constexpr int kWideP = 4;                     // passes (of 16 vectors) of a row per chunk
 
-template <typename CT>
+template <typename CT, int G>
 __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_params P, const uint32_t row_vecs)
 {
   extern __shared__ double2 s_all[];
@@ -844,7 +847,8 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
   constexpr uint32_t emask = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
   using ACC = typename acc_of<CT>::type;
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t g = lane >> 4, q = lane & 15;           // row within a step, vector within a pass
+  constexpr uint32_t kRPS = 64 / G;                      // rows per step
+  const uint32_t g = lane / G, q = lane % G;             // row within a step, vector within a pass
   const uint32_t S = (uint32_t)(P.nc + P.nk), nc = (uint32_t)P.nc;
   wave_queue Q;
   {
@@ -858,7 +862,7 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
   const n4* __restrict__ base = static_cast<const n4*>(P.counts);
   const size_t n_tiles = (P.n_rows + 63) / 64;
   const size_t n_waves = (size_t)gridDim.x * (kWideBlock / 64);
-  const uint32_t n_pass = (row_vecs + 15) / 16;
+  const uint32_t n_pass = (row_vecs + G - 1) / G;
 
   if (blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
@@ -866,7 +870,7 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
   for (size_t t = (size_t)blockIdx.x * (kWideBlock / 64) + w; t < n_tiles; t += n_waves)
   {
     const size_t row0 = t * 64;
-    for (uint32_t step0 = 0; step0 < 16; step0 += kWideU)
+    for (uint32_t step0 = 0; step0 < (uint32_t)G; step0 += kWideU)
     {
       ACC sc[kWideU], sk[kWideU];
 #pragma unroll
@@ -877,13 +881,13 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
 #pragma unroll
         for (int u = 0; u < kWideU; ++u)
         {
-          size_t row = row0 + (size_t)(step0 + u) * 4 + g;
+          size_t row = row0 + (size_t)(step0 + u) * kRPS + g;
           if (row >= P.n_rows) row = P.n_rows - 1;       // re-read the last row (never used)
           const n4* __restrict__ rp = base + row * ld_vecs;
 #pragma unroll
           for (int p = 0; p < kWideP; ++p)
           {
-            const uint32_t c = (p0 + p) * 16 + q;
+            const uint32_t c = (p0 + p) * G + q;
             buf[u][p] = n4{ 0, 0, 0, 0 };
             if (c < row_vecs) buf[u][p] = __builtin_nontemporal_load(rp + c);
           }
@@ -891,10 +895,10 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
 #pragma unroll
         for (int p = 0; p < kWideP; ++p)
         {
-          const uint32_t c = (p0 + p) * 16 + q;
+          const uint32_t c = (p0 + p) * G + q;
           const uint32_t e0 = c * epv;                   // first count of this lane's vector
           // whole pass on one side of the control / case boundary: wave-uniform fast path
-          const uint32_t pe0 = (p0 + p) * 16 * epv, pe1 = pe0 + 16 * epv;
+          const uint32_t pe0 = (p0 + p) * G * epv, pe1 = pe0 + G * epv;
           const bool all_c = pe1 <= nc, all_k = pe0 >= nc && pe1 <= S;
 #pragma unroll
           for (int u = 0; u < kWideU; ++u)
@@ -932,19 +936,19 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
           }
         }
       }
-      // 16-lane butterflies: every lane of a row's group ends with the row's sums
+      // G-lane butterflies: every lane of a row's group ends with the row's sums
 #pragma unroll
       for (int u = 0; u < kWideU; ++u)
       {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1)
+        for (int o = G / 2; o > 0; o >>= 1)
         {
           sc[u] += (ACC)__shfl_xor((unsigned long long)sc[u], o, 64);
           sk[u] += (ACC)__shfl_xor((unsigned long long)sk[u], o, 64);
         }
         if (q == 0)
         {
-          const uint32_t slot = (step0 + (uint32_t)u) * 4 + g;
+          const uint32_t slot = (step0 + (uint32_t)u) * kRPS + g;
           strip[2 * slot] = (unsigned long long)sc[u];
           strip[2 * slot + 1] = (unsigned long long)sk[u];
         }
@@ -1194,11 +1198,11 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
     if (row_vecs <= 4) return launch(k_filter_rows_wave<CT, 4, 1024, true>, 4, 1024, true);
     if (row_vecs <= 8) return launch(k_filter_rows_wave<CT, 8, 768, true>, 8, 768, true);
     if (row_vecs <= 10) return launch(k_filter_rows_wave<CT, 10, 768, false>, 10, 768, false);
-    // the 16-lanes-per-row kernel is bound at ~9.5e9 rows/s by its per-step work; it wins from ~32
-    // vectors (512 B) per row on (S=200 u32: 6.4 vs 4.4 TB/s; S=100: 3.7 vs 4.0; S=48: 1.9 vs 5.2)
-    if (row_vecs < 32 || std::getenv("KMD_ROWS_WIDE_OFF")) return launch(k_filter_rows_wave<CT, 16, 512, false>, 16, 512, false);
+    // G lanes per row: bound by the per-step work at ~9.5e9 rows/s (G = 16) / ~1.9e10 (G = 8); the
+    // tile kernel above stays the choice where that is below what it reaches
+    const int wide_g = std::getenv("KMD_ROWS_WIDE_OFF") ? 0 : row_vecs >= 32 ? 16 : row_vecs >= KMD_WIDE8_MIN ? 8 : 0;
+    if (wide_g == 0) return launch(k_filter_rows_wave<CT, 16, 512, false>, 16, 512, false);
     {
-      // wide rows: 16 lanes per row, no LDS tile
       const size_t wpb = kWideBlock / 64;
       const size_t extra = wpb * kQueueBytesPerWave + wpb * 128 * sizeof(unsigned long long);
       const size_t avail = m->lds_per_block_max - 256 - extra;
@@ -1208,9 +1212,18 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
       const size_t n_wtiles = (P.n_rows + 63) / 64;
       size_t grid = (size_t)m->n_cu;
       if (grid > (n_wtiles + wpb - 1) / wpb) grid = (n_wtiles + wpb - 1) / wpb;
-      int rc = allow_big_lds(k_filter_rows_wide<CT>, want + extra);
-      if (rc != KMD_OK) return rc;
-      hipLaunchKernelGGL((k_filter_rows_wide<CT>), dim3((unsigned)grid), dim3(kWideBlock), want + extra, stream, P, row_vecs);
+      if (wide_g == 16)
+      {
+        int rc = allow_big_lds(k_filter_rows_wide<CT, 16>, want + extra);
+        if (rc != KMD_OK) return rc;
+        hipLaunchKernelGGL((k_filter_rows_wide<CT, 16>), dim3((unsigned)grid), dim3(kWideBlock), want + extra, stream, P, row_vecs);
+      }
+      else
+      {
+        int rc = allow_big_lds(k_filter_rows_wide<CT, 8>, want + extra);
+        if (rc != KMD_OK) return rc;
+        hipLaunchKernelGGL((k_filter_rows_wide<CT, 8>), dim3((unsigned)grid), dim3(kWideBlock), want + extra, stream, P, row_vecs);
+      }
       KMD_HIP(hipGetLastError());
       return KMD_OK;
     }
