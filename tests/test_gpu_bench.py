@@ -50,3 +50,11 @@ def test_bench_two_ranks_on_one_gpu(correction):
     c = d["config"]["counters"]
     assert c["total"] == ROWS * 4 * 2 and c["n_sig"] == c["n_sig_control"] + c["n_sig_case"]
     assert 0 < c["kept_after_correction"] <= c["n_sig"]
+
+
+def test_collectives_through_rccl():
+    """tests/nccl_probe.py: the dtypes and calls of kmdiff_amd/dist.py over backend "nccl" (= RCCL)."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "tests", "nccl_probe.py")],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "nccl probe ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
