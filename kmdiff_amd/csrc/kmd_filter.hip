@@ -20,6 +20,7 @@
 #include "kmd_math.h"
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 
@@ -1124,14 +1125,17 @@ int launch_soa(const filter_params& P, const kmd_model* m, size_t lds_bytes, int
 template <typename K>
 int allow_big_lds(K kernel, size_t lds_bytes)
 {
-  // one hipFuncSetAttribute per kernel and size class, not per launch (kernels of different
-  // instantiations share the function TYPE, so the cache is keyed by address)
+  // one hipFuncSetAttribute per kernel, device and size class, not per launch (kernels of
+  // different instantiations share the function TYPE, so the cache is keyed by address; the
+  // attribute belongs to the device the call is made on)
   static std::mutex mu;
-  static std::unordered_map<const void*, size_t> allowed;
+  static std::map<std::pair<const void*, int>, size_t> allowed;
   if (lds_bytes <= 64 * 1024) return KMD_OK;
   const void* fn = reinterpret_cast<const void*>(kernel);
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
-  size_t& have = allowed[fn];
+  size_t& have = allowed[{ fn, dev }];
   if (lds_bytes > have)
   {
     KMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

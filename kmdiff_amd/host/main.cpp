@@ -51,7 +51,7 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   double kmer_pca = 0.001;                  // proportion of k-mers sampled for the PCA (cli.cpp:286-289)
   size_t ploidy = 2, seed = 0;              // cli.cpp:298-302, :349-351
   size_t threads = std::max(1u, std::thread::hardware_concurrency());   // -t: host threads decoding the k-mer files (cli.cpp:72-76)
-  int device = 0, verbose = 1;
+  int device = 0, devices = 1, verbose = 1;   // first GPU, number of GPUs (0 = all): partition p on GPU (device + p % devices)
 };
 
 [[noreturn]] void die(const std::string& msg)
@@ -83,7 +83,8 @@ void usage()
             "  --ploidy INT       2: diploid normalisation of the PCA, else haploid {2}\n"
             "  --random-seed INT  seed of the PCA row sampler {0}\n"
             "  --n-pc             number of principal components in [2, 10] {2}\n"
-            "  --device           GPU index {0}\n"
+            "  --device           GPU index (the first one with --devices) {0}\n"
+            "  --devices INT      number of GPUs, 0 = all: partition p goes to GPU p mod N {1}\n"
             "  --keep-tmp         keep partitions/p<i>_uncorrected (+ options.bin): a later run resumes from them\n"
             "  --save-sk          write the significant rows to positive_kmer_matrix/matrices/matrix_<p>.count.lz4\n"
             "  -t/--threads INT   host threads decoding the per-sample k-mer files {all}\n"
@@ -111,6 +112,7 @@ diff_options parse(int argc, char** argv)
     else if (a == "--n-pc") o.npc = std::stoull(need(i));
     else if (a == "--max-iteration") o.max_iteration = std::stoull(need(i));
     else if (a == "--device") o.device = std::stoi(need(i));
+    else if (a == "--devices") o.devices = std::stoi(need(i));
     else if (a == "--keep-tmp") o.keep_tmp = true;
     else if (a == "--save-sk") o.save_sk = true;
     else if (a == "--kmer-pca") o.kmer_pca = std::stod(need(i));
@@ -183,10 +185,11 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < opt.nb_controls; ++i) total_controls[i] = sample_total(opt.kmtricks_dir, fof[i], cfg.abundance_min);
     for (size_t i = 0; i < opt.nb_cases; ++i) total_cases[i] = sample_total(opt.kmtricks_dir, fof[opt.nb_controls + i], cfg.abundance_min);
 
-    kmd_model* model = nullptr;                                                               // cmd/diff.hpp:117-123
-    ck(kmd_model_create(&model, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
+    kmd_model* model0 = nullptr;                                                              // cmd/diff.hpp:117-123
+    ck(kmd_model_create(&model0, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
        "kmd_model_create");
     const double first_threshold = opt.threshold / (double)opt.cutoff;                       // cmd/diff.hpp:147
+    const size_t n_workers = (size_t)std::max(1, opt.devices == 0 ? ndev : opt.devices);       // GPUs (folded onto the ones there are)
 
     // ---- what a previous run left behind (cmd/diff.hpp:278-303)
     const std::string part_dir = opt.output_directory + "/partitions";
@@ -218,12 +221,8 @@ int main(int argc, char** argv)
     const bool device_pca = opt.pop_correction && opt.pcs.empty();
     const bool have_pcs = fs::exists(pop_dir + "/pcs.evec");
     const bool run_stage1 = !prev_1 || (action & 0b1) || (device_pca && !have_pcs);
-    kmd_pca* pca = nullptr;
     std::vector<double> Z_device;                  // [S][10] when the device PCA ran
-    if (run_stage1 && device_pca)
-    {
-      ck(kmd_pca_create(&pca, (int)S, opt.kmer_pca, opt.seed, opt.ploidy == 2 ? 1 : 0, (size_t)1 << 20), "kmd_pca_create");   // grows
-    }
+    const bool run_pca = run_stage1 && device_pca;
     if (run_stage1)
     {
       // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
@@ -240,8 +239,6 @@ int main(int argc, char** argv)
           if (fs::exists(opt.kmtricks_dir + dname))
             fs::copy(opt.kmtricks_dir + dname, sk + dname, fs::copy_options::recursive | fs::copy_options::overwrite_existing);
       }
-      dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
-              d_smk, d_sc;
       const size_t T = 4096;
       // one accumulator per entry of counts/ (cmd/diff.hpp:103-107); matrix files map onto them in order
       const size_t n_units = from_matrix ? std::min(mpaths.size(), cfg.nb_partitions) : cfg.nb_partitions;
@@ -274,7 +271,7 @@ int main(int argc, char** argv)
           }
         };
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < std::min(opt.threads, S); ++t) pool.emplace_back(work);
+        for (size_t t = 1; t < std::min(std::max<size_t>(opt.threads / n_workers, 1), S); ++t) pool.emplace_back(work);
         work();
         for (auto& t : pool) t.join();
         if (err) std::rethrow_exception(err);
@@ -290,14 +287,45 @@ int main(int argc, char** argv)
         }
         return in;
       };
+      // One worker thread per GPU; partition p belongs to worker p % n_workers (the sharding of
+      // kmdiff_amd/dist.py, in one process).  A worker keeps its survivors in its own set; they are
+      // put in partition order afterwards.
+      struct worker_result
+      {
+        survivor_set sv;
+        std::vector<std::pair<size_t, size_t>> span;     // per partition of this worker: (begin, count) in sv
+        uint64_t total = 0, n_sig = 0, n_ctrl = 0, n_case = 0, n_sampled = 0;
+        std::vector<double> xtx;                         // the worker's PCA Gram matrix
+        std::string error;
+      };
+      std::vector<worker_result> results(n_workers);
+      auto worker = [&](size_t wi)
+      {
+      worker_result& R = results[wi];
+      try
+      {
+      const int dev = (opt.device + (int)wi) % ndev;
+      ck(kmd_set_device(dev), "kmd_set_device");
+      kmd_model* model = wi == 0 ? model0 : nullptr;                                             // a model lives on one device
+      if (wi != 0)
+        ck(kmd_model_create(&model, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
+           "kmd_model_create");
+      kmd_pca* pca = nullptr;
+      if (run_pca) ck(kmd_pca_create(&pca, (int)S, opt.kmer_pca, opt.seed, opt.ploidy == 2 ? 1 : 0, (size_t)1 << 20), "kmd_pca_create");   // grows
+      survivor_set& sv_all = R.sv;                       // (this worker's)
+      sv_all.n_counts = want_counts ? S : 0;
+      sv_all.kmer_bytes = two_limbs ? 16 : 8;
+      uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+      dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
+              d_smk, d_sc;
       std::future<partition_input> ahead;
-      if (n_units) ahead = std::async(std::launch::async, load_partition, (size_t)0);
-      for (size_t p = 0; p < n_units; ++p)
+      if (wi < n_units) ahead = std::async(std::launch::async, load_partition, wi);
+      for (size_t p = wi; p < n_units; p += n_workers)
       {
         kmd_tile tile {};
         uint64_t n_rows = 0;
         partition_input in = ahead.get();
-        if (p + 1 < n_units) ahead = std::async(std::launch::async, load_partition, p + 1);
+        if (p + n_workers < n_units) ahead = std::async(std::launch::async, load_partition, p + n_workers);
         if (from_matrix)
         {
           // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
@@ -381,7 +409,7 @@ int main(int argc, char** argv)
           }
           total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
         }
-        part_begin[p + 1] = base + ns;
+        R.span.emplace_back(base, ns);
         if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
         {
           matrix_rows sk; sk.kmer_size = (uint32_t)cfg.kmer_size; sk.count_bytes = 4; sk.nb_counts = (uint32_t)S; sk.partition = (uint32_t)p;
@@ -392,17 +420,57 @@ int main(int argc, char** argv)
           write_matrix_file(opt.output_directory + "/positive_kmer_matrix/matrices/matrix_" + std::to_string(p) + ".count.lz4", sk);
         }
       }
+      R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case;
+      if (pca)
+      {
+        ck(kmd_pca_count(pca, &R.n_sampled), "kmd_pca_count");
+        R.xtx.assign(S * S, 0.0);
+        ck(kmd_pca_gram(pca, R.xtx.data(), nullptr), "kmd_pca_gram");
+        kmd_pca_destroy(pca);
+      }
+      if (wi != 0) kmd_model_destroy(model);
+      }
+      catch (const std::exception& e) { R.error = e.what(); }
+      };   // worker
+      {
+        std::vector<std::thread> gpus;
+        for (size_t wi = 1; wi < n_workers; ++wi) gpus.emplace_back(worker, wi);
+        worker(0);
+        for (auto& t : gpus) t.join();
+        ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
+        for (auto& R : results) if (!R.error.empty()) die(R.error);
+      }
+      // survivors in partition order (the order one GPU would have produced)
+      {
+        std::vector<size_t> taken(n_workers, 0);
+        for (size_t p = 0; p < n_units; ++p)
+        {
+          worker_result& R = results[p % n_workers];
+          const auto [b, cnt] = R.span[taken[p % n_workers]++];
+          sv_all.kmer.insert(sv_all.kmer.end(), R.sv.kmer.begin() + b, R.sv.kmer.begin() + b + cnt);
+          if (two_limbs) sv_all.kmer_hi.insert(sv_all.kmer_hi.end(), R.sv.kmer_hi.begin() + b, R.sv.kmer_hi.begin() + b + cnt);
+          sv_all.p.insert(sv_all.p.end(), R.sv.p.begin() + b, R.sv.p.begin() + b + cnt);
+          sv_all.sign.insert(sv_all.sign.end(), R.sv.sign.begin() + b, R.sv.sign.begin() + b + cnt);
+          sv_all.mean_control.insert(sv_all.mean_control.end(), R.sv.mean_control.begin() + b, R.sv.mean_control.begin() + b + cnt);
+          sv_all.mean_case.insert(sv_all.mean_case.end(), R.sv.mean_case.begin() + b, R.sv.mean_case.begin() + b + cnt);
+          if (want_counts) sv_all.counts.insert(sv_all.counts.end(), R.sv.counts.begin() + b * S, R.sv.counts.begin() + (b + cnt) * S);
+          part_begin[p + 1] = sv_all.size();
+        }
+        for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; }
+      }
       for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
-      if (pca)                                                                                 // run_eigenstrat_smartpca
+      if (run_pca)                                                                             // run_eigenstrat_smartpca
       {
         uint64_t n_sampled = 0;
-        ck(kmd_pca_count(pca, &n_sampled), "kmd_pca_count");
-        std::vector<double> xtx(S * S), evec(S * 10, 0.0), eval(10, 0.0);
-        ck(kmd_pca_gram(pca, xtx.data(), nullptr), "kmd_pca_gram");
+        std::vector<double> xtx(S * S, 0.0);
+        for (auto& R : results)                                                                // in worker order
+        {
+          n_sampled += R.n_sampled;
+          for (size_t i = 0; i < S * S; ++i) xtx[i] += R.xtx[i];
+        }
         const int n_out = (int)std::min<size_t>(S, 10);                                        // popstrat.cpp:118
         std::vector<double> ev(S * n_out), el(n_out);
         ck(kmd_pca_eigen((int)S, xtx.data(), n_out, ev.data(), el.data()), "kmd_pca_eigen");
-        kmd_pca_destroy(pca); pca = nullptr;
         fs::create_directories(pop_dir);
         std::ofstream pf(pop_dir + "/pcs.evec");
         Z_device.assign(S * 10, 0.0);
@@ -530,7 +598,7 @@ int main(int argc, char** argv)
     js << "{\"total_kmers\": " << total_kmers << ", \"n_sig\": " << n_sig << ", \"n_sig_control\": " << n_sig_control
        << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
        << ", \"kept_case\": " << c_cases << ", \"kmer_size\": " << cfg.kmer_size << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
-    kmd_model_destroy(model);
+    kmd_model_destroy(model0);
   }
   catch (const std::exception& e) { die(e.what()); }                                          // src/main.cc:93-102 logs and exits
   return 0;

@@ -200,6 +200,21 @@ def test_cli_two_limb_kmers_k63(tmp_path):
         assert got == want[name] and all(len(q) == 63 for q in got)
 
 
+def test_cli_partitions_sharded_over_gpus(synth_run, tmp_path):
+    """--devices N: one worker thread per GPU, partition p on GPU p mod N (folded onto the GPUs the
+    box has); survivors, files, PCA and decisions equal the one-GPU run."""
+    run_dir, nc, nk, k, mats, kms = synth_run
+    common = ["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-c", "benjamini", "--keep-tmp", "--pop-correction", "--kmer-pca", 0.05]
+    a, _ = run_cli(common + ["--devices", 1], tmp_path / "a")
+    b, err = run_cli(common + ["--devices", 2], tmp_path / "b")
+    c, _ = run_cli(common + ["--devices", 5], tmp_path / "c")           # more workers than partitions
+    assert a == b == c and a["n_sig"] > 10
+    for name in ("control_kmers.fasta", "case_kmers.fasta", "popstrat/pcs.evec", "partitions/p0_uncorrected", "partitions/p2_uncorrected",
+                 "partitions/p1_popstrat_uncorrected"):
+        ref = open(tmp_path / "a" / name, "rb").read()
+        assert open(tmp_path / "b" / name, "rb").read() == ref and open(tmp_path / "c" / name, "rb").read() == ref, name
+
+
 def test_cli_pop_correction(synth_run, tmp_path):
     run_dir, nc, nk, k, mats, kms = synth_run
     o = OL.load()
