@@ -28,6 +28,12 @@ lo = mat.kmers_to_host()[0]
 if a.keys == "random":
     lo = np.unique(np.random.default_rng(5).integers(0, 1 << 62, int(a.rows * 1.02), dtype=np.uint64))[:a.rows]
     assert len(lo) == a.rows
+if a.keys == "clustered":   # 2000 dense clusters (consecutive values) scattered over the range: what minimizer partitions may look like
+    rng = np.random.default_rng(6)
+    starts = np.sort(rng.integers(0, 1 << 61, 2000, dtype=np.uint64))
+    per = a.rows // 2000 + 1
+    lo = np.unique((starts[:, None] + np.arange(per, dtype=np.uint64)[None, :] * np.uint64(3)).ravel())[:a.rows]
+    assert len(lo) == a.rows
 hi = None
 if a.limbs == 2:          # the same order as 128-bit keys: hi = top bits, lo = the rest moved to the top of the low limb
     hi = lo >> np.uint64(20)
