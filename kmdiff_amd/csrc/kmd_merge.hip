@@ -84,9 +84,10 @@ __global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ ke
 // ---------------------------------------------------------------------------------------------
 // Bucketed LDS merge (enough records).
 //
-//   k_bucket_starts     one streaming pass over the keys; because every stream is sorted, the
-//                       first record of bucket j in stream s is where bucket(key) changes: a
-//                       table of start offsets, no searching (written stream-major, coalesced)
+//   k_splitter_coarse / buckets = runs between splitters taken from the data (every r-th key of the
+//   k_splitter_fine     longest stream): where each stream enters each bucket, a table of start
+//                       offsets (stream-major).  KMD_MERGE_SLICES=1: k_bucket_starts instead --
+//                       buckets = equal slices of the key range, one streaming pass, no searching
 //   k_transpose_starts  -> [bucket][sample]: the S offsets of a bucket in one contiguous span
 //   k_bucket_split /    buckets holding more records than a wave takes (random keys: Poisson
 //   k_refine_starts     sizes; real partitions cluster) are cut again, level by level, on the
@@ -96,8 +97,8 @@ __global__ void __launch_bounds__(256) k_scatter(const uint64_t* __restrict__ ke
 //                       decoupled look-back; the bucket's d x S block assembled in LDS and
 //                       written whole.  Stage A of the next bucket runs before stage B of the
 //                       current one (software pipeline, see the kernel).
-// Buckets start as equal slices of [min key, max key].  Input that is mostly clusters, or a
-// bucket still over capacity after kMaxLevels cuts, hands over to the sort-based path.
+// A table that grows 2.5-fold under the cuts, or a bucket still over capacity after kMaxLevels,
+// hands over to the sort-based path.
 constexpr uint64_t kEmpty = ~0ull;
 
 // bucket(key) = floor((key - kmin) * nb / (span + 1)) as a 64x64 -> high-64 multiply: equal
@@ -134,6 +135,64 @@ __global__ void __launch_bounds__(256) k_bucket_starts(const uint64_t* __restric
     if (i == end - 1)
       for (uint32_t j = bi + 1; j <= B.nb; ++j) start[(size_t)s * (B.nb + 1) + j] = (uint32_t)end;
   }
+}
+
+// Data-adaptive buckets: boundary j = every r-th key of the LONGEST stream (b_0 = -inf, b_nb = +inf),
+// so buckets are narrow where k-mers are dense and wide where they are sparse -- equal slices of
+// the key range fit evenly spread keys only.  start[s][j] = first record of stream s with key >=
+// b_j, in two steps: every 64th boundary by binary search over the stream, the ones in between
+// inside the short run of records those enclose.
+constexpr uint32_t kSplitChunk = 64;                      // boundaries per wave
+
+// every kSplitChunk-th boundary by binary search over the whole stream: coarse[s][c]
+__global__ void __launch_bounds__(256) k_splitter_coarse(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ offs,
+                                                         uint32_t S, uint32_t L, uint32_t r, uint32_t nb, uint32_t n_chunks,
+                                                         uint32_t* __restrict__ coarse)
+{
+  const uint32_t s = blockIdx.y;
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_chunks) return;
+  const size_t begin = offs[s], end = offs[s + 1], j = c * kSplitChunk;
+  size_t pos = begin;
+  if (j >= nb) pos = end;
+  else if (j > 0)
+  {
+    const uint64_t b = keys[offs[L] + j * r];
+    size_t lo = begin, hi = end;                         // first index in [begin, end) with key >= b
+    while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < b) lo = mid + 1; else hi = mid; }
+    pos = lo;
+  }
+  coarse[(size_t)s * (n_chunks + 1) + c] = (uint32_t)pos;
+}
+
+// the boundaries in between: one wave per (chunk, stream) loads the chunk's records -- a short
+// contiguous run of the stream, coalesced -- into LDS, and every lane places its boundary in it
+__global__ void __launch_bounds__(256) k_splitter_fine(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ offs,
+                                                       uint32_t S, uint32_t L, uint32_t r, uint32_t nb, uint32_t n_chunks,
+                                                       const uint32_t* __restrict__ coarse, uint32_t* __restrict__ start)
+{
+  __shared__ unsigned long long s_win_all[4][256];
+  const uint32_t s = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t c = (size_t)blockIdx.x * 4 + w;
+  if (c >= n_chunks) return;
+  unsigned long long* win = s_win_all[w];
+  const size_t j = c * kSplitChunk + lane;
+  const size_t p0 = coarse[(size_t)s * (n_chunks + 1) + c], p1 = coarse[(size_t)s * (n_chunks + 1) + c + 1];
+  const bool inner = j > 0 && j < nb;
+  const uint64_t b = inner ? keys[offs[L] + j * r] : 0ull;
+  size_t below = 0;                                      // records of [p0, p1) below this lane's boundary
+  for (size_t w0 = p0; w0 < p1; w0 += 256)               // (wave-uniform)
+  {
+    const uint32_t m = (uint32_t)((p1 - w0) < 256 ? (p1 - w0) : 256);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < m; t += 64) win[t] = keys[w0 + t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t lo = 0, hi = m;                             // first index of the window with key >= b
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (win[mid] < b) lo = mid + 1; else hi = mid; }
+    below += lo;
+  }
+  if (j <= nb) start[(size_t)s * (nb + 1) + j] = (uint32_t)(j == 0 ? offs[s] : j == nb ? offs[s + 1] : p0 + below);
 }
 
 // [S][nb + 1] (what k_bucket_starts writes, coalesced) -> [nb + 1][S] (what a bucket reads: its S
@@ -887,7 +946,21 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   if (span == ~0ull) B.mult = nb_target;
   else B.mult = (uint64_t)((((unsigned __int128)nb_target) << 64) / ((unsigned __int128)span + 1));
   if (span + 1 != 0 && nb_target > span + 1) { B.nb = (uint32_t)(span + 1); B.mult = (uint64_t)((((unsigned __int128)B.nb) << 64) / ((unsigned __int128)span + 1)); }
-  const size_t nb0 = B.nb;                                    // equal key slices; nb = buckets after cutting the heavy ones
+  // buckets by splitters (default) or by equal slices of the key range (KMD_MERGE_SLICES=1)
+  const bool splitters = std::getenv("KMD_MERGE_SLICES") == nullptr;
+  uint32_t L = 0, r_split = 1;
+  if (splitters)
+  {
+    for (int s2 = 1; s2 < S; ++s2) if (offsets[s2 + 1] - offsets[s2] > offsets[L + 1] - offsets[L]) L = (uint32_t)s2;
+    const uint64_t n_l = offsets[L + 1] - offsets[L];
+    uint64_t r = (uint64_t)((unsigned __int128)n_l * (cap / 2) / n);       // every r-th key of the longest stream
+    if (r < 1) r = 1;
+    uint64_t nbs = (n_l + r - 1) / r;
+    if (nbs > nb_target) { r = (n_l + nb_target - 1) / nb_target; nbs = (n_l + r - 1) / r; }
+    r_split = (uint32_t)r;
+    B.nb = (uint32_t)nbs;
+  }
+  const size_t nb0 = B.nb;                                    // first buckets; nb = buckets after cutting the heavy ones
   if (dbg) std::fprintf(stderr, "[merge_fast] n=%zu kmin=%llu kmax=%llu mult=%llu nb0=%zu\n", n,
                         (unsigned long long)range[0], (unsigned long long)range[1], (unsigned long long)B.mult, nb0);
 
@@ -904,7 +977,18 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     if (nb0 + 1 > longest) longest = nb0 + 1;
     size_t gx = (longest + 255) / 256;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, d_kmers, d_offs, (uint32_t)S, B, start_sm);
+    if (splitters)
+    {
+      const size_t n_chunks = nb0 / kSplitChunk + 1;                           // chunk c: boundaries [64 c, 64 c + 64)
+      void* p_coarse = nullptr;
+      KMD_HIP(sc.take(&p_coarse, (n_chunks + 1) * (size_t)S * 4));
+      hipLaunchKernelGGL(k_splitter_coarse, dim3((unsigned)((n_chunks + 1 + 255) / 256), (unsigned)S), dim3(256), 0, st, d_kmers,
+                         d_offs, (uint32_t)S, L, r_split, (uint32_t)nb0, (uint32_t)n_chunks, static_cast<uint32_t*>(p_coarse));
+      hipLaunchKernelGGL(k_splitter_fine, dim3((unsigned)((n_chunks + 3) / 4), (unsigned)S), dim3(256), 0, st, d_kmers, d_offs,
+                         (uint32_t)S, L, r_split, (uint32_t)nb0, (uint32_t)n_chunks, static_cast<const uint32_t*>(p_coarse), start_sm);
+    }
+    else
+      hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, d_kmers, d_offs, (uint32_t)S, B, start_sm);
     hipLaunchKernelGGL(k_transpose_starts, dim3((unsigned)((nb0 + 1 + 63) / 64)), dim3(256), 0, st, start_sm, (uint32_t)S,
                        (uint32_t)(nb0 + 1), start);
   }
@@ -1037,7 +1121,7 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   for (int level = 0;; ++level)
   {
     int n_over = 0;
-    const int rc_l = refine_level(level, level == 0, &n_over);
+    const int rc_l = refine_level(level, level == 0 && !splitters, &n_over);
     if (rc_l != KMD_OK) return rc_l;
     if (n_over == 0) break;
     if (n_over < 0 || level == kMaxLevels) return KMD_OK;    // mostly clusters / cannot be cut: sort path
