@@ -953,7 +953,10 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   {
     for (int s2 = 1; s2 < S; ++s2) if (offsets[s2 + 1] - offsets[s2] > offsets[L + 1] - offsets[L]) L = (uint32_t)s2;
     const uint64_t n_l = offsets[L + 1] - offsets[L];
-    uint64_t r = (uint64_t)((unsigned __int128)n_l * (cap / 2) / n);       // every r-th key of the longest stream
+    uint64_t fill = cap / 2;                                               // records per bucket aimed at
+    if (const char* e = std::getenv("KMD_MERGE_FILL")) fill = (uint64_t)cap * (uint64_t)std::atoi(e) / 100;   // dev: % of CAP
+    if (fill < 16) fill = 16;
+    uint64_t r = (uint64_t)((unsigned __int128)n_l * fill / n);            // every r-th key of the longest stream
     if (r < 1) r = 1;
     uint64_t nbs = (n_l + r - 1) / r;
     if (nbs > nb_target) { r = (n_l + nb_target - 1) / nb_target; nbs = (n_l + r - 1) / r; }
