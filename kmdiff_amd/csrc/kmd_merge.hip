@@ -927,10 +927,15 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     d_kmers = static_cast<const uint64_t*>(p_top);
     if (dbg) std::fprintf(stderr, "[merge_fast] two-limb keys, high limbs of %d bits\n", bits);
   }
-  hipLaunchKernelGGL(k_key_range, dim3(1), dim3(64), 0, st, d_kmers, d_offs, (uint32_t)S, d_range);
-  uint64_t range[2];
-  KMD_HIP(hipMemcpyAsync(range, d_range, 16, hipMemcpyDeviceToHost, st));
-  KMD_HIP(hipStreamSynchronize(st));
+  // buckets by splitters (default) or by equal slices of the key range (KMD_MERGE_SLICES=1)
+  const bool splitters = std::getenv("KMD_MERGE_SLICES") == nullptr;
+  uint64_t range[2] = { 0, ~0ull };
+  if (!splitters)                                               // only the slices need the key range
+  {
+    hipLaunchKernelGGL(k_key_range, dim3(1), dim3(64), 0, st, d_kmers, d_offs, (uint32_t)S, d_range);
+    KMD_HIP(hipMemcpyAsync(range, d_range, 16, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+  }
   const uint64_t span = range[1] - range[0];                    // kmax - kmin
   // a bucket must hold a few whole rows, and a row has up to S records: capacity by sample count;
   // half the capacity per bucket on average (one wave each); the start table is capped at 1 GiB
@@ -946,8 +951,6 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   if (span == ~0ull) B.mult = nb_target;
   else B.mult = (uint64_t)((((unsigned __int128)nb_target) << 64) / ((unsigned __int128)span + 1));
   if (span + 1 != 0 && nb_target > span + 1) { B.nb = (uint32_t)(span + 1); B.mult = (uint64_t)((((unsigned __int128)B.nb) << 64) / ((unsigned __int128)span + 1)); }
-  // buckets by splitters (default) or by equal slices of the key range (KMD_MERGE_SLICES=1)
-  const bool splitters = std::getenv("KMD_MERGE_SLICES") == nullptr;
   uint32_t L = 0, r_split = 1;
   if (splitters)
   {
