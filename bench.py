@@ -174,7 +174,7 @@ def main():
         total_rows = float(args.rows) * args.steps * world
         value = total_rows / elapsed
         achieved = args.rows * BYTES_PER_ROW / (avg_kernel_ms * 1e-3) / 1e9
-        copy_gbs = None
+        copy_gbs = read_gbs = None
         try:
             nb = 1 << 30
             a, b = K.DeviceBuffer(nb), K.DeviceBuffer(nb)
@@ -186,6 +186,15 @@ def main():
                 K._native.check(lib.kmd_copy_probe(b.ptr, a.ptr, nb, None))
             e1.record()
             copy_gbs = 5 * 2 * nb / (e0.elapsed_ms(e1) * 1e-3) / 1e9
+            # bare streaming read, 16-byte non-temporal loads: the measured read ceiling of this GPU
+            sink = K.DeviceBuffer(8).zero()
+            for _ in range(2):
+                K._native.check(lib.kmd_read_probe(a.ptr, nb, 64 + 16, sink.ptr, None))
+            e0.record()
+            for _ in range(8):
+                K._native.check(lib.kmd_read_probe(a.ptr, nb, 64 + 16, sink.ptr, None))
+            e1.record()
+            read_gbs = 8 * nb / (e0.elapsed_ms(e1) * 1e-3) / 1e9
             a.free(); b.free()
         except Exception:
             pass
@@ -210,7 +219,7 @@ def main():
                        "counters": {"total": int(g_counters[0]), "n_sig": int(g_counters[1]),
                                     "n_sig_control": int(g_counters[2]), "n_sig_case": int(g_counters[3]),
                                     "kept_after_correction": int(kept[0])},
-                       "copy_probe_GBs": copy_gbs},
+                       "copy_probe_GBs": copy_gbs, "read_probe_GBs": read_gbs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_filter_%s<u32>" % ("rows" if args.layout == "rows" else "soa"), "avg_kernel_ms": avg_kernel_ms},
