@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <filesystem>
 #include <future>
 #include <mutex>
@@ -155,6 +156,13 @@ std::string shortest(double v)
   return buf;
 }
 
+// Timer (src/time.cpp:8-49): wall time of a stage, logged like cmd/diff.hpp:158,197,221,372
+struct stopwatch
+{
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct dev_buf
 {
   void* p = nullptr; size_t cap = 0;
@@ -169,6 +177,7 @@ int main(int argc, char** argv)
   diff_options opt = parse(argc, argv);
   try
   {
+    const stopwatch whole_time;
     int ndev = 0;
     if (kmd_device_count(&ndev) != KMD_OK || ndev < 1) die("no HIP device: kmdiff-hip has no CPU path");
     ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
@@ -227,6 +236,7 @@ int main(int argc, char** argv)
     {
       // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
       std::fprintf(stderr, "[kmdiff-hip] Process partitions\n");
+      const stopwatch merge_time;
       const auto mpaths = matrix_paths(opt.kmtricks_dir);                                     // cmd/diff.hpp:80-101
       const bool from_matrix = !mpaths.empty();
       if (opt.save_sk)                                                                        // cmd/diff.hpp:52-64,137-143
@@ -490,6 +500,7 @@ int main(int argc, char** argv)
       if (opt.keep_tmp)                                                                       // FileAccumulator, del = !keep_tmp
         for (size_t p = 0; p < cfg.nb_partitions; ++p)
           write_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
+      std::fprintf(stderr, "[kmdiff-hip] Partitions processed (%.3f s)\n", merge_time.seconds());                // cmd/diff.hpp:158
       std::fprintf(stderr, "[kmdiff-hip] %" PRIu64 "/%" PRIu64 " significant k-mers.\n", n_sig, total_kmers);      // cmd/diff.hpp:160
       std::fprintf(stderr, "[kmdiff-hip] Before correction: %" PRIu64 " (control), %" PRIu64 " (case).\n", n_sig_control, n_sig_case);
     }
@@ -532,6 +543,7 @@ int main(int argc, char** argv)
       if (ps.size() != n) die("previous run's pop-strat survivor files do not match");
       s_p = ps.p;
     }
+    const stopwatch pop_time;
     if (run_stage2 && n)
     {
       std::vector<double> Z(S * 10, 0.0), Y(S, 0.0);
@@ -555,7 +567,7 @@ int main(int argc, char** argv)
       ck(kmd_popstrat_apply(ps, (const double*)d_c.p, 0, 0, n, (double*)d_p.p, nullptr), "kmd_popstrat_apply");
       ck(kmd_memcpy_d2h(s_p.data(), d_p.p, n * 8, nullptr), "d2h");                                                  // ks.set_pval
       kmd_popstrat_destroy(ps);
-      std::fprintf(stderr, "[kmdiff-hip] Population correction done.\n");
+      std::fprintf(stderr, "[kmdiff-hip] Population correction done. (%.3f s)\n", pop_time.seconds());              // cmd/diff.hpp:221
     }
     if (run_stage2 && opt.keep_tmp)
       for (size_t p = 0; p < cfg.nb_partitions; ++p)
@@ -599,6 +611,7 @@ int main(int argc, char** argv)
        << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
        << ", \"kept_case\": " << c_cases << ", \"kmer_size\": " << cfg.kmer_size << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
     kmd_model_destroy(model0);
+    std::fprintf(stderr, "[kmdiff-hip] Done in %.3f s.\n", whole_time.seconds());                                   // cmd/diff.hpp:372-376
   }
   catch (const std::exception& e) { die(e.what()); }                                          // src/main.cc:93-102 logs and exits
   return 0;
