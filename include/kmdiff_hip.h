@@ -65,6 +65,10 @@ int kmd_set_device(int device);
 int kmd_device_name(char* buf, size_t len);
 int kmd_malloc(void** d_ptr, size_t bytes);
 int kmd_free(void* d_ptr);
+/* page-locked host memory for staging buffers (hipHostMalloc): host-to-device copies from it run
+ * at the link's rate instead of through the driver's bounce buffers */
+int kmd_malloc_host(void** h_ptr, size_t bytes);
+int kmd_free_host(void* h_ptr);
 int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream);
 int kmd_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream);
 int kmd_memset(void* d_dst, int value, size_t bytes, void* stream);

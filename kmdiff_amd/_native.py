@@ -47,6 +47,8 @@ SIGNATURES = {
     "kmd_device_name": (_i, [C.c_char_p, _sz]),
     "kmd_malloc": (_i, [C.POINTER(_vp), _sz]),
     "kmd_free": (_i, [_vp]),
+    "kmd_malloc_host": (_i, [C.POINTER(_vp), _sz]),
+    "kmd_free_host": (_i, [_vp]),
     "kmd_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
     "kmd_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "kmd_memset": (_i, [_vp, _i, _sz, _vp]),

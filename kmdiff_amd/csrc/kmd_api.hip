@@ -144,6 +144,13 @@ int kmd_malloc(void** d_ptr, size_t bytes)
   return KMD_OK;
 }
 int kmd_free(void* d_ptr) { if (d_ptr) KMD_HIP(hipFree(d_ptr)); return KMD_OK; }
+int kmd_malloc_host(void** h_ptr, size_t bytes)
+{
+  KMD_REQUIRE(h_ptr, "kmd_malloc_host: NULL");
+  KMD_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocPortable));   // usable from any device of the process
+  return KMD_OK;
+}
+int kmd_free_host(void* h_ptr) { if (h_ptr) KMD_HIP(hipHostFree(h_ptr)); return KMD_OK; }
 int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream)
 {
   if (!bytes) return KMD_OK;

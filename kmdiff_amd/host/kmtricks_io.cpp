@@ -90,15 +90,20 @@ std::vector<fof_entry> read_fof(const std::string& run_dir)
 
 static std::vector<char> slurp(const std::string& path)
 {
-  std::ifstream in(path, std::ios::binary);
+  std::ifstream in(path, std::ios::binary | std::ios::ate);
   if (!in) throw std::runtime_error("cannot open " + path);
-  return std::vector<char>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  const std::streamsize size = in.tellg();
+  std::vector<char> d((size_t)(size > 0 ? size : 0));
+  in.seekg(0);
+  if (size > 0 && !in.read(d.data(), size)) throw std::runtime_error("cannot read " + path);
+  return d;
 }
 
 // one LZ4 frame (what lz4_stream and kmtricks write) starting at d[off]
 static std::vector<char> lz4_frame_decode(const std::vector<char>& d, size_t off, const std::string& path)
 {
   std::vector<char> raw;
+  raw.reserve((d.size() - off) * 2);
   LZ4F_dctx* ctx = nullptr;
   if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
   std::vector<char> buf(1 << 20);
@@ -334,6 +339,38 @@ unsigned compare_opt(const resume_options& opt, const resume_options& prev)     
   if (opt.correction != prev.correction) r |= 0b100;
   if (prev.pop_correction && !opt.pop_correction) r |= 0b100;
   return r;
+}
+
+kmer_file_raw decode_kmer_file(const std::string& path, size_t expected_k)
+{
+  auto d = slurp(path);
+  if (d.size() < 41 || std::memcmp(d.data(), "kmtricks", 8) != 0 || std::memcmp(d.data() + 13, "kmer", 4) != 0)
+    throw std::runtime_error(path + ": not a kmtricks k-mer file");
+  kmer_file_raw f;
+  const uint8_t compressed = rd<uint8_t>(d, 12);
+  const uint32_t k = rd<uint32_t>(d, 21);
+  f.slots = rd<uint32_t>(d, 25); f.count_bytes = rd<uint32_t>(d, 29);
+  if (expected_k && k != expected_k) throw std::runtime_error(path + ": k-mer size differs from the run's");
+  if (f.slots != 1 && f.slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
+  if (f.count_bytes != 1 && f.count_bytes != 2 && f.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
+  if (compressed) f.payload = lz4_frame_decode(d, 41, path); else f.payload.assign(d.begin() + 41, d.end());
+  f.records = f.payload.size() / (8 * (size_t)f.slots + f.count_bytes);
+  return f;
+}
+
+void split_records(const kmer_file_raw& f, uint64_t* kmers, uint64_t* kmers_hi, uint32_t* counts)
+{
+  const size_t rec = 8 * (size_t)f.slots + f.count_bytes;
+  const char* p = f.payload.data();
+  for (size_t i = 0; i < f.records; ++i, p += rec)
+  {
+    std::memcpy(&kmers[i], p, 8);
+    if (f.slots == 2) std::memcpy(&kmers_hi[i], p + 8, 8);
+    else if (kmers_hi) kmers_hi[i] = 0;
+    uint32_t c = 0;
+    std::memcpy(&c, p + 8 * f.slots, f.count_bytes);
+    counts[i] = c;
+  }
 }
 
 std::string kmer_to_string(uint64_t hi, uint64_t lo, size_t k)

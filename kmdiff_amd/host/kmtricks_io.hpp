@@ -35,6 +35,13 @@ uint64_t sample_total(const std::string& run_dir, const fof_entry& sample, size_
 size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<uint64_t>& kmers,
                       std::vector<uint32_t>& counts, std::vector<uint64_t>* kmers_hi = nullptr);
 
+// The same file in two steps, for hosts that place the records of many files in one buffer:
+// the decoded payload with its layout, then the split of [k-mer limbs][count] records into arrays
+// the caller owns (dst arrays hold at least `records` elements; hi may be NULL for one limb).
+struct kmer_file_raw { std::vector<char> payload; uint32_t slots = 1, count_bytes = 4; size_t records = 0; };
+kmer_file_raw decode_kmer_file(const std::string& path, size_t expected_k);
+void split_records(const kmer_file_raw& f, uint64_t* kmers, uint64_t* kmers_hi, uint32_t* counts);
+
 std::string kmer_file_path(const std::string& run_dir, size_t partition, const std::string& id);
 
 // 2-bit code A=0 C=1 T=2 G=3, first base most significant (km::Kmer::to_string)

@@ -26,6 +26,7 @@
 #include <atomic>
 #include <chrono>
 #include <filesystem>
+#include <functional>
 #include <future>
 #include <mutex>
 #include <thread>
@@ -257,18 +258,28 @@ int main(int argc, char** argv)
       // spends -t on whole partitions, merge.hpp:239-307; here the device takes the partitions one
       // after the other and the threads take the files), and partition p + 1 is decoded while the
       // device works on partition p.
+      struct pinned                                         // page-locked staging array, grown as needed, reused
+      {
+        void* p = nullptr; size_t cap = 0;
+        void reserve(size_t bytes)
+        {
+          if (bytes <= cap) return;
+          if (p) kmd_free_host(p);
+          p = nullptr; cap = 0;
+          ck(kmd_malloc_host(&p, bytes + bytes / 8), "kmd_malloc_host");
+          cap = bytes + bytes / 8;
+        }
+        ~pinned() { if (p) kmd_free_host(p); }
+      };
       struct partition_input
       {
         matrix_rows m;
-        std::vector<uint64_t> kmers, kmers_hi, offs;
-        std::vector<uint32_t> counts;
+        pinned kmers, kmers_hi, counts;                     // the S streams one after the other
+        std::vector<uint64_t> offs;
+        size_t n = 0;
       };
-      auto load_partition = [&](size_t p) -> partition_input
+      auto parallel_for_samples = [&](const std::function<void(size_t)>& body)
       {
-        partition_input in;
-        if (from_matrix) { in.m = read_matrix_file(mpaths[p]); return in; }
-        std::vector<std::vector<uint64_t>> k(S), kh(S);
-        std::vector<std::vector<uint32_t>> c(S);
         std::atomic<size_t> next { 0 };
         std::mutex mu;
         std::exception_ptr err;
@@ -276,7 +287,7 @@ int main(int argc, char** argv)
         {
           for (size_t s2; (s2 = next++) < S;)
           {
-            try { read_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s2].id), cfg.kmer_size, k[s2], c[s2], two_limbs ? &kh[s2] : nullptr); }
+            try { body(s2); }
             catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
           }
         };
@@ -285,17 +296,29 @@ int main(int argc, char** argv)
         work();
         for (auto& t : pool) t.join();
         if (err) std::rethrow_exception(err);
-        in.offs.assign(S + 1, 0);
-        for (size_t s2 = 0; s2 < S; ++s2) in.offs[s2 + 1] = in.offs[s2] + k[s2].size();             // KmDir::get_files_to_merge order
-        in.kmers.reserve(in.offs[S]); in.counts.reserve(in.offs[S]);
-        if (two_limbs) in.kmers_hi.reserve(in.offs[S]);
-        for (size_t s2 = 0; s2 < S; ++s2)
+      };
+      // decode the S files in parallel, then split their records -- in parallel again -- straight into
+      // the partition's page-locked arrays at the offsets the record counts give
+      auto load_partition = [&](size_t p, partition_input* in)
+      {
+        if (from_matrix) { in->m = read_matrix_file(mpaths[p]); return; }
+        std::vector<kmer_file_raw> raw(S);
+        parallel_for_samples([&](size_t s2) { raw[s2] = decode_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s2].id), cfg.kmer_size); });
+        in->offs.assign(S + 1, 0);
+        for (size_t s2 = 0; s2 < S; ++s2)                                                      // KmDir::get_files_to_merge order
         {
-          in.kmers.insert(in.kmers.end(), k[s2].begin(), k[s2].end());
-          in.counts.insert(in.counts.end(), c[s2].begin(), c[s2].end());
-          if (two_limbs) in.kmers_hi.insert(in.kmers_hi.end(), kh[s2].begin(), kh[s2].end());
+          if ((raw[s2].slots == 2) != two_limbs) throw std::runtime_error("k-mer width of a sample file differs from the run's");
+          in->offs[s2 + 1] = in->offs[s2] + raw[s2].records;
         }
-        return in;
+        in->n = in->offs[S];
+        in->kmers.reserve(in->n * 8); in->counts.reserve(in->n * 4);
+        if (two_limbs) in->kmers_hi.reserve(in->n * 8);
+        parallel_for_samples([&](size_t s2)
+        {
+          split_records(raw[s2], (uint64_t*)in->kmers.p + in->offs[s2], two_limbs ? (uint64_t*)in->kmers_hi.p + in->offs[s2] : nullptr,
+                        (uint32_t*)in->counts.p + in->offs[s2]);
+          raw[s2].payload = std::vector<char>();
+        });
       };
       // One worker thread per GPU; partition p belongs to worker p % n_workers (the sharding of
       // kmdiff_amd/dist.py, in one process).  A worker keeps its survivors in its own set; they are
@@ -328,14 +351,17 @@ int main(int argc, char** argv)
       uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
       dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
               d_smk, d_sc;
-      std::future<partition_input> ahead;
-      if (wi < n_units) ahead = std::async(std::launch::async, load_partition, wi);
-      for (size_t p = wi; p < n_units; p += n_workers)
+      partition_input staging[2];                          // the one being processed, the one being decoded
+      std::future<void> ahead;
+      size_t turn = 0;
+      if (wi < n_units) ahead = std::async(std::launch::async, load_partition, wi, &staging[0]);
+      for (size_t p = wi; p < n_units; p += n_workers, turn ^= 1)
       {
         kmd_tile tile {};
         uint64_t n_rows = 0;
-        partition_input in = ahead.get();
-        if (p + n_workers < n_units) ahead = std::async(std::launch::async, load_partition, p + n_workers);
+        ahead.get();
+        partition_input& in = staging[turn];
+        if (p + n_workers < n_units) ahead = std::async(std::launch::async, load_partition, p + n_workers, &staging[turn ^ 1]);
         if (from_matrix)
         {
           // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
@@ -359,19 +385,18 @@ int main(int argc, char** argv)
         }
         else
         {
-          const std::vector<uint64_t>&kmers = in.kmers, &kmers_hi = in.kmers_hi, &offs = in.offs;
-          const std::vector<uint32_t>& counts = in.counts;
-          const size_t n = kmers.size();
+          const std::vector<uint64_t>& offs = in.offs;
+          const size_t n = in.n;
           if (n)
           {
             d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
-            ck(kmd_memcpy_h2d(d_kmers.p, kmers.data(), n * 8, nullptr), "h2d");
-            ck(kmd_memcpy_h2d(d_counts.p, counts.data(), n * 4, nullptr), "h2d");
+            ck(kmd_memcpy_h2d(d_kmers.p, in.kmers.p, n * 8, nullptr), "h2d");
+            ck(kmd_memcpy_h2d(d_counts.p, in.counts.p, n * 4, nullptr), "h2d");
             d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
             if (two_limbs)
             {
               d_kmers_hi.reserve(n * 8); d_kmer_col_hi.reserve(n * 8);
-              ck(kmd_memcpy_h2d(d_kmers_hi.p, kmers_hi.data(), n * 8, nullptr), "h2d");
+              ck(kmd_memcpy_h2d(d_kmers_hi.p, in.kmers_hi.p, n * 8, nullptr), "h2d");
             }
             ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
                                    (const uint32_t*)d_counts.p, offs.data(), 4, KMD_LAYOUT_TILED, T, n, d_matrix.p,

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""End-to-end `kmdiff-hip diff` on a fabricated kmtricks run directory (host side included: LZ4
+decode of the per-sample files, H2D copies): how the command scales with -t and --devices.
+usage: python3 tools/cli_throughput.py [--rows 1000000] [--parts 4] [--nc 20 --nk 20]"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kmdiff_amd as K          # noqa: E402
+import kmtricks_files as KF     # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=1_000_000)
+ap.add_argument("--parts", type=int, default=4)
+ap.add_argument("--nc", type=int, default=20)
+ap.add_argument("--nk", type=int, default=20)
+a = ap.parse_args()
+S = a.nc + a.nk
+root = tempfile.mkdtemp(prefix="kmrun_")
+t0 = time.time()
+parts, records = [], 0
+for p in range(a.parts):
+    mat = K.synth_matrix(0x6B6D64696666, p, a.rows, a.nc, a.nk, 4, K.LAYOUT_ROWS)
+    host, lo = mat.to_host(), mat.kmers_to_host()[0]
+    streams = []
+    for s in range(S):
+        sel = host[:, s] > 0
+        streams.append((lo[sel], host[sel, s]))
+        records += int(sel.sum())
+    parts.append(streams)
+ids = ["C%d" % i for i in range(a.nc)] + ["K%d" % i for i in range(a.nk)]
+KF.write_run_dir(os.path.join(root, "km"), 31, ids, parts)
+size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
+print("run dir: %d partitions x %d rows, %d samples, %d records, %.1f MB on disk, written in %.0f s"
+      % (a.parts, a.rows, S, records, size / 1e6, time.time() - t0), flush=True)
+cli = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
+for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "64", "--devices", "2"]):
+    out = os.path.join(root, "out")
+    shutil.rmtree(out, ignore_errors=True)
+    t0 = time.time()
+    r = subprocess.run([cli, "diff", "-d", os.path.join(root, "km"), "-1", str(a.nc), "-2", str(a.nk), "-o", out] + extra,
+                       capture_output=True, text=True)
+    dt = time.time() - t0
+    assert r.returncode == 0, r.stderr
+    stage1 = [l for l in r.stderr.split("\n") if "Partitions processed" in l][0].split("(")[1].split(" s")[0]
+    print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s"
+          % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1)), flush=True)
+shutil.rmtree(root, ignore_errors=True)
