@@ -351,17 +351,28 @@ int main(int argc, char** argv)
       uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
       dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
               d_smk, d_sc;
-      partition_input staging[2];                          // the one being processed, the one being decoded
-      std::future<void> ahead;
+      // a ring of staging sets: the partition being processed and `depth` more being decoded (deeper
+      // than 1 measured no gain with 256 host threads: the decode is not what is left to hide)
+      const size_t depth = 1;
+      std::vector<partition_input> staging(depth + 1);
+      std::vector<std::future<void>> ahead(depth + 1);
+      size_t issued = 0;                                   // partitions of this worker handed to the loader
+      auto issue = [&]()
+      {
+        const size_t p_next = wi + issued * n_workers;
+        if (p_next < n_units)
+          ahead[issued % (depth + 1)] = std::async(std::launch::async, load_partition, p_next, &staging[issued % (depth + 1)]);
+        ++issued;
+      };
+      for (size_t d = 0; d < depth; ++d) issue();
       size_t turn = 0;
-      if (wi < n_units) ahead = std::async(std::launch::async, load_partition, wi, &staging[0]);
-      for (size_t p = wi; p < n_units; p += n_workers, turn ^= 1)
+      for (size_t p = wi; p < n_units; p += n_workers, ++turn)
       {
         kmd_tile tile {};
         uint64_t n_rows = 0;
-        ahead.get();
-        partition_input& in = staging[turn];
-        if (p + n_workers < n_units) ahead = std::async(std::launch::async, load_partition, p + n_workers, &staging[turn ^ 1]);
+        issue();                                           // into the slot processed one ring turn ago
+        ahead[turn % (depth + 1)].get();
+        partition_input& in = staging[turn % (depth + 1)];
         if (from_matrix)
         {
           // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are

@@ -43,7 +43,7 @@ size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) f
 print("run dir: %d partitions x %d rows, %d samples, %d records, %.1f MB on disk, written in %.0f s"
       % (a.parts, a.rows, S, records, size / 1e6, time.time() - t0), flush=True)
 cli = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
-for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "64", "--devices", "2"]):
+for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64", "--devices", "2"]):
     out = os.path.join(root, "out")
     shutil.rmtree(out, ignore_errors=True)
     t0 = time.time()
