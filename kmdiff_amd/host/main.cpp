@@ -53,6 +53,7 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   double kmer_pca = 0.001;                  // proportion of k-mers sampled for the PCA (cli.cpp:286-289)
   size_t ploidy = 2, seed = 0;              // cli.cpp:298-302, :349-351
   size_t threads = std::max(1u, std::thread::hardware_concurrency());   // -t: host threads decoding the k-mer files (cli.cpp:72-76)
+  bool verbose_timing = std::getenv("KMD_HOST_TIMING") != nullptr;   // dev: where stage 1 spends its time
   int device = 0, devices = 1, verbose = 1;   // first GPU, number of GPUs (0 = all): partition p on GPU (device + p % devices)
 };
 
@@ -356,6 +357,7 @@ int main(int argc, char** argv)
       const size_t depth = 1;
       std::vector<partition_input> staging(depth + 1);
       std::vector<std::future<void>> ahead(depth + 1);
+      double t_loader = 0, t_device = 0;                   // waiting for the decoder / copies + kernels + survivors back
       size_t issued = 0;                                   // partitions of this worker handed to the loader
       auto issue = [&]()
       {
@@ -371,7 +373,10 @@ int main(int argc, char** argv)
         kmd_tile tile {};
         uint64_t n_rows = 0;
         issue();                                           // into the slot processed one ring turn ago
+        const stopwatch t_wait;
         ahead[turn % (depth + 1)].get();
+        t_loader += t_wait.seconds();
+        const stopwatch t_dev;
         partition_input& in = staging[turn % (depth + 1)];
         if (from_matrix)
         {
@@ -455,6 +460,7 @@ int main(int argc, char** argv)
           }
           total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
         }
+        t_device += t_dev.seconds();
         R.span.emplace_back(base, ns);
         if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
         {
@@ -467,6 +473,8 @@ int main(int argc, char** argv)
         }
       }
       R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case;
+      if (opt.verbose_timing)
+        std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder, %.3f s in copies + kernels\n", dev, t_loader, t_device);
       if (pca)
       {
         ck(kmd_pca_count(pca, &R.n_sampled), "kmd_pca_count");

@@ -48,10 +48,13 @@ for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64"
     shutil.rmtree(out, ignore_errors=True)
     t0 = time.time()
     r = subprocess.run([cli, "diff", "-d", os.path.join(root, "km"), "-1", str(a.nc), "-2", str(a.nk), "-o", out] + extra,
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=dict(os.environ, KMD_HOST_TIMING="1"))
     dt = time.time() - t0
     assert r.returncode == 0, r.stderr
     stage1 = [l for l in r.stderr.split("\n") if "Partitions processed" in l][0].split("(")[1].split(" s")[0]
+    for l in r.stderr.split("\n"):
+        if "waited" in l:
+            print("   ", l)
     print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s"
           % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1)), flush=True)
 shutil.rmtree(root, ignore_errors=True)
