@@ -16,8 +16,11 @@
 // at rate --kmer-pca during stage 1, smartpca's normalisation and eigen-decomposition; written to
 // popstrat/pcs.evec in evec2pca's format) or, with --pcs FILE, from a file computed elsewhere.
 //
-// Not carried over (out of scope): `count`/`infos` sub-commands, --cmodel plugins
-// (the IModel plugin of this build is libkmdiff_hip_model.so), KFF output, progress bars.
+// --cmodel / --config load a user's IModel plugin the way plugin_manager does; its process() is
+// called row by row on the host (it is arbitrary host code), merge and correction stay on the GPU.
+//
+// Not carried over (out of scope): `count`/`infos` sub-commands, KFF output (-f is
+// accepted and FASTA is written), progress bars.
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
@@ -36,7 +39,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/kmdiff_hip.h"
+#include "imodel_abi.hpp"
 #include "kmtricks_io.hpp"
 
 namespace fs = std::filesystem;
@@ -47,6 +53,7 @@ namespace {
 struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-40
 {
   std::string kmtricks_dir, output_directory = "./kmdiff_output", correction = "bonferroni", pcs;
+  std::string model_lib_path, model_config;          // --cmodel / --config: a user's IModel plugin (cli.cpp:246-262)
   size_t nb_controls = 0, nb_cases = 0, cutoff = 100000, log_size = 10000, npc = 2, max_iteration = 0;
   double threshold = 0.05;
   bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false;
@@ -86,6 +93,9 @@ void usage()
             "  --ploidy INT       2: diploid normalisation of the PCA, else haploid {2}\n"
             "  --random-seed INT  seed of the PCA row sampler {0}\n"
             "  --n-pc             number of principal components in [2, 10] {2}\n"
+            "  --cmodel FILE      a model plugin (shared library exporting plugin_name / create32, imodel.hpp); its\n"
+            "                     process() is called row by row ON THE HOST, as the reference does; --config STR is\n"
+            "                     handed to its configure()\n"
             "  --device           GPU index (the first one with --devices) {0}\n"
             "  --devices INT      number of GPUs, 0 = all: partition p goes to GPU p mod N {1}\n"
             "  --keep-tmp         keep partitions/p<i>_uncorrected (+ options.bin): a later run resumes from them\n"
@@ -112,6 +122,8 @@ diff_options parse(int argc, char** argv)
     else if (a == "--log-factorial") o.log_size = std::stoull(need(i));
     else if (a == "--pop-correction") o.pop_correction = true;
     else if (a == "--pcs") o.pcs = need(i);
+    else if (a == "--cmodel") o.model_lib_path = need(i);
+    else if (a == "--config") o.model_config = need(i);
     else if (a == "--n-pc") o.npc = std::stoull(need(i));
     else if (a == "--max-iteration") o.max_iteration = std::stoull(need(i));
     else if (a == "--device") o.device = std::stoi(need(i));
@@ -200,6 +212,25 @@ int main(int argc, char** argv)
     ck(kmd_model_create(&model0, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
        "kmd_model_create");
     const double first_threshold = opt.threshold / (double)opt.cutoff;                       // cmd/diff.hpp:147
+    // A user's model plugin (model_manager.hpp:33-94: dlopen, plugin_name, create<bits>, configure).
+    // Arbitrary host code cannot run on the device: its rows are evaluated by the reference's own
+    // loop -- process(controls, cases) per row, one instance shared by all workers (it has to be
+    // re-entrant there too, merge.hpp:418) --, everything around it (merge, correction) stays on
+    // the GPU.  Pop-strat correction is switched off with custom models, cmd/diff.hpp:127-132.
+    std::shared_ptr<kmdiff::IModel<kmdiff::maxc32>> plugin;
+    if (!opt.model_lib_path.empty())
+    {
+      void* h = dlopen(opt.model_lib_path.c_str(), RTLD_LAZY);
+      if (!h) die(std::string("--cmodel: ") + dlerror());
+      auto name = reinterpret_cast<std::string (*)()>(dlsym(h, "plugin_name"));
+      auto create = reinterpret_cast<kmdiff::IModel<kmdiff::maxc32>* (*)()>(dlsym(h, "create32"));
+      if (!name || !create) die(std::string("--cmodel: ") + dlerror());
+      std::fprintf(stderr, "[kmdiff-hip] model plugin: %s\n", name().c_str());
+      plugin.reset(create());
+      plugin->configure(opt.model_config);
+      if (opt.pop_correction) std::fprintf(stderr, "[kmdiff-hip] warning: population stratification correction disabled with custom models.\n");
+      opt.pop_correction = false;
+    }
     const size_t n_workers = (size_t)std::max(1, opt.devices == 0 ? ndev : opt.devices);       // GPUs (folded onto the ones there are)
 
     // ---- what a previous run left behind (cmd/diff.hpp:278-303)
@@ -408,24 +439,53 @@ int main(int argc, char** argv)
             d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
             ck(kmd_memcpy_h2d(d_kmers.p, in.kmers.p, n * 8, nullptr), "h2d");
             ck(kmd_memcpy_h2d(d_counts.p, in.counts.p, n * 4, nullptr), "h2d");
-            d_matrix.reserve(((n + T - 1) / T) * T * S * 4); d_kmer_col.reserve(n * 8);
+            d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
             if (two_limbs)
             {
               d_kmers_hi.reserve(n * 8); d_kmer_col_hi.reserve(n * 8);
               ck(kmd_memcpy_h2d(d_kmers_hi.p, in.kmers_hi.p, n * 8, nullptr), "h2d");
             }
             ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
-                                   (const uint32_t*)d_counts.p, offs.data(), 4, KMD_LAYOUT_TILED, T, n, d_matrix.p,
+                                   (const uint32_t*)d_counts.p, offs.data(), 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED,
+                                   plugin ? S : T, n, d_matrix.p,
                                    (uint64_t*)d_kmer_col.p, two_limbs ? (uint64_t*)d_kmer_col_hi.p : nullptr, &n_rows, nullptr),
                "kmd_merge_partition");
           }
-          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p,
+          tile = kmd_tile { d_matrix.p, 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED, plugin ? S : T, (const uint64_t*)d_kmer_col.p,
                             two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
         }
         size_t ns = 0;
         const size_t base = sv_all.size();
         if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");             // merge.hpp:150-152
-        if (n_rows)
+        if (n_rows && plugin)
+        {
+          // diff_observer::process with the user's model (merge.hpp:68-103): the merged rows come
+          // back to the host, row-major, and go through process() one by one
+          std::vector<uint32_t> rows(n_rows * S);
+          std::vector<uint64_t> km(n_rows), kmh(two_limbs ? n_rows : 0);
+          ck(kmd_memcpy_d2h(rows.data(), d_matrix.p, n_rows * S * 4, nullptr), "d2h");
+          ck(kmd_memcpy_d2h(km.data(), d_kmer_col.p, n_rows * 8, nullptr), "d2h");
+          if (two_limbs) ck(kmd_memcpy_d2h(kmh.data(), d_kmer_col_hi.p, n_rows * 8, nullptr), "d2h");
+          std::vector<uint32_t> row(S);
+          for (size_t i = 0; i < n_rows; ++i)
+          {
+            std::copy(rows.begin() + i * S, rows.begin() + (i + 1) * S, row.begin());
+            kmdiff::Range<uint32_t> controls(row, 0, opt.nb_controls), cases(row, opt.nb_controls, opt.nb_cases);
+            auto [pv, sg, mc, mk] = plugin->process(controls, cases);
+            ++total_kmers;
+            if (pv <= first_threshold)
+            {
+              sv_all.kmer.push_back(km[i]);
+              if (two_limbs) sv_all.kmer_hi.push_back(kmh[i]);
+              sv_all.p.push_back(pv); sv_all.sign.push_back((int32_t)sg);
+              sv_all.mean_control.push_back(mc); sv_all.mean_case.push_back(mk);
+              if (want_counts) for (size_t s2 = 0; s2 < S; ++s2) sv_all.counts.push_back((double)row[s2]);
+              if (sg == kmdiff::Significance::CONTROL) ++n_sig_control; else ++n_sig_case;        // merge.hpp:95-98
+              ++n_sig; ++ns;
+            }
+          }
+        }
+        else if (n_rows)
         {
           // survivor sink sized for the worst case of this partition (every row)
           d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);

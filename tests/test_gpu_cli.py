@@ -215,6 +215,27 @@ def test_cli_partitions_sharded_over_gpus(synth_run, tmp_path):
         assert open(tmp_path / "b" / name, "rb").read() == ref and open(tmp_path / "c" / name, "rb").read() == ref, name
 
 
+def test_cli_cmodel_plugin_row_loop(synth_run, tmp_path):
+    """--cmodel / --config (cli.cpp:246-262, model_manager.hpp:33-94): a user's IModel plugin is
+    loaded with dlopen and called row by row on the host, like the reference; here the plugin is this
+    build's own libkmdiff_hip_model.so, so the result must equal the native path's."""
+    run_dir, nc, nk, k, mats, kms = synth_run
+    totals = np.sum([m.sum(axis=0, dtype=np.uint64) for m in mats], axis=0)
+    cfgs = "controls=%d;cases=%d;total_controls=%s;total_cases=%s;log_factorial=10000" % (
+        nc, nk, ",".join(str(int(t)) for t in totals[:nc]), ",".join(str(int(t)) for t in totals[nc:]))
+    plugin = os.path.join(ROOT, "kmdiff_amd", "lib", "libkmdiff_hip_model.so")
+    a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 100, "-c", "benjamini", "--keep-tmp"], tmp_path / "a")
+    b, err = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 100, "-c", "benjamini", "--keep-tmp", "--cmodel", plugin, "--config", cfgs,
+                      "--pop-correction"], tmp_path / "b")
+    assert "model plugin:" in err and "disabled with custom models" in err
+    assert a == b and a["n_sig"] > 50
+    for name in ("control_kmers.fasta", "case_kmers.fasta", "partitions/p1_uncorrected"):
+        assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read(), name
+    r = subprocess.run([CLI, "diff", "-d", run_dir, "-1", str(nc), "-2", str(nk), "-o", str(tmp_path / "c"), "--cmodel", "/nonexistent.so"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "--cmodel" in r.stderr
+
+
 def test_cli_pop_correction(synth_run, tmp_path):
     run_dir, nc, nk, k, mats, kms = synth_run
     o = OL.load()
