@@ -136,7 +136,10 @@ diff_options parse(int argc, char** argv)
     else if (a == "-t" || a == "--threads") o.threads = std::max<size_t>(1, std::stoull(need(i)));
     else if (a == "-v" || a == "--verbose" ||
              a == "--gender" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
-    else if (a == "-f" || a == "--kff-output" || a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
+    else if (a == "-f" || a == "--kff-output")
+      std::fprintf(stderr, "[kmdiff-hip] warning: KFF output is not part of this build (kff-cpp-api is an un-vendored, un-pinned "
+                           "dependency of the reference); writing FASTA\n");
+    else if (a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
              a == "--stand" || a == "--irls") {}
     else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
     else die("unknown option " + a);
