@@ -7,6 +7,10 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace fs = std::filesystem;
 
 // liblz4 frame API (lz4frame.h), declared here so the build needs only the shared library
@@ -371,6 +375,106 @@ void split_records(const kmer_file_raw& f, uint64_t* kmers, uint64_t* kmers_hi, 
     std::memcpy(&c, p + 8 * f.slots, f.count_bytes);
     counts[i] = c;
   }
+}
+
+// [limb(s)][count] records -> arrays, n whole records starting at p
+template <int SLOTS, int CB>
+static void split_fixed(const char* p, size_t n, uint64_t* kmers, uint64_t* kmers_hi, uint32_t* counts)
+{
+  constexpr size_t rec = 8 * SLOTS + CB;
+  for (size_t i = 0; i < n; ++i, p += rec)
+  {
+    std::memcpy(&kmers[i], p, 8);
+    if (SLOTS == 2) std::memcpy(&kmers_hi[i], p + 8, 8);
+    else if (kmers_hi) kmers_hi[i] = 0;
+    uint32_t c = 0;
+    std::memcpy(&c, p + 8 * SLOTS, CB);
+    counts[i] = c;
+  }
+}
+
+kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, record_sink& sink)
+{
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw std::runtime_error("cannot open " + path);
+  struct closer { int fd; ~closer() { ::close(fd); } } guard { fd };
+  struct stat st;
+  if (::fstat(fd, &st) != 0) throw std::runtime_error("cannot stat " + path);
+  auto read_some = [&](char* dst, size_t want) -> size_t
+  {
+    size_t got = 0;
+    while (got < want)
+    {
+      const ssize_t r = ::read(fd, dst + got, want - got);
+      if (r < 0) throw std::runtime_error("cannot read " + path);
+      if (r == 0) break;
+      got += (size_t)r;
+    }
+    return got;
+  };
+  char head[41];
+  if (read_some(head, 41) != 41 || std::memcmp(head, "kmtricks", 8) != 0 || std::memcmp(head + 13, "kmer", 4) != 0)
+    throw std::runtime_error(path + ": not a kmtricks k-mer file");
+  kmer_file_info f;
+  const uint8_t compressed = (uint8_t)head[12];
+  uint32_t k;
+  std::memcpy(&k, head + 21, 4); std::memcpy(&f.slots, head + 25, 4); std::memcpy(&f.count_bytes, head + 29, 4);
+  if (expected_k && k != expected_k) throw std::runtime_error(path + ": k-mer size differs from the run's");
+  if (f.slots != 1 && f.slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
+  if (f.count_bytes != 1 && f.count_bytes != 2 && f.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
+  sink.slots = f.slots;
+  const size_t rec = 8 * (size_t)f.slots + f.count_bytes;
+  const size_t chunk = (size_t)1 << 20;
+  if (sink.in.size() < chunk) sink.in.resize(chunk);
+  if (sink.out.size() < chunk + rec) sink.out.resize(chunk + rec);
+  char* const out = sink.out.data();
+  size_t carry = 0;                                        // bytes of a record cut by the chunk boundary, at the front of out
+  auto take = [&](size_t fresh)                            // out[0, carry + fresh) -> whole records to the sink
+  {
+    const size_t avail = carry + fresh, whole = avail / rec;
+    if (f.records + whole > sink.capacity)
+    {
+      const size_t guess = ((size_t)st.st_size * 2) / rec + 1024;          // k-mer files shrink by 1.3-1.6 under LZ4
+      sink.reserve(sink, std::max({ f.records + whole, sink.capacity + sink.capacity / 2, guess }));
+      if (sink.capacity < f.records + whole || (f.slots == 2 && !sink.kmers_hi)) throw std::runtime_error("record sink did not grow");
+    }
+    uint64_t* km = sink.kmers + f.records;
+    uint64_t* kh = sink.kmers_hi ? sink.kmers_hi + f.records : nullptr;
+    uint32_t* ct = sink.counts + f.records;
+    if (f.slots == 1 && f.count_bytes == 4) split_fixed<1, 4>(out, whole, km, kh, ct);
+    else if (f.slots == 1 && f.count_bytes == 2) split_fixed<1, 2>(out, whole, km, kh, ct);
+    else if (f.slots == 1) split_fixed<1, 1>(out, whole, km, kh, ct);
+    else if (f.count_bytes == 4) split_fixed<2, 4>(out, whole, km, kh, ct);
+    else if (f.count_bytes == 2) split_fixed<2, 2>(out, whole, km, kh, ct);
+    else split_fixed<2, 1>(out, whole, km, kh, ct);
+    f.records += whole;
+    carry = avail - whole * rec;
+    if (carry) std::memmove(out, out + whole * rec, carry);
+  };
+  if (!compressed)
+  {
+    for (size_t got; (got = read_some(out + carry, chunk)) != 0;) take(got);
+    return f;                                              // a trailing partial record is dropped, as decode_kmer_file does
+  }
+  LZ4F_dctx* ctx = nullptr;
+  if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
+  struct freer { LZ4F_dctx* c; ~freer() { LZ4F_freeDecompressionContext(c); } } ctx_guard { ctx };
+  bool done = false;
+  for (size_t got; !done && (got = read_some(sink.in.data(), chunk)) != 0;)
+  {
+    for (size_t pos = 0;;)
+    {
+      size_t dn = chunk, sn = got - pos;
+      const size_t r = LZ4F_decompress(ctx, out + carry, &dn, sink.in.data() + pos, &sn, nullptr);
+      if (LZ4F_isError(r)) throw std::runtime_error(path + ": " + LZ4F_getErrorName(r));
+      pos += sn;
+      if (dn) take(dn);
+      if (r == 0) { done = true; break; }                  // end of the frame
+      if (pos >= got && dn < chunk) break;                 // input used up and nothing left to flush
+      if (sn == 0 && dn == 0) throw std::runtime_error(path + ": LZ4 frame makes no progress");
+    }
+  }
+  return f;
 }
 
 std::string kmer_to_string(uint64_t hi, uint64_t lo, size_t k)

@@ -10,6 +10,7 @@
 //   km::KmerReader / lz4_stream (kmtricks)
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,21 @@ size_t read_kmer_file(const std::string& path, size_t expected_k, std::vector<ui
 struct kmer_file_raw { std::vector<char> payload; uint32_t slots = 1, count_bytes = 4; size_t records = 0; };
 kmer_file_raw decode_kmer_file(const std::string& path, size_t expected_k);
 void split_records(const kmer_file_raw& f, uint64_t* kmers, uint64_t* kmers_hi, uint32_t* counts);
+
+// The same file as a stream: the LZ4 frame is decoded chunk by chunk and the records go straight
+// into arrays the caller owns and reuses from file to file (page-locked in the CLI), so that no
+// pass over the data allocates.  `reserve(n)` must make the three arrays hold at least n records,
+// keeping what is already there, and set the pointers (kmers_hi may stay NULL for one limb).
+struct record_sink
+{
+  uint64_t* kmers = nullptr; uint64_t* kmers_hi = nullptr; uint32_t* counts = nullptr;
+  size_t capacity = 0;                                    // records the arrays hold
+  uint32_t slots = 1;                                     // limbs per k-mer of the file being read (set before reserve is called)
+  std::function<void(record_sink&, size_t)> reserve;
+  std::vector<char> in, out;                              // scratch of the decoder, kept between files
+};
+struct kmer_file_info { uint32_t slots = 1, count_bytes = 4; size_t records = 0; };
+kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, record_sink& sink);
 
 std::string kmer_file_path(const std::string& run_dir, size_t partition, const std::string& id);
 

@@ -296,20 +296,27 @@ int main(int argc, char** argv)
       struct pinned                                         // page-locked staging array, grown as needed, reused
       {
         void* p = nullptr; size_t cap = 0;
-        void reserve(size_t bytes)
+        void reserve(size_t bytes, size_t keep = 0)         // the first `keep` bytes survive
         {
           if (bytes <= cap) return;
+          void* q = nullptr;
+          ck(kmd_malloc_host(&q, bytes), "kmd_malloc_host");
+          if (keep) std::memcpy(q, p, keep);
           if (p) kmd_free_host(p);
-          p = nullptr; cap = 0;
-          ck(kmd_malloc_host(&p, bytes + bytes / 8), "kmd_malloc_host");
-          cap = bytes + bytes / 8;
+          p = q; cap = bytes;
         }
         ~pinned() { if (p) kmd_free_host(p); }
+      };
+      struct sample_stream                                  // one sample's file of a partition, decoded
+      {
+        pinned kmers, kmers_hi, counts;
+        record_sink sink;
+        size_t n = 0;
       };
       struct partition_input
       {
         matrix_rows m;
-        pinned kmers, kmers_hi, counts;                     // the S streams one after the other
+        std::vector<sample_stream> st;                      // the S streams, each in its own page-locked arrays
         std::vector<uint64_t> offs;
         size_t n = 0;
       };
@@ -332,28 +339,38 @@ int main(int argc, char** argv)
         for (auto& t : pool) t.join();
         if (err) std::rethrow_exception(err);
       };
-      // decode the S files in parallel, then split their records -- in parallel again -- straight into
-      // the partition's page-locked arrays at the offsets the record counts give
+      // the S files of a partition are decoded in parallel, each as a stream (LZ4 chunk -> records ->
+      // the sample's page-locked arrays, which live as long as the staging slot: nothing is
+      // allocated per partition once the arrays have grown to the run's file sizes)
       auto load_partition = [&](size_t p, partition_input* in)
       {
         if (from_matrix) { in->m = read_matrix_file(mpaths[p]); return; }
-        std::vector<kmer_file_raw> raw(S);
-        parallel_for_samples([&](size_t s2) { raw[s2] = decode_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s2].id), cfg.kmer_size); });
-        in->offs.assign(S + 1, 0);
-        for (size_t s2 = 0; s2 < S; ++s2)                                                      // KmDir::get_files_to_merge order
+        if (in->st.size() != S)
         {
-          if ((raw[s2].slots == 2) != two_limbs) throw std::runtime_error("k-mer width of a sample file differs from the run's");
-          in->offs[s2 + 1] = in->offs[s2] + raw[s2].records;
+          in->st = std::vector<sample_stream>(S);
+          for (auto& st : in->st)
+          {
+            sample_stream* self = &st;
+            st.sink.reserve = [self, two_limbs](record_sink& k, size_t n)
+            {
+              const size_t keep = k.capacity;                // grows only while a file is being read: all of it is live
+              self->kmers.reserve(n * 8, keep * 8); self->counts.reserve(n * 4, keep * 4);
+              if (two_limbs) self->kmers_hi.reserve(n * 8, keep * 8);
+              k.kmers = (uint64_t*)self->kmers.p; k.counts = (uint32_t*)self->counts.p;
+              k.kmers_hi = two_limbs ? (uint64_t*)self->kmers_hi.p : nullptr;
+              k.capacity = n;
+            };
+          }
         }
-        in->n = in->offs[S];
-        in->kmers.reserve(in->n * 8); in->counts.reserve(in->n * 4);
-        if (two_limbs) in->kmers_hi.reserve(in->n * 8);
         parallel_for_samples([&](size_t s2)
         {
-          split_records(raw[s2], (uint64_t*)in->kmers.p + in->offs[s2], two_limbs ? (uint64_t*)in->kmers_hi.p + in->offs[s2] : nullptr,
-                        (uint32_t*)in->counts.p + in->offs[s2]);
-          raw[s2].payload = std::vector<char>();
+          const kmer_file_info f = stream_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s2].id), cfg.kmer_size, in->st[s2].sink);
+          if ((f.slots == 2) != two_limbs) throw std::runtime_error("k-mer width of a sample file differs from the run's");
+          in->st[s2].n = f.records;
         });
+        in->offs.assign(S + 1, 0);
+        for (size_t s2 = 0; s2 < S; ++s2) in->offs[s2 + 1] = in->offs[s2] + in->st[s2].n;         // KmDir::get_files_to_merge order
+        in->n = in->offs[S];
       };
       // One worker thread per GPU; partition p belongs to worker p % n_workers (the sharding of
       // kmdiff_amd/dist.py, in one process).  A worker keeps its survivors in its own set; they are
@@ -391,7 +408,8 @@ int main(int argc, char** argv)
       const size_t depth = 1;
       std::vector<partition_input> staging(depth + 1);
       std::vector<std::future<void>> ahead(depth + 1);
-      double t_loader = 0, t_device = 0;                   // waiting for the decoder / copies + kernels + survivors back
+      double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
+                                                           // the wait spent on the ring's first turn (its arrays get page-locked then)
       size_t issued = 0;                                   // partitions of this worker handed to the loader
       auto issue = [&]()
       {
@@ -400,6 +418,7 @@ int main(int argc, char** argv)
           ahead[issued % (depth + 1)] = std::async(std::launch::async, load_partition, p_next, &staging[issued % (depth + 1)]);
         ++issued;
       };
+      if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] GPU %d: worker ready %.3f s into stage 1\n", dev, merge_time.seconds());
       for (size_t d = 0; d < depth; ++d) issue();
       size_t turn = 0;
       for (size_t p = wi; p < n_units; p += n_workers, ++turn)
@@ -410,6 +429,7 @@ int main(int argc, char** argv)
         const stopwatch t_wait;
         ahead[turn % (depth + 1)].get();
         t_loader += t_wait.seconds();
+        if (turn <= depth) t_first += t_wait.seconds();
         const stopwatch t_dev;
         partition_input& in = staging[turn % (depth + 1)];
         if (from_matrix)
@@ -440,13 +460,18 @@ int main(int argc, char** argv)
           if (n)
           {
             d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
-            ck(kmd_memcpy_h2d(d_kmers.p, in.kmers.p, n * 8, nullptr), "h2d");
-            ck(kmd_memcpy_h2d(d_counts.p, in.counts.p, n * 4, nullptr), "h2d");
+            if (two_limbs) d_kmers_hi.reserve(n * 8);
+            for (size_t s2 = 0; s2 < S; ++s2)                 // each stream to its place in the partition's arrays
+            {
+              const sample_stream& st = in.st[s2];
+              ck(kmd_memcpy_h2d((char*)d_kmers.p + offs[s2] * 8, st.kmers.p, st.n * 8, nullptr), "h2d");
+              ck(kmd_memcpy_h2d((char*)d_counts.p + offs[s2] * 4, st.counts.p, st.n * 4, nullptr), "h2d");
+              if (two_limbs) ck(kmd_memcpy_h2d((char*)d_kmers_hi.p + offs[s2] * 8, st.kmers_hi.p, st.n * 8, nullptr), "h2d");
+            }
             d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
             if (two_limbs)
             {
-              d_kmers_hi.reserve(n * 8); d_kmer_col_hi.reserve(n * 8);
-              ck(kmd_memcpy_h2d(d_kmers_hi.p, in.kmers_hi.p, n * 8, nullptr), "h2d");
+              d_kmer_col_hi.reserve(n * 8);
             }
             ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
                                    (const uint32_t*)d_counts.p, offs.data(), 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED,
@@ -524,6 +549,7 @@ int main(int argc, char** argv)
           total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
         }
         t_device += t_dev.seconds();
+        if (turn > depth) t_steady += t_wait.seconds();       // decoder wait + device work of this partition
         R.span.emplace_back(base, ns);
         if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
         {
@@ -537,7 +563,14 @@ int main(int argc, char** argv)
       }
       R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case;
       if (opt.verbose_timing)
-        std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder, %.3f s in copies + kernels\n", dev, t_loader, t_device);
+      {
+        std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder (%.3f s of it for the first %zu partitions, whose staging arrays "
+                             "get page-locked), %.3f s in copies + kernels\n", dev, t_loader, t_first, depth + 1, t_device);
+        std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1\n", dev, merge_time.seconds());
+        if (turn > depth + 1)
+          std::fprintf(stderr, "[kmdiff-hip] GPU %d: steady state %.2f ms per partition (%zu partitions after the first %zu)\n", dev,
+                       1e3 * t_steady / (double)(turn - depth - 1), turn - depth - 1, depth + 1);
+      }
       if (pca)
       {
         ck(kmd_pca_count(pca, &R.n_sampled), "kmd_pca_count");
@@ -554,6 +587,7 @@ int main(int argc, char** argv)
         for (size_t wi = 1; wi < n_workers; ++wi) gpus.emplace_back(worker, wi);
         worker(0);
         for (auto& t : gpus) t.join();
+        if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] workers done %.3f s into stage 1 (staging arrays released)\n", merge_time.seconds());
         ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
         for (auto& R : results) if (!R.error.empty()) die(R.error);
       }

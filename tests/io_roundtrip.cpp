@@ -1,11 +1,12 @@
 // Test harness (no GPU): reads a file with the host readers of kmdiff_amd/host/kmtricks_io.cpp and
 // writes it back with the host writers, so that tests/test_host_io.py can compare both directions
 // with the independent Python reader/writer of tests/kmtricks_files.py.
-//   io_roundtrip matrix <in> <out> | survivors <in> <out> | survivors16 <in> <out> | options <in> <out>
+//   io_roundtrip matrix <in> <out> | survivors <in> <out> | survivors16 <in> <out> | options <in> <out> | kmers <in> <out>
 #include <cstdio>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "../kmdiff_amd/host/kmtricks_io.hpp"
 
@@ -30,6 +31,32 @@ int main(int argc, char** argv)
       const size_t n = kmd_host::read_survivor_file(in, s);
       std::printf("records=%zu n_counts=%zu\n", n, s.n_counts);
       kmd_host::write_survivor_file(out, s, 0, n);
+    }
+    else if (what == "kmers")
+    {
+      // the streaming reader (what the CLI uses) into plain vectors, next to the whole-file reader;
+      // <out> = the streamed arrays as raw little-endian bytes: kmers, kmers_hi (two limbs only), counts
+      std::vector<uint64_t> km, kh; std::vector<uint32_t> ct;
+      kmd_host::record_sink sink;
+      sink.reserve = [&](kmd_host::record_sink& k, size_t n)
+      {
+        const bool two = k.slots == 2;
+        km.resize(n); ct.resize(n); if (two) kh.resize(n);
+        k.kmers = km.data(); k.counts = ct.data(); k.kmers_hi = two ? kh.data() : nullptr; k.capacity = n;
+      };
+      const kmd_host::kmer_file_info f = kmd_host::stream_kmer_file(in, 0, sink);
+      std::vector<uint64_t> km2, kh2; std::vector<uint32_t> ct2;
+      const size_t n2 = kmd_host::read_kmer_file(in, 0, km2, ct2, &kh2);
+      bool same = n2 == f.records;
+      for (size_t i = 0; same && i < n2; ++i)
+        same = km[i] == km2[i] && ct[i] == ct2[i] && (f.slots == 1 || kh[i] == kh2[i]);
+      std::printf("records=%zu slots=%u count_bytes=%u same=%d\n", f.records, f.slots, f.count_bytes, (int)same);
+      std::FILE* o = std::fopen(out.c_str(), "wb");
+      if (!o) return 1;
+      std::fwrite(km.data(), 8, f.records, o);
+      if (f.slots == 2) std::fwrite(kh.data(), 8, f.records, o);
+      std::fwrite(ct.data(), 4, f.records, o);
+      std::fclose(o);
     }
     else if (what == "options")
     {

@@ -113,3 +113,25 @@ def test_options_bin_layout(tmp_path):
     assert open(tmp_path / "back.bin", "rb").read() == blob
     open(tmp_path / "short.bin", "wb").write(blob[:20])
     assert tool("options", tmp_path / "short.bin", tmp_path / "x")[0] == 1
+
+
+@pytest.mark.parametrize("count_bytes,two,compressed,n", [(4, False, True, 300_000), (2, False, True, 70_001), (1, True, True, 90_000),
+                                                          (4, True, True, 200_003), (4, False, False, 100_000), (4, False, True, 0),
+                                                          (4, False, True, 1)])
+def test_streaming_kmer_reader(tmp_path, count_bytes, two, compressed, n):
+    """stream_kmer_file (LZ4 chunk -> records -> caller's arrays; records straddle the 1 MB chunks: 12,
+    10, 17 and 20 bytes do not divide 2^20) against the whole-file reader and the Python reader."""
+    rng = np.random.default_rng(n + count_bytes)
+    km = np.sort(rng.integers(0, 1 << 62, n, dtype=np.uint64))
+    hi = np.sort(rng.integers(0, 1 << 60, n, dtype=np.uint64)) if two else None
+    ct = rng.integers(1, 1 << (8 * count_bytes), n, dtype=np.uint64).astype(np.uint32)
+    KF.write_kmer_file(str(tmp_path / "s.kmer.lz4"), 63 if two else 31, 3, 7, km, ct, count_bytes, compressed, hi)
+    rc, out, err = tool("kmers", tmp_path / "s.kmer.lz4", tmp_path / "dump")
+    assert rc == 0, err
+    assert out.split() == ["records=%d" % n, "slots=%d" % (2 if two else 1), "count_bytes=%d" % count_bytes, "same=1"]
+    raw = open(tmp_path / "dump", "rb").read()
+    assert len(raw) == n * (8 * (2 if two else 1) + 4)
+    assert (np.frombuffer(raw[:8 * n], "<u8") == km).all()
+    if two:
+        assert (np.frombuffer(raw[8 * n:16 * n], "<u8") == hi).all()
+    assert (np.frombuffer(raw[-4 * n:] if n else b"", "<u4") == ct).all()

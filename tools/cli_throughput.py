@@ -53,7 +53,7 @@ for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64"
     assert r.returncode == 0, r.stderr
     stage1 = [l for l in r.stderr.split("\n") if "Partitions processed" in l][0].split("(")[1].split(" s")[0]
     for l in r.stderr.split("\n"):
-        if "waited" in l:
+        if "waited" in l or "steady state" in l or "into stage 1" in l:
             print("   ", l)
     print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s"
           % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1)), flush=True)
