@@ -49,7 +49,8 @@ enum { KMD_CORR_NOTHING = 0, KMD_CORR_BONFERRONI = 1, KMD_CORR_BENJAMINI = 2,
  *                    what km::MatrixReader / KmerMerger hand the observer
  *                    (include/kmdiff/merge.hpp:68,194-203); staged through LDS.
  *   KMD_LAYOUT_TILED: counts[row / T][sample][row % T] with T = ld rows per block
- *                    (T a multiple of 4096; the buffer holds ceil(n_rows / T) whole blocks).
+ *                    (T a multiple of 4096; the buffer holds ceil(n_rows / T) whole blocks; with 1-byte
+ *                    counts prefer a multiple of 8192: 8-byte loads per lane, +16 %).
  *                    SoA inside a block, so lanes stay coalesced, but one block of rows is
  *                    one contiguous span of S*T counts: better DRAM page locality than S
  *                    far-apart columns (measured +3..10 % over plain SoA). */

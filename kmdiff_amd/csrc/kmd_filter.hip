@@ -44,6 +44,9 @@ namespace {
 #ifndef KMD_RPL_U16
 #define KMD_RPL_U16 4
 #endif
+#ifndef KMD_U8_DOT4
+#define KMD_U8_DOT4 1
+#endif
 #ifndef KMD_RPL_U8
 #define KMD_RPL_U8 8
 #endif
@@ -391,7 +394,15 @@ struct soa_batch
       for (int d = 0; d < ndw; ++d)
 #pragma unroll
         for (int e = 0; e < per; ++e)
+        {
+#if KMD_U8_DOT4
+          // byte e of the dword added in one instruction: v_dot4_u32_u8 against a one-hot selector
+          if constexpr (sizeof(CT) == 1 && sizeof(ACC) == 4)
+            acc[d * per + e] = __builtin_amdgcn_udot4(w[d], 1u << (8 * e), acc[d * per + e], false);
+          else
+#endif
           acc[d * per + e] += (w[d] >> (8 * sizeof(CT) * e)) & mask;
+        }
     }
   }
 
@@ -816,6 +827,138 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
   flush_beyond(P, n_beyond);
 }
 
+// ---- row-major rows, ANY pitch: wave-private flat staging --------------------------------------
+// A matrix with 21 + 21 four-byte counts has 168-byte rows: no 16-byte vector of a row is
+// aligned, yet R consecutive rows are one contiguous span that starts on a 16-byte boundary
+// whenever R x pitch is a multiple of 16 (R = 64 always is; the buffer itself is aligned).  A
+// wave copies such a span into its own LDS tile with 16-byte non-temporal loads that are
+// contiguous across the lanes -- the bytes land where they were, no re-pitching -- and then
+// G = 64 / R lanes share a row: lane (r, g) adds the counts g, g + G, ... of row r with typed
+// LDS reads, a butterfly over the G lanes yields the row's two sums, and the R row lanes go
+// through the pre-filter and the deferred-evaluation queue.  R is the largest of 64, 32, ... 2
+// whose span fits the tile and keeps the alignment.  The loads of the next span are in flight
+// while the current one is summed.  The matrix's last vector may be cut by the end of the
+// buffer: it is fetched count by count.
+#ifndef KMD_FLAT_BLOCK
+#define KMD_FLAT_BLOCK 1024
+#endif
+#ifndef KMD_FLAT_VECS
+#define KMD_FLAT_VECS 4
+#endif
+constexpr int kFlatBlock = KMD_FLAT_BLOCK;
+constexpr int kFlatVecs = KMD_FLAT_VECS;      // 16-byte vectors per lane per span: 4 KB tiles, 16 waves per CU
+                                              // (measured: 8 KB x 12 waves 4.3 TB/s, 4 KB x 16 waves 4.6 TB/s at 21v21)
+template <typename CT>
+__global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_params P, const uint32_t R)
+{
+  extern __shared__ double2 s_all[];
+  double2* s_lf = s_all;
+  stage_table(P, s_lf);
+  uint32_t n_beyond = 0;
+  typedef uint32_t n4 __attribute__((ext_vector_type(4)));
+  using ACC = typename acc_of<CT>::type;
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t S = (uint32_t)(P.nc + P.nk), nc = (uint32_t)P.nc;
+  wave_queue Q;
+  {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s_all + P.lds_n) + (size_t)w * kQueueCap * 3;
+    Q.sc = q; Q.sk = q + kQueueCap; Q.row = q + 2 * kQueueCap; Q.n = 0;
+  }
+  n4* tile = reinterpret_cast<n4*>(reinterpret_cast<char*>(s_all + P.lds_n) + (size_t)(kFlatBlock / 64) * kQueueBytesPerWave) +
+             (size_t)w * 64 * kFlatVecs;
+  const CT* tile_ct = reinterpret_cast<const CT*>(tile);
+  const size_t pitch = P.ld * sizeof(CT);               // bytes
+  const size_t total_vecs = (P.n_rows * pitch) / 16;    // whole vectors inside the buffer
+  const uint32_t span_vecs = (uint32_t)(R * pitch / 16);
+  const n4* __restrict__ base = static_cast<const n4*>(P.counts);
+  const CT* __restrict__ base_ct = static_cast<const CT*>(P.counts);
+  const size_t n_tiles = (P.n_rows + R - 1) / R;
+  const size_t n_waves = (size_t)gridDim.x * (kFlatBlock / 64);
+  const uint32_t G = 64u / R, r = lane & (R - 1), g = lane / R;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
+
+  n4 buf[kFlatVecs];
+  auto issue = [&](size_t t)
+  {
+    const size_t v0 = t * span_vecs;
+#pragma unroll
+    for (int k = 0; k < kFlatVecs; ++k)
+    {
+      const uint32_t i = (uint32_t)k * 64 + lane;
+      if ((uint32_t)k * 64 < span_vecs)                  // wave-uniform
+      {
+        const size_t v = v0 + i;
+        if (i < span_vecs && v < total_vecs) buf[k] = __builtin_nontemporal_load(base + v);   // never past the span / the buffer
+      }
+    }
+  };
+
+  size_t t = (size_t)blockIdx.x * (kFlatBlock / 64) + w;
+  if (t < n_tiles) issue(t);
+  for (; t < n_tiles; t += n_waves)
+  {
+    const size_t v0 = t * span_vecs;
+#pragma unroll
+    for (int k = 0; k < kFlatVecs; ++k)
+    {
+      const uint32_t i = (uint32_t)k * 64 + lane;
+      if ((uint32_t)k * 64 < span_vecs && i < span_vecs)
+      {
+        if (v0 + i < total_vecs) tile[i] = buf[k];
+        else
+        {
+          // the vector the end of the buffer cuts (at most one in the matrix): count by count
+          const size_t e0 = (v0 + i) * (16 / sizeof(CT)), e_end = P.n_rows * P.ld;
+          CT* d = reinterpret_cast<CT*>(tile + i);
+          for (uint32_t j = 0; j < 16 / sizeof(CT); ++j) d[j] = e0 + j < e_end ? base_ct[e0 + j] : (CT)0;
+        }
+      }
+    }
+    queue_fence();
+    if (t + n_waves < n_tiles) issue(t + n_waves);       // next span in flight while this one is added up
+    const CT* __restrict__ mine = tile_ct + (size_t)r * P.ld;
+    ACC sc = 0, sk = 0;
+    // eight LDS reads in flight per lane (the walk is latency-bound otherwise)
+    uint32_t e = g;
+    for (; e + 7 * G < nc; e += 8 * G)
+    {
+      CT x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = mine[e + j * G];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sc += x[j];
+    }
+    for (; e < nc; e += G) sc += mine[e];
+    // the case lanes start at the first count >= nc that is theirs
+    e = nc + ((g + G - nc % G) % G);
+    for (; e + 7 * G < S; e += 8 * G)
+    {
+      CT x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = mine[e + j * G];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sk += x[j];
+    }
+    for (; e < S; e += G) sk += mine[e];
+    for (uint32_t o = R; o < 64; o <<= 1)
+    {
+      sc += (ACC)__shfl_xor((unsigned long long)sc, (int)o, 64);
+      sk += (ACC)__shfl_xor((unsigned long long)sk, (int)o, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // tile read before it is overwritten
+    __builtin_amdgcn_wave_barrier();
+    row_state st;
+    st.row = t * R + r;
+    st.valid = g == 0 && st.row < P.n_rows;
+    st.sum_c = sc; st.sum_k = sk;
+    defer_row(P, s_lf, st, n_beyond, Q);
+  }
+  drain_queue(P, s_lf, Q);
+  flush_beyond(P, n_beyond);
+}
+
 // ---- row-major WIDE rows: G = 8 or 16 lanes per row -------------------------------------------
 // A row of hundreds of bytes needs no transposition through LDS: G consecutive lanes read 16 G
 // consecutive bytes of ONE row per load (one or two whole cache lines), 64 / G rows per wave
@@ -1152,6 +1295,32 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   const size_t half = m->lds_per_block_max / 2 - 256;
   const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
   const bool dword_rows = (P.ld % per == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 3u) == 0);
+  // pitch not a multiple of 16 bytes (21v21 four-byte counts: 168 B): the flat wave-private kernel,
+  // with the most rows per span (64, 32, ... 2) that fit its 4 KB tile and keep spans 16-byte aligned
+  if (((P.ld * sizeof(CT)) % 16 != 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
+      std::getenv("KMD_ROWS_FLAT_OFF") == nullptr)
+  {
+    const size_t pitch = P.ld * sizeof(CT);
+    uint32_t R = 64;
+    while (R >= 2 && (R * pitch > (size_t)64 * kFlatVecs * 16 || (R * pitch) % 16 != 0)) R >>= 1;
+    if (R >= 2)
+    {
+      const size_t wpb = kFlatBlock / 64;
+      const size_t extra = wpb * kQueueBytesPerWave + wpb * 64 * kFlatVecs * 16;
+      const size_t avail = m->lds_per_block_max - 256 - extra;
+      size_t want = (size_t)P.lf_n * sizeof(double2);
+      if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
+      P.lds_n = (uint32_t)(want / sizeof(double2));
+      const size_t n_wtiles = (P.n_rows + R - 1) / R;
+      size_t grid = (size_t)m->n_cu;
+      if (grid > (n_wtiles + wpb - 1) / wpb) grid = (n_wtiles + wpb - 1) / wpb;
+      int rc = allow_big_lds(k_filter_rows_flat<CT>, want + extra);
+      if (rc != KMD_OK) return rc;
+      hipLaunchKernelGGL((k_filter_rows_flat<CT>), dim3((unsigned)grid), dim3(kFlatBlock), want + extra, stream, P, R);
+      KMD_HIP(hipGetLastError());
+      return KMD_OK;
+    }
+  }
   if (!dword_rows)
   {
     size_t want = (size_t)P.lf_n * sizeof(double2);

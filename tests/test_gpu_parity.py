@@ -254,6 +254,40 @@ def test_row_major_16_byte_pitch_shapes(K, oracle):
         assert got["mean_control"].tolist() == want["mean_control"].tolist() and got["mean_case"].tolist() == want["mean_case"].tolist()
 
 
+def test_row_major_any_pitch_shapes(K, oracle):
+    """Row-major with a pitch that is NOT a multiple of 16 bytes (21v21 four-byte counts: 168 B) takes
+    the flat wave-private kernel: 64 rows per span, or 32 ... 4 with several lanes per row when the rows
+    are wide or only a smaller group of rows keeps spans 16-byte aligned (odd byte pitches); the
+    control/case boundary at any position of the lane interleave; padding columns full of garbage;
+    matrices whose last 16-byte vector is cut by the end of the buffer; fewer rows than one span."""
+    rng = np.random.default_rng(78)
+    lf = oracle.lf_table(10000)
+    # (nc, nk, count bytes, spare columns)
+    shapes = [(21, 21, 4, 0), (20, 21, 4, 0), (10, 11, 4, 0), (3, 3, 4, 0), (1, 1, 4, 0), (2, 1, 4, 0), (21, 21, 2, 0),
+              (20, 21, 2, 0), (1, 2, 2, 0), (20, 20, 1, 0), (20, 21, 1, 0), (1, 2, 1, 0), (4, 3, 1, 0), (101, 101, 4, 0),
+              (64, 65, 4, 0), (129, 130, 4, 0), (250, 251, 4, 0), (300, 261, 2, 0), (500, 501, 1, 0), (33, 32, 4, 0),
+              (20, 20, 4, 1), (20, 20, 4, 3), (20, 20, 2, 3), (20, 20, 1, 7), (7, 6, 4, 2), (60, 61, 1, 0), (5, 5, 2, 1)]
+    for it, (nc, nk, cb, spare) in enumerate(shapes):
+        S = nc + nk
+        ld = S + spare
+        assert (ld * cb) % 16 != 0, (nc, nk, cb, spare)
+        n = int(rng.choice([1, 3, 5, 31, 63, 64, 65, 1000, 4099, 8193]))
+        host, lo, _ = oracle.synth_rows(SEED + 300 + it, it, 0, n, nc, nk, cb)
+        padded = rng.integers(1, 200, (n, ld)).astype(host.dtype)
+        padded[:, :S] = host
+        m = K.CountMatrix(n, S, cb, K.LAYOUT_ROWS, ld=ld, with_kmers=False)
+        K._native.check(K._native.lib().kmd_memcpy_h2d(m.counts.ptr, padded.ctypes.data, padded.nbytes, None))
+        tcs, tks = totals_of(host, nc)
+        want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), lf, 0.05)
+        obs, acc, ns = run_filter(K, m, nc, nk, tcs, tks, 10000, 0.05)
+        got = acc.get()
+        assert obs.total() == n, (nc, nk, cb, n)
+        assert got["row"].tolist() == want["row"].tolist(), (nc, nk, cb, n, ld)
+        assert got["sign"].tolist() == want["sign"].tolist()
+        assert np.allclose(got["pvalue"], want["pvalue"], rtol=0, atol=1e-10)
+        assert got["mean_control"].tolist() == want["mean_control"].tolist() and got["mean_case"].tolist() == want["mean_case"].tolist()
+
+
 def test_survivor_capacity_overflow_is_reported(K, oracle):
     n = 5000
     mat = K.synth_matrix(SEED, 1, n, 4, 4, 4, K.LAYOUT_SOA)

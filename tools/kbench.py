@@ -21,7 +21,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--thr", type=float, default=5e-7)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--tile-rows", type=int, default=0, help="T of the tiled layout (default 4096)")
     a = ap.parse_args()
+    if a.tile_rows:
+        import kmdiff_amd.hip as H
+        H.TILED_BLOCK_ROWS = a.tile_rows
     layout = {"soa": K.LAYOUT_SOA, "rows": K.LAYOUT_ROWS, "tiled": K.LAYOUT_TILED}[a.layout]
     mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, a.nc, a.nk, a.count_bytes, layout)
     tot = K.column_sums(mat)
