@@ -15,6 +15,9 @@ kb rows_4v4      --layout rows --nc 4 --nk 4 --rows 100000000
 kb rows_50v50    --layout rows --nc 50 --nk 50 --rows 16000000
 kb rows_100v100  --layout rows --nc 100 --nk 100 --rows 8000000
 kb rows_u16      --layout rows --count-bytes 2
+kb rows_21v21    --layout rows --nc 21 --nk 21
+kb rows_3v3      --layout rows --nc 3 --nk 3 --rows 100000000
+kb rows_u8       --layout rows --count-bytes 1
 for k in even random clustered; do
   for s in 4 20 100; do
     KMD_MERGE_PATH=fast-only run tools/kbench_merge.py --nc $s --nk $s --rows $((80000000 / s)) --iters 3 --keys $k
