@@ -94,6 +94,15 @@ template <> struct vec_of<uint8_t, 16> { using type = uint4; };
 template <typename CT> struct acc_of { using type = uint32_t; };
 template <> struct acc_of<uint32_t> { using type = uint64_t; };
 
+// the 4 / 2 counts packed in a dword added to acc in one instruction (v_sad_u8 / v_sad_u16 against
+// zero): for the row-major kernels, where a lane's dword holds counts of ONE row
+template <typename CT>
+__device__ __forceinline__ uint32_t add_packed(uint32_t w, uint32_t acc)
+{
+  if constexpr (sizeof(CT) == 1) return __builtin_amdgcn_sad_u8(w, 0u, acc);
+  else return __builtin_amdgcn_sad_u16(w, 0u, acc);
+}
+
 // LogFactorialTable::operator[] for k >= table size (log_factorial_table.hpp:14-18 falls back
 // to the O(k) loop log(k) + log(k-1) + ... + log(2), src/log_factorial_table.cpp:13-22).
 //   k <  kStirlingMin : the same descending loop, per lane (bounded, reference order);
@@ -799,18 +808,29 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
         {
           const uint32_t d[4] = { v.x, v.y, v.z, v.w };
           const bool all_c = e0 + epv <= nc, all_k = e0 >= nc && e0 + epv <= S;
+          if (all_c)
+          {
 #pragma unroll
-          for (uint32_t j = 0; j < 4; ++j)
+            for (uint32_t j = 0; j < 4; ++j) sc = add_packed<CT>(d[j], sc);
+          }
+          else if (all_k)
+          {
 #pragma unroll
-            for (uint32_t e = 0; e < per; ++e)
-            {
-              const uint32_t x = (d[j] >> (8 * sizeof(CT) * e)) & emask;
-              const uint32_t el = e0 + j * per + e;
-              if (all_c) sc += x;
-              else if (all_k) sk += x;
-              else if (el < nc) sc += x;
-              else if (el < S) sk += x;
-            }
+            for (uint32_t j = 0; j < 4; ++j) sk = add_packed<CT>(d[j], sk);
+          }
+          else
+          {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+              for (uint32_t e = 0; e < per; ++e)
+              {
+                const uint32_t x = (d[j] >> (8 * sizeof(CT) * e)) & emask;
+                const uint32_t el = e0 + j * per + e;
+                if (el < nc) sc += x;
+                else if (el < S) sk += x;
+              }
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // tile consumed before it is overwritten
@@ -1065,17 +1085,28 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
             }
             else
             {
+              if (all_c)
+              {
 #pragma unroll
-              for (uint32_t j = 0; j < 4; ++j)
+                for (uint32_t j = 0; j < 4; ++j) sc[u] = add_packed<CT>(d[j], sc[u]);
+              }
+              else if (all_k)
+              {
 #pragma unroll
-                for (uint32_t e = 0; e < per; ++e)
-                {
-                  const uint32_t x = (d[j] >> (8 * sizeof(CT) * e)) & emask;
-                  const uint32_t el = e0 + j * per + e;
-                  if (all_c) sc[u] += x;
-                  else if (all_k) sk[u] += x;
-                  else { sc[u] += el < nc ? x : 0u; sk[u] += (el >= nc && el < S) ? x : 0u; }
-                }
+                for (uint32_t j = 0; j < 4; ++j) sk[u] = add_packed<CT>(d[j], sk[u]);
+              }
+              else
+              {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+                  for (uint32_t e = 0; e < per; ++e)
+                  {
+                    const uint32_t x = (d[j] >> (8 * sizeof(CT) * e)) & emask;
+                    const uint32_t el = e0 + j * per + e;
+                    sc[u] += el < nc ? x : 0u; sk[u] += (el >= nc && el < S) ? x : 0u;
+                  }
+              }
             }
           }
         }
@@ -1297,7 +1328,7 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   const bool dword_rows = (P.ld % per == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 3u) == 0);
   // pitch not a multiple of 16 bytes (21v21 four-byte counts: 168 B): the flat wave-private kernel,
   // with the most rows per span (64, 32, ... 2) that fit its 4 KB tile and keep spans 16-byte aligned
-  if (((P.ld * sizeof(CT)) % 16 != 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
+  if ((((P.ld * sizeof(CT)) % 16 != 0) || std::getenv("KMD_ROWS_FLAT_ALL")) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
       std::getenv("KMD_ROWS_FLAT_OFF") == nullptr)
   {
     const size_t pitch = P.ld * sizeof(CT);
