@@ -135,3 +135,17 @@ def test_streaming_kmer_reader(tmp_path, count_bytes, two, compressed, n):
     if two:
         assert (np.frombuffer(raw[8 * n:16 * n], "<u8") == hi).all()
     assert (np.frombuffer(raw[-4 * n:] if n else b"", "<u4") == ct).all()
+
+
+def test_streaming_kmer_reader_rejects_a_truncated_frame(tmp_path):
+    rng = np.random.default_rng(9)
+    n = 50_000
+    km = np.sort(rng.integers(0, 1 << 62, n, dtype=np.uint64))
+    KF.write_kmer_file(str(tmp_path / "s.kmer.lz4"), 31, 0, 0, km, np.ones(n, dtype=np.uint32))
+    whole = open(tmp_path / "s.kmer.lz4", "rb").read()
+    open(tmp_path / "cut.kmer.lz4", "wb").write(whole[:len(whole) // 2])
+    rc, out, err = tool("kmers", tmp_path / "cut.kmer.lz4", tmp_path / "dump")
+    assert rc == 1 and "truncated LZ4 frame" in err
+    open(tmp_path / "nomark.kmer.lz4", "wb").write(whole[:-4])          # the 4-byte end mark cut off
+    rc, out, err = tool("kmers", tmp_path / "nomark.kmer.lz4", tmp_path / "dump")
+    assert rc == 1 and "truncated LZ4 frame" in err
