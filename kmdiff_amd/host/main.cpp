@@ -187,58 +187,673 @@ struct dev_buf
   ~dev_buf() { if (p) kmd_free(p); }
 };
 
+
+// ---- the run: what parse() and the run directory fix once, shared by the stages -------------
+struct run_context
+{
+  diff_options opt;
+  int ndev = 0;
+  kmtricks_config cfg;
+  bool two_limbs = false;                                // KSIZE 32 / 64, src/main.cc:75
+  std::vector<fof_entry> fof;
+  size_t S = 0;                                          // controls + cases
+  std::vector<uint64_t> total_controls, total_cases;     // cmd/diff.hpp:111
+  kmd_model* model0 = nullptr;                           // the model on the first device (cmd/diff.hpp:117-123)
+  double first_threshold = 0;                            // cmd/diff.hpp:147
+  std::shared_ptr<kmdiff::IModel<kmdiff::maxc32>> plugin;    // --cmodel
+  size_t n_workers = 1;                                  // GPUs (folded onto the ones there are)
+  std::string part_dir, pop_dir;
+  bool want_counts = false;                              // survivors carry their count rows (pop-strat, --keep-tmp, --save-sk)
+};
+
+// ---- what stage 1 (or the files of a previous run) hands to the later stages
+struct survivors_of_run
+{
+  survivor_set sv_all;                                   // survivors of all partitions, partition after partition
+  std::vector<size_t> part_begin;                        // [nb_partitions + 1] into sv_all
+  uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+  std::vector<double> Z_device;                          // [S][10] when the device PCA ran
+};
+
+// ---- host side of a partition ------------------------------------------------------------------
+// Its S files are LZ4-decoded by up to -t threads (the reference spends -t on whole partitions,
+// merge.hpp:239-307; here the device takes the partitions one after the other and the threads take
+// the files), and partition p + 1 is decoded while the device works on partition p.
+struct pinned                                           // page-locked staging array, grown as needed, reused
+{
+  void* p = nullptr; size_t cap = 0;
+  void reserve(size_t bytes, size_t keep = 0)           // the first `keep` bytes survive
+  {
+    if (bytes <= cap) return;
+    void* q = nullptr;
+    ck(kmd_malloc_host(&q, bytes), "kmd_malloc_host");
+    if (keep) std::memcpy(q, p, keep);
+    if (p) kmd_free_host(p);
+    p = q; cap = bytes;
+  }
+  ~pinned() { if (p) kmd_free_host(p); }
+};
+struct sample_stream                                    // one sample's file of a partition, decoded
+{
+  pinned kmers, kmers_hi, counts;
+  record_sink sink;
+  size_t n = 0;
+};
+struct partition_input
+{
+  matrix_rows m;                                        // the matrices/ feed
+  std::vector<sample_stream> st;                        // the S streams, each in its own page-locked arrays
+  std::vector<uint64_t> offs;
+  size_t n = 0;
+};
+
+class partition_loader
+{
+public:
+  partition_loader(const run_context& C, std::vector<std::string> matrix_files)
+    : C_(C), mpaths_(std::move(matrix_files)), threads_(std::max<size_t>(C.opt.threads / C.n_workers, 1)) {}
+  bool from_matrix() const { return !mpaths_.empty(); }
+  const std::vector<std::string>& matrix_files() const { return mpaths_; }
+
+  // The S files of partition p are decoded in parallel, each as a stream (LZ4 chunk -> records ->
+  // the sample's page-locked arrays, which live as long as the staging slot: nothing is allocated
+  // per partition once the arrays have grown to the run's file sizes).
+  void load(size_t p, partition_input* in) const
+  {
+    if (from_matrix()) { in->m = read_matrix_file(mpaths_[p]); return; }
+    const size_t S = C_.S;
+    const bool two_limbs = C_.two_limbs;
+    if (in->st.size() != S)
+    {
+      in->st = std::vector<sample_stream>(S);
+      for (auto& st : in->st)
+      {
+        sample_stream* self = &st;
+        st.sink.reserve = [self, two_limbs](record_sink& k, size_t n)
+        {
+          const size_t keep = k.capacity;                // grows only while a file is being read: all of it is live
+          self->kmers.reserve(n * 8, keep * 8); self->counts.reserve(n * 4, keep * 4);
+          if (two_limbs) self->kmers_hi.reserve(n * 8, keep * 8);
+          k.kmers = (uint64_t*)self->kmers.p; k.counts = (uint32_t*)self->counts.p;
+          k.kmers_hi = two_limbs ? (uint64_t*)self->kmers_hi.p : nullptr;
+          k.capacity = n;
+        };
+      }
+    }
+    for_samples([&](size_t s2)
+    {
+      const kmer_file_info f = stream_kmer_file(kmer_file_path(C_.opt.kmtricks_dir, p, C_.fof[s2].id), C_.cfg.kmer_size, in->st[s2].sink);
+      if ((f.slots == 2) != two_limbs) throw std::runtime_error("k-mer width of a sample file differs from the run's");
+      in->st[s2].n = f.records;
+    });
+    in->offs.assign(S + 1, 0);
+    for (size_t s2 = 0; s2 < S; ++s2) in->offs[s2 + 1] = in->offs[s2] + in->st[s2].n;         // KmDir::get_files_to_merge order
+    in->n = in->offs[S];
+  }
+
+private:
+  // body(s) for every sample on this worker's share of the -t threads; the first exception is rethrown
+  void for_samples(const std::function<void(size_t)>& body) const
+  {
+    const size_t S = C_.S;
+    std::atomic<size_t> next { 0 };
+    std::mutex mu;
+    std::exception_ptr err;
+    auto work = [&]()
+    {
+      for (size_t s2; (s2 = next++) < S;)
+      {
+        try { body(s2); }
+        catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < std::min(threads_, S); ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (err) std::rethrow_exception(err);
+  }
+
+  const run_context& C_;
+  std::vector<std::string> mpaths_;
+  size_t threads_;
+};
+
+// ---- one GPU of stage 1 ------------------------------------------------------------------------
+// One worker thread per GPU; partition p belongs to worker p % n_workers (the sharding of
+// kmdiff_amd/dist.py, in one process).  A worker keeps its survivors in its own set; they are put
+// in partition order afterwards.
+struct worker_result
+{
+  survivor_set sv;
+  std::vector<std::pair<size_t, size_t>> span;     // per partition of this worker: (begin, count) in sv
+  uint64_t total = 0, n_sig = 0, n_ctrl = 0, n_case = 0, n_sampled = 0;
+  std::vector<double> xtx;                         // the worker's PCA Gram matrix
+  std::string error;
+};
+
+// worker wi: partitions wi, wi + n_workers, ... of the n_units there are -> R
+void gpu_worker_partitions(const run_context& C, const partition_loader& loader, const size_t wi, const size_t n_units, const bool run_pca,
+                    const stopwatch& merge_time, worker_result& R)
+{
+  const diff_options& opt = C.opt;
+  const kmtricks_config& cfg = C.cfg;
+  const size_t S = C.S, n_workers = C.n_workers;
+  const int ndev = C.ndev;
+  const bool two_limbs = C.two_limbs, want_counts = C.want_counts;
+  const std::vector<uint64_t>& total_controls = C.total_controls;
+  const std::vector<uint64_t>& total_cases = C.total_cases;
+  kmd_model* const model0 = C.model0;
+  const double first_threshold = C.first_threshold;
+  const std::shared_ptr<kmdiff::IModel<kmdiff::maxc32>>& plugin = C.plugin;
+  const bool from_matrix = loader.from_matrix();
+  const std::vector<std::string>& mpaths = loader.matrix_files();
+  const size_t T = 4096;                                 // rows per block of the tiled layout K2 writes
+  const int dev = (opt.device + (int)wi) % ndev;
+  ck(kmd_set_device(dev), "kmd_set_device");
+  kmd_model* model = wi == 0 ? model0 : nullptr;                                             // a model lives on one device
+  if (wi != 0)
+    ck(kmd_model_create(&model, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
+       "kmd_model_create");
+  kmd_pca* pca = nullptr;
+  if (run_pca) ck(kmd_pca_create(&pca, (int)S, opt.kmer_pca, opt.seed, opt.ploidy == 2 ? 1 : 0, (size_t)1 << 20), "kmd_pca_create");   // grows
+  survivor_set& sv_all = R.sv;                       // (this worker's)
+  sv_all.n_counts = want_counts ? S : 0;
+  sv_all.kmer_bytes = two_limbs ? 16 : 8;
+  uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+  dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
+          d_smk, d_sc;
+  // a ring of staging sets: the partition being processed and `depth` more being decoded (deeper
+  // than 1 measured no gain with 256 host threads: the decode is not what is left to hide)
+  const size_t depth = 1;
+  std::vector<partition_input> staging(depth + 1);
+  std::vector<std::future<void>> ahead(depth + 1);
+  double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
+                                                       // the wait spent on the ring's first turn (its arrays get page-locked then)
+  size_t issued = 0;                                   // partitions of this worker handed to the loader
+  auto issue = [&]()
+  {
+    const size_t p_next = wi + issued * n_workers;
+    if (p_next < n_units)
+      ahead[issued % (depth + 1)] = std::async(std::launch::async, [&loader, p_next, in = &staging[issued % (depth + 1)]]() { loader.load(p_next, in); });
+    ++issued;
+  };
+  if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] GPU %d: worker ready %.3f s into stage 1\n", dev, merge_time.seconds());
+  for (size_t d = 0; d < depth; ++d) issue();
+  size_t turn = 0;
+  for (size_t p = wi; p < n_units; p += n_workers, ++turn)
+  {
+    kmd_tile tile {};
+    uint64_t n_rows = 0;
+    issue();                                           // into the slot processed one ring turn ago
+    const stopwatch t_wait;
+    ahead[turn % (depth + 1)].get();
+    t_loader += t_wait.seconds();
+    if (turn <= depth) t_first += t_wait.seconds();
+    const stopwatch t_dev;
+    partition_input& in = staging[turn % (depth + 1)];
+    if (from_matrix)
+    {
+      // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
+      const matrix_rows& m = in.m;
+      if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
+      if (two_limbs != !m.kmers_hi.empty()) die(mpaths[p] + ": k-mer width differs from the run's");
+      n_rows = m.kmers.size();
+      if (n_rows)
+      {
+        d_matrix.reserve(n_rows * S * 4); d_kmer_col.reserve(n_rows * 8);
+        ck(kmd_memcpy_h2d(d_matrix.p, m.counts.data(), n_rows * S * 4, nullptr), "h2d");
+        ck(kmd_memcpy_h2d(d_kmer_col.p, m.kmers.data(), n_rows * 8, nullptr), "h2d");
+        if (two_limbs)
+        {
+          d_kmer_col_hi.reserve(n_rows * 8);
+          ck(kmd_memcpy_h2d(d_kmer_col_hi.p, m.kmers_hi.data(), n_rows * 8, nullptr), "h2d");
+        }
+      }
+      tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p,
+                        two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
+    }
+    else
+    {
+      const std::vector<uint64_t>& offs = in.offs;
+      const size_t n = in.n;
+      if (n)
+      {
+        d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
+        if (two_limbs) d_kmers_hi.reserve(n * 8);
+        for (size_t s2 = 0; s2 < S; ++s2)                 // each stream to its place in the partition's arrays
+        {
+          const sample_stream& st = in.st[s2];
+          ck(kmd_memcpy_h2d((char*)d_kmers.p + offs[s2] * 8, st.kmers.p, st.n * 8, nullptr), "h2d");
+          ck(kmd_memcpy_h2d((char*)d_counts.p + offs[s2] * 4, st.counts.p, st.n * 4, nullptr), "h2d");
+          if (two_limbs) ck(kmd_memcpy_h2d((char*)d_kmers_hi.p + offs[s2] * 8, st.kmers_hi.p, st.n * 8, nullptr), "h2d");
+        }
+        d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
+        if (two_limbs)
+        {
+          d_kmer_col_hi.reserve(n * 8);
+        }
+        ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
+                               (const uint32_t*)d_counts.p, offs.data(), 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED,
+                               plugin ? S : T, n, d_matrix.p,
+                               (uint64_t*)d_kmer_col.p, two_limbs ? (uint64_t*)d_kmer_col_hi.p : nullptr, &n_rows, nullptr),
+           "kmd_merge_partition");
+      }
+      tile = kmd_tile { d_matrix.p, 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED, plugin ? S : T, (const uint64_t*)d_kmer_col.p,
+                        two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
+    }
+    size_t ns = 0;
+    const size_t base = sv_all.size();
+    if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");             // merge.hpp:150-152
+    if (n_rows && plugin)
+    {
+      // diff_observer::process with the user's model (merge.hpp:68-103): the merged rows come
+      // back to the host, row-major, and go through process() one by one
+      std::vector<uint32_t> rows(n_rows * S);
+      std::vector<uint64_t> km(n_rows), kmh(two_limbs ? n_rows : 0);
+      ck(kmd_memcpy_d2h(rows.data(), d_matrix.p, n_rows * S * 4, nullptr), "d2h");
+      ck(kmd_memcpy_d2h(km.data(), d_kmer_col.p, n_rows * 8, nullptr), "d2h");
+      if (two_limbs) ck(kmd_memcpy_d2h(kmh.data(), d_kmer_col_hi.p, n_rows * 8, nullptr), "d2h");
+      std::vector<uint32_t> row(S);
+      for (size_t i = 0; i < n_rows; ++i)
+      {
+        std::copy(rows.begin() + i * S, rows.begin() + (i + 1) * S, row.begin());
+        kmdiff::Range<uint32_t> controls(row, 0, opt.nb_controls), cases(row, opt.nb_controls, opt.nb_cases);
+        auto [pv, sg, mc, mk] = plugin->process(controls, cases);
+        ++total_kmers;
+        if (pv <= first_threshold)
+        {
+          sv_all.kmer.push_back(km[i]);
+          if (two_limbs) sv_all.kmer_hi.push_back(kmh[i]);
+          sv_all.p.push_back(pv); sv_all.sign.push_back((int32_t)sg);
+          sv_all.mean_control.push_back(mc); sv_all.mean_case.push_back(mk);
+          if (want_counts) for (size_t s2 = 0; s2 < S; ++s2) sv_all.counts.push_back((double)row[s2]);
+          if (sg == kmdiff::Significance::CONTROL) ++n_sig_control; else ++n_sig_case;        // merge.hpp:95-98
+          ++n_sig; ++ns;
+        }
+      }
+    }
+    else if (n_rows)
+    {
+      // survivor sink sized for the worst case of this partition (every row)
+      d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
+      d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
+      if (two_limbs) d_skmer_hi.reserve(n_rows * 8);
+      ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
+      kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, two_limbs ? (uint64_t*)d_skmer_hi.p : nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
+                         (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
+      ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
+      uint64_t c[KMD_NCOUNTERS];
+      ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+      ns = (size_t)c[KMD_CNT_SIG];
+      ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                     // reference push order
+      sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
+      sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);
+      if (two_limbs) sv_all.kmer_hi.resize(base + ns);
+      if (ns)
+      {
+        ck(kmd_memcpy_d2h(sv_all.kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
+        if (two_limbs) ck(kmd_memcpy_d2h(sv_all.kmer_hi.data() + base, d_skmer_hi.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.mean_control.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.mean_case.data() + base, d_smk.p, ns * 8, nullptr), "d2h");
+        if (want_counts)                                                                  // merge.hpp:91-92
+        {
+          d_sc.reserve(ns * S * 8);
+          ck(kmd_survivors_gather_counts(&tile, (int)S, (const uint64_t*)d_srow.p, ns, (double*)d_sc.p, nullptr), "gather_counts");
+          sv_all.counts.resize((base + ns) * S);
+          ck(kmd_memcpy_d2h(sv_all.counts.data() + base * S, d_sc.p, ns * S * 8, nullptr), "d2h");
+        }
+      }
+      total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
+    }
+    t_device += t_dev.seconds();
+    if (turn > depth) t_steady += t_wait.seconds();       // decoder wait + device work of this partition
+    R.span.emplace_back(base, ns);
+    if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
+    {
+      matrix_rows sk; sk.kmer_size = (uint32_t)cfg.kmer_size; sk.count_bytes = 4; sk.nb_counts = (uint32_t)S; sk.partition = (uint32_t)p;
+      sk.kmers.assign(sv_all.kmer.begin() + base, sv_all.kmer.end());
+      if (two_limbs) sk.kmers_hi.assign(sv_all.kmer_hi.begin() + base, sv_all.kmer_hi.end());
+      sk.counts.resize(ns * S);
+      for (size_t i = 0; i < ns * S; ++i) sk.counts[i] = (uint32_t)sv_all.counts[base * S + i];
+      write_matrix_file(opt.output_directory + "/positive_kmer_matrix/matrices/matrix_" + std::to_string(p) + ".count.lz4", sk);
+    }
+  }
+  R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case;
+  if (opt.verbose_timing)
+  {
+    std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder (%.3f s of it for the first %zu partitions, whose staging arrays "
+                         "get page-locked), %.3f s in copies + kernels\n", dev, t_loader, t_first, depth + 1, t_device);
+    std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1\n", dev, merge_time.seconds());
+    if (turn > depth + 1)
+      std::fprintf(stderr, "[kmdiff-hip] GPU %d: steady state %.2f ms per partition (%zu partitions after the first %zu)\n", dev,
+                   1e3 * t_steady / (double)(turn - depth - 1), turn - depth - 1, depth + 1);
+  }
+  if (pca)
+  {
+    ck(kmd_pca_count(pca, &R.n_sampled), "kmd_pca_count");
+    R.xtx.assign(S * S, 0.0);
+    ck(kmd_pca_gram(pca, R.xtx.data(), nullptr), "kmd_pca_gram");
+    kmd_pca_destroy(pca);
+  }
+  if (wi != 0) kmd_model_destroy(model);
+}
+
+// the thread body: a worker's failure is reported by the launching thread (R.error)
+void run_gpu_worker(const run_context& C, const partition_loader& loader, const size_t wi, const size_t n_units, const bool run_pca,
+                    const stopwatch& merge_time, worker_result& R)
+{
+  try { gpu_worker_partitions(C, loader, wi, n_units, run_pca, merge_time, R); }
+  catch (const std::exception& e) { R.error = e.what(); }
+}
+
+// ---- stage 1: do_diff (cmd/diff.hpp:66-164): merge + Poisson test + threshold, partition after
+// partition on every GPU of the run; with run_pca the rows are sampled for the device PCA as they pass
+void do_diff(const run_context& C, survivors_of_run& O, const bool run_pca)
+{
+  const diff_options& opt = C.opt;
+  const kmtricks_config& cfg = C.cfg;
+  const size_t S = C.S, n_workers = C.n_workers;
+  const int ndev = C.ndev;
+  const bool two_limbs = C.two_limbs, want_counts = C.want_counts;
+  const std::string& part_dir = C.part_dir;
+  const std::string& pop_dir = C.pop_dir;
+  survivor_set& sv_all = O.sv_all;
+  std::vector<size_t>& part_begin = O.part_begin;
+  uint64_t& total_kmers = O.total_kmers; uint64_t& n_sig = O.n_sig; uint64_t& n_sig_control = O.n_sig_control; uint64_t& n_sig_case = O.n_sig_case;
+  std::vector<double>& Z_device = O.Z_device;
+
+  // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
+  std::fprintf(stderr, "[kmdiff-hip] Process partitions\n");
+  const stopwatch merge_time;
+  const partition_loader loader(C, matrix_paths(opt.kmtricks_dir));                       // cmd/diff.hpp:80-101
+  const bool from_matrix = loader.from_matrix();
+  const std::vector<std::string>& mpaths = loader.matrix_files();
+  if (opt.save_sk)                                                                        // cmd/diff.hpp:52-64,137-143
+  {
+    const std::string sk = opt.output_directory + "/positive_kmer_matrix";
+    fs::create_directories(sk + "/matrices");
+    for (const char* f : { "/options.txt", "/kmtricks.fof" })
+      if (fs::exists(opt.kmtricks_dir + f)) fs::copy(opt.kmtricks_dir + f, sk, fs::copy_options::overwrite_existing);
+    for (const char* dname : { "/config_gatb", "/repartition_gatb" })
+      if (fs::exists(opt.kmtricks_dir + dname))
+        fs::copy(opt.kmtricks_dir + dname, sk + dname, fs::copy_options::recursive | fs::copy_options::overwrite_existing);
+  }
+  // one accumulator per entry of counts/ (cmd/diff.hpp:103-107); matrix files map onto them in order
+  const size_t n_units = from_matrix ? std::min(mpaths.size(), cfg.nb_partitions) : cfg.nb_partitions;
+  if (from_matrix && mpaths.size() > cfg.nb_partitions) die("more files in matrices/ than partitions in counts/");
+  std::vector<worker_result> results(n_workers);
+  {
+    std::vector<std::thread> gpus;
+    for (size_t wi = 1; wi < n_workers; ++wi)
+      gpus.emplace_back([&, wi]() { run_gpu_worker(C, loader, wi, n_units, run_pca, merge_time, results[wi]); });
+    run_gpu_worker(C, loader, 0, n_units, run_pca, merge_time, results[0]);
+    for (auto& t : gpus) t.join();
+    if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] workers done %.3f s into stage 1 (staging arrays released)\n", merge_time.seconds());
+    ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
+    for (auto& R : results) if (!R.error.empty()) die(R.error);
+  }
+  // survivors in partition order (the order one GPU would have produced)
+  {
+    std::vector<size_t> taken(n_workers, 0);
+    for (size_t p = 0; p < n_units; ++p)
+    {
+      worker_result& R = results[p % n_workers];
+      const auto [b, cnt] = R.span[taken[p % n_workers]++];
+      sv_all.kmer.insert(sv_all.kmer.end(), R.sv.kmer.begin() + b, R.sv.kmer.begin() + b + cnt);
+      if (two_limbs) sv_all.kmer_hi.insert(sv_all.kmer_hi.end(), R.sv.kmer_hi.begin() + b, R.sv.kmer_hi.begin() + b + cnt);
+      sv_all.p.insert(sv_all.p.end(), R.sv.p.begin() + b, R.sv.p.begin() + b + cnt);
+      sv_all.sign.insert(sv_all.sign.end(), R.sv.sign.begin() + b, R.sv.sign.begin() + b + cnt);
+      sv_all.mean_control.insert(sv_all.mean_control.end(), R.sv.mean_control.begin() + b, R.sv.mean_control.begin() + b + cnt);
+      sv_all.mean_case.insert(sv_all.mean_case.end(), R.sv.mean_case.begin() + b, R.sv.mean_case.begin() + b + cnt);
+      if (want_counts) sv_all.counts.insert(sv_all.counts.end(), R.sv.counts.begin() + b * S, R.sv.counts.begin() + (b + cnt) * S);
+      part_begin[p + 1] = sv_all.size();
+    }
+    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; }
+  }
+  for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
+  if (run_pca)                                                                             // run_eigenstrat_smartpca
+  {
+    uint64_t n_sampled = 0;
+    std::vector<double> xtx(S * S, 0.0);
+    for (auto& R : results)                                                                // in worker order
+    {
+      n_sampled += R.n_sampled;
+      for (size_t i = 0; i < S * S; ++i) xtx[i] += R.xtx[i];
+    }
+    const int n_out = (int)std::min<size_t>(S, 10);                                        // popstrat.cpp:118
+    std::vector<double> ev(S * n_out), el(n_out);
+    ck(kmd_pca_eigen((int)S, xtx.data(), n_out, ev.data(), el.data()), "kmd_pca_eigen");
+    fs::create_directories(pop_dir);
+    std::ofstream pf(pop_dir + "/pcs.evec");
+    Z_device.assign(S * 10, 0.0);
+    for (size_t i = 0; i < S; ++i)
+    {
+      for (int k = 0; k < n_out; ++k)
+      {
+        char b[32]; std::snprintf(b, sizeof b, "%.04f", ev[i * n_out + k]);                 // evec2pca.perl
+        pf << ' ' << (ev[i * n_out + k] > 0 ? " " : "") << b;
+        Z_device[i * 10 + k] = std::strtod(b, nullptr);                                    // what load_Z reads back
+      }
+      pf << '\n';
+    }
+    std::fprintf(stderr, "[kmdiff-hip] PCA done: %" PRIu64 " k-mers sampled, eigenvalues %.4f %.4f\n", n_sampled, el[0],
+                 n_out > 1 ? el[1] : 0.0);
+  }
+  if (opt.keep_tmp)                                                                       // FileAccumulator, del = !keep_tmp
+    for (size_t p = 0; p < cfg.nb_partitions; ++p)
+      write_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
+  std::fprintf(stderr, "[kmdiff-hip] Partitions processed (%.3f s)\n", merge_time.seconds());                // cmd/diff.hpp:158
+  std::fprintf(stderr, "[kmdiff-hip] %" PRIu64 "/%" PRIu64 " significant k-mers.\n", n_sig, total_kmers);      // cmd/diff.hpp:160
+  std::fprintf(stderr, "[kmdiff-hip] Before correction: %" PRIu64 " (control), %" PRIu64 " (case).\n", n_sig_control, n_sig_case);
+}
+
+// ---- stage 1 skipped: the survivors of the previous run (cmd/diff.hpp:329-337).  The reference
+// takes total_kmers from the loaded options, which options.bin does not hold (diff_opt.hpp:78-88);
+// here it is kept in resume.txt next to options.bin.
+void load_previous_survivors(const run_context& C, survivors_of_run& O)
+{
+  const diff_options& opt = C.opt;
+  const kmtricks_config& cfg = C.cfg;
+  const size_t S = C.S;
+  const bool want_counts = C.want_counts;
+  const std::string& part_dir = C.part_dir;
+  survivor_set& sv_all = O.sv_all;
+  std::vector<size_t>& part_begin = O.part_begin;
+  uint64_t& total_kmers = O.total_kmers; uint64_t& n_sig = O.n_sig; uint64_t& n_sig_control = O.n_sig_control; uint64_t& n_sig_case = O.n_sig_case;
+
+  std::fprintf(stderr, "[kmdiff-hip] Resume: partitions/p*_uncorrected of the previous run\n");
+  for (size_t p = 0; p < cfg.nb_partitions; ++p)
+  {
+    read_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all);
+    part_begin[p + 1] = sv_all.size();
+  }
+  std::ifstream rs(opt.output_directory + "/resume.txt");
+  if (!(rs >> total_kmers >> n_sig >> n_sig_control >> n_sig_case)) die("resume.txt of the previous run is missing");
+  if (want_counts && sv_all.size() && sv_all.n_counts != S) die("previous run's survivor files hold another sample count");
+}
+
+
+// ---- the run directory and the devices -> run_context (src/main.cc:74-75, cmd/diff.hpp:109-133)
+void open_run(run_context& C)
+{
+  diff_options& opt = C.opt;
+  int& ndev = C.ndev;
+  if (kmd_device_count(&ndev) != KMD_OK || ndev < 1) die("no HIP device: kmdiff-hip has no CPU path");
+  ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
+  char dn[256]; ck(kmd_device_name(dn, sizeof dn), "kmd_device_name");
+  std::fprintf(stderr, "[kmdiff-hip] device %d: %s\n", opt.device % ndev, dn);
+
+  C.cfg = get_kmtricks_config(opt.kmtricks_dir);
+  const kmtricks_config& cfg = C.cfg;                       // src/main.cc:74
+  if (cfg.kmer_size > 64) die("k > 64 is not supported");
+  C.two_limbs = cfg.kmer_size > 32;                                                // KSIZE 32 / 64, src/main.cc:75
+  C.fof = read_fof(opt.kmtricks_dir);
+  const std::vector<fof_entry>& fof = C.fof;
+  C.S = opt.nb_controls + opt.nb_cases;
+  const size_t S = C.S;
+  if (fof.size() < S) die("kmtricks.fof has fewer samples than -1 + -2");
+  C.total_controls.assign(opt.nb_controls, 0); C.total_cases.assign(opt.nb_cases, 0);
+  std::vector<uint64_t>& total_controls = C.total_controls;
+  std::vector<uint64_t>& total_cases = C.total_cases;       // cmd/diff.hpp:111
+  for (size_t i = 0; i < opt.nb_controls; ++i) total_controls[i] = sample_total(opt.kmtricks_dir, fof[i], cfg.abundance_min);
+  for (size_t i = 0; i < opt.nb_cases; ++i) total_cases[i] = sample_total(opt.kmtricks_dir, fof[opt.nb_controls + i], cfg.abundance_min);
+
+  kmd_model*& model0 = C.model0;                                                              // cmd/diff.hpp:117-123
+  ck(kmd_model_create(&model0, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
+     "kmd_model_create");
+  C.first_threshold = opt.threshold / (double)opt.cutoff;                       // cmd/diff.hpp:147
+  // A user's model plugin (model_manager.hpp:33-94: dlopen, plugin_name, create<bits>, configure).
+  // Arbitrary host code cannot run on the device: its rows are evaluated by the reference's own
+  // loop -- process(controls, cases) per row, one instance shared by all workers (it has to be
+  // re-entrant there too, merge.hpp:418) --, everything around it (merge, correction) stays on
+  // the GPU.  Pop-strat correction is switched off with custom models, cmd/diff.hpp:127-132.
+  std::shared_ptr<kmdiff::IModel<kmdiff::maxc32>>& plugin = C.plugin;
+  if (!opt.model_lib_path.empty())
+  {
+    void* h = dlopen(opt.model_lib_path.c_str(), RTLD_LAZY);
+    if (!h) die(std::string("--cmodel: ") + dlerror());
+    auto name = reinterpret_cast<std::string (*)()>(dlsym(h, "plugin_name"));
+    auto create = reinterpret_cast<kmdiff::IModel<kmdiff::maxc32>* (*)()>(dlsym(h, "create32"));
+    if (!name || !create) die(std::string("--cmodel: ") + dlerror());
+    std::fprintf(stderr, "[kmdiff-hip] model plugin: %s\n", name().c_str());
+    plugin.reset(create());
+    plugin->configure(opt.model_config);
+    if (opt.pop_correction) std::fprintf(stderr, "[kmdiff-hip] warning: population stratification correction disabled with custom models.\n");
+    opt.pop_correction = false;
+  }
+  C.n_workers = (size_t)std::max(1, opt.devices == 0 ? ndev : opt.devices);       // GPUs (folded onto the ones there are)
+  C.part_dir = opt.output_directory + "/partitions";
+  C.pop_dir = opt.output_directory + "/popstrat";
+  C.want_counts = opt.pop_correction || opt.keep_tmp || opt.save_sk;
+}
+
+// ---- stage 2: do_pop (cmd/diff.hpp:167-224): the survivors' p-values from the pop-strat model, or
+// (resume) from the p<i>_popstrat_uncorrected files of the previous run
+void do_pop(const run_context& C, survivors_of_run& O, const bool run_stage2)
+{
+  const diff_options& opt = C.opt;
+  const kmtricks_config& cfg = C.cfg;
+  const size_t S = C.S;
+  const std::vector<uint64_t>& total_controls = C.total_controls;
+  const std::vector<uint64_t>& total_cases = C.total_cases;
+  const std::string& part_dir = C.part_dir;
+  const std::string& pop_dir = C.pop_dir;
+  survivor_set& sv_all = O.sv_all;
+  const std::vector<size_t>& part_begin = O.part_begin;
+  const std::vector<double>& Z_device = O.Z_device;
+  std::vector<double>& s_p = sv_all.p;
+  const std::vector<double>& s_counts = sv_all.counts;
+  const size_t n = s_p.size();
+  if (opt.pop_correction && !run_stage2)
+  {
+    std::fprintf(stderr, "[kmdiff-hip] Resume: partitions/p*_popstrat_uncorrected of the previous run\n");
+    survivor_set ps;
+    for (size_t p = 0; p < cfg.nb_partitions; ++p) read_survivor_file(part_dir + "/p" + std::to_string(p) + "_popstrat_uncorrected", ps);
+    if (ps.size() != n) die("previous run's pop-strat survivor files do not match");
+    s_p = ps.p;
+  }
+  const stopwatch pop_time;
+  if (run_stage2 && n)
+  {
+    std::vector<double> Z(S * 10, 0.0), Y(S, 0.0);
+    if (!Z_device.empty()) Z = Z_device;
+    else
+    {
+      const std::string zpath = opt.pcs.empty() ? pop_dir + "/pcs.evec" : opt.pcs;
+      std::ifstream zin(zpath);
+      if (!zin) die("cannot open " + zpath);
+      const size_t per_row = opt.pcs.empty() ? std::min<size_t>(S, 10) : 10;
+      for (size_t i = 0; i < S; ++i)
+        for (size_t k = 0; k < per_row; ++k)
+          if (!(zin >> Z[i * 10 + k])) die(zpath + ": expected " + std::to_string(per_row) + " values per sample");   // popstrat.cpp:153-161
+    }
+    for (size_t i = 0; i < opt.nb_controls; ++i) Y[i] = 1.0;                                                       // popstrat.cpp:168
+    kmd_popstrat* ps = nullptr;
+    ck(kmd_popstrat_create(&ps, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), Z.data(), 10,
+                           (int)opt.npc, Y.data(), opt.stand ? 1 : 0, (int)opt.max_iteration), "kmd_popstrat_create");
+    dev_buf d_c, d_p; d_c.reserve(n * S * 8); d_p.reserve(n * 8);
+    ck(kmd_memcpy_h2d(d_c.p, s_counts.data(), n * S * 8, nullptr), "h2d");
+    ck(kmd_popstrat_apply(ps, (const double*)d_c.p, 0, 0, n, (double*)d_p.p, nullptr), "kmd_popstrat_apply");
+    ck(kmd_memcpy_d2h(s_p.data(), d_p.p, n * 8, nullptr), "d2h");                                                  // ks.set_pval
+    kmd_popstrat_destroy(ps);
+    std::fprintf(stderr, "[kmdiff-hip] Population correction done. (%.3f s)\n", pop_time.seconds());              // cmd/diff.hpp:221
+  }
+  if (run_stage2 && opt.keep_tmp)
+    for (size_t p = 0; p < cfg.nb_partitions; ++p)
+      write_survivor_file(part_dir + "/p" + std::to_string(p) + "_popstrat_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
+}
+
+// ---- stage 3: do_correction (cmd/diff.hpp:227-260) and the writers (aggregator.hpp:26-71)
+void do_correction(const run_context& C, survivors_of_run& O)
+{
+  const diff_options& opt = C.opt;
+  const kmtricks_config& cfg = C.cfg;
+  const bool two_limbs = C.two_limbs;
+  const survivor_set& sv_all = O.sv_all;
+  const uint64_t total_kmers = O.total_kmers, n_sig = O.n_sig, n_sig_control = O.n_sig_control, n_sig_case = O.n_sig_case;
+  const std::vector<uint64_t>& s_kmer = sv_all.kmer;
+  const std::vector<double>& s_p = sv_all.p;
+  const std::vector<double>& s_mc = sv_all.mean_control;
+  const std::vector<double>& s_mk = sv_all.mean_case;
+  const std::vector<int32_t>& s_sign = sv_all.sign;
+  const size_t n = s_p.size();
+  dev_buf d_p, d_sign, d_keep;
+  d_p.reserve(std::max<size_t>(n, 1) * 8); d_sign.reserve(std::max<size_t>(n, 1) * 4); d_keep.reserve(std::max<size_t>(n, 1));
+  uint64_t kept = 0, c_controls = 0, c_cases = 0;
+  std::vector<uint8_t> keep(n, 0);
+  if (n)
+  {
+    ck(kmd_memcpy_h2d(d_p.p, s_p.data(), n * 8, nullptr), "h2d");
+    ck(kmd_memcpy_h2d(d_sign.p, s_sign.data(), n * 4, nullptr), "h2d");
+    ck(kmd_correct(correction_type(opt.correction), opt.threshold, total_kmers, (const double*)d_p.p, (const int32_t*)d_sign.p, n,
+                   (uint8_t*)d_keep.p, &kept, &c_controls, &c_cases, nullptr), "kmd_correct");
+    ck(kmd_memcpy_d2h(keep.data(), d_keep.p, n, nullptr), "d2h");
+  }
+  fs::create_directories(opt.output_directory);
+  // writers (aggregator.hpp:26-71).  BH/Holm emit in ascending p (the order the sorted
+  // aggregator pops them); the stateless correctors in partition order.
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = i;
+  if (opt.correction == "benjamini" || opt.correction == "holm")
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return s_p[a] < s_p[b]; });
+  std::ofstream fc(opt.output_directory + "/control_kmers.fasta"), fk(opt.output_directory + "/case_kmers.fasta");
+  size_t ic = 0, ik = 0;
+  for (size_t i : order)
+  {
+    if (!keep[i]) continue;
+    const bool control = s_sign[i] == KMD_SIGN_CONTROL;                                     // aggregator.hpp:155-162
+    std::ofstream& f = control ? fc : fk;
+    size_t& idx = control ? ic : ik;
+    char pv[64]; std::snprintf(pv, sizeof pv, "%g", s_p[i]);                               // {:g}
+    f << '>' << idx << "_pval=" << pv << "_control=" << (uint64_t)s_mc[i] << "_case=" << shortest(s_mk[i]) << '\n'
+      << (two_limbs ? kmer_to_string(sv_all.kmer_hi[i], s_kmer[i], cfg.kmer_size) : kmer_to_string(s_kmer[i], cfg.kmer_size)) << '\n';
+    ++idx;
+  }
+  std::fprintf(stderr, "[kmdiff-hip] Significant k-mers: %" PRIu64 " (control), %" PRIu64 " (case).\n", c_controls, c_cases);   // cmd/diff.hpp:259
+  // machine-readable summary for tests and scripts
+  std::ofstream js(opt.output_directory + "/summary.json");
+  js << "{\"total_kmers\": " << total_kmers << ", \"n_sig\": " << n_sig << ", \"n_sig_control\": " << n_sig_control
+     << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
+     << ", \"kept_case\": " << c_cases << ", \"kmer_size\": " << cfg.kmer_size << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
+}
+
 } // namespace
 
 int main(int argc, char** argv)
 {
-  diff_options opt = parse(argc, argv);
+  run_context C;
+  C.opt = parse(argc, argv);
   try
   {
     const stopwatch whole_time;
-    int ndev = 0;
-    if (kmd_device_count(&ndev) != KMD_OK || ndev < 1) die("no HIP device: kmdiff-hip has no CPU path");
-    ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
-    char dn[256]; ck(kmd_device_name(dn, sizeof dn), "kmd_device_name");
-    std::fprintf(stderr, "[kmdiff-hip] device %d: %s\n", opt.device % ndev, dn);
-
-    const kmtricks_config cfg = get_kmtricks_config(opt.kmtricks_dir);                       // src/main.cc:74
-    if (cfg.kmer_size > 64) die("k > 64 is not supported");
-    const bool two_limbs = cfg.kmer_size > 32;                                                // KSIZE 32 / 64, src/main.cc:75
-    const auto fof = read_fof(opt.kmtricks_dir);
-    const size_t S = opt.nb_controls + opt.nb_cases;
-    if (fof.size() < S) die("kmtricks.fof has fewer samples than -1 + -2");
-    std::vector<uint64_t> total_controls(opt.nb_controls), total_cases(opt.nb_cases);       // cmd/diff.hpp:111
-    for (size_t i = 0; i < opt.nb_controls; ++i) total_controls[i] = sample_total(opt.kmtricks_dir, fof[i], cfg.abundance_min);
-    for (size_t i = 0; i < opt.nb_cases; ++i) total_cases[i] = sample_total(opt.kmtricks_dir, fof[opt.nb_controls + i], cfg.abundance_min);
-
-    kmd_model* model0 = nullptr;                                                              // cmd/diff.hpp:117-123
-    ck(kmd_model_create(&model0, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
-       "kmd_model_create");
-    const double first_threshold = opt.threshold / (double)opt.cutoff;                       // cmd/diff.hpp:147
-    // A user's model plugin (model_manager.hpp:33-94: dlopen, plugin_name, create<bits>, configure).
-    // Arbitrary host code cannot run on the device: its rows are evaluated by the reference's own
-    // loop -- process(controls, cases) per row, one instance shared by all workers (it has to be
-    // re-entrant there too, merge.hpp:418) --, everything around it (merge, correction) stays on
-    // the GPU.  Pop-strat correction is switched off with custom models, cmd/diff.hpp:127-132.
-    std::shared_ptr<kmdiff::IModel<kmdiff::maxc32>> plugin;
-    if (!opt.model_lib_path.empty())
-    {
-      void* h = dlopen(opt.model_lib_path.c_str(), RTLD_LAZY);
-      if (!h) die(std::string("--cmodel: ") + dlerror());
-      auto name = reinterpret_cast<std::string (*)()>(dlsym(h, "plugin_name"));
-      auto create = reinterpret_cast<kmdiff::IModel<kmdiff::maxc32>* (*)()>(dlsym(h, "create32"));
-      if (!name || !create) die(std::string("--cmodel: ") + dlerror());
-      std::fprintf(stderr, "[kmdiff-hip] model plugin: %s\n", name().c_str());
-      plugin.reset(create());
-      plugin->configure(opt.model_config);
-      if (opt.pop_correction) std::fprintf(stderr, "[kmdiff-hip] warning: population stratification correction disabled with custom models.\n");
-      opt.pop_correction = false;
-    }
-    const size_t n_workers = (size_t)std::max(1, opt.devices == 0 ? ndev : opt.devices);       // GPUs (folded onto the ones there are)
+    open_run(C);
+    const diff_options& opt = C.opt;
 
     // ---- what a previous run left behind (cmd/diff.hpp:278-303)
-    const std::string part_dir = opt.output_directory + "/partitions";
-    fs::create_directories(part_dir);
+    fs::create_directories(C.part_dir);
     resume_options ropt; ropt.threshold = opt.threshold; ropt.cutoff = (double)opt.cutoff;
     ropt.correction = correction_type(opt.correction); ropt.pop_correction = opt.pop_correction;
     ropt.kmer_pca = opt.kmer_pca; ropt.npc = opt.npc;
@@ -246,512 +861,33 @@ int main(int argc, char** argv)
     const bool prev_run = load_opt(opt.output_directory + "/options.bin", prev);
     auto all_exist = [&](const char* suffix)
     {
-      for (size_t p = 0; p < cfg.nb_partitions; ++p)
-        if (!fs::exists(part_dir + "/p" + std::to_string(p) + suffix)) return false;
+      for (size_t p = 0; p < C.cfg.nb_partitions; ++p)
+        if (!fs::exists(C.part_dir + "/p" + std::to_string(p) + suffix)) return false;
       return true;
     };
     const unsigned action = prev_run ? compare_opt(ropt, prev) : 0;
     const bool prev_1 = prev_run && all_exist("_uncorrected");
     const bool prev_2 = prev_run && all_exist("_popstrat_uncorrected");
-    const bool want_counts = opt.pop_correction || opt.keep_tmp || opt.save_sk;
 
-    survivor_set sv_all;                           // survivors of all partitions, partition after partition
-    sv_all.n_counts = want_counts ? S : 0;
-    sv_all.kmer_bytes = two_limbs ? 16 : 8;
-    std::vector<size_t> part_begin(cfg.nb_partitions + 1, 0);
-    uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+    survivors_of_run O;
+    O.sv_all.n_counts = C.want_counts ? C.S : 0;
+    O.sv_all.kmer_bytes = C.two_limbs ? 16 : 8;
+    O.part_begin.assign(C.cfg.nb_partitions + 1, 0);
     // the device PCA needs stage 1 (it samples the rows as they pass); its result of a previous
     // run is popstrat/pcs.evec
-    const std::string pop_dir = opt.output_directory + "/popstrat";
     const bool device_pca = opt.pop_correction && opt.pcs.empty();
-    const bool have_pcs = fs::exists(pop_dir + "/pcs.evec");
+    const bool have_pcs = fs::exists(C.pop_dir + "/pcs.evec");
     const bool run_stage1 = !prev_1 || (action & 0b1) || (device_pca && !have_pcs);
-    std::vector<double> Z_device;                  // [S][10] when the device PCA ran
-    const bool run_pca = run_stage1 && device_pca;
-    if (run_stage1)
-    {
-      // ---- stage 1: do_diff (cmd/diff.hpp:66-164), one partition after the other on this GPU
-      std::fprintf(stderr, "[kmdiff-hip] Process partitions\n");
-      const stopwatch merge_time;
-      const auto mpaths = matrix_paths(opt.kmtricks_dir);                                     // cmd/diff.hpp:80-101
-      const bool from_matrix = !mpaths.empty();
-      if (opt.save_sk)                                                                        // cmd/diff.hpp:52-64,137-143
-      {
-        const std::string sk = opt.output_directory + "/positive_kmer_matrix";
-        fs::create_directories(sk + "/matrices");
-        for (const char* f : { "/options.txt", "/kmtricks.fof" })
-          if (fs::exists(opt.kmtricks_dir + f)) fs::copy(opt.kmtricks_dir + f, sk, fs::copy_options::overwrite_existing);
-        for (const char* dname : { "/config_gatb", "/repartition_gatb" })
-          if (fs::exists(opt.kmtricks_dir + dname))
-            fs::copy(opt.kmtricks_dir + dname, sk + dname, fs::copy_options::recursive | fs::copy_options::overwrite_existing);
-      }
-      const size_t T = 4096;
-      // one accumulator per entry of counts/ (cmd/diff.hpp:103-107); matrix files map onto them in order
-      const size_t n_units = from_matrix ? std::min(mpaths.size(), cfg.nb_partitions) : cfg.nb_partitions;
-      if (from_matrix && mpaths.size() > cfg.nb_partitions) die("more files in matrices/ than partitions in counts/");
-      // Host side of a partition: its S files are LZ4-decoded by up to -t threads (the reference
-      // spends -t on whole partitions, merge.hpp:239-307; here the device takes the partitions one
-      // after the other and the threads take the files), and partition p + 1 is decoded while the
-      // device works on partition p.
-      struct pinned                                         // page-locked staging array, grown as needed, reused
-      {
-        void* p = nullptr; size_t cap = 0;
-        void reserve(size_t bytes, size_t keep = 0)         // the first `keep` bytes survive
-        {
-          if (bytes <= cap) return;
-          void* q = nullptr;
-          ck(kmd_malloc_host(&q, bytes), "kmd_malloc_host");
-          if (keep) std::memcpy(q, p, keep);
-          if (p) kmd_free_host(p);
-          p = q; cap = bytes;
-        }
-        ~pinned() { if (p) kmd_free_host(p); }
-      };
-      struct sample_stream                                  // one sample's file of a partition, decoded
-      {
-        pinned kmers, kmers_hi, counts;
-        record_sink sink;
-        size_t n = 0;
-      };
-      struct partition_input
-      {
-        matrix_rows m;
-        std::vector<sample_stream> st;                      // the S streams, each in its own page-locked arrays
-        std::vector<uint64_t> offs;
-        size_t n = 0;
-      };
-      auto parallel_for_samples = [&](const std::function<void(size_t)>& body)
-      {
-        std::atomic<size_t> next { 0 };
-        std::mutex mu;
-        std::exception_ptr err;
-        auto work = [&]()
-        {
-          for (size_t s2; (s2 = next++) < S;)
-          {
-            try { body(s2); }
-            catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
-          }
-        };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < std::min(std::max<size_t>(opt.threads / n_workers, 1), S); ++t) pool.emplace_back(work);
-        work();
-        for (auto& t : pool) t.join();
-        if (err) std::rethrow_exception(err);
-      };
-      // the S files of a partition are decoded in parallel, each as a stream (LZ4 chunk -> records ->
-      // the sample's page-locked arrays, which live as long as the staging slot: nothing is
-      // allocated per partition once the arrays have grown to the run's file sizes)
-      auto load_partition = [&](size_t p, partition_input* in)
-      {
-        if (from_matrix) { in->m = read_matrix_file(mpaths[p]); return; }
-        if (in->st.size() != S)
-        {
-          in->st = std::vector<sample_stream>(S);
-          for (auto& st : in->st)
-          {
-            sample_stream* self = &st;
-            st.sink.reserve = [self, two_limbs](record_sink& k, size_t n)
-            {
-              const size_t keep = k.capacity;                // grows only while a file is being read: all of it is live
-              self->kmers.reserve(n * 8, keep * 8); self->counts.reserve(n * 4, keep * 4);
-              if (two_limbs) self->kmers_hi.reserve(n * 8, keep * 8);
-              k.kmers = (uint64_t*)self->kmers.p; k.counts = (uint32_t*)self->counts.p;
-              k.kmers_hi = two_limbs ? (uint64_t*)self->kmers_hi.p : nullptr;
-              k.capacity = n;
-            };
-          }
-        }
-        parallel_for_samples([&](size_t s2)
-        {
-          const kmer_file_info f = stream_kmer_file(kmer_file_path(opt.kmtricks_dir, p, fof[s2].id), cfg.kmer_size, in->st[s2].sink);
-          if ((f.slots == 2) != two_limbs) throw std::runtime_error("k-mer width of a sample file differs from the run's");
-          in->st[s2].n = f.records;
-        });
-        in->offs.assign(S + 1, 0);
-        for (size_t s2 = 0; s2 < S; ++s2) in->offs[s2 + 1] = in->offs[s2] + in->st[s2].n;         // KmDir::get_files_to_merge order
-        in->n = in->offs[S];
-      };
-      // One worker thread per GPU; partition p belongs to worker p % n_workers (the sharding of
-      // kmdiff_amd/dist.py, in one process).  A worker keeps its survivors in its own set; they are
-      // put in partition order afterwards.
-      struct worker_result
-      {
-        survivor_set sv;
-        std::vector<std::pair<size_t, size_t>> span;     // per partition of this worker: (begin, count) in sv
-        uint64_t total = 0, n_sig = 0, n_ctrl = 0, n_case = 0, n_sampled = 0;
-        std::vector<double> xtx;                         // the worker's PCA Gram matrix
-        std::string error;
-      };
-      std::vector<worker_result> results(n_workers);
-      auto worker = [&](size_t wi)
-      {
-      worker_result& R = results[wi];
-      try
-      {
-      const int dev = (opt.device + (int)wi) % ndev;
-      ck(kmd_set_device(dev), "kmd_set_device");
-      kmd_model* model = wi == 0 ? model0 : nullptr;                                             // a model lives on one device
-      if (wi != 0)
-        ck(kmd_model_create(&model, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), opt.log_size),
-           "kmd_model_create");
-      kmd_pca* pca = nullptr;
-      if (run_pca) ck(kmd_pca_create(&pca, (int)S, opt.kmer_pca, opt.seed, opt.ploidy == 2 ? 1 : 0, (size_t)1 << 20), "kmd_pca_create");   // grows
-      survivor_set& sv_all = R.sv;                       // (this worker's)
-      sv_all.n_counts = want_counts ? S : 0;
-      sv_all.kmer_bytes = two_limbs ? 16 : 8;
-      uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
-      dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
-              d_smk, d_sc;
-      // a ring of staging sets: the partition being processed and `depth` more being decoded (deeper
-      // than 1 measured no gain with 256 host threads: the decode is not what is left to hide)
-      const size_t depth = 1;
-      std::vector<partition_input> staging(depth + 1);
-      std::vector<std::future<void>> ahead(depth + 1);
-      double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
-                                                           // the wait spent on the ring's first turn (its arrays get page-locked then)
-      size_t issued = 0;                                   // partitions of this worker handed to the loader
-      auto issue = [&]()
-      {
-        const size_t p_next = wi + issued * n_workers;
-        if (p_next < n_units)
-          ahead[issued % (depth + 1)] = std::async(std::launch::async, load_partition, p_next, &staging[issued % (depth + 1)]);
-        ++issued;
-      };
-      if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] GPU %d: worker ready %.3f s into stage 1\n", dev, merge_time.seconds());
-      for (size_t d = 0; d < depth; ++d) issue();
-      size_t turn = 0;
-      for (size_t p = wi; p < n_units; p += n_workers, ++turn)
-      {
-        kmd_tile tile {};
-        uint64_t n_rows = 0;
-        issue();                                           // into the slot processed one ring turn ago
-        const stopwatch t_wait;
-        ahead[turn % (depth + 1)].get();
-        t_loader += t_wait.seconds();
-        if (turn <= depth) t_first += t_wait.seconds();
-        const stopwatch t_dev;
-        partition_input& in = staging[turn % (depth + 1)];
-        if (from_matrix)
-        {
-          // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
-          const matrix_rows& m = in.m;
-          if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
-          if (two_limbs != !m.kmers_hi.empty()) die(mpaths[p] + ": k-mer width differs from the run's");
-          n_rows = m.kmers.size();
-          if (n_rows)
-          {
-            d_matrix.reserve(n_rows * S * 4); d_kmer_col.reserve(n_rows * 8);
-            ck(kmd_memcpy_h2d(d_matrix.p, m.counts.data(), n_rows * S * 4, nullptr), "h2d");
-            ck(kmd_memcpy_h2d(d_kmer_col.p, m.kmers.data(), n_rows * 8, nullptr), "h2d");
-            if (two_limbs)
-            {
-              d_kmer_col_hi.reserve(n_rows * 8);
-              ck(kmd_memcpy_h2d(d_kmer_col_hi.p, m.kmers_hi.data(), n_rows * 8, nullptr), "h2d");
-            }
-          }
-          tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p,
-                            two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
-        }
-        else
-        {
-          const std::vector<uint64_t>& offs = in.offs;
-          const size_t n = in.n;
-          if (n)
-          {
-            d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
-            if (two_limbs) d_kmers_hi.reserve(n * 8);
-            for (size_t s2 = 0; s2 < S; ++s2)                 // each stream to its place in the partition's arrays
-            {
-              const sample_stream& st = in.st[s2];
-              ck(kmd_memcpy_h2d((char*)d_kmers.p + offs[s2] * 8, st.kmers.p, st.n * 8, nullptr), "h2d");
-              ck(kmd_memcpy_h2d((char*)d_counts.p + offs[s2] * 4, st.counts.p, st.n * 4, nullptr), "h2d");
-              if (two_limbs) ck(kmd_memcpy_h2d((char*)d_kmers_hi.p + offs[s2] * 8, st.kmers_hi.p, st.n * 8, nullptr), "h2d");
-            }
-            d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
-            if (two_limbs)
-            {
-              d_kmer_col_hi.reserve(n * 8);
-            }
-            ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
-                                   (const uint32_t*)d_counts.p, offs.data(), 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED,
-                                   plugin ? S : T, n, d_matrix.p,
-                                   (uint64_t*)d_kmer_col.p, two_limbs ? (uint64_t*)d_kmer_col_hi.p : nullptr, &n_rows, nullptr),
-               "kmd_merge_partition");
-          }
-          tile = kmd_tile { d_matrix.p, 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED, plugin ? S : T, (const uint64_t*)d_kmer_col.p,
-                            two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
-        }
-        size_t ns = 0;
-        const size_t base = sv_all.size();
-        if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");             // merge.hpp:150-152
-        if (n_rows && plugin)
-        {
-          // diff_observer::process with the user's model (merge.hpp:68-103): the merged rows come
-          // back to the host, row-major, and go through process() one by one
-          std::vector<uint32_t> rows(n_rows * S);
-          std::vector<uint64_t> km(n_rows), kmh(two_limbs ? n_rows : 0);
-          ck(kmd_memcpy_d2h(rows.data(), d_matrix.p, n_rows * S * 4, nullptr), "d2h");
-          ck(kmd_memcpy_d2h(km.data(), d_kmer_col.p, n_rows * 8, nullptr), "d2h");
-          if (two_limbs) ck(kmd_memcpy_d2h(kmh.data(), d_kmer_col_hi.p, n_rows * 8, nullptr), "d2h");
-          std::vector<uint32_t> row(S);
-          for (size_t i = 0; i < n_rows; ++i)
-          {
-            std::copy(rows.begin() + i * S, rows.begin() + (i + 1) * S, row.begin());
-            kmdiff::Range<uint32_t> controls(row, 0, opt.nb_controls), cases(row, opt.nb_controls, opt.nb_cases);
-            auto [pv, sg, mc, mk] = plugin->process(controls, cases);
-            ++total_kmers;
-            if (pv <= first_threshold)
-            {
-              sv_all.kmer.push_back(km[i]);
-              if (two_limbs) sv_all.kmer_hi.push_back(kmh[i]);
-              sv_all.p.push_back(pv); sv_all.sign.push_back((int32_t)sg);
-              sv_all.mean_control.push_back(mc); sv_all.mean_case.push_back(mk);
-              if (want_counts) for (size_t s2 = 0; s2 < S; ++s2) sv_all.counts.push_back((double)row[s2]);
-              if (sg == kmdiff::Significance::CONTROL) ++n_sig_control; else ++n_sig_case;        // merge.hpp:95-98
-              ++n_sig; ++ns;
-            }
-          }
-        }
-        else if (n_rows)
-        {
-          // survivor sink sized for the worst case of this partition (every row)
-          d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
-          d_smc.reserve(n_rows * 8); d_smk.reserve(n_rows * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
-          if (two_limbs) d_skmer_hi.reserve(n_rows * 8);
-          ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
-          kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, two_limbs ? (uint64_t*)d_skmer_hi.p : nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
-                             (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
-          ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
-          uint64_t c[KMD_NCOUNTERS];
-          ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
-          ns = (size_t)c[KMD_CNT_SIG];
-          ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                     // reference push order
-          sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
-          sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);
-          if (two_limbs) sv_all.kmer_hi.resize(base + ns);
-          if (ns)
-          {
-            ck(kmd_memcpy_d2h(sv_all.kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
-            if (two_limbs) ck(kmd_memcpy_d2h(sv_all.kmer_hi.data() + base, d_skmer_hi.p, ns * 8, nullptr), "d2h");
-            ck(kmd_memcpy_d2h(sv_all.p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
-            ck(kmd_memcpy_d2h(sv_all.sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
-            ck(kmd_memcpy_d2h(sv_all.mean_control.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
-            ck(kmd_memcpy_d2h(sv_all.mean_case.data() + base, d_smk.p, ns * 8, nullptr), "d2h");
-            if (want_counts)                                                                  // merge.hpp:91-92
-            {
-              d_sc.reserve(ns * S * 8);
-              ck(kmd_survivors_gather_counts(&tile, (int)S, (const uint64_t*)d_srow.p, ns, (double*)d_sc.p, nullptr), "gather_counts");
-              sv_all.counts.resize((base + ns) * S);
-              ck(kmd_memcpy_d2h(sv_all.counts.data() + base * S, d_sc.p, ns * S * 8, nullptr), "d2h");
-            }
-          }
-          total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
-        }
-        t_device += t_dev.seconds();
-        if (turn > depth) t_steady += t_wait.seconds();       // decoder wait + device work of this partition
-        R.span.emplace_back(base, ns);
-        if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
-        {
-          matrix_rows sk; sk.kmer_size = (uint32_t)cfg.kmer_size; sk.count_bytes = 4; sk.nb_counts = (uint32_t)S; sk.partition = (uint32_t)p;
-          sk.kmers.assign(sv_all.kmer.begin() + base, sv_all.kmer.end());
-          if (two_limbs) sk.kmers_hi.assign(sv_all.kmer_hi.begin() + base, sv_all.kmer_hi.end());
-          sk.counts.resize(ns * S);
-          for (size_t i = 0; i < ns * S; ++i) sk.counts[i] = (uint32_t)sv_all.counts[base * S + i];
-          write_matrix_file(opt.output_directory + "/positive_kmer_matrix/matrices/matrix_" + std::to_string(p) + ".count.lz4", sk);
-        }
-      }
-      R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case;
-      if (opt.verbose_timing)
-      {
-        std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder (%.3f s of it for the first %zu partitions, whose staging arrays "
-                             "get page-locked), %.3f s in copies + kernels\n", dev, t_loader, t_first, depth + 1, t_device);
-        std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1\n", dev, merge_time.seconds());
-        if (turn > depth + 1)
-          std::fprintf(stderr, "[kmdiff-hip] GPU %d: steady state %.2f ms per partition (%zu partitions after the first %zu)\n", dev,
-                       1e3 * t_steady / (double)(turn - depth - 1), turn - depth - 1, depth + 1);
-      }
-      if (pca)
-      {
-        ck(kmd_pca_count(pca, &R.n_sampled), "kmd_pca_count");
-        R.xtx.assign(S * S, 0.0);
-        ck(kmd_pca_gram(pca, R.xtx.data(), nullptr), "kmd_pca_gram");
-        kmd_pca_destroy(pca);
-      }
-      if (wi != 0) kmd_model_destroy(model);
-      }
-      catch (const std::exception& e) { R.error = e.what(); }
-      };   // worker
-      {
-        std::vector<std::thread> gpus;
-        for (size_t wi = 1; wi < n_workers; ++wi) gpus.emplace_back(worker, wi);
-        worker(0);
-        for (auto& t : gpus) t.join();
-        if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] workers done %.3f s into stage 1 (staging arrays released)\n", merge_time.seconds());
-        ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
-        for (auto& R : results) if (!R.error.empty()) die(R.error);
-      }
-      // survivors in partition order (the order one GPU would have produced)
-      {
-        std::vector<size_t> taken(n_workers, 0);
-        for (size_t p = 0; p < n_units; ++p)
-        {
-          worker_result& R = results[p % n_workers];
-          const auto [b, cnt] = R.span[taken[p % n_workers]++];
-          sv_all.kmer.insert(sv_all.kmer.end(), R.sv.kmer.begin() + b, R.sv.kmer.begin() + b + cnt);
-          if (two_limbs) sv_all.kmer_hi.insert(sv_all.kmer_hi.end(), R.sv.kmer_hi.begin() + b, R.sv.kmer_hi.begin() + b + cnt);
-          sv_all.p.insert(sv_all.p.end(), R.sv.p.begin() + b, R.sv.p.begin() + b + cnt);
-          sv_all.sign.insert(sv_all.sign.end(), R.sv.sign.begin() + b, R.sv.sign.begin() + b + cnt);
-          sv_all.mean_control.insert(sv_all.mean_control.end(), R.sv.mean_control.begin() + b, R.sv.mean_control.begin() + b + cnt);
-          sv_all.mean_case.insert(sv_all.mean_case.end(), R.sv.mean_case.begin() + b, R.sv.mean_case.begin() + b + cnt);
-          if (want_counts) sv_all.counts.insert(sv_all.counts.end(), R.sv.counts.begin() + b * S, R.sv.counts.begin() + (b + cnt) * S);
-          part_begin[p + 1] = sv_all.size();
-        }
-        for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; }
-      }
-      for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
-      if (run_pca)                                                                             // run_eigenstrat_smartpca
-      {
-        uint64_t n_sampled = 0;
-        std::vector<double> xtx(S * S, 0.0);
-        for (auto& R : results)                                                                // in worker order
-        {
-          n_sampled += R.n_sampled;
-          for (size_t i = 0; i < S * S; ++i) xtx[i] += R.xtx[i];
-        }
-        const int n_out = (int)std::min<size_t>(S, 10);                                        // popstrat.cpp:118
-        std::vector<double> ev(S * n_out), el(n_out);
-        ck(kmd_pca_eigen((int)S, xtx.data(), n_out, ev.data(), el.data()), "kmd_pca_eigen");
-        fs::create_directories(pop_dir);
-        std::ofstream pf(pop_dir + "/pcs.evec");
-        Z_device.assign(S * 10, 0.0);
-        for (size_t i = 0; i < S; ++i)
-        {
-          for (int k = 0; k < n_out; ++k)
-          {
-            char b[32]; std::snprintf(b, sizeof b, "%.04f", ev[i * n_out + k]);                 // evec2pca.perl
-            pf << ' ' << (ev[i * n_out + k] > 0 ? " " : "") << b;
-            Z_device[i * 10 + k] = std::strtod(b, nullptr);                                    // what load_Z reads back
-          }
-          pf << '\n';
-        }
-        std::fprintf(stderr, "[kmdiff-hip] PCA done: %" PRIu64 " k-mers sampled, eigenvalues %.4f %.4f\n", n_sampled, el[0],
-                     n_out > 1 ? el[1] : 0.0);
-      }
-      if (opt.keep_tmp)                                                                       // FileAccumulator, del = !keep_tmp
-        for (size_t p = 0; p < cfg.nb_partitions; ++p)
-          write_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
-      std::fprintf(stderr, "[kmdiff-hip] Partitions processed (%.3f s)\n", merge_time.seconds());                // cmd/diff.hpp:158
-      std::fprintf(stderr, "[kmdiff-hip] %" PRIu64 "/%" PRIu64 " significant k-mers.\n", n_sig, total_kmers);      // cmd/diff.hpp:160
-      std::fprintf(stderr, "[kmdiff-hip] Before correction: %" PRIu64 " (control), %" PRIu64 " (case).\n", n_sig_control, n_sig_case);
-    }
-    else
-    {
-      // ---- stage 1 skipped: the survivors of the previous run (cmd/diff.hpp:329-337).  The
-      // reference takes total_kmers from the loaded options, which options.bin does not hold
-      // (diff_opt.hpp:78-88); here it is kept in resume.txt next to options.bin.
-      std::fprintf(stderr, "[kmdiff-hip] Resume: partitions/p*_uncorrected of the previous run\n");
-      for (size_t p = 0; p < cfg.nb_partitions; ++p)
-      {
-        read_survivor_file(part_dir + "/p" + std::to_string(p) + "_uncorrected", sv_all);
-        part_begin[p + 1] = sv_all.size();
-      }
-      std::ifstream rs(opt.output_directory + "/resume.txt");
-      if (!(rs >> total_kmers >> n_sig >> n_sig_control >> n_sig_case)) die("resume.txt of the previous run is missing");
-      if (want_counts && sv_all.size() && sv_all.n_counts != S) die("previous run's survivor files hold another sample count");
-    }
+    if (run_stage1) do_diff(C, O, /* run_pca */ device_pca);
+    else load_previous_survivors(C, O);
     dump_opt(ropt, opt.output_directory + "/options.bin");
     {
       std::ofstream rs(opt.output_directory + "/resume.txt");
-      rs << total_kmers << ' ' << n_sig << ' ' << n_sig_control << ' ' << n_sig_case << '\n';
+      rs << O.total_kmers << ' ' << O.n_sig << ' ' << O.n_sig_control << ' ' << O.n_sig_case << '\n';
     }
-    std::vector<uint64_t>& s_kmer = sv_all.kmer;
-    std::vector<double>& s_p = sv_all.p; std::vector<double>& s_mc = sv_all.mean_control; std::vector<double>& s_mk = sv_all.mean_case;
-    std::vector<int32_t>& s_sign = sv_all.sign;
-    std::vector<double>& s_counts = sv_all.counts;
-
-    const size_t n = s_p.size();
-    dev_buf d_p, d_sign, d_keep;
-    d_p.reserve(std::max<size_t>(n, 1) * 8); d_sign.reserve(std::max<size_t>(n, 1) * 4); d_keep.reserve(std::max<size_t>(n, 1));
-
-    // ---- stage 2: do_pop (cmd/diff.hpp:167-224) with externally computed principal components
-    const bool run_stage2 = opt.pop_correction && ((!prev_2 || (action & 0b10)) || run_stage1);            // cmd/diff.hpp:349
-    if (opt.pop_correction && !run_stage2)
-    {
-      std::fprintf(stderr, "[kmdiff-hip] Resume: partitions/p*_popstrat_uncorrected of the previous run\n");
-      survivor_set ps;
-      for (size_t p = 0; p < cfg.nb_partitions; ++p) read_survivor_file(part_dir + "/p" + std::to_string(p) + "_popstrat_uncorrected", ps);
-      if (ps.size() != n) die("previous run's pop-strat survivor files do not match");
-      s_p = ps.p;
-    }
-    const stopwatch pop_time;
-    if (run_stage2 && n)
-    {
-      std::vector<double> Z(S * 10, 0.0), Y(S, 0.0);
-      if (!Z_device.empty()) Z = Z_device;
-      else
-      {
-        const std::string zpath = opt.pcs.empty() ? pop_dir + "/pcs.evec" : opt.pcs;
-        std::ifstream zin(zpath);
-        if (!zin) die("cannot open " + zpath);
-        const size_t per_row = opt.pcs.empty() ? std::min<size_t>(S, 10) : 10;
-        for (size_t i = 0; i < S; ++i)
-          for (size_t k = 0; k < per_row; ++k)
-            if (!(zin >> Z[i * 10 + k])) die(zpath + ": expected " + std::to_string(per_row) + " values per sample");   // popstrat.cpp:153-161
-      }
-      for (size_t i = 0; i < opt.nb_controls; ++i) Y[i] = 1.0;                                                       // popstrat.cpp:168
-      kmd_popstrat* ps = nullptr;
-      ck(kmd_popstrat_create(&ps, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), Z.data(), 10,
-                             (int)opt.npc, Y.data(), opt.stand ? 1 : 0, (int)opt.max_iteration), "kmd_popstrat_create");
-      dev_buf d_c; d_c.reserve(n * S * 8);
-      ck(kmd_memcpy_h2d(d_c.p, s_counts.data(), n * S * 8, nullptr), "h2d");
-      ck(kmd_popstrat_apply(ps, (const double*)d_c.p, 0, 0, n, (double*)d_p.p, nullptr), "kmd_popstrat_apply");
-      ck(kmd_memcpy_d2h(s_p.data(), d_p.p, n * 8, nullptr), "d2h");                                                  // ks.set_pval
-      kmd_popstrat_destroy(ps);
-      std::fprintf(stderr, "[kmdiff-hip] Population correction done. (%.3f s)\n", pop_time.seconds());              // cmd/diff.hpp:221
-    }
-    if (run_stage2 && opt.keep_tmp)
-      for (size_t p = 0; p < cfg.nb_partitions; ++p)
-        write_survivor_file(part_dir + "/p" + std::to_string(p) + "_popstrat_uncorrected", sv_all, part_begin[p], part_begin[p + 1] - part_begin[p]);
-
-    // ---- stage 3: do_correction (cmd/diff.hpp:227-260)
-    uint64_t kept = 0, c_controls = 0, c_cases = 0;
-    std::vector<uint8_t> keep(n, 0);
-    if (n)
-    {
-      ck(kmd_memcpy_h2d(d_p.p, s_p.data(), n * 8, nullptr), "h2d");
-      ck(kmd_memcpy_h2d(d_sign.p, s_sign.data(), n * 4, nullptr), "h2d");
-      ck(kmd_correct(correction_type(opt.correction), opt.threshold, total_kmers, (const double*)d_p.p, (const int32_t*)d_sign.p, n,
-                     (uint8_t*)d_keep.p, &kept, &c_controls, &c_cases, nullptr), "kmd_correct");
-      ck(kmd_memcpy_d2h(keep.data(), d_keep.p, n, nullptr), "d2h");
-    }
-    fs::create_directories(opt.output_directory);
-    // writers (aggregator.hpp:26-71).  BH/Holm emit in ascending p (the order the sorted
-    // aggregator pops them); the stateless correctors in partition order.
-    std::vector<size_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = i;
-    if (opt.correction == "benjamini" || opt.correction == "holm")
-      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return s_p[a] < s_p[b]; });
-    std::ofstream fc(opt.output_directory + "/control_kmers.fasta"), fk(opt.output_directory + "/case_kmers.fasta");
-    size_t ic = 0, ik = 0;
-    for (size_t i : order)
-    {
-      if (!keep[i]) continue;
-      const bool control = s_sign[i] == KMD_SIGN_CONTROL;                                     // aggregator.hpp:155-162
-      std::ofstream& f = control ? fc : fk;
-      size_t& idx = control ? ic : ik;
-      char pv[64]; std::snprintf(pv, sizeof pv, "%g", s_p[i]);                               // {:g}
-      f << '>' << idx << "_pval=" << pv << "_control=" << (uint64_t)s_mc[i] << "_case=" << shortest(s_mk[i]) << '\n'
-        << (two_limbs ? kmer_to_string(sv_all.kmer_hi[i], s_kmer[i], cfg.kmer_size) : kmer_to_string(s_kmer[i], cfg.kmer_size)) << '\n';
-      ++idx;
-    }
-    std::fprintf(stderr, "[kmdiff-hip] Significant k-mers: %" PRIu64 " (control), %" PRIu64 " (case).\n", c_controls, c_cases);   // cmd/diff.hpp:259
-    // machine-readable summary for tests and scripts
-    std::ofstream js(opt.output_directory + "/summary.json");
-    js << "{\"total_kmers\": " << total_kmers << ", \"n_sig\": " << n_sig << ", \"n_sig_control\": " << n_sig_control
-       << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
-       << ", \"kept_case\": " << c_cases << ", \"kmer_size\": " << cfg.kmer_size << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
-    kmd_model_destroy(model0);
+    if (opt.pop_correction) do_pop(C, O, /* run_stage2 */ !prev_2 || (action & 0b10) || run_stage1);       // cmd/diff.hpp:349
+    do_correction(C, O);
+    kmd_model_destroy(C.model0);
     std::fprintf(stderr, "[kmdiff-hip] Done in %.3f s.\n", whole_time.seconds());                                   // cmd/diff.hpp:372-376
   }
   catch (const std::exception& e) { die(e.what()); }                                          // src/main.cc:93-102 logs and exits
