@@ -315,3 +315,31 @@ def test_imodel_plugin_loaded_like_the_reference_does(tmp_path, bits, dtype):
     for i, g in enumerate(got):
         assert int(g[1]) == s[i] and float.fromhex(g[2]) == mc[i] and float.fromhex(g[3]) == mk[i]
         assert abs(float.fromhex(g[0]) - p[i]) <= 1e-10 and abs(float.fromhex(g[0]) - p[i]) <= 1e-9 * p[i] + 1e-300
+
+
+def test_cli_empty_sample_files_and_an_empty_partition(tmp_path):
+    """A sample without k-mers in a partition (an LZ4 frame of nothing), a partition where every
+    sample file is empty, and one-record files: the streaming reader, the merge and the survivor
+    bookkeeping take them; same counters as the oracle on the non-empty rows."""
+    o = OL.load()
+    nc, nk, n, k = 3, 3, 20_000, 31
+    parts, mats, kms = [], [], []
+    for p in range(4):
+        host, lo, _ = o.synth_rows(SEED + 9, p, 0, n, nc, nk, 4)
+        if p == 1:
+            host = host.copy(); host[:, 0] = 0; host[:, 4] = 0           # two samples absent from this partition
+            keep_rows = host.sum(axis=1) > 0
+            host, lo = host[keep_rows], lo[keep_rows]
+        if p == 2:
+            host, lo = host[:0], lo[:0]                                  # nothing at all
+        if p == 3:
+            host, lo = host[:1], lo[:1]                                  # one row
+        parts.append([(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(nc + nk)])
+        mats.append(host); kms.append(lo)
+    ids = ["C%d" % i for i in range(nc)] + ["K%d" % i for i in range(nk)]
+    KF.write_run_dir(str(tmp_path / "km"), k, ids, parts)
+    s, _ = run_cli(["-d", tmp_path / "km", "-1", nc, "-2", nk, "-c", "disabled", "-s", 0.05, "-u", 100, "-t", 3], tmp_path / "o")
+    surv, keep, total = oracle_pipeline(o, nc, nk, [m for m in mats if len(m)], [km for m, km in zip(mats, kms) if len(m)], 0.05 / 100,
+                                        "disabled", 0.05)
+    assert s["total_kmers"] == total == sum(len(m) for m in mats)
+    assert s["n_sig"] == len(surv["p"]) > 0 and s["kept"] == int(keep.sum())
