@@ -393,14 +393,29 @@ static void split_fixed(const char* p, size_t n, uint64_t* kmers, uint64_t* kmer
   }
 }
 
-kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, record_sink& sink)
+namespace {
+
+// A kmtricks file as a stream: header, then the payload (one LZ4 frame, or plain bytes) handed on in
+// chunks of whole records.  `on_records(ptr, n)` gets n records starting at ptr; the bytes of a
+// record cut by a chunk boundary are carried to the front of the next chunk.
+struct payload_stream
 {
-  const int fd = ::open(path.c_str(), O_RDONLY);
-  if (fd < 0) throw std::runtime_error("cannot open " + path);
-  struct closer { int fd; ~closer() { ::close(fd); } } guard { fd };
-  struct stat st;
-  if (::fstat(fd, &st) != 0) throw std::runtime_error("cannot stat " + path);
-  auto read_some = [&](char* dst, size_t want) -> size_t
+  int fd = -1;
+  std::string path;
+  size_t file_size = 0;
+  explicit payload_stream(const std::string& p) : path(p)
+  {
+    fd = ::open(p.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + p);
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat " + p); }
+    file_size = (size_t)st.st_size;
+  }
+  ~payload_stream() { if (fd >= 0) ::close(fd); }
+  payload_stream(const payload_stream&) = delete;
+  payload_stream& operator=(const payload_stream&) = delete;
+
+  size_t read_some(char* dst, size_t want)
   {
     size_t got = 0;
     while (got < want)
@@ -411,9 +426,71 @@ kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, reco
       got += (size_t)r;
     }
     return got;
-  };
+  }
+
+  // everything after the header; `in` / `out` are the caller's scratch vectors (kept between files)
+  // returns the bytes left over after the last whole record
+  size_t records(bool compressed, size_t rec, std::vector<char>& in, std::vector<char>& outv,
+                 const std::function<void(const char*, size_t)>& on_records)
+  {
+    const size_t chunk = (size_t)1 << 20;
+    if (in.size() < chunk) in.resize(chunk);
+    if (outv.size() < chunk + rec) outv.resize(chunk + rec);
+    char* const out = outv.data();
+    size_t carry = 0;                                      // bytes of a record cut by the chunk boundary, at the front of out
+    auto take = [&](size_t fresh)                          // out[0, carry + fresh) -> whole records
+    {
+      const size_t avail = carry + fresh, whole = avail / rec;
+      if (whole) on_records(out, whole);
+      carry = avail - whole * rec;
+      if (carry) std::memmove(out, out + whole * rec, carry);
+    };
+    if (!compressed)
+    {
+      for (size_t got; (got = read_some(out + carry, chunk)) != 0;) take(got);
+      return carry;
+    }
+    LZ4F_dctx* ctx = nullptr;
+    if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
+    struct freer { LZ4F_dctx* c; ~freer() { LZ4F_freeDecompressionContext(c); } } ctx_guard { ctx };
+    bool done = false;
+    for (size_t got; !done && (got = read_some(in.data(), chunk)) != 0;)
+    {
+      for (size_t pos = 0;;)
+      {
+        size_t dn = chunk, sn = got - pos;
+        const size_t r = LZ4F_decompress(ctx, out + carry, &dn, in.data() + pos, &sn, nullptr);
+        if (LZ4F_isError(r)) throw std::runtime_error(path + ": " + LZ4F_getErrorName(r));
+        pos += sn;
+        if (dn) take(dn);
+        if (r == 0) { done = true; break; }                // end of the frame
+        if (pos >= got && dn < chunk) break;               // input used up and nothing left to flush
+        if (sn == 0 && dn == 0) throw std::runtime_error(path + ": LZ4 frame makes no progress");
+      }
+    }
+    if (!done) throw std::runtime_error(path + ": truncated LZ4 frame (no end mark)");
+    return carry;
+  }
+};
+
+// room for `more` records after the `have` the sink holds: first guess from the file size (sorted
+// k-mers + small counts shrink by 1.3-1.5 under LZ4), then by quarters -- page-locking the arrays is
+// the fixed cost of a run (~0.15 s per GB, and again to release)
+void grow_sink(record_sink& sink, size_t have, size_t more, size_t file_size, size_t rec)
+{
+  if (have + more <= sink.capacity) return;
+  const size_t guess = (file_size * 3 / 2) / rec + 1024;
+  sink.reserve(sink, std::max({ have + more, sink.capacity + sink.capacity / 4, guess }));
+  if (sink.capacity < have + more || (sink.slots == 2 && !sink.kmers_hi)) throw std::runtime_error("record sink did not grow");
+}
+
+} // namespace
+
+kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, record_sink& sink)
+{
+  payload_stream ps(path);
   char head[41];
-  if (read_some(head, 41) != 41 || std::memcmp(head, "kmtricks", 8) != 0 || std::memcmp(head + 13, "kmer", 4) != 0)
+  if (ps.read_some(head, 41) != 41 || std::memcmp(head, "kmtricks", 8) != 0 || std::memcmp(head + 13, "kmer", 4) != 0)
     throw std::runtime_error(path + ": not a kmtricks k-mer file");
   kmer_file_info f;
   const uint8_t compressed = (uint8_t)head[12];
@@ -422,61 +499,60 @@ kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, reco
   if (expected_k && k != expected_k) throw std::runtime_error(path + ": k-mer size differs from the run's");
   if (f.slots != 1 && f.slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
   if (f.count_bytes != 1 && f.count_bytes != 2 && f.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
-  sink.slots = f.slots;
+  if (sink.slots != f.slots || sink.nb_counts != 1) sink.capacity = 0;      // arrays sized for records of another shape
+  sink.slots = f.slots; sink.nb_counts = 1;
   const size_t rec = 8 * (size_t)f.slots + f.count_bytes;
-  const size_t chunk = (size_t)1 << 20;
-  if (sink.in.size() < chunk) sink.in.resize(chunk);
-  if (sink.out.size() < chunk + rec) sink.out.resize(chunk + rec);
-  char* const out = sink.out.data();
-  size_t carry = 0;                                        // bytes of a record cut by the chunk boundary, at the front of out
-  auto take = [&](size_t fresh)                            // out[0, carry + fresh) -> whole records to the sink
+  // (bytes after the last whole record are dropped, as read_kmer_file does)
+  ps.records(compressed != 0, rec, sink.in, sink.out, [&](const char* p, size_t whole)
   {
-    const size_t avail = carry + fresh, whole = avail / rec;
-    if (f.records + whole > sink.capacity)
-    {
-      // first guess from the file size (sorted k-mers + small counts shrink by 1.3-1.5 under LZ4), then
-      // by quarters: page-locking the arrays is the fixed cost of a run (~0.15 s per GB, and again to release)
-      const size_t guess = ((size_t)st.st_size * 3 / 2) / rec + 1024;
-      sink.reserve(sink, std::max({ f.records + whole, sink.capacity + sink.capacity / 4, guess }));
-      if (sink.capacity < f.records + whole || (f.slots == 2 && !sink.kmers_hi)) throw std::runtime_error("record sink did not grow");
-    }
+    grow_sink(sink, f.records, whole, ps.file_size, rec);
     uint64_t* km = sink.kmers + f.records;
     uint64_t* kh = sink.kmers_hi ? sink.kmers_hi + f.records : nullptr;
     uint32_t* ct = sink.counts + f.records;
-    if (f.slots == 1 && f.count_bytes == 4) split_fixed<1, 4>(out, whole, km, kh, ct);
-    else if (f.slots == 1 && f.count_bytes == 2) split_fixed<1, 2>(out, whole, km, kh, ct);
-    else if (f.slots == 1) split_fixed<1, 1>(out, whole, km, kh, ct);
-    else if (f.count_bytes == 4) split_fixed<2, 4>(out, whole, km, kh, ct);
-    else if (f.count_bytes == 2) split_fixed<2, 2>(out, whole, km, kh, ct);
-    else split_fixed<2, 1>(out, whole, km, kh, ct);
+    if (f.slots == 1 && f.count_bytes == 4) split_fixed<1, 4>(p, whole, km, kh, ct);
+    else if (f.slots == 1 && f.count_bytes == 2) split_fixed<1, 2>(p, whole, km, kh, ct);
+    else if (f.slots == 1) split_fixed<1, 1>(p, whole, km, kh, ct);
+    else if (f.count_bytes == 4) split_fixed<2, 4>(p, whole, km, kh, ct);
+    else if (f.count_bytes == 2) split_fixed<2, 2>(p, whole, km, kh, ct);
+    else split_fixed<2, 1>(p, whole, km, kh, ct);
     f.records += whole;
-    carry = avail - whole * rec;
-    if (carry) std::memmove(out, out + whole * rec, carry);
-  };
-  if (!compressed)
+  });
+  return f;
+}
+
+matrix_file_info stream_matrix_file(const std::string& path, record_sink& sink)
+{
+  payload_stream ps(path);
+  char head[45];
+  if (ps.read_some(head, 45) != 45 || std::memcmp(head, "kmtricks", 8) != 0 || std::memcmp(head + 13, "matrix", 6) != 0)
+    throw std::runtime_error(path + ": not a kmtricks count matrix");
+  matrix_file_info f;
+  const uint8_t compressed = (uint8_t)head[12];
+  std::memcpy(&f.kmer_size, head + 21, 4); std::memcpy(&f.slots, head + 25, 4); std::memcpy(&f.count_bytes, head + 29, 4);
+  std::memcpy(&f.nb_counts, head + 33, 4); std::memcpy(&f.partition, head + 41, 4);
+  if (f.slots != 1 && f.slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
+  if (f.count_bytes != 1 && f.count_bytes != 2 && f.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
+  if (sink.slots != f.slots || sink.nb_counts != f.nb_counts) sink.capacity = 0;   // arrays sized for rows of another shape
+  sink.slots = f.slots; sink.nb_counts = f.nb_counts;
+  const size_t kb = 8 * (size_t)f.slots, rec = kb + (size_t)f.count_bytes * f.nb_counts;
+  const uint32_t S = f.nb_counts, cb = f.count_bytes;
+  const size_t left = ps.records(compressed != 0, rec, sink.in, sink.out, [&](const char* p, size_t whole)
   {
-    for (size_t got; (got = read_some(out + carry, chunk)) != 0;) take(got);
-    return f;                                              // a trailing partial record is dropped, as decode_kmer_file does
-  }
-  LZ4F_dctx* ctx = nullptr;
-  if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) throw std::runtime_error("LZ4F context");
-  struct freer { LZ4F_dctx* c; ~freer() { LZ4F_freeDecompressionContext(c); } } ctx_guard { ctx };
-  bool done = false;
-  for (size_t got; !done && (got = read_some(sink.in.data(), chunk)) != 0;)
-  {
-    for (size_t pos = 0;;)
+    grow_sink(sink, f.rows, whole, ps.file_size, rec);
+    uint64_t* km = sink.kmers + f.rows;
+    uint64_t* kh = sink.kmers_hi ? sink.kmers_hi + f.rows : nullptr;
+    uint32_t* ct = sink.counts + f.rows * (size_t)S;
+    for (size_t i = 0; i < whole; ++i, p += rec, ct += S)
     {
-      size_t dn = chunk, sn = got - pos;
-      const size_t r = LZ4F_decompress(ctx, out + carry, &dn, sink.in.data() + pos, &sn, nullptr);
-      if (LZ4F_isError(r)) throw std::runtime_error(path + ": " + LZ4F_getErrorName(r));
-      pos += sn;
-      if (dn) take(dn);
-      if (r == 0) { done = true; break; }                  // end of the frame
-      if (pos >= got && dn < chunk) break;                 // input used up and nothing left to flush
-      if (sn == 0 && dn == 0) throw std::runtime_error(path + ": LZ4 frame makes no progress");
+      std::memcpy(&km[i], p, 8);
+      if (f.slots == 2) std::memcpy(&kh[i], p + 8, 8);
+      if (cb == 4) std::memcpy(ct, p + kb, (size_t)S * 4);                                // rows of 4-byte counts as they are
+      else if (cb == 2) for (uint32_t s2 = 0; s2 < S; ++s2) { uint16_t v; std::memcpy(&v, p + kb + 2 * (size_t)s2, 2); ct[s2] = v; }
+      else for (uint32_t s2 = 0; s2 < S; ++s2) ct[s2] = (uint8_t)p[kb + s2];
     }
-  }
-  if (!done) throw std::runtime_error(path + ": truncated LZ4 frame (no end mark)");
+    f.rows += whole;
+  });
+  if (left) throw std::runtime_error(path + ": truncated row");
   return f;
 }
 

@@ -45,18 +45,24 @@ void split_records(const kmer_file_raw& f, uint64_t* kmers, uint64_t* kmers_hi, 
 
 // The same file as a stream: the LZ4 frame is decoded chunk by chunk and the records go straight
 // into arrays the caller owns and reuses from file to file (page-locked in the CLI), so that no
-// pass over the data allocates.  `reserve(n)` must make the three arrays hold at least n records,
+// pass over the data allocates.  `reserve(n)` must make the arrays hold at least n records (counts:
+// n * nb_counts),
 // keeping what is already there, and set the pointers (kmers_hi may stay NULL for one limb).
 struct record_sink
 {
   uint64_t* kmers = nullptr; uint64_t* kmers_hi = nullptr; uint32_t* counts = nullptr;
   size_t capacity = 0;                                    // records the arrays hold
   uint32_t slots = 1;                                     // limbs per k-mer of the file being read (set before reserve is called)
+  uint32_t nb_counts = 1;                                 // counts per record: 1 for k-mer files, the samples of a matrix row
   std::function<void(record_sink&, size_t)> reserve;
   std::vector<char> in, out;                              // scratch of the decoder, kept between files
 };
 struct kmer_file_info { uint32_t slots = 1, count_bytes = 4; size_t records = 0; };
 kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, record_sink& sink);
+// <run>/matrices/* the same way: rows go to kmers[/kmers_hi] and, widened to 4 bytes, to
+// counts[row * nb_counts + sample]; reserve(n) must provide n * nb_counts counts
+struct matrix_file_info { uint32_t kmer_size = 0, slots = 1, count_bytes = 4, nb_counts = 0, partition = 0; size_t rows = 0; };
+matrix_file_info stream_matrix_file(const std::string& path, record_sink& sink);
 
 std::string kmer_file_path(const std::string& run_dir, size_t partition, const std::string& id);
 

@@ -241,8 +241,9 @@ struct sample_stream                                    // one sample's file of 
 };
 struct partition_input
 {
-  matrix_rows m;                                        // the matrices/ feed
-  std::vector<sample_stream> st;                        // the S streams, each in its own page-locked arrays
+  std::vector<sample_stream> st;                        // the S streams, each in its own page-locked arrays; the
+                                                        // matrices/ feed: one stream of rows (counts [row][sample])
+  matrix_file_info m;                                   // matrices/ feed: what the file says
   std::vector<uint64_t> offs;
   size_t n = 0;
 };
@@ -260,25 +261,32 @@ public:
   // per partition once the arrays have grown to the run's file sizes).
   void load(size_t p, partition_input* in) const
   {
-    if (from_matrix()) { in->m = read_matrix_file(mpaths_[p]); return; }
     const size_t S = C_.S;
     const bool two_limbs = C_.two_limbs;
-    if (in->st.size() != S)
+    const size_t n_streams = from_matrix() ? 1 : S;
+    if (in->st.size() != n_streams)
     {
-      in->st = std::vector<sample_stream>(S);
+      in->st = std::vector<sample_stream>(n_streams);
       for (auto& st : in->st)
       {
         sample_stream* self = &st;
-        st.sink.reserve = [self, two_limbs](record_sink& k, size_t n)
+        st.sink.reserve = [self](record_sink& k, size_t n)
         {
           const size_t keep = k.capacity;                // grows only while a file is being read: all of it is live
-          self->kmers.reserve(n * 8, keep * 8); self->counts.reserve(n * 4, keep * 4);
-          if (two_limbs) self->kmers_hi.reserve(n * 8, keep * 8);
+          const size_t per = (size_t)k.nb_counts * 4;    // bytes of counts per record
+          self->kmers.reserve(n * 8, keep * 8); self->counts.reserve(n * per, keep * per);
+          if (k.slots == 2) self->kmers_hi.reserve(n * 8, keep * 8);
           k.kmers = (uint64_t*)self->kmers.p; k.counts = (uint32_t*)self->counts.p;
-          k.kmers_hi = two_limbs ? (uint64_t*)self->kmers_hi.p : nullptr;
+          k.kmers_hi = k.slots == 2 ? (uint64_t*)self->kmers_hi.p : nullptr;
           k.capacity = n;
         };
       }
+    }
+    if (from_matrix())                                   // pre-merged rows (matrix_proxy::merge): one file, one thread
+    {
+      in->m = stream_matrix_file(mpaths_[p], in->st[0].sink);
+      in->st[0].n = in->n = in->m.rows;
+      return;
     }
     for_samples([&](size_t s2)
     {
@@ -363,9 +371,16 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
   dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
           d_smk, d_sc;
-  // a ring of staging sets: the partition being processed and `depth` more being decoded (deeper
-  // than 1 measured no gain with 256 host threads: the decode is not what is left to hide)
-  const size_t depth = 1;
+  // a ring of staging sets: the partition being processed and `depth` more being decoded.  K-mer
+  // files: one partition ahead, its S files on this worker's share of the -t threads (deeper
+  // measured no gain: the decode is hidden already).  matrices/: one file = one LZ4 frame = one
+  // thread per partition, so up to 8 partitions are decoded at once, like the reference's -t
+  // threads each taking a partition (merge.hpp:239-307) -- but no more slots than a quarter of this
+  // worker's partitions: every slot is page-locked once (~0.15 s per GB, and again to release),
+  // which a short run does not earn back (12 partitions of 336 MB: depth 8 cost 1.1 s more than depth 1).
+  const size_t my_units = (n_units + n_workers - 1 - wi) / n_workers;
+  const size_t depth = !from_matrix ? 1 :
+    std::max<size_t>(1, std::min({ std::max<size_t>(opt.threads / n_workers, 1), (size_t)8, my_units / 4 }));
   std::vector<partition_input> staging(depth + 1);
   std::vector<std::future<void>> ahead(depth + 1);
   double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
@@ -395,19 +410,20 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     if (from_matrix)
     {
       // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
-      const matrix_rows& m = in.m;
+      const matrix_file_info& m = in.m;
+      const sample_stream& rows = in.st[0];
       if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
-      if (two_limbs != !m.kmers_hi.empty()) die(mpaths[p] + ": k-mer width differs from the run's");
-      n_rows = m.kmers.size();
+      if (two_limbs != (m.slots == 2)) die(mpaths[p] + ": k-mer width differs from the run's");
+      n_rows = m.rows;
       if (n_rows)
       {
         d_matrix.reserve(n_rows * S * 4); d_kmer_col.reserve(n_rows * 8);
-        ck(kmd_memcpy_h2d(d_matrix.p, m.counts.data(), n_rows * S * 4, nullptr), "h2d");
-        ck(kmd_memcpy_h2d(d_kmer_col.p, m.kmers.data(), n_rows * 8, nullptr), "h2d");
+        ck(kmd_memcpy_h2d(d_matrix.p, rows.counts.p, n_rows * S * 4, nullptr), "h2d");
+        ck(kmd_memcpy_h2d(d_kmer_col.p, rows.kmers.p, n_rows * 8, nullptr), "h2d");
         if (two_limbs)
         {
           d_kmer_col_hi.reserve(n_rows * 8);
-          ck(kmd_memcpy_h2d(d_kmer_col_hi.p, m.kmers_hi.data(), n_rows * 8, nullptr), "h2d");
+          ck(kmd_memcpy_h2d(d_kmer_col_hi.p, rows.kmers_hi.p, n_rows * 8, nullptr), "h2d");
         }
       }
       tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p,

@@ -22,6 +22,25 @@ int main(int argc, char** argv)
       if (!m.kmers_hi.empty()) std::printf("two-limb ");
       std::printf("rows=%zu k=%u count_bytes=%u nb_counts=%u partition=%u\n", m.kmers.size(), m.kmer_size, m.count_bytes,
                   m.nb_counts, m.partition);
+      {
+        // the streaming reader (what the CLI uses) must deliver the same rows
+        std::vector<uint64_t> km, kh; std::vector<uint32_t> ct;
+        kmd_host::record_sink sink;
+        sink.reserve = [&](kmd_host::record_sink& k, size_t n)
+        {
+          km.resize(n); ct.resize(n * k.nb_counts); if (k.slots == 2) kh.resize(n);
+          k.kmers = km.data(); k.counts = ct.data(); k.kmers_hi = k.slots == 2 ? kh.data() : nullptr; k.capacity = n;
+        };
+        const kmd_host::matrix_file_info f = kmd_host::stream_matrix_file(in, sink);
+        bool same = f.rows == m.kmers.size() && f.nb_counts == m.nb_counts && f.count_bytes == m.count_bytes &&
+                    f.partition == m.partition && f.kmer_size == m.kmer_size && (f.slots == 2) == !m.kmers_hi.empty();
+        for (size_t i = 0; same && i < f.rows; ++i)
+        {
+          same = km[i] == m.kmers[i] && (f.slots == 1 || kh[i] == m.kmers_hi[i]);
+          for (uint32_t s2 = 0; same && s2 < f.nb_counts; ++s2) same = ct[i * f.nb_counts + s2] == m.counts[i * m.nb_counts + s2];
+        }
+        if (!same) { std::fprintf(stderr, "error: stream_matrix_file differs from read_matrix_file\n"); return 1; }
+      }
       kmd_host::write_matrix_file(out, m);
     }
     else if (what == "survivors" || what == "survivors16")

@@ -23,11 +23,12 @@ ap.add_argument("--rows", type=int, default=1_000_000)
 ap.add_argument("--parts", type=int, default=4)
 ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
+ap.add_argument("--matrix", action="store_true", help="also write <run>/matrices: the pre-merged feed (matrix_proxy)")
 a = ap.parse_args()
 S = a.nc + a.nk
 root = tempfile.mkdtemp(prefix="kmrun_")
 t0 = time.time()
-parts, records = [], 0
+parts, records, merged = [], 0, []
 for p in range(a.parts):
     mat = K.synth_matrix(0x6B6D64696666, p, a.rows, a.nc, a.nk, 4, K.LAYOUT_ROWS)
     host, lo = mat.to_host(), mat.kmers_to_host()[0]
@@ -37,8 +38,12 @@ for p in range(a.parts):
         streams.append((lo[sel], host[sel, s]))
         records += int(sel.sum())
     parts.append(streams)
+    if a.matrix:
+        merged.append((lo, host))
 ids = ["C%d" % i for i in range(a.nc)] + ["K%d" % i for i in range(a.nk)]
 KF.write_run_dir(os.path.join(root, "km"), 31, ids, parts)
+for p, (lo, host) in enumerate(merged):
+    KF.write_matrix_file(os.path.join(root, "km", "matrices", "matrix_%d.count.lz4" % p), 31, p, lo, host)
 size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
 print("run dir: %d partitions x %d rows, %d samples, %d records, %.1f MB on disk, written in %.0f s"
       % (a.parts, a.rows, S, records, size / 1e6, time.time() - t0), flush=True)
