@@ -74,6 +74,13 @@ int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream);
 int kmd_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream);
 int kmd_memset(void* d_dst, int value, size_t bytes, void* stream);
 int kmd_stream_sync(void* stream);
+/* A stream of the caller's own (non-blocking: it does not synchronise with the default stream the
+ * compute entry points use when `stream` is NULL), and a host-to-device copy that only enqueues:
+ * a host can upload the next partition from page-locked memory while the kernels of the current
+ * one run.  kmd_stream_sync(stream) waits for the copies. */
+int kmd_stream_create(void** stream);
+int kmd_stream_destroy(void* stream);
+int kmd_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes, void* stream);
 /* The library parks its internal scratch buffers (sort keys, flags, tallies) instead of
  * returning them to the driver after every call; this frees the parked ones. */
 int kmd_release_cache(void);

@@ -50,6 +50,9 @@ SIGNATURES = {
     "kmd_malloc_host": (_i, [C.POINTER(_vp), _sz]),
     "kmd_free_host": (_i, [_vp]),
     "kmd_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "kmd_memcpy_h2d_async": (_i, [_vp, _vp, _sz, _vp]),
+    "kmd_stream_create": (_i, [C.POINTER(_vp)]),
+    "kmd_stream_destroy": (_i, [_vp]),
     "kmd_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "kmd_memset": (_i, [_vp, _i, _sz, _vp]),
     "kmd_stream_sync": (_i, [_vp]),

@@ -158,6 +158,25 @@ int kmd_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream)
   KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return KMD_OK;
 }
+int kmd_stream_create(void** stream)
+{
+  KMD_REQUIRE(stream, "kmd_stream_create: NULL argument");
+  hipStream_t st = nullptr;
+  KMD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = st;
+  return KMD_OK;
+}
+int kmd_stream_destroy(void* stream)
+{
+  if (stream) KMD_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return KMD_OK;
+}
+int kmd_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes, void* stream)
+{
+  if (!bytes) return KMD_OK;
+  KMD_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  return KMD_OK;
+}
 int kmd_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream)
 {
   if (!bytes) return KMD_OK;

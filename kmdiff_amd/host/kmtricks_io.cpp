@@ -1,6 +1,7 @@
 #include "kmtricks_io.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -433,7 +434,7 @@ struct payload_stream
   size_t records(bool compressed, size_t rec, std::vector<char>& in, std::vector<char>& outv,
                  const std::function<void(const char*, size_t)>& on_records)
   {
-    const size_t chunk = (size_t)1 << 20;
+    static const size_t chunk = []() { const char* e = std::getenv("KMD_IO_CHUNK_KB"); return (size_t)(e ? std::atoi(e) : 1024) << 10; }();
     if (in.size() < chunk) in.resize(chunk);
     if (outv.size() < chunk + rec) outv.resize(chunk + rec);
     char* const out = outv.data();

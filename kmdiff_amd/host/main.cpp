@@ -261,6 +261,16 @@ public:
   // per partition once the arrays have grown to the run's file sizes).
   void load(size_t p, partition_input* in) const
   {
+    const stopwatch t;
+    load_files(p, in);
+    std::lock_guard<std::mutex> g(mu_);
+    busy_ += t.seconds();
+  }
+  double busy_seconds() const { std::lock_guard<std::mutex> g(mu_); return busy_; }
+
+private:
+  void load_files(size_t p, partition_input* in) const
+  {
     const size_t S = C_.S;
     const bool two_limbs = C_.two_limbs;
     const size_t n_streams = from_matrix() ? 1 : S;
@@ -299,7 +309,6 @@ public:
     in->n = in->offs[S];
   }
 
-private:
   // body(s) for every sample on this worker's share of the -t threads; the first exception is rethrown
   void for_samples(const std::function<void(size_t)>& body) const
   {
@@ -325,6 +334,8 @@ private:
   const run_context& C_;
   std::vector<std::string> mpaths_;
   size_t threads_;
+  mutable std::mutex mu_;
+  mutable double busy_ = 0;                              // seconds spent in load() (KMD_HOST_TIMING)
 };
 
 // ---- one GPU of stage 1 ------------------------------------------------------------------------
@@ -369,8 +380,20 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   sv_all.n_counts = want_counts ? S : 0;
   sv_all.kmer_bytes = two_limbs ? 16 : 8;
   uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
-  dev_buf d_kmers, d_kmers_hi, d_counts, d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc,
-          d_smk, d_sc;
+  // what a partition brings to the device, twice: the set of partition t + 1 is filled by the copy
+  // stream while the kernels of partition t read the other one.  K-mer feed: the S streams one after
+  // the other (the input of K2); matrices/ feed: the rows themselves (the tile K1 reads).
+  struct device_input
+  {
+    dev_buf kmers, kmers_hi, counts;
+    std::vector<uint64_t> offs;                          // k-mer feed: stream s is [offs[s], offs[s + 1])
+    size_t n = 0;                                        // records (k-mer feed) or rows (matrices/)
+  };
+  device_input dset[2];
+  void* copy_stream = nullptr;
+  ck(kmd_stream_create(&copy_stream), "kmd_stream_create");
+  struct stream_guard { void* s; ~stream_guard() { kmd_stream_sync(s); kmd_stream_destroy(s); } } copy_guard { copy_stream };
+  dev_buf d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc, d_smk, d_sc;
   // a ring of staging sets: the partition being processed and `depth` more being decoded.  K-mer
   // files: one partition ahead, its S files on this worker's share of the -t threads (deeper
   // measured no gain: the decode is hidden already).  matrices/: one file = one LZ4 frame = one
@@ -379,11 +402,11 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   // worker's partitions: every slot is page-locked once (~0.15 s per GB, and again to release),
   // which a short run does not earn back (12 partitions of 336 MB: depth 8 cost 1.1 s more than depth 1).
   const size_t my_units = (n_units + n_workers - 1 - wi) / n_workers;
-  const size_t depth = !from_matrix ? 1 :
+  const size_t depth = std::getenv("KMD_RING_DEPTH") ? (size_t)std::max(1, std::atoi(std::getenv("KMD_RING_DEPTH"))) : !from_matrix ? 1 :
     std::max<size_t>(1, std::min({ std::max<size_t>(opt.threads / n_workers, 1), (size_t)8, my_units / 4 }));
   std::vector<partition_input> staging(depth + 1);
   std::vector<std::future<void>> ahead(depth + 1);
-  double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
+  double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0, t_copy_wait = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
                                                        // the wait spent on the ring's first turn (its arrays get page-locked then)
   size_t issued = 0;                                   // partitions of this worker handed to the loader
   auto issue = [&]()
@@ -393,64 +416,77 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       ahead[issued % (depth + 1)] = std::async(std::launch::async, [&loader, p_next, in = &staging[issued % (depth + 1)]]() { loader.load(p_next, in); });
     ++issued;
   };
+  // turn t of this worker = its t-th partition.  upload(t): wait for the decoder of turn t, then
+  // enqueue its host-to-device copies (page-locked arrays -> device set t % 2) on the copy stream.
+  auto upload = [&](size_t t)
+  {
+    const size_t p = wi + t * n_workers;
+    if (p >= n_units) return;
+    ahead[t % (depth + 1)].get();
+    const partition_input& in = staging[t % (depth + 1)];
+    device_input& D = dset[t % 2];
+    D.n = in.n;
+    if (from_matrix)
+    {
+      // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
+      if (in.m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
+      if (two_limbs != (in.m.slots == 2)) die(mpaths[p] + ": k-mer width differs from the run's");
+      const sample_stream& rows = in.st[0];
+      D.counts.reserve(D.n * S * 4); D.kmers.reserve(D.n * 8);
+      ck(kmd_memcpy_h2d_async(D.counts.p, rows.counts.p, D.n * S * 4, copy_stream), "h2d");
+      ck(kmd_memcpy_h2d_async(D.kmers.p, rows.kmers.p, D.n * 8, copy_stream), "h2d");
+      if (two_limbs)
+      {
+        D.kmers_hi.reserve(D.n * 8);
+        ck(kmd_memcpy_h2d_async(D.kmers_hi.p, rows.kmers_hi.p, D.n * 8, copy_stream), "h2d");
+      }
+      return;
+    }
+    D.offs = in.offs;                                    // the slot is refilled while this partition is merged
+    D.kmers.reserve(D.n * 8); D.counts.reserve(D.n * 4);
+    if (two_limbs) D.kmers_hi.reserve(D.n * 8);
+    for (size_t s2 = 0; s2 < S; ++s2)                     // each stream to its place in the partition's arrays
+    {
+      const sample_stream& st = in.st[s2];
+      ck(kmd_memcpy_h2d_async((char*)D.kmers.p + D.offs[s2] * 8, st.kmers.p, st.n * 8, copy_stream), "h2d");
+      ck(kmd_memcpy_h2d_async((char*)D.counts.p + D.offs[s2] * 4, st.counts.p, st.n * 4, copy_stream), "h2d");
+      if (two_limbs) ck(kmd_memcpy_h2d_async((char*)D.kmers_hi.p + D.offs[s2] * 8, st.kmers_hi.p, st.n * 8, copy_stream), "h2d");
+    }
+  };
   if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] GPU %d: worker ready %.3f s into stage 1\n", dev, merge_time.seconds());
-  for (size_t d = 0; d < depth; ++d) issue();
+  for (size_t d = 0; d < depth + 1; ++d) issue();        // every slot of the ring gets a decoder
+  upload(0);
   size_t turn = 0;
   for (size_t p = wi; p < n_units; p += n_workers, ++turn)
   {
     kmd_tile tile {};
     uint64_t n_rows = 0;
-    issue();                                           // into the slot processed one ring turn ago
+    // copies of this partition done: its page-locked slot goes to the decoder of turn + depth + 1,
+    // and the next partition (decoded during the previous turn) is uploaded behind the kernels of this one
     const stopwatch t_wait;
-    ahead[turn % (depth + 1)].get();
+    ck(kmd_stream_sync(copy_stream), "kmd_stream_sync");
+    t_copy_wait += t_wait.seconds();
+    issue();
+    upload(turn + 1);
     t_loader += t_wait.seconds();
     if (turn <= depth) t_first += t_wait.seconds();
     const stopwatch t_dev;
-    partition_input& in = staging[turn % (depth + 1)];
+    const device_input& D = dset[turn % 2];
     if (from_matrix)
     {
-      // pre-merged rows (matrix_proxy::merge): row-major counts go to the device as they are
-      const matrix_file_info& m = in.m;
-      const sample_stream& rows = in.st[0];
-      if (m.nb_counts != S) die(mpaths[p] + ": number of samples differs from -1 + -2");
-      if (two_limbs != (m.slots == 2)) die(mpaths[p] + ": k-mer width differs from the run's");
-      n_rows = m.rows;
-      if (n_rows)
-      {
-        d_matrix.reserve(n_rows * S * 4); d_kmer_col.reserve(n_rows * 8);
-        ck(kmd_memcpy_h2d(d_matrix.p, rows.counts.p, n_rows * S * 4, nullptr), "h2d");
-        ck(kmd_memcpy_h2d(d_kmer_col.p, rows.kmers.p, n_rows * 8, nullptr), "h2d");
-        if (two_limbs)
-        {
-          d_kmer_col_hi.reserve(n_rows * 8);
-          ck(kmd_memcpy_h2d(d_kmer_col_hi.p, rows.kmers_hi.p, n_rows * 8, nullptr), "h2d");
-        }
-      }
-      tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)d_kmer_col.p,
-                        two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
+      n_rows = D.n;
+      tile = kmd_tile { D.counts.p, 4, KMD_LAYOUT_ROWS, S, (const uint64_t*)D.kmers.p,
+                        two_limbs ? (const uint64_t*)D.kmers_hi.p : nullptr, (size_t)n_rows, 0 };
     }
     else
     {
-      const std::vector<uint64_t>& offs = in.offs;
-      const size_t n = in.n;
+      const size_t n = D.n;
       if (n)
       {
-        d_kmers.reserve(n * 8); d_counts.reserve(n * 4);
-        if (two_limbs) d_kmers_hi.reserve(n * 8);
-        for (size_t s2 = 0; s2 < S; ++s2)                 // each stream to its place in the partition's arrays
-        {
-          const sample_stream& st = in.st[s2];
-          ck(kmd_memcpy_h2d((char*)d_kmers.p + offs[s2] * 8, st.kmers.p, st.n * 8, nullptr), "h2d");
-          ck(kmd_memcpy_h2d((char*)d_counts.p + offs[s2] * 4, st.counts.p, st.n * 4, nullptr), "h2d");
-          if (two_limbs) ck(kmd_memcpy_h2d((char*)d_kmers_hi.p + offs[s2] * 8, st.kmers_hi.p, st.n * 8, nullptr), "h2d");
-        }
         d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
-        if (two_limbs)
-        {
-          d_kmer_col_hi.reserve(n * 8);
-        }
-        ck(kmd_merge_partition((int)S, (const uint64_t*)d_kmers.p, two_limbs ? (const uint64_t*)d_kmers_hi.p : nullptr,
-                               (const uint32_t*)d_counts.p, offs.data(), 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED,
+        if (two_limbs) d_kmer_col_hi.reserve(n * 8);
+        ck(kmd_merge_partition((int)S, (const uint64_t*)D.kmers.p, two_limbs ? (const uint64_t*)D.kmers_hi.p : nullptr,
+                               (const uint32_t*)D.counts.p, D.offs.data(), 4, plugin ? KMD_LAYOUT_ROWS : KMD_LAYOUT_TILED,
                                plugin ? S : T, n, d_matrix.p,
                                (uint64_t*)d_kmer_col.p, two_limbs ? (uint64_t*)d_kmer_col_hi.p : nullptr, &n_rows, nullptr),
            "kmd_merge_partition");
@@ -467,9 +503,9 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       // back to the host, row-major, and go through process() one by one
       std::vector<uint32_t> rows(n_rows * S);
       std::vector<uint64_t> km(n_rows), kmh(two_limbs ? n_rows : 0);
-      ck(kmd_memcpy_d2h(rows.data(), d_matrix.p, n_rows * S * 4, nullptr), "d2h");
-      ck(kmd_memcpy_d2h(km.data(), d_kmer_col.p, n_rows * 8, nullptr), "d2h");
-      if (two_limbs) ck(kmd_memcpy_d2h(kmh.data(), d_kmer_col_hi.p, n_rows * 8, nullptr), "d2h");
+      ck(kmd_memcpy_d2h(rows.data(), tile.d_counts, n_rows * S * 4, nullptr), "d2h");
+      ck(kmd_memcpy_d2h(km.data(), tile.d_kmer_lo, n_rows * 8, nullptr), "d2h");
+      if (two_limbs) ck(kmd_memcpy_d2h(kmh.data(), tile.d_kmer_hi, n_rows * 8, nullptr), "d2h");
       std::vector<uint32_t> row(S);
       for (size_t i = 0; i < n_rows; ++i)
       {
@@ -542,7 +578,8 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   {
     std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder (%.3f s of it for the first %zu partitions, whose staging arrays "
                          "get page-locked), %.3f s in copies + kernels\n", dev, t_loader, t_first, depth + 1, t_device);
-    std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1\n", dev, merge_time.seconds());
+    std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1; of the wait, %.3f s for the copies; decoders busy %.3f s in all\n",
+                 dev, merge_time.seconds(), t_copy_wait, loader.busy_seconds());
     if (turn > depth + 1)
       std::fprintf(stderr, "[kmdiff-hip] GPU %d: steady state %.2f ms per partition (%zu partitions after the first %zu)\n", dev,
                    1e3 * t_steady / (double)(turn - depth - 1), turn - depth - 1, depth + 1);

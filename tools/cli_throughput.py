@@ -23,10 +23,14 @@ ap.add_argument("--rows", type=int, default=1_000_000)
 ap.add_argument("--parts", type=int, default=4)
 ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
+ap.add_argument("--keep", default="", help="write the run directory here, keep it, and stop")
 ap.add_argument("--matrix", action="store_true", help="also write <run>/matrices: the pre-merged feed (matrix_proxy)")
 a = ap.parse_args()
 S = a.nc + a.nk
 root = tempfile.mkdtemp(prefix="kmrun_")
+if a.keep:
+    os.makedirs(a.keep, exist_ok=True)
+    root = a.keep
 t0 = time.time()
 parts, records, merged = [], 0, []
 for p in range(a.parts):
@@ -47,6 +51,12 @@ for p, (lo, host) in enumerate(merged):
 size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
 print("run dir: %d partitions x %d rows, %d samples, %d records, %.1f MB on disk, written in %.0f s"
       % (a.parts, a.rows, S, records, size / 1e6, time.time() - t0), flush=True)
+if a.keep:
+    sys.exit(0)
+for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/proc/loadavg"):
+    if os.path.exists(f):
+        print(f, open(f).read().strip(), flush=True)
+print("cpus in affinity mask:", len(os.sched_getaffinity(0)), flush=True)
 cli = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
 for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64", "--devices", "2"]):
     out = os.path.join(root, "out")
@@ -58,7 +68,7 @@ for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64"
     assert r.returncode == 0, r.stderr
     stage1 = [l for l in r.stderr.split("\n") if "Partitions processed" in l][0].split("(")[1].split(" s")[0]
     for l in r.stderr.split("\n"):
-        if "waited" in l or "steady state" in l or "into stage 1" in l:
+        if "waited" in l or "steady state" in l or "last partition" in l:
             print("   ", l)
     print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s"
           % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1)), flush=True)
