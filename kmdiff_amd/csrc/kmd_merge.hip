@@ -1074,6 +1074,7 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
       int per_cu = 0;
       KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
       if (per_cu < 1) per_cu = 1;
+      if (const char* e = std::getenv("KMD_MERGE_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));   // dev: only honoured by the cooperative launch
       const size_t want = (nb + wpb - 1) / wpb;
       uint32_t S32 = (uint32_t)S, nb32 = (uint32_t)nb;
       int lay = layout;
@@ -1094,6 +1095,7 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
       if (e != hipSuccess)
       {
         (void)hipGetLastError();
+        if (std::getenv("KMD_MERGE_BLOCKS_PER_CU")) KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
         grid = std::min((size_t)n_cu * (size_t)std::max(per_cu - 1, 1), want);
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers_lo, d_kmers_hi, d_counts, start,
                            (uint32_t)S, (uint32_t)nb, status, group, layout, ld, row_capacity, d_matrix, d_kmer_out,
