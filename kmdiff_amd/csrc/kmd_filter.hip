@@ -859,16 +859,11 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
 // whose span fits the tile and keeps the alignment.  The loads of the next span are in flight
 // while the current one is summed.  The matrix's last vector may be cut by the end of the
 // buffer: it is fetched count by count.
-#ifndef KMD_FLAT_BLOCK
-#define KMD_FLAT_BLOCK 1024
-#endif
-#ifndef KMD_FLAT_VECS
-#define KMD_FLAT_VECS 4
-#endif
-constexpr int kFlatBlock = KMD_FLAT_BLOCK;
-constexpr int kFlatVecs = KMD_FLAT_VECS;      // 16-byte vectors per lane per span: 4 KB tiles, 16 waves per CU
-                                              // (measured: 8 KB x 12 waves 4.3 TB/s, 4 KB x 16 waves 4.6 TB/s at 21v21)
-template <typename CT>
+// kFlatVecs = 16-byte vectors per lane per span, i.e. the tile is kFlatVecs KB per wave: 4 KB tiles x 16
+// waves per CU for ordinary rows (measured: 8 KB x 12 waves 4.3 TB/s, 4 KB x 16 waves 4.6 TB/s at
+// 21v21); 8 and 16 KB tiles (12 / 8 waves) only for rows so wide that no aligned group of rows fits
+// the smaller tile (501 four-byte counts: 4 rows = 8016 B).
+template <typename CT, int kFlatVecs, int kFlatBlock>
 __global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_params P, const uint32_t R)
 {
   extern __shared__ double2 s_all[];
@@ -1327,17 +1322,22 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
   const bool dword_rows = (P.ld % per == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 3u) == 0);
   // pitch not a multiple of 16 bytes (21v21 four-byte counts: 168 B): the flat wave-private kernel,
-  // with the most rows per span (64, 32, ... 2) that fit its 4 KB tile and keep spans 16-byte aligned
+  // with the most rows per span (64, 32, ... 2) that fit its tile (4 KB; 8 or 16 KB for very wide rows)
+  // and keep spans 16-byte aligned
   if ((((P.ld * sizeof(CT)) % 16 != 0) || std::getenv("KMD_ROWS_FLAT_ALL")) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
       std::getenv("KMD_ROWS_FLAT_OFF") == nullptr)
   {
     const size_t pitch = P.ld * sizeof(CT);
-    uint32_t R = 64;
-    while (R >= 2 && (R * pitch > (size_t)64 * kFlatVecs * 16 || (R * pitch) % 16 != 0)) R >>= 1;
-    if (R >= 2)
+    auto rows_per_span = [&](size_t tile_bytes) -> uint32_t
     {
-      const size_t wpb = kFlatBlock / 64;
-      const size_t extra = wpb * kQueueBytesPerWave + wpb * 64 * kFlatVecs * 16;
+      uint32_t R = 64;
+      while (R >= 2 && (R * pitch > tile_bytes || (R * pitch) % 16 != 0)) R >>= 1;
+      return R >= 2 ? R : 0;
+    };
+    auto launch = [&](auto kernel, int vecs, int block, uint32_t R) -> int
+    {
+      const size_t wpb = (size_t)block / 64;
+      const size_t extra = wpb * kQueueBytesPerWave + wpb * 64 * (size_t)vecs * 16;
       const size_t avail = m->lds_per_block_max - 256 - extra;
       size_t want = (size_t)P.lf_n * sizeof(double2);
       if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
@@ -1345,12 +1345,15 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
       const size_t n_wtiles = (P.n_rows + R - 1) / R;
       size_t grid = (size_t)m->n_cu;
       if (grid > (n_wtiles + wpb - 1) / wpb) grid = (n_wtiles + wpb - 1) / wpb;
-      int rc = allow_big_lds(k_filter_rows_flat<CT>, want + extra);
+      int rc = allow_big_lds(kernel, want + extra);
       if (rc != KMD_OK) return rc;
-      hipLaunchKernelGGL((k_filter_rows_flat<CT>), dim3((unsigned)grid), dim3(kFlatBlock), want + extra, stream, P, R);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), want + extra, stream, P, R);
       KMD_HIP(hipGetLastError());
       return KMD_OK;
-    }
+    };
+    if (const uint32_t R = rows_per_span(4096)) return launch(k_filter_rows_flat<CT, 4, 1024>, 4, 1024, R);
+    if (const uint32_t R = rows_per_span(8192)) return launch(k_filter_rows_flat<CT, 8, 768>, 8, 768, R);
+    if (const uint32_t R = rows_per_span(16384)) return launch(k_filter_rows_flat<CT, 16, 512>, 16, 512, R);
   }
   if (!dword_rows)
   {
