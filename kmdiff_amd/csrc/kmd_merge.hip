@@ -270,13 +270,14 @@ __global__ void __launch_bounds__(256) k_bucket_split(const uint64_t* __restrict
 // The refined start table: row first[j] + t = slice t of old bucket j (first = exclusive prefix
 // of split); a kept bucket copies its row, a cut one searches its short segments for the slice
 // boundaries klo + t * kstep (saturating: the same monotone rule for every stream is all it takes)
+// and adds its share to the record counts of the slices (child_n, zeroed by the caller)
 __global__ void __launch_bounds__(256) k_refine_starts(const uint64_t* __restrict__ keys,
                                                        const uint32_t* __restrict__ start, uint32_t S, uint32_t nb,
                                                        const uint32_t* __restrict__ split,
                                                        const uint64_t* __restrict__ klo,
                                                        const uint64_t* __restrict__ kstep,
                                                        const uint32_t* __restrict__ first, uint32_t nb_new,
-                                                       uint32_t* __restrict__ out)
+                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ child_n)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ((size_t)nb + 1) * S) return;
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(256) k_refine_starts(const uint64_t* __restric
   if (m == 1) return;
   const uint32_t end = start[i + S];
   const uint64_t k0 = klo[j], step = kstep[j];
-  uint32_t lo = beg;
+  uint32_t lo = beg, prev = beg;
   for (uint32_t t = 1; t < m; ++t)
   {
     uint64_t bound = k0 + (uint64_t)t * step;
@@ -301,7 +302,19 @@ __global__ void __launch_bounds__(256) k_refine_starts(const uint64_t* __restric
       if (keys[mid] < bound) lo = mid + 1; else hi = mid;
     }
     out[(row + t) * S + s] = lo;
+    if (lo > prev) atomicAdd(child_n + row + t - 1, lo - prev);     // records of this stream in slice t - 1
+    prev = lo;
   }
+  if (end > prev) atomicAdd(child_n + row + m - 1, end - prev);
+}
+
+// pieces of cut buckets that are still over capacity (child_n is zero for kept buckets): the check
+// that would otherwise be another pass over the whole start table
+__global__ void __launch_bounds__(256) k_count_over(const uint32_t* __restrict__ child_n, uint32_t nb, uint32_t cap,
+                                                    uint32_t* __restrict__ counter)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb && child_n[i] > cap) atomicAdd(counter, 1u);
 }
 
 // keys of one bucket differ in their low ~40 bits: fold them to 32 and take the TOP bits of a
@@ -1009,9 +1022,11 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   constexpr int kMaxLevels = 6;
   const uint64_t wq = (uint64_t)((((unsigned __int128)1) << 64) / B.mult);          // 2^64 = wq mult + wr
   const uint64_t wr = (uint64_t)((((unsigned __int128)1) << 64) % B.mult);
-  // returns buckets over capacity before the cut (0: table unchanged), -1: give up (sort path), -2: error
-  auto refine_level = [&](int level, bool arith, int* n_over_out) -> int
+  // returns buckets over capacity before the cut (0: table unchanged), -1: give up (sort path), -2: error;
+  // *pieces_over = pieces of the cut buckets that are still over capacity
+  auto refine_level = [&](int level, bool arith, int* n_over_out, uint32_t* pieces_over) -> int
   {
+    *pieces_over = 0;
     uint32_t n_over = 0;
     void *p_split = nullptr, *p_klo = nullptr, *p_kstep = nullptr;
     KMD_HIP(sc.take(&p_split, (nb + 1) * 4));
@@ -1044,11 +1059,21 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     // faster tool (2000 clusters of 2000 consecutive k-mers: 22.7 ms here against 8.9 ms sorted)
     if ((uint64_t)nb_new > table_cap || 2 * (uint64_t)nb_new > 5 * (uint64_t)nb0) { *n_over_out = -1; return KMD_OK; }
     KMD_HIP(sc.take(&p_refined, ((size_t)nb_new + 1) * (size_t)S * 4));
+    void* p_child = nullptr;
+    KMD_HIP(sc.take(&p_child, (size_t)nb_new * 4));
+    KMD_HIP(hipMemsetAsync(p_child, 0, (size_t)nb_new * 4, st));
+    KMD_HIP(hipMemsetAsync(overflow + 2, 0, 4, st));
     const size_t cells = (nb + 1) * (size_t)S;
     hipLaunchKernelGGL(k_refine_starts, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_kmers, start,
                        (uint32_t)S, (uint32_t)nb, split, static_cast<const uint64_t*>(p_klo),
-                       static_cast<const uint64_t*>(p_kstep), first, nb_new, static_cast<uint32_t*>(p_refined));
+                       static_cast<const uint64_t*>(p_kstep), first, nb_new, static_cast<uint32_t*>(p_refined),
+                       static_cast<uint32_t*>(p_child));
+    hipLaunchKernelGGL(k_count_over, dim3((unsigned)(((size_t)nb_new + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const uint32_t*>(p_child), nb_new, cap, overflow + 2);
     KMD_HIP(hipGetLastError());
+    KMD_HIP(hipMemcpyAsync(pieces_over, overflow + 2, 4, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    if (dbg) std::fprintf(stderr, "[merge_fast] level %d: %u pieces still over capacity\n", level, *pieces_over);
     start = static_cast<uint32_t*>(p_refined);
     nb = nb_new;
     return KMD_OK;
@@ -1125,14 +1150,18 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
     return KMD_OK;
   };
 
-  // cut until every bucket fits (a level that finds nothing over capacity is the check), then merge
+  // cut until every bucket fits, then merge.  Whether the pieces of a level's cut buckets fit is
+  // known from their record counts, added up while the refined table is written: another level --
+  // another pass over the whole table -- follows only if one of them does not.
   for (int level = 0;; ++level)
   {
     int n_over = 0;
-    const int rc_l = refine_level(level, level == 0 && !splitters, &n_over);
+    uint32_t pieces_over = 0;
+    const int rc_l = refine_level(level, level == 0 && !splitters, &n_over, &pieces_over);
     if (rc_l != KMD_OK) return rc_l;
     if (n_over == 0) break;
     if (n_over < 0 || level == kMaxLevels) return KMD_OK;    // mostly clusters / cannot be cut: sort path
+    if (pieces_over == 0) break;
   }
   {
     const int rc_m = run_merge();
