@@ -551,7 +551,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
       if ((int)lane >= o) incl += up;
     }
     uint32_t run = incl - lsum;                         // records before this lane's first sample
-    const uint32_t n = __shfl(incl, 63, 64);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));   // wave-uniform: slots past it are skipped by scalar branches
     const bool too_big = n > kWaveCap;
     if (too_big && lane == 0) atomicAdd(overflow, 1u);  // the caller falls back to the sort path
 #pragma unroll
@@ -571,9 +571,10 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
 
     TICK(0);
     // hash set sized to the bucket; every lane keeps its records in registers
-    uint32_t d = 0;
+    uint32_t d = 0, filled = 0;                         // distinct keys (with / without the empty-marker key)
     bool any_max = false;
     uint32_t slots = 64;
+    uint16_t* s_tslot = reinterpret_cast<uint16_t*>(s_keys);        // slot of each compacted key (s_keys is written last)
     uint64_t key_r[kPerLane];
     uint64_t keyh_r[kTwo ? kPerLane : 1];
     uint32_t slot_r[kPerLane];                          // hash slot of the record's key (kNoSlot: the empty-marker key)
@@ -592,7 +593,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
       {
         const uint32_t f = (uint32_t)r * 64 + lane;
         key_r[r] = 0; st.cnt_r[r] = 0; st.sr_r[r] = 0; slot_r[r] = kNoSlot;
-        if (f < n)
+        if ((uint32_t)r * 64 < n && f < n)
         {
           const uint32_t lo = smp_of[f];                // the stream this record comes from
           const uint32_t i = s_beg[lo] + (f - pref[lo]);
@@ -607,7 +608,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
         for (int r = 0; r < kPerLane; ++r)
         {
           const uint32_t f = (uint32_t)r * 64 + lane;
-          if (f < n) { s_rk[f] = key_r[r]; s_rk[kWaveCap + f] = keyh_r[r]; }
+          if ((uint32_t)r * 64 < n && f < n) { s_rk[f] = key_r[r]; s_rk[kWaveCap + f] = keyh_r[r]; }
         }
         wave_sync();
       }
@@ -618,6 +619,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
 #pragma unroll
       for (int r = 0; r < kPerLane; ++r)
       {
+        if ((uint32_t)r * 64 >= n) continue;              // wave-uniform: nothing in this slot
         const uint32_t f = (uint32_t)r * 64 + lane;
         bool fresh = false;
         if constexpr (kTwo)
@@ -653,8 +655,19 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
             slot_r[r] = h;
           }
         }
-        if ((uint32_t)r * 64 < n) d += (uint32_t)__popcll(__ballot(fresh));
+        // the lanes that claimed a slot hold the bucket's distinct keys: compacted here (ballot
+        // prefix), with their slots, for the ranking below -- no scan of the hash table for them
+        const unsigned long long fm = __ballot(fresh);
+        if (fresh)
+        {
+          const uint32_t e = d + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+          s_tmp[e] = key_r[r];
+          if constexpr (kTwo) s_tmp[kWaveCap + e] = keyh_r[r];
+          s_tslot[e] = (uint16_t)slot_r[r];
+        }
+        d += (uint32_t)__popcll(fm);
       }
+      filled = d;
       any_max = __ballot(has_max_key) != 0;
       d += any_max ? 1u : 0u;
     }
@@ -669,35 +682,12 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
     st.j = j; st.n = n; st.d = d; st.work = work;
 
     TICK(2);
-    // rank the distinct keys: compact them (ballot prefix), every lane counts how many are
+    // rank the distinct keys (compacted at insertion): every lane counts how many are
     // smaller than its own (broadcast LDS reads, no dependent chain -- a bitonic sort of ~100
     // keys is ~30 dependent LDS round trips); rank = row within the bucket
     wave_sync();
     if (work)
     {
-      uint16_t* s_tslot = reinterpret_cast<uint16_t*>(s_keys);      // slot of each compacted key (s_keys is written last)
-      uint32_t filled = 0;
-      for (uint32_t t0 = 0; t0 < slots; t0 += 64)
-      {
-        unsigned long long k = 0, kh = 0;
-        bool occ;
-        if constexpr (kTwo)
-        {
-          const uint32_t own = s_own[t0 + lane];
-          occ = own != kEmpty32;
-          if (occ) { k = s_rk[own]; kh = s_rk[kWaveCap + own]; }
-        }
-        else { k = s_hash[t0 + lane]; occ = k != kEmpty; }
-        const unsigned long long m = __ballot(occ);
-        if (occ)
-        {
-          const uint32_t e = filled + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          s_tmp[e] = k;
-          if constexpr (kTwo) s_tmp[kWaveCap + e] = kh;
-          s_tslot[e] = (uint16_t)(t0 + lane);
-        }
-        filled += (uint32_t)__popcll(m);
-      }
       wave_sync();
       unsigned long long mk[kPerLane], mkh[kTwo ? kPerLane : 1];
       uint32_t ms[kPerLane], below[kPerLane];
@@ -746,7 +736,8 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
 #pragma unroll
       for (int r = 0; r < kPerLane; ++r)
       {
-        if ((uint32_t)r * 64 + lane < n) st.sr_r[r] |= (slot_r[r] == kNoSlot ? d - 1 : (uint32_t)s_rank[slot_r[r]]) << 16;
+        if ((uint32_t)r * 64 < n && (uint32_t)r * 64 + lane < n)
+          st.sr_r[r] |= (slot_r[r] == kNoSlot ? d - 1 : (uint32_t)s_rank[slot_r[r]]) << 16;
       }
       wave_sync();                                      // the segment tables of the next bucket go here
     }
@@ -755,7 +746,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
   // ---------------- stage B: row number by look-back, LDS block, write-out
   auto stage_b = [&](const state_t& st, const unsigned long long* s_keys, bool have_rb, unsigned long long early_rb)
   {
-    const uint32_t j = st.j, n = st.n, d = st.d;
+    const uint32_t j = st.j, n = __builtin_amdgcn_readfirstlane(st.n), d = __builtin_amdgcn_readfirstlane(st.d);
     TICK(3);
     const unsigned long long rb64 = have_rb ? early_rb : rows_before(status, group, j, lane);
     TICK(4);
@@ -795,7 +786,7 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
     for (int r = 0; r < kPerLane; ++r)
     {
       const uint32_t f = (uint32_t)r * 64 + lane;
-      if (f < n)
+      if ((uint32_t)r * 64 < n && f < n)
       {
         uint32_t c = st.cnt_r[r];
         if (c > cmax) c = cmax;
