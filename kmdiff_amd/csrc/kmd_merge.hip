@@ -616,6 +616,24 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
       if (key_r[0] == 12345 && st.cnt_r[0] == 77) T[7]++;   // forces the loads to complete here
 #endif
       TICK(1);
+      // one-limb keys: the first probe of every record slot goes out before any answer is looked at
+      // (an LDS compare-and-swap that returns is ~200 cycles; slot after slot they add up)
+      unsigned long long first_old[kTwo ? 1 : kPerLane];
+      if constexpr (!kTwo)
+      {
+#pragma unroll
+        for (int r = 0; r < kPerLane; ++r)
+        {
+          first_old[r] = 0;
+          const uint32_t f = (uint32_t)r * 64 + lane;
+          if ((uint32_t)r * 64 < n && f < n && key_r[r] != kEmpty)
+          {
+            const uint32_t h = (hash_slot(key_r[r]) >> 16) & mask;   // slots <= 2048: bits 16.. of the product
+            slot_r[r] = h;
+            first_old[r] = atomicCAS(&s_hash[h], kEmpty, (unsigned long long)key_r[r]);
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < kPerLane; ++r)
       {
@@ -644,13 +662,14 @@ k_bucket_merge(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ k
           if (k == kEmpty) has_max_key = true;
           else
           {
-            uint32_t h = (hash_slot(k) >> 16) & mask;          // slots <= 2048: bits 16.. of the product
+            uint32_t h = slot_r[r];                            // first probe: issued above, for all slots at once
+            unsigned long long old = first_old[r];
             for (;;)
             {
-              const unsigned long long old = atomicCAS(&s_hash[h], kEmpty, (unsigned long long)k);
               if (old == kEmpty) { fresh = true; break; }
               if (old == k) break;
               h = (h + 1) & mask;
+              old = atomicCAS(&s_hash[h], kEmpty, (unsigned long long)k);
             }
             slot_r[r] = h;
           }
