@@ -366,6 +366,9 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x)
 __device__ __forceinline__ unsigned long long rows_before(const unsigned long long* status, merge_group* group,
                                                           uint32_t j, uint32_t lane)
 {
+#ifdef KMD_MERGE_FAKE_LOOKBACK   // dev experiment: what the kernel costs without its look-back (rows are wrong)
+  return (unsigned long long)j * 5ull;
+#endif
   const uint32_t g = j >> 6, r = j & 63;
   unsigned long long base = 0;
   if (r == 0)
