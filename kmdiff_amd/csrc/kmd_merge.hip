@@ -914,7 +914,23 @@ struct scratch
   }
 };
 
-inline uint32_t fast_bucket_cap(int S) { return S <= 64 ? 256u : S <= 128 ? 512u : 1024u; }
+// A bucket must hold a few whole rows (a row has up to S records: cap >= 4 S, the kernel's tables),
+// and the larger the buckets the smaller the [bucket][sample] start table that five passes read and
+// write -- against 2 and 1 waves per SIMD for the 512- and 1024-record kernels.  Measured
+// (tools/cap_sweep.sh, 50 M records): S=20 256: 1.16 / 512: 1.20 ms; S=32 1.27 / 1.27; S=40 1.37 / 1.27;
+// S=64 2.32 / 1.32; S=100 512: 1.61 / 1024: 1.80; S=128 2.25 / 1.81.
+// Two-limb keys (their 512- and 1024-record kernels hold one wave per workgroup and more state):
+// the smallest capacity that serves S stays best (S=40 256: 3.9 / 512: 4.7 ms; S=100 512: 5.6 / 1024: 6.6).
+inline uint32_t fast_bucket_cap(int S, bool two_limbs)
+{
+  uint32_t cap = two_limbs ? (S <= 64 ? 256u : S <= 128 ? 512u : 1024u) : (S <= 32 ? 256u : S <= 104 ? 512u : 1024u);
+  if (const char* e = std::getenv("KMD_MERGE_CAP"))       // dev: another capacity that still serves S (A/B)
+  {
+    const uint32_t c = (uint32_t)std::atoi(e);
+    if ((c == 256 || c == 512 || c == 1024) && c >= 4u * (uint32_t)S) cap = c;
+  }
+  return cap;
+}
 
 // The bucketed LDS merge.  *used = false (and nothing written) when the input does not suit
 // it (clustered keys overflow a bucket): the caller then takes the sort-based path.
@@ -965,7 +981,7 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   const uint64_t span = range[1] - range[0];                    // kmax - kmin
   // a bucket must hold a few whole rows, and a row has up to S records: capacity by sample count;
   // half the capacity per bucket on average (one wave each); the start table is capped at 1 GiB
-  const uint32_t cap = fast_bucket_cap(S);
+  const uint32_t cap = fast_bucket_cap(S, two);
   uint64_t nb_target = n / (cap / 2) + 1;
   const uint64_t table_cap = (1ull << 30) / (4ull * (uint64_t)S);
   if (nb_target > table_cap) nb_target = table_cap;
