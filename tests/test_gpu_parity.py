@@ -491,6 +491,27 @@ def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes, pat
     assert e.n_rows == 0
 
 
+@pytest.mark.parametrize("S", [32, 33, 64, 65, 104, 105, 128, 129, 256])
+@pytest.mark.parametrize("presence", [0.6, 0.05])
+def test_merge_bucket_capacity_boundaries(K, oracle, S, presence, monkeypatch):
+    """The bucketed merge picks its kernel by sample count (256 / 512 / 1024 records per bucket from
+    33 / 105 samples on): both sides of every switch, with rows of many records (a k-mer in 60 % of the
+    samples) and of few (5 %: a bucket then holds dozens to hundreds of rows -- ranking over several
+    key registers per lane, a row block larger than the LDS tile), forced onto the bucketed path."""
+    monkeypatch.setenv("KMD_MERGE_PATH", "fast-only")
+    rng = np.random.default_rng(1000 + S)
+    universe = np.unique(rng.integers(0, 1 << 62, int(140_000 / (S * presence)) + 2000, dtype=np.uint64))
+    streams = []
+    for s in range(S):
+        pick = rng.random(len(universe)) < presence
+        streams.append((universe[pick], rng.integers(1, 5000, int(pick.sum())).astype(np.uint32)))
+    want, kmers = oracle.merge_partition(streams)
+    m = K.merge_partition(streams, count_bytes=4, layout=K.LAYOUT_TILED)
+    assert m.n_rows == want.shape[0]
+    assert (m.kmers_to_host()[0] == kmers).all()
+    assert (m.to_host() == want).all()
+
+
 def test_merge_partition_clustered_keys_and_extremes(K, oracle, monkeypatch):
     """Heavily clustered keys overflow a bucket of the LDS merge: it must hand over to the sort
     path and still be exact; the all-ones key (k = 32, GGG...G) is a legal k-mer."""
