@@ -390,9 +390,6 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     size_t n = 0;                                        // records (k-mer feed) or rows (matrices/)
   };
   device_input dset[2];
-  void* copy_stream = nullptr;
-  ck(kmd_stream_create(&copy_stream), "kmd_stream_create");
-  struct stream_guard { void* s; ~stream_guard() { kmd_stream_sync(s); kmd_stream_destroy(s); } } copy_guard { copy_stream };
   dev_buf d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc, d_smk, d_sc;
   // a ring of staging sets: the partition being processed and `depth` more being decoded.  K-mer
   // files: one partition ahead, its S files on this worker's share of the -t threads (deeper
@@ -406,6 +403,11 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     std::max<size_t>(1, std::min({ std::max<size_t>(opt.threads / n_workers, 1), (size_t)8, my_units / 4 }));
   std::vector<partition_input> staging(depth + 1);
   std::vector<std::future<void>> ahead(depth + 1);
+  // declared after the staging ring: on any way out the copies are waited for before their page-locked
+  // sources are released
+  void* copy_stream = nullptr;
+  ck(kmd_stream_create(&copy_stream), "kmd_stream_create");
+  struct stream_guard { void* s; ~stream_guard() { kmd_stream_sync(s); kmd_stream_destroy(s); } } copy_guard { copy_stream };
   double t_loader = 0, t_device = 0, t_first = 0, t_steady = 0, t_copy_wait = 0;      // waiting for the decoder / copies + kernels + survivors back / the part of
                                                        // the wait spent on the ring's first turn (its arrays get page-locked then)
   size_t issued = 0;                                   // partitions of this worker handed to the loader
