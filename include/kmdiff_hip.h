@@ -217,6 +217,21 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
                         uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out,
                         void* stream);
 
+/* The same merge for a consumer that needs only the two count sums of a k-mer -- which is all
+ * PoissonLikelihood::process reads of a row (model.hpp:144-145): no matrix is written, every distinct
+ * k-mer leaves as (k-mer, sum of its control counts, sum of its case counts), 24 bytes instead of
+ * 8 + 4 S.  Samples [0, nb_controls) are the controls (merge.hpp:70-72).  The rows come in no
+ * particular order (identify them by their k-mer).  One-limb k-mers, at most 256 samples; inputs the
+ * bucketed merge cannot take (k-mers in dense clusters) are refused with KMD_E_INVALID -- use
+ * kmd_merge_partition then.  kmd_poisson_filter_sums tests such rows; its survivors' `row` is the
+ * index into these arrays. */
+int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint32_t* d_counts,
+                   const uint64_t* offsets, size_t row_capacity, uint64_t* d_kmer_out,
+                   uint64_t* d_sum_control, uint64_t* d_sum_case, uint64_t* n_rows_out, void* stream);
+int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_sum_control,
+                            const uint64_t* d_sum_case, size_t n_rows, double threshold,
+                            const kmd_survivors* out, uint64_t* d_counters, void* stream);
+
 /* ---- stage 2 (optional): population-stratification re-test ---------------------------------
  * Replaces pop_strat_corrector (include/kmdiff/popstrat.hpp:148-367): constructor
  * (src/popstrat.cpp:136-151), load_Z / load_Y (:153-171), init_global_features +

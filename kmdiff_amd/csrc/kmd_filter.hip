@@ -694,6 +694,39 @@ __global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params 
   flush_beyond(P, n_beyond);
 }
 
+// ---- rows given by their two sums (the fused merge, kmd_merge_sums) ---------------------------
+// One lane per row: 16 bytes in, straight into the pre-filter and the deferred-evaluation queue.
+__global__ void __launch_bounds__(kBlock) k_filter_sums(const filter_params P, const unsigned long long* __restrict__ sum_c,
+                                                        const unsigned long long* __restrict__ sum_k)
+{
+  extern __shared__ double2 s_lf[];
+  stage_table(P, s_lf);
+  uint32_t n_beyond = 0;
+  wave_queue Q;
+  {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s_lf + P.lds_n) + (size_t)(threadIdx.x >> 6) * kQueueCap * 3;
+    Q.sc = q; Q.sk = q + kQueueCap; Q.row = q + 2 * kQueueCap; Q.n = 0;
+  }
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n_round = (P.n_rows + stride - 1) / stride * stride;          // whole waves take every step together
+  uint32_t n_valid = 0;                                                      // entries that are rows, not holes
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
+  {
+    row_state st;
+    st.row = i;
+    st.valid = i < P.n_rows;
+    st.sum_c = st.valid ? __builtin_nontemporal_load(sum_c + i) : 0ull;
+    st.sum_k = st.valid ? __builtin_nontemporal_load(sum_k + i) : 0ull;
+    if (st.sum_c == ~0ull) st.valid = false;                                 // a hole kmd_merge_sums left
+    n_valid += st.valid ? 1u : 0u;
+    defer_row(P, s_lf, st, n_beyond, Q);
+  }
+  drain_queue(P, s_lf, Q);
+  flush_beyond(P, n_beyond);
+  for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_down(n_valid, o, 64);
+  if ((threadIdx.x & 63) == 0 && n_valid) atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)n_valid);   // merge.hpp:76
+}
+
 // ---- row-major rows, 16-byte aligned pitch: wave-private staging -------------------------
 // What a host that hands over kmtricks rows (matrix_proxy, merge.hpp:194-203) delivers.  A wave
 // owns 64 consecutive rows at a time.  Their bytes are fetched with 16-byte loads that are
@@ -1523,6 +1556,37 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
       default: return launch_rows<uint32_t>(P, m, st);
     }
   }
+}
+
+// kmd_poisson_filter for rows that come as (k-mer, control sum, case sum): what kmd_merge_sums
+// writes.  The survivors' `row` is the index into those arrays.
+extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_sum_control,
+                                       const uint64_t* d_sum_case, size_t n_rows, double threshold,
+                                       const kmd_survivors* out, uint64_t* d_counters, void* stream)
+{
+  KMD_REQUIRE(m && d_counters, "kmd_poisson_filter_sums: NULL model or counters");
+  KMD_REQUIRE(n_rows == 0 || (d_sum_control && d_sum_case), "kmd_poisson_filter_sums: NULL sums");
+  kmd_tile t { d_sum_control, 4, KMD_LAYOUT_SOA, n_rows, d_kmer, nullptr, n_rows, 0 };   // for the shared checks; counts are never read
+  filter_params P;
+  int rc = fill_params(P, m, &t, threshold);
+  if (rc != KMD_OK) return rc;
+  P.counters = reinterpret_cast<unsigned long long*>(d_counters);
+  if (out) P.out = *out;
+  if (n_rows == 0) return KMD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  size_t want = m->lf_n * sizeof(double2);
+  const size_t queues = (size_t)(kBlock / 64) * kQueueBytesPerWave;
+  const size_t budget = m->lds_per_block_max - 256 - queues;
+  if (want > budget) want = budget / sizeof(double2) * sizeof(double2);
+  P.lds_n = (uint32_t)(want / sizeof(double2));
+  size_t grid = (size_t)m->n_cu;
+  if (grid > (n_rows + kBlock - 1) / kBlock) grid = (n_rows + kBlock - 1) / kBlock;
+  rc = allow_big_lds(k_filter_sums, want + queues);
+  if (rc != KMD_OK) return rc;
+  hipLaunchKernelGGL(k_filter_sums, dim3((unsigned)grid), dim3(kBlock), want + queues, st, P,
+                     reinterpret_cast<const unsigned long long*>(d_sum_control), reinterpret_cast<const unsigned long long*>(d_sum_case));
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
 }
 
 extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, double* d_pvalue,

@@ -328,6 +328,14 @@ class diff_observer:
                                        self.acc.counters.ptr, stream), "kmd_poisson_filter")
         self.acc._size = None
 
+    def process_sums(self, sums, stream=None):
+        """The rows as merge_sums leaves them: (k-mer, control sum, case sum).  Survivor `row` = index
+        into those arrays."""
+        s = self.acc.struct()
+        check(lib().kmd_poisson_filter_sums(self.model.handle, sums.kmers.ptr, sums.sum_c.ptr, sums.sum_k.ptr, sums.n_rows,
+                                            self.threshold, C.byref(s), self.acc.counters.ptr, stream), "kmd_poisson_filter_sums")
+        self.acc._size = None
+
     def _c(self, i):
         return int(self.acc.read_counters()[i])
 
@@ -366,6 +374,42 @@ def merge_partition(streams, n_samples=None, count_bytes=4, layout=N.LAYOUT_TILE
                                     C.byref(n_rows), None), "kmd_merge_partition")
     m.n_rows = int(n_rows.value)
     return m
+
+
+class RowSums:
+    """What kmd_merge_sums leaves on the device: n_rows entries (k-mer, control sum, case sum), unordered,
+    some of them holes (control sum = 2^64 - 1) that kmd_poisson_filter_sums skips."""
+
+    def __init__(self, capacity):
+        self.kmers = DeviceBuffer(max(capacity, 1) * 8)
+        self.sum_c = DeviceBuffer(max(capacity, 1) * 8)
+        self.sum_k = DeviceBuffer(max(capacity, 1) * 8)
+        self.capacity, self.n_rows = int(capacity), 0
+
+    def to_host(self):
+        """(k-mers, control sums, case sums, entry index) of the rows, holes left out."""
+        n = self.n_rows
+        km, sc, sk = self.kmers.to_host(np.uint64, n), self.sum_c.to_host(np.uint64, n), self.sum_k.to_host(np.uint64, n)
+        rows = np.nonzero(sc != np.uint64(2 ** 64 - 1))[0]
+        return km[rows], sc[rows], sk[rows], rows
+
+
+def merge_sums(streams, nb_controls, row_capacity=None):
+    """The merge of one partition for a consumer that only needs every k-mer's two count sums
+    (PoissonLikelihood::process reads nothing else of a row, model.hpp:144-145): no matrix."""
+    n_samples = len(streams)
+    offs = np.zeros(n_samples + 1, dtype=np.uint64)
+    for s, t in enumerate(streams):
+        offs[s + 1] = offs[s] + len(t[0])
+    total = int(offs[-1])
+    cat = lambda i, dt: (np.concatenate([np.asarray(t[i], dtype=dt) for t in streams]) if total else np.zeros(0, dt))
+    dk, dc = DeviceBuffer.from_host(cat(0, np.uint64)), DeviceBuffer.from_host(cat(1, np.uint32))
+    out = RowSums(total + (1 << 22) if row_capacity is None else int(row_capacity))   # room for the waves' unfinished chunks
+    n_rows = C.c_uint64(0)
+    check(lib().kmd_merge_sums(n_samples, int(nb_controls), dk.ptr if total else None, dc.ptr if total else None, offs.ctypes.data,
+                               out.capacity, out.kmers.ptr, out.sum_c.ptr, out.sum_k.ptr, C.byref(n_rows), None), "kmd_merge_sums")
+    out.n_rows = int(n_rows.value)
+    return out
 
 
 class pop_strat_corrector:

@@ -512,6 +512,53 @@ def test_merge_bucket_capacity_boundaries(K, oracle, S, presence, monkeypatch):
     assert (m.to_host() == want).all()
 
 
+@pytest.mark.parametrize("S,nc,presence", [(9, 4, 0.5), (40, 20, 0.65), (40, 20, 0.05), (33, 1, 0.3), (64, 63, 0.2), (105, 50, 0.4),
+                                           (200, 100, 0.1), (256, 128, 0.02)])
+def test_merge_sums_equals_merge_then_sum(K, oracle, S, nc, presence):
+    """kmd_merge_sums + kmd_poisson_filter_sums (no matrix: every distinct k-mer leaves the merge as
+    its control and case count sums) against the oracle merge: same k-mers, same two sums for every
+    row -- with counts that take the sums past 2^32 --, and the same survivors (k-mer, sign, means
+    bit-exact, p within 1e-10) as the oracle's diff_partition on the merged matrix; the all-ones
+    k-mer and a sample without k-mers included."""
+    rng = np.random.default_rng(4000 + S)
+    universe = np.unique(np.concatenate([rng.integers(0, 1 << 62, int(120_000 / (S * presence)) + 3000, dtype=np.uint64),
+                                         np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
+    picks = []
+    for s in range(S):
+        pick = rng.random(len(universe)) < presence
+        pick[-1] = s % 3 == 0                                            # the all-ones k-mer in a third of the samples
+        if s == 2:
+            pick[:] = False                                              # a sample with no k-mer here
+        picks.append(pick)
+    for big in (True, False):       # huge counts: the sums only (the oracle's table fallback loops over the count sum)
+        streams = [(universe[p], rng.integers(1, 2 ** 32 - 1 if (big and s % 5 == 0) else 300, int(p.sum())).astype(np.uint32))
+                   for s, p in enumerate(picks)]
+        want, kmers = oracle.merge_partition(streams)
+        sums = K.merge_sums(streams, nc)
+        km, sc, sk, entry = sums.to_host()
+        assert len(km) == want.shape[0]
+        order = np.argsort(km, kind="stable")
+        assert (km[order] == kmers).all()
+        assert (sc[order] == want[:, :nc].sum(axis=1, dtype=np.uint64)).all()
+        assert (sk[order] == want[:, nc:].sum(axis=1, dtype=np.uint64)).all()
+    tcs, tks = totals_of(want, nc)
+    ref = oracle.diff_partition(want, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(10000), 0.01)
+    model = K.PoissonLikelihood(nc, S - nc, tcs, tks, 10000)
+    acc = K.SurvivorAccumulator(max(sums.n_rows, 1))
+    obs = K.diff_observer(model, acc, 0.01)
+    obs.process_sums(sums)
+    acc.finish(sort=False)
+    got = acc.get()
+    assert obs.total() == want.shape[0] and len(got["row"]) == len(ref["row"])
+    km_all = sums.kmers.to_host(np.uint64, sums.n_rows)
+    got_km = km_all[got["row"].astype(np.int64)]
+    by_kmer = np.argsort(got_km, kind="stable")
+    assert (got_km[by_kmer] == kmers[ref["row"].astype(np.int64)]).all()
+    assert got["sign"][by_kmer].tolist() == ref["sign"].tolist()
+    assert got["mean_control"][by_kmer].tolist() == ref["mean_control"].tolist() and got["mean_case"][by_kmer].tolist() == ref["mean_case"].tolist()
+    assert np.allclose(got["pvalue"][by_kmer], ref["pvalue"], rtol=0, atol=1e-10)
+
+
 def test_merge_partition_clustered_keys_and_extremes(K, oracle, monkeypatch):
     """Heavily clustered keys overflow a bucket of the LDS merge: it must hand over to the sort
     path and still be exact; the all-ones key (k = 32, GGG...G) is a legal k-mer."""

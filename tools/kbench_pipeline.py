@@ -51,6 +51,24 @@ for _ in range(a.iters + 1):
     obs.process(out)
     lib.kmd_stream_sync(None)
     best = min(best, time.perf_counter() - t0)
+sig_matrix = int(acc.read_counters()[1])
+# the same partition without the matrix: (k-mer, control sum, case sum) per row, then the test on the sums
+sums = K.RowSums(a.rows + (1 << 22))        # rows + the waves' unfinished chunks (holes)
+best_s = 1e9
+for _ in range(a.iters + 1):
+    acc.counters.zero()
+    lib.kmd_stream_sync(None)
+    t0 = time.perf_counter()
+    K._native.check(lib.kmd_merge_sums(S, a.nc, dk.ptr, dc.ptr, offs.ctypes.data, sums.capacity, sums.kmers.ptr, sums.sum_c.ptr, sums.sum_k.ptr,
+                                       C.byref(nr), None))
+    sums.n_rows = int(nr.value)
+    obs.process_sums(sums)
+    lib.kmd_stream_sync(None)
+    best_s = min(best_s, time.perf_counter() - t0)
+sig_sums = int(acc.read_counters()[1])
+assert int(acc.read_counters()[0]) == out.n_rows and sig_sums == sig_matrix, (int(acc.read_counters()[0]), out.n_rows, sig_sums, sig_matrix)
+print("pipeline keys=%s S=%d records=%d rows=%d  sums path (no matrix) %.2f ms  %.3e rows/s  %.3e records/s  sig=%d"
+      % (a.keys, S, n, out.n_rows, best_s * 1e3, out.n_rows / best_s, n / best_s, sig_sums))
 c = acc.read_counters()
 print("pipeline keys=%s S=%d records=%d rows=%d  merge+filter %.2f ms  %.3e rows/s  %.3e records/s  sig=%d"
-      % (a.keys, S, n, out.n_rows, best * 1e3, out.n_rows / best, n / best, int(c[1])))
+      % (a.keys, S, n, out.n_rows, best * 1e3, out.n_rows / best, n / best, sig_matrix))
