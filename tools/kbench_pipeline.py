@@ -18,6 +18,7 @@ ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--keys", default="random")
+ap.add_argument("--sparse", type=float, default=1.0, help="keep each record with this probability (rows of few records)")
 a = ap.parse_args()
 S = a.nc + a.nk
 lib = K._native.lib()
@@ -28,8 +29,14 @@ if a.keys == "random":
     lo = np.unique(np.random.default_rng(5).integers(0, 1 << 62, int(a.rows * 1.02), dtype=np.uint64))[:a.rows]
 offs = np.zeros(S + 1, dtype=np.uint64)
 ks, cs = [], []
+rng_sp = np.random.default_rng(11)
+any_kept = np.zeros(a.rows, dtype=bool)
 for s in range(S):
     sel = host[:, s] > 0
+    if a.sparse < 1.0:
+        sel &= rng_sp.random(a.rows) < a.sparse
+        host[~sel, s] = 0
+    any_kept |= sel
     ks.append(lo[sel]); cs.append(host[sel, s]); offs[s + 1] = offs[s] + int(sel.sum())
 kmers = np.concatenate(ks); counts = np.concatenate(cs).astype(np.uint32)
 n = len(kmers)
