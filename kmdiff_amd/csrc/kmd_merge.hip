@@ -948,6 +948,7 @@ k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ co
   uint32_t* s_beg = reinterpret_cast<uint32_t*>(s_seg_all[w]);
   uint32_t* pref = s_beg + kMaxS;
   uint16_t* smp_of = reinterpret_cast<uint16_t*>(s_seg_all[w] + kWaveCap / 2);
+  uint16_t* s_slot = reinterpret_cast<uint16_t*>(s_seg_all[w]);   // slots of the distinct keys (over the segment tables, read by then)
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   // Output positions: a wave takes kChunk entries at a time from the global counter (one atomic per
   // chunk: one per bucket -- 400 k additions to ONE address -- cost 4 ms) and fills what it leaves
@@ -1050,6 +1051,7 @@ k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ co
       if (r * 64 >= n) continue;
       const uint32_t f = r * 64 + lane;
       bool fresh = false;
+      uint32_t my_slot = 0;
       if (f < n)
       {
         const uint64_t k = key_r[r];
@@ -1065,9 +1067,14 @@ k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ co
             h = (h + 1) & mask;
           }
           atomicAdd(ctl_r[r] ? &s_sc[h] : &s_sk[h], (unsigned long long)cnt_r[r]);
+          if (fresh) my_slot = h;
         }
       }
-      d += (uint32_t)__popcll(__ballot(fresh));
+      // the lanes that claimed a slot list it (ballot prefix): the output below walks the bucket's
+      // d keys, not the whole hash table
+      const unsigned long long fm = __ballot(fresh);
+      if (fresh) s_slot[d + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint16_t)my_slot;
+      d += (uint32_t)__popcll(fm);
     }
     const bool any_max = __ballot(has_max) != 0;
     if (any_max) { max_c = wave_sum64(max_c); max_k = wave_sum64(max_k); }
@@ -1084,18 +1091,10 @@ k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ co
     const unsigned long long base = chunk_at;
     chunk_at += d_all; chunk_left -= d_all;
     if (base + d_all > row_capacity) { if (lane == 0) atomicAdd(overflow + 1, 1u); continue; }
-    uint32_t filled = 0;
-    for (uint32_t t0 = 0; t0 < slots; t0 += 64)
+    for (uint32_t t = lane; t < d; t += 64)
     {
-      const unsigned long long k = s_hash[t0 + lane];
-      const bool occ = k != kEmpty;
-      const unsigned long long m = __ballot(occ);
-      if (occ)
-      {
-        const size_t e = (size_t)base + filled + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        kmer_out[e] = k; sum_c_out[e] = s_sc[t0 + lane]; sum_k_out[e] = s_sk[t0 + lane];
-      }
-      filled += (uint32_t)__popcll(m);
+      const uint32_t h = s_slot[t];
+      kmer_out[base + t] = s_hash[h]; sum_c_out[base + t] = s_sc[h]; sum_k_out[base + t] = s_sk[h];
     }
     if (any_max && lane == 0) { kmer_out[base + d] = kEmpty; sum_c_out[base + d] = max_c; sum_k_out[base + d] = max_k; }
     wave_sync();                                        // the tables of the next bucket go into the same LDS
