@@ -1574,10 +1574,10 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
   if (out) P.out = *out;
   if (n_rows == 0) return KMD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  size_t want = m->lf_n * sizeof(double2);
+  // a short table head in LDS: this kernel runs for ~0.1 ms, staging the 112 KB head K1 keeps would be
+  // most of it; the table is read for candidates only, the rest of it from L2
+  size_t want = std::min<size_t>(m->lf_n, 1024) * sizeof(double2);
   const size_t queues = (size_t)(kBlock / 64) * kQueueBytesPerWave;
-  const size_t budget = m->lds_per_block_max - 256 - queues;
-  if (want > budget) want = budget / sizeof(double2) * sizeof(double2);
   P.lds_n = (uint32_t)(want / sizeof(double2));
   size_t grid = (size_t)m->n_cu;
   if (grid > (n_rows + kBlock - 1) / kBlock) grid = (n_rows + kBlock - 1) / kBlock;

@@ -559,6 +559,20 @@ def test_merge_sums_equals_merge_then_sum(K, oracle, S, nc, presence):
     assert np.allclose(got["pvalue"][by_kmer], ref["pvalue"], rtol=0, atol=1e-10)
 
 
+def test_merge_sums_tiny_and_empty_inputs(K, oracle):
+    """A handful of records, one stream only, nothing at all."""
+    e = K.merge_sums([(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * 3, 1)
+    assert e.n_rows == 0
+    streams = [(np.array([5, 9], np.uint64), np.array([2, 3], np.uint32)), (np.array([9], np.uint64), np.array([7], np.uint32)),
+               (np.zeros(0, np.uint64), np.zeros(0, np.uint32))]
+    km, sc, sk, _ = K.merge_sums(streams, 1).to_host()
+    order = np.argsort(km)
+    assert km[order].tolist() == [5, 9] and sc[order].tolist() == [2, 3] and sk[order].tolist() == [0, 7]
+    one = [(np.arange(1, 2001, dtype=np.uint64) * np.uint64(977), np.full(2000, 4, np.uint32))]
+    km, sc, sk, _ = K.merge_sums(one, 0).to_host()
+    assert len(km) == 2000 and (np.sort(km) == one[0][0]).all() and (sc == 0).all() and (sk == 4).all()
+
+
 def test_merge_partition_clustered_keys_and_extremes(K, oracle, monkeypatch):
     """Heavily clustered keys overflow a bucket of the LDS merge: it must hand over to the sort
     path and still be exact; the all-ones key (k = 32, GGG...G) is a legal k-mer."""
