@@ -223,8 +223,13 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
  * 8 + 4 S.  Samples [0, nb_controls) are the controls (merge.hpp:70-72).  The rows come in no
  * particular order (identify them by their k-mer).  One-limb k-mers, at most 256 samples; inputs the
  * bucketed merge cannot take (k-mers in dense clusters) are refused with KMD_E_INVALID -- use
- * kmd_merge_partition then.  kmd_poisson_filter_sums tests such rows; its survivors' `row` is the
- * index into these arrays. */
+ * kmd_merge_partition then.
+ *   *n_rows_out     : ENTRIES written to the three arrays -- rows and holes: the waves take output
+ *                     positions 512 (1024 for more than 104 samples) at a time, and what one leaves
+ *                     unused is marked sum_control = UINT64_MAX.  row_capacity must cover them: the
+ *                     number of distinct k-mers + 4 M is always enough on this chip.
+ * kmd_poisson_filter_sums tests the entries (holes skipped); the number of k-mers (m_total) is what it
+ * adds to d_counters[KMD_CNT_TOTAL], its survivors' `row` is the index into these arrays. */
 int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint32_t* d_counts,
                    const uint64_t* offsets, size_t row_capacity, uint64_t* d_kmer_out,
                    uint64_t* d_sum_control, uint64_t* d_sum_case, uint64_t* n_rows_out, void* stream);
