@@ -225,9 +225,10 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
  * bucketed merge cannot take (k-mers in dense clusters) are refused with KMD_E_INVALID -- use
  * kmd_merge_partition then.
  *   *n_rows_out     : ENTRIES written to the three arrays -- rows and holes: the waves take output
- *                     positions 512 (1024 for more than 104 samples) at a time, and what one leaves
- *                     unused is marked sum_control = UINT64_MAX.  row_capacity must cover them: the
- *                     number of distinct k-mers + 4 M is always enough on this chip.
+ *                     positions 1024 at a time, and what a wave has left of its last chunk when the
+ *                     kernel ends is marked sum_control = UINT64_MAX.  row_capacity must cover them:
+ *                     the number of distinct k-mers + 6 M is always enough on this chip (at most 5120
+ *                     waves x 1024 entries).
  * kmd_poisson_filter_sums tests the entries (holes skipped); the number of k-mers (m_total) is what it
  * adds to d_counters[KMD_CNT_TOTAL], its survivors' `row` is the index into these arrays. */
 int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint32_t* d_counts,

@@ -951,9 +951,10 @@ k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ co
   uint16_t* s_slot = reinterpret_cast<uint16_t*>(s_seg_all[w]);   // slots of the distinct keys (over the segment tables, read by then)
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   // Output positions: a wave takes kChunk entries at a time from the global counter (one atomic per
-  // chunk: one per bucket -- 400 k additions to ONE address -- cost 4 ms) and fills what it leaves
-  // unused with holes (sum_c = ~0, which no row can have); kmd_poisson_filter_sums skips them.
-  constexpr uint32_t kChunk = kWaveCap > 512 ? kWaveCap : 512;
+  // chunk: one per bucket -- 400 k additions to ONE address -- cost 4 ms) and, at the end of the kernel,
+  // fills what it leaves unused with holes (sum_c = ~0, which no row can have); kmd_poisson_filter_sums
+  // skips them.
+  constexpr uint32_t kChunk = 1024;                   // >= the entries of one bucket: at most two pieces (256: 78 k atomics at 4v4, +0.35 ms)
   unsigned long long chunk_at = 0;                      // next free entry of the wave's chunk (wave-uniform)
   uint32_t chunk_left = 0;
   auto fill_holes = [&]()
@@ -1080,23 +1081,33 @@ k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ co
     if (any_max) { max_c = wave_sum64(max_c); max_k = wave_sum64(max_k); }
     const uint32_t d_all = d + (any_max ? 1u : 0u);
     wave_sync();
-    if (d_all > chunk_left)
+    // the bucket's entries fill what is left of the wave's chunk and go on in a fresh one: the only
+    // holes are the chunks left unfinished at the end of the kernel
+    const uint32_t part_a = d_all <= chunk_left ? d_all : chunk_left;
+    const unsigned long long base_a = chunk_at;
+    unsigned long long base_b = 0;
+    chunk_at += part_a; chunk_left -= part_a;
+    if (part_a < d_all)
     {
-      fill_holes();
       unsigned long long got = 0;
       if (lane == 0) got = atomicAdd(n_rows, (unsigned long long)kChunk);
-      chunk_at = __shfl(got, 0, 64);
-      chunk_left = kChunk;
+      base_b = __shfl(got, 0, 64);
+      chunk_at = base_b + (d_all - part_a);
+      chunk_left = kChunk - (d_all - part_a);
     }
-    const unsigned long long base = chunk_at;
-    chunk_at += d_all; chunk_left -= d_all;
-    if (base + d_all > row_capacity) { if (lane == 0) atomicAdd(overflow + 1, 1u); continue; }
+    if (base_a + part_a > row_capacity || (part_a < d_all && base_b + (d_all - part_a) > row_capacity))
+    {
+      if (lane == 0) atomicAdd(overflow + 1, 1u);
+      continue;
+    }
+    auto entry_of = [&](uint32_t t) -> unsigned long long { return t < part_a ? base_a + t : base_b + (t - part_a); };
     for (uint32_t t = lane; t < d; t += 64)
     {
       const uint32_t h = s_slot[t];
-      kmer_out[base + t] = s_hash[h]; sum_c_out[base + t] = s_sc[h]; sum_k_out[base + t] = s_sk[h];
+      const unsigned long long e = entry_of(t);
+      kmer_out[e] = s_hash[h]; sum_c_out[e] = s_sc[h]; sum_k_out[e] = s_sk[h];
     }
-    if (any_max && lane == 0) { kmer_out[base + d] = kEmpty; sum_c_out[base + d] = max_c; sum_k_out[base + d] = max_k; }
+    if (any_max && lane == 0) { const unsigned long long e = entry_of(d); kmer_out[e] = kEmpty; sum_c_out[e] = max_c; sum_k_out[e] = max_k; }
     wave_sync();                                        // the tables of the next bucket go into the same LDS
   }
   fill_holes();

@@ -404,7 +404,7 @@ def merge_sums(streams, nb_controls, row_capacity=None):
     total = int(offs[-1])
     cat = lambda i, dt: (np.concatenate([np.asarray(t[i], dtype=dt) for t in streams]) if total else np.zeros(0, dt))
     dk, dc = DeviceBuffer.from_host(cat(0, np.uint64)), DeviceBuffer.from_host(cat(1, np.uint32))
-    out = RowSums(total + (1 << 22) if row_capacity is None else int(row_capacity))   # room for the waves' unfinished chunks
+    out = RowSums(total + (6 << 20) if row_capacity is None else int(row_capacity))   # room for the waves' unfinished chunks
     n_rows = C.c_uint64(0)
     check(lib().kmd_merge_sums(n_samples, int(nb_controls), dk.ptr if total else None, dc.ptr if total else None, offs.ctypes.data,
                                out.capacity, out.kmers.ptr, out.sum_c.ptr, out.sum_k.ptr, C.byref(n_rows), None), "kmd_merge_sums")

@@ -60,7 +60,7 @@ for _ in range(a.iters + 1):
     best = min(best, time.perf_counter() - t0)
 sig_matrix = int(acc.read_counters()[1])
 # the same partition without the matrix: (k-mer, control sum, case sum) per row, then the test on the sums
-sums = K.RowSums(a.rows + (1 << 22))        # rows + the waves' unfinished chunks (holes)
+sums = K.RowSums(a.rows + (6 << 20))        # rows + the waves' unfinished chunks (holes)
 best_s = 1e9
 for _ in range(a.iters + 1):
     acc.counters.zero()
