@@ -237,6 +237,13 @@ int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, cons
 int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_sum_control,
                             const uint64_t* d_sum_case, size_t n_rows, double threshold,
                             const kmd_survivors* out, uint64_t* d_counters, void* stream);
+/* KmerSign::m_counts_ratio (merge.hpp:91-92) for survivors of that path, which has no matrix to gather
+ * from: d_out[i*S + s] = (double) count of k-mer d_row_kmer[d_rows[i]] in sample s (0 when absent),
+ * looked up in the per-sample streams the merge was given.  d_rows = the survivors' `row` (NULL:
+ * d_row_kmer[i] itself).  Synchronous. */
+int kmd_survivors_gather_counts_streams(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
+                                        const uint64_t* offsets, const uint64_t* d_row_kmer,
+                                        const uint64_t* d_rows, size_t n, double* d_out, void* stream);
 
 /* ---- stage 2 (optional): population-stratification re-test ---------------------------------
  * Replaces pop_strat_corrector (include/kmdiff/popstrat.hpp:148-367): constructor

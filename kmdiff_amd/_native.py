@@ -78,6 +78,7 @@ SIGNATURES = {
                                    C.POINTER(_u64), _vp]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
+    "kmd_survivors_gather_counts_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "kmd_poisson_filter_sums": (_i, [_vp, _vp, _vp, _vp, _sz, _d, C.POINTER(Survivors), _vp, _vp]),
     "kmd_popstrat_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i]),
     "kmd_popstrat_destroy": (_i, [_vp]),

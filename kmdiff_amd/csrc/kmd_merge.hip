@@ -1445,6 +1445,52 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
 
 } // namespace
 
+// KmerSign::m_counts_ratio (merge.hpp:91-92) of survivors that came out of the sums path: there is no
+// matrix to gather from, so every (survivor, sample) pair looks its k-mer up in the sample's sorted
+// stream.  Survivors are few: n x S binary searches.
+namespace {
+__global__ void __launch_bounds__(256) k_gather_from_streams(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
+                                                             const uint64_t* __restrict__ offs, uint32_t S,
+                                                             const uint64_t* __restrict__ row_kmer,
+                                                             const uint64_t* __restrict__ rows, size_t n,
+                                                             double* __restrict__ out)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * S) return;
+  const size_t i = t / S;
+  const uint32_t s = (uint32_t)(t - i * S);
+  const uint64_t k = row_kmer[rows ? rows[i] : i];
+  size_t lo = (size_t)offs[s], hi = (size_t)offs[s + 1];
+  const size_t end = hi;
+  while (lo < hi)
+  {
+    const size_t mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  out[t] = (lo < end && keys[lo] == k) ? (double)counts[lo] : 0.0;
+}
+} // namespace
+
+extern "C" int kmd_survivors_gather_counts_streams(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
+                                                   const uint64_t* offsets, const uint64_t* d_row_kmer,
+                                                   const uint64_t* d_rows, size_t n, double* d_out, void* stream)
+{
+  KMD_REQUIRE(n_samples > 0 && offsets, "kmd_survivors_gather_counts_streams: arguments");
+  if (n == 0) return KMD_OK;
+  KMD_REQUIRE(d_row_kmer && d_out && (offsets[n_samples] == 0 || (d_kmers && d_counts)), "kmd_survivors_gather_counts_streams: NULL device buffers");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  scratch sc;
+  void* p_offs = nullptr;
+  KMD_HIP(sc.take(&p_offs, ((size_t)n_samples + 1) * 8));
+  KMD_HIP(hipMemcpyAsync(p_offs, offsets, ((size_t)n_samples + 1) * 8, hipMemcpyHostToDevice, st));
+  const size_t cells = n * (size_t)n_samples;
+  hipLaunchKernelGGL(k_gather_from_streams, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_kmers, d_counts,
+                     static_cast<const uint64_t*>(p_offs), (uint32_t)n_samples, d_row_kmer, d_rows, n, d_out);
+  KMD_HIP(hipGetLastError());
+  KMD_HIP(hipStreamSynchronize(st));                     // the offsets copy reads the caller's host array
+  return KMD_OK;
+}
+
 // The merge for a consumer that only needs each k-mer's two count sums (kmd_poisson_filter_sums):
 // no matrix is written.  One-limb k-mers, at most 256 samples (the bucketed path).
 extern "C" int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint32_t* d_counts,

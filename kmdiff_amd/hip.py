@@ -409,7 +409,18 @@ def merge_sums(streams, nb_controls, row_capacity=None):
     check(lib().kmd_merge_sums(n_samples, int(nb_controls), dk.ptr if total else None, dc.ptr if total else None, offs.ctypes.data,
                                out.capacity, out.kmers.ptr, out.sum_c.ptr, out.sum_k.ptr, C.byref(n_rows), None), "kmd_merge_sums")
     out.n_rows = int(n_rows.value)
+    out.streams = (n_samples, dk, dc, offs)                 # kept for gather_counts_streams
     return out
+
+
+def gather_counts_streams(sums, rows_buf, n):
+    """KmerSign::m_counts_ratio for n survivors of the sums path (rows_buf: their `row` on the device):
+    host array [n][S] of doubles, every count looked up in the per-sample streams."""
+    n_samples, dk, dc, offs = sums.streams
+    out = DeviceBuffer(max(n, 1) * n_samples * 8)
+    check(lib().kmd_survivors_gather_counts_streams(n_samples, dk.ptr, dc.ptr, offs.ctypes.data, sums.kmers.ptr, rows_buf.ptr, n,
+                                                    out.ptr, None), "kmd_survivors_gather_counts_streams")
+    return out.to_host(np.float64, n * n_samples).reshape(n, n_samples)
 
 
 class pop_strat_corrector:

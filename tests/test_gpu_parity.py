@@ -559,6 +559,32 @@ def test_merge_sums_equals_merge_then_sum(K, oracle, S, nc, presence):
     assert np.allclose(got["pvalue"][by_kmer], ref["pvalue"], rtol=0, atol=1e-10)
 
 
+def test_sums_path_survivor_counts_from_the_streams(K, oracle):
+    """The count rows of the sums path's survivors (what pop-strat and --keep-tmp need of a KmerSign,
+    merge.hpp:91-92), looked up in the per-sample streams, against the rows of the oracle's merged matrix."""
+    rng = np.random.default_rng(77)
+    S, nc = 12, 5
+    universe = np.unique(rng.integers(0, 1 << 62, 40_000, dtype=np.uint64))
+    streams = []
+    for s in range(S):
+        pick = rng.random(len(universe)) < 0.5
+        streams.append((universe[pick], rng.integers(1, 400 if s < nc else 40, int(pick.sum())).astype(np.uint32)))
+    want, kmers = oracle.merge_partition(streams)
+    sums = K.merge_sums(streams, nc)
+    tcs, tks = totals_of(want, nc)
+    model = K.PoissonLikelihood(nc, S - nc, tcs, tks, 10000)
+    acc = K.SurvivorAccumulator(max(sums.n_rows, 1))
+    K.diff_observer(model, acc, 1e-3).process_sums(sums)
+    n = acc.finish(sort=False)
+    assert n > 50
+    got = K.gather_counts_streams(sums, acc.bufs["row"], n)
+    km_all = sums.kmers.to_host(np.uint64, sums.n_rows)
+    surv_km = km_all[acc.get()["row"].astype(np.int64)]
+    idx = np.searchsorted(kmers, surv_km)
+    assert (kmers[idx] == surv_km).all()
+    assert (got == want[idx].astype(np.float64)).all()
+
+
 def test_merge_sums_tiny_and_empty_inputs(K, oracle):
     """A handful of records, one stream only, nothing at all."""
     e = K.merge_sums([(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * 3, 1)
