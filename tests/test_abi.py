@@ -55,3 +55,22 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "kmd_oracle" not in txt and "oracle/" not in txt.replace(
                     "CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def test_command_line_fails_loudly_without_a_device(tmp_path):
+    """`kmdiff-hip diff` has no CPU path either: without a GPU it says so and exits 1 (and `--help` works)."""
+    import subprocess
+    import kmdiff_amd as K
+    cli = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
+    if not os.path.exists(cli):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kmdiff_amd", "host")], check=True, capture_output=True)
+    h = subprocess.run([cli, "diff", "--help"], capture_output=True, text=True, timeout=60)
+    assert h.returncode == 0 and "--nb-controls" in h.stdout
+    u = subprocess.run([cli, "diff", "-d", "x", "-1", "1", "-2", "1", "--no-such-flag"], capture_output=True, text=True, timeout=60)
+    assert u.returncode == 1 and "unknown option" in u.stderr
+    if K.device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([cli, "diff", "-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", "1", "-2", "1", "-o", str(tmp_path / "o")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU path" in r.stderr
+    assert not (tmp_path / "o" / "control_kmers.fasta").exists()
