@@ -32,5 +32,11 @@ run tools/kbench_popstrat.py --thr 0.05
 run tools/kbench_popstrat.py --nc 20 --nk 20 2>/dev/null
 run tools/kbench_pca.py
 run tools/kbench_pca.py --nc 100 --nk 100 --rows 8000000 --rate 0.01
-for k in even random; do run tools/kbench_pipeline.py --keys $k; done
-run tools/kbench_pipeline.py --nc 100 --nk 100 --rows 800000
+# streams -> survivors: the matrix path (K2 + K1) and the sums path (K2s + K1s), two lines per run
+run2() { timeout 300 python3 "$@" 2>/dev/null < /dev/null | tail -2; }
+for k in even random clustered; do run2 tools/kbench_pipeline.py --keys $k; done
+run2 tools/kbench_pipeline.py --nc 4 --nk 4 --rows 20000000
+run2 tools/kbench_pipeline.py --nc 100 --nk 100 --rows 800000
+run2 tools/kbench_pipeline.py --sparse 0.3 --rows 13333333 --iters 3
+run2 tools/kbench_pipeline.py --sparse 0.1 --rows 40000000 --iters 3
+KMD_MERGE_PATH=fast-only run tools/kbench_merge.py --sparse 0.1 --rows 40000000 --iters 3 --keys random
