@@ -27,6 +27,13 @@ host = mat.to_host()
 lo = mat.kmers_to_host()[0]
 if a.keys == "random":
     lo = np.unique(np.random.default_rng(5).integers(0, 1 << 62, int(a.rows * 1.02), dtype=np.uint64))[:a.rows]
+elif a.keys == "clustered":   # 2000 dense clusters scattered over the range (as tools/kbench_merge.py)
+    starts = np.sort(np.random.default_rng(6).integers(0, 1 << 61, 2000, dtype=np.uint64))
+    per = a.rows // 2000 + 1
+    lo = np.unique((starts[:, None] + np.arange(per, dtype=np.uint64)[None, :] * np.uint64(3)).ravel())[:a.rows]
+    assert len(lo) == a.rows
+else:
+    assert a.keys == "even", a.keys
 offs = np.zeros(S + 1, dtype=np.uint64)
 ks, cs = [], []
 rng_sp = np.random.default_rng(11)
