@@ -343,3 +343,26 @@ def test_cli_empty_sample_files_and_an_empty_partition(tmp_path):
                                         "disabled", 0.05)
     assert s["total_kmers"] == total == sum(len(m) for m in mats)
     assert s["n_sig"] == len(surv["p"]) > 0 and s["kept"] == int(keep.sum())
+
+
+def test_cli_no_matrix_equals_matrix_path(synth_run, tmp_path):
+    """--no-matrix (kmd_merge_sums + kmd_poisson_filter_sums: the streams are merged straight to each k-mer's
+    control and case count sums) writes what the matrix path writes: summary, both FASTA files, and -- the
+    survivors' count rows then come from the streams -- the --keep-tmp survivor files byte for byte; also
+    with BH (ascending-p order) and on the reference's fixture."""
+    import shutil
+    run_dir, nc, nk, k, mats, kms = synth_run
+    for extra in (["-c", "bonferroni"], ["-c", "benjamini", "--keep-tmp"]):
+        a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3] + extra, tmp_path / "a")
+        b, err = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3, "--no-matrix"] + extra, tmp_path / "b")
+        assert a == b and a["n_sig"] > 10
+        for name in ("control_kmers.fasta", "case_kmers.fasta"):
+            assert open(tmp_path / "a" / name).read() == open(tmp_path / "b" / name).read()
+        if "--keep-tmp" in extra:
+            for p in range(3):
+                fa = KF.lz4_frame_decode(open(tmp_path / "a" / "partitions" / ("p%d_uncorrected" % p), "rb").read())
+                fb = KF.lz4_frame_decode(open(tmp_path / "b" / "partitions" / ("p%d_uncorrected" % p), "rb").read())
+                assert fa == fb and len(fa) > 0
+        shutil.rmtree(tmp_path / "a"); shutil.rmtree(tmp_path / "b")
+    s, _ = run_cli(["-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", 1, "-2", 1, "-u", 10000, "--no-matrix"], tmp_path / "f")
+    assert (s["total_kmers"], s["n_sig"], s["kept"]) == (320, 0, 0)
