@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KMD_ABI_VERSION 1
+#define KMD_ABI_VERSION 2
 
 typedef enum {
   KMD_OK = 0,
@@ -166,6 +166,9 @@ int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, double* d_pval
 /* Sort the first n survivor records by `row` ascending (the order the reference pushes
  * them in, merge.hpp:100).  Synchronous. */
 int kmd_survivors_sort_by_row(const kmd_survivors* s, size_t n, void* stream);
+/* The same order for survivors that carry their k-mer but no row index (kmd_merge_filter): ascending
+ * (d_kmer_hi, d_kmer_lo) -- the order the merge emits rows in.  Synchronous. */
+int kmd_survivors_sort_by_kmer(const kmd_survivors* s, size_t n, void* stream);
 
 /* Gather the count vectors of survivors as doubles, KmerSign::m_counts_ratio
  * (merge.hpp:91-92): d_out[i*S + s] = (double) counts[row_i - row_base][s]. */
@@ -217,32 +220,48 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
                         uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out,
                         void* stream);
 
-/* The same merge for a consumer that needs only the two count sums of a k-mer -- which is all
- * PoissonLikelihood::process reads of a row (model.hpp:144-145): no matrix is written, every distinct
- * k-mer leaves as (k-mer, sum of its control counts, sum of its case counts), 24 bytes instead of
- * 8 + 4 S.  Samples [0, nb_controls) are the controls (merge.hpp:70-72).  The rows come in no
- * particular order (identify them by their k-mer).  One-limb k-mers, at most 256 samples; inputs the
- * bucketed merge cannot take (k-mers in dense clusters) are refused with KMD_E_INVALID -- use
- * kmd_merge_partition then.
- *   *n_rows_out     : ENTRIES written to the three arrays -- rows and holes: the waves take output
- *                     positions 1024 at a time, and what a wave has left of its last chunk when the
- *                     kernel ends is marked sum_control = UINT64_MAX.  row_capacity must cover them:
- *                     the number of distinct k-mers + 6 M is always enough on this chip (at most 5120
- *                     waves x 1024 entries).
- * kmd_poisson_filter_sums tests the entries (holes skipped); the number of k-mers (m_total) is what it
- * adds to d_counters[KMD_CNT_TOTAL], its survivors' `row` is the index into these arrays. */
-int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint32_t* d_counts,
-                   const uint64_t* offsets, size_t row_capacity, uint64_t* d_kmer_out,
-                   uint64_t* d_sum_control, uint64_t* d_sum_case, uint64_t* n_rows_out, void* stream);
+/* ---- stage 0 + 1 fused: streams in, survivors out ---------------------------------------------
+ * km::KmerMerger<KSIZE,CMAX>::merge(diff_observer) as kmdiff runs it per partition (include/kmdiff/
+ * merge.hpp:265-289 with the observer of :68-103): the S sorted streams are merged and every distinct
+ * k-mer is tested at once.  All PoissonLikelihood::process reads of a row are the sum of its control
+ * counts and the sum of its case counts (model.hpp:144-145), so no matrix is built: the streams are
+ * read once (12 bytes per record), rows exist only in LDS (kmd_tilemerge.hip).
+ *   m          : the model; n_samples must be its controls + cases, samples [0, nc) are the controls
+ *                (merge.hpp:70-72); at most 1024 samples
+ *   d_kmers_hi : high limbs for 32 < k <= 64, else NULL
+ *   out        : survivor sink as in kmd_poisson_filter.  A row has no index here: `row` holds the low
+ *                limb of the k-mer; kmd_survivors_sort_by_kmer gives the reference's ascending order
+ *   d_counters : as kmd_poisson_filter (KMD_CNT_TOTAL += distinct k-mers of the partition)
+ *   n_rows_out : host output (may be NULL), distinct k-mers of this partition
+ * Any key distribution is taken (tiles of the key range that hold too many records are cut again on
+ * the device; no fallback, no refusal).  Synchronous. */
+int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                     const uint32_t* d_counts, const uint64_t* offsets, double threshold,
+                     const kmd_survivors* out, uint64_t* d_counters, uint64_t* n_rows_out, void* stream);
+
+/* The same merge for a consumer that wants the rows themselves: every distinct k-mer leaves as
+ * (k-mer, sum of its control counts, sum of its case counts), 24 (two limbs: 32) bytes instead of
+ * 8 + 4 S; compact, in no particular order (identify rows by their k-mer).  Samples [0, nb_controls)
+ * are the controls.  d_kmers_hi / d_kmer_hi_out: NULL for k <= 32.
+ *   *n_rows_out : distinct k-mers.  KMD_E_OVERFLOW (with *n_rows_out = rows needed, the first
+ *                 row_capacity of them written) if row_capacity is too small.
+ * kmd_poisson_filter_sums tests such rows; its survivors' `row` is the index into these arrays.
+ * Synchronous. */
+int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                   const uint32_t* d_counts, const uint64_t* offsets, size_t row_capacity, uint64_t* d_kmer_out,
+                   uint64_t* d_kmer_hi_out, uint64_t* d_sum_control, uint64_t* d_sum_case, uint64_t* n_rows_out,
+                   void* stream);
 int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_sum_control,
                             const uint64_t* d_sum_case, size_t n_rows, double threshold,
                             const kmd_survivors* out, uint64_t* d_counters, void* stream);
-/* KmerSign::m_counts_ratio (merge.hpp:91-92) for survivors of that path, which has no matrix to gather
- * from: d_out[i*S + s] = (double) count of k-mer d_row_kmer[d_rows[i]] in sample s (0 when absent),
- * looked up in the per-sample streams the merge was given.  d_rows = the survivors' `row` (NULL:
- * d_row_kmer[i] itself).  Synchronous. */
-int kmd_survivors_gather_counts_streams(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
-                                        const uint64_t* offsets, const uint64_t* d_row_kmer,
+/* KmerSign::m_counts_ratio (merge.hpp:91-92) for survivors of the fused paths, which have no matrix to
+ * gather from: d_out[i*S + s] = (double) count of k-mer d_row_kmer[j] (high limb d_row_kmer_hi[j]) in
+ * sample s (0 when absent), looked up in the per-sample streams the merge was given; j = d_rows[i], or i
+ * when d_rows is NULL (the survivors' own k-mer columns).  d_kmers_hi / d_row_kmer_hi: NULL for k <= 32.
+ * Synchronous. */
+int kmd_survivors_gather_counts_streams(int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                                        const uint32_t* d_counts, const uint64_t* offsets,
+                                        const uint64_t* d_row_kmer, const uint64_t* d_row_kmer_hi,
                                         const uint64_t* d_rows, size_t n, double* d_out, void* stream);
 
 /* ---- stage 2 (optional): population-stratification re-test ---------------------------------

@@ -77,8 +77,10 @@ SIGNATURES = {
     "kmd_correct_from_rank": (_i, [_i, _d, _u64, _u64, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
                                    C.POINTER(_u64), _vp]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
-    "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
-    "kmd_survivors_gather_counts_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
+    "kmd_merge_filter": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, C.POINTER(Survivors), _vp, C.POINTER(_u64), _vp]),
+    "kmd_survivors_gather_counts_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "kmd_survivors_sort_by_kmer": (_i, [C.POINTER(Survivors), _sz, _vp]),
     "kmd_poisson_filter_sums": (_i, [_vp, _vp, _vp, _vp, _sz, _d, C.POINTER(Survivors), _vp, _vp]),
     "kmd_popstrat_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i]),
     "kmd_popstrat_destroy": (_i, [_vp]),

@@ -14,6 +14,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <cmath>
+#include <utility>
 
 namespace {
 
@@ -255,6 +256,7 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
     C.sidak_cut = 1 - std::pow(1 - threshold, 1.0 / (double)total_kmers); // corrector.cpp:52
     C.rank0 = rank_offset;
     unsigned long long* d_t = nullptr;       // [0] kept, [1] kept controls, [2] first reject
+    uint32_t* d_order = nullptr; uint64_t* d_ps = nullptr;   // BH / Holm: the ascending-p order
     KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_t), 3 * sizeof(unsigned long long)));
     hipError_t e = hipMemcpyAsync(d_t, h_t, sizeof h_t, hipMemcpyHostToDevice, st);
     int rc = KMD_OK;
@@ -263,7 +265,6 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
     {
       if (correction == KMD_CORR_BENJAMINI || correction == KMD_CORR_HOLM)      // aggregator.hpp:358-360
       {
-        uint32_t* d_order = nullptr; uint64_t* d_ps = nullptr;
         e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t));
         if (e == hipSuccess) e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_ps), n * sizeof(uint64_t));
         if (e != hipSuccess) rc = kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__);
@@ -276,8 +277,6 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
           e = hipGetLastError();
           if (e != hipSuccess) rc = kmd::hip_fail(e, "launch", __FILE__, __LINE__);
         }
-        if (d_order) kmd::scratch_free(d_order);
-        if (d_ps) kmd::scratch_free(d_ps);
       }
       else
       {
@@ -292,6 +291,11 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) rc = kmd::hip_fail(e, "read tallies", __FILE__, __LINE__);
     }
+    // the sort buffers go back to the (process-wide) cache only now: the kernels that read them have
+    // finished -- or, on an error path, the stream is drained first
+    if (rc != KMD_OK) (void)hipStreamSynchronize(st);
+    if (d_order) kmd::scratch_free(d_order);
+    if (d_ps) kmd::scratch_free(d_ps);
     kmd::scratch_free(d_t);
     if (rc != KMD_OK) return rc;
   }
@@ -322,6 +326,55 @@ int kmd_survivors_sort_by_row(const kmd_survivors* s, size_t n, void* stream)
   if (rc == KMD_OK) rc = permute_in_place(s->d_mean_case, d_order, n, d_scratch, st);
   hipError_t e2 = hipStreamSynchronize(st);
   kmd::scratch_free(d_order); kmd::scratch_free(d_scratch);
+  if (rc != KMD_OK) return rc;
+  if (e2 != hipSuccess) return kmd::hip_fail(e2, "sync", __FILE__, __LINE__);
+  return KMD_OK;
+}
+
+// The reference's order of a partition's survivors is ascending k-mer (they are pushed as the merge
+// emits rows, merge.hpp:100).  For survivors that carry their k-mer but no row index
+// (kmd_merge_filter): stable LSD sort on (high limb, low limb).
+int kmd_survivors_sort_by_kmer(const kmd_survivors* s, size_t n, void* stream)
+{
+  KMD_REQUIRE(s && s->d_kmer_lo, "kmd_survivors_sort_by_kmer: needs d_kmer_lo");
+  KMD_REQUIRE(n <= s->capacity, "kmd_survivors_sort_by_kmer: n > capacity");
+  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_survivors_sort_by_kmer: too many survivors");
+  if (n < 2) return KMD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t *d_order = nullptr, *d_order2 = nullptr;
+  void *d_scratch = nullptr, *d_hs = nullptr, *d_tmp = nullptr;
+  auto release = [&]() { for (void* q : { (void*)d_order, (void*)d_order2, d_scratch, d_hs, d_tmp }) if (q) kmd::scratch_free(q); };
+  hipError_t e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t));
+  if (e == hipSuccess) e = kmd::scratch_alloc(&d_scratch, n * sizeof(uint64_t));
+  if (e != hipSuccess) { release(); return kmd::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+  int rc = sort_order_u64(s->d_kmer_lo, n, nullptr, d_order, st);
+  if (rc == KMD_OK && s->d_kmer_hi)
+  {
+    // second pass: high limbs in low-limb order, stable sort carrying the first permutation
+    size_t tmp_bytes = 0;
+    uint64_t* hi_g = static_cast<uint64_t*>(d_scratch);
+    e = kmd::scratch_alloc(reinterpret_cast<void**>(&d_order2), n * sizeof(uint32_t));
+    if (e == hipSuccess) e = kmd::scratch_alloc(&d_hs, n * sizeof(uint64_t));
+    if (e == hipSuccess)
+    {
+      hipLaunchKernelGGL((k_permute<uint64_t>), dim3(blocks_for(n)), dim3(256), 0, st, s->d_kmer_hi, hi_g, d_order, n);
+      e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, hi_g, static_cast<uint64_t*>(d_hs), d_order, d_order2, n, 0, 64, st);
+    }
+    if (e == hipSuccess) e = kmd::scratch_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, hi_g, static_cast<uint64_t*>(d_hs), d_order, d_order2, n, 0, 64, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { release(); return kmd::hip_fail(e, "radix sort", __FILE__, __LINE__); }
+    std::swap(d_order, d_order2);
+  }
+  if (rc == KMD_OK) rc = permute_in_place(s->d_row, d_order, n, d_scratch, st);
+  if (rc == KMD_OK) rc = permute_in_place(s->d_kmer_lo, d_order, n, d_scratch, st);
+  if (rc == KMD_OK) rc = permute_in_place(s->d_kmer_hi, d_order, n, d_scratch, st);
+  if (rc == KMD_OK) rc = permute_in_place(s->d_pvalue, d_order, n, d_scratch, st);
+  if (rc == KMD_OK) rc = permute_in_place(s->d_sign, d_order, n, d_scratch, st);
+  if (rc == KMD_OK) rc = permute_in_place(s->d_mean_control, d_order, n, d_scratch, st);
+  if (rc == KMD_OK) rc = permute_in_place(s->d_mean_case, d_order, n, d_scratch, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  release();
   if (rc != KMD_OK) return rc;
   if (e2 != hipSuccess) return kmd::hip_fail(e2, "sync", __FILE__, __LINE__);
   return KMD_OK;

@@ -18,11 +18,14 @@
 //     reference's O(k) loop would stall a wave for milliseconds on one high-count row).
 #include "kmd_internal.h"
 #include "kmd_math.h"
+#include "kmd_eval.h"
 
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <unordered_map>
+
+using namespace kmd::eval;
 
 namespace {
 
@@ -55,27 +58,6 @@ namespace {
 #endif
 constexpr int kBlock = KMD_BLOCK;
 
-struct filter_params
-{
-  const void* counts;
-  size_t ld;            // SoA: column stride; rows: row stride; tiled: T (= column stride)
-  size_t tiles_per_blk; // tiled: kernel tiles per T-row block (T / tile_rows); else 0
-  size_t blk_stride;    // tiled: S * T elements between blocks
-  size_t n_rows;
-  uint64_t row_base;
-  const uint64_t* kmer_lo;
-  const uint64_t* kmer_hi;
-  int nc, nk;
-  double dT, dTc, dTk, lg_half, lr_cut, threshold;
-  double dTcTk;             // dTc * dTk
-  double pf_cut;            // chi-square pre-filter cut on the likelihood ratio (or -inf: off)
-  const double* lf;         // lf[k]                        (k_process_all)
-  const double2* tab;       // { lf[k], log(double(k)) }    (filter kernels; head staged in LDS)
-  uint32_t lf_n;
-  uint32_t lds_n;           // table entries held in LDS
-  kmd_survivors out;
-  unsigned long long* counters;
-};
 
 template <typename T, int N> struct vec_of;
 template <> struct vec_of<uint32_t, 1> { using type = uint32_t; };
@@ -103,134 +85,7 @@ __device__ __forceinline__ uint32_t add_packed(uint32_t w, uint32_t acc)
   else return __builtin_amdgcn_sad_u16(w, 0u, acc);
 }
 
-// LogFactorialTable::operator[] for k >= table size (log_factorial_table.hpp:14-18 falls back
-// to the O(k) loop log(k) + log(k-1) + ... + log(2), src/log_factorial_table.cpp:13-22).
-//   k <  kStirlingMin : the same descending loop, per lane (bounded, reference order);
-//   k >= kStirlingMin : ln k! by the Stirling series, O(1):
-//        (k + 1/2) ln k - k + ln(2 pi)/2 + 1/(12k) - 1/(360k^3) + 1/(1260k^5)
-//     truncation error < 1e-20 for k >= 256; the result is within ~1 ulp of ln k!, whereas
-//     the reference's k-term running sum carries its own rounding error of order
-//     sqrt(k) ulp.  The table value enters alt and null hypotheses identically
-//     (model.hpp:152-156), so this difference cancels in the likelihood ratio down to the
-//     rounding of the individual terms (tests/test_gpu_parity.py::test_table_fallback*).
-constexpr uint32_t kStirlingMin = 256;
 
-__device__ __forceinline__ double lf_beyond_table(uint32_t k)
-{
-  if (k < kStirlingMin)
-  {
-    double res = 0;
-    for (uint32_t j = k; j > 1; --j) res += ::log((double)j);
-    return res;
-  }
-  const double x = (double)k;
-  const double r = 1.0 / x, r2 = r * r;
-  const double corr = r * (8.3333333333333333e-02 - r2 * (2.7777777777777778e-03 - r2 * 7.9365079365079365e-04));
-  return ((x + 0.5) * ::log(x) - x) + (0.91893853320467274178 + corr);
-}
-
-struct row_state
-{
-  uint64_t sum_c, sum_k;
-  uint64_t row;        // local row index in the tile
-  bool valid;
-};
-
-// One row from its two count sums to the survivor sink.  Must be called by all 64 lanes of
-// the wave together (ballots / cooperative fallback inside).
-// Can this row still reach `p <= threshold`?  (Also counts the rows beyond the table.)
-__device__ __forceinline__ bool row_may_pass(const filter_params& P, const row_state& st, uint32_t& n_beyond)
-{
-  if (st.valid && (st.sum_c >= P.lf_n || st.sum_k >= P.lf_n))
-    ++n_beyond;        // rows beyond the table; flushed once per wave at kernel end (with many
-                       // samples most waves see such rows: a global atomic here serialises the chip)
-
-  // Pre-filter.  In exact arithmetic LR = n KL(x || q) with n = sc + sk, x = sc / n,
-  // q = Tc / (Tc + Tk) (the lf[k] and -lambda terms of model.hpp:152-156 cancel), and
-  // KL(x || q) <= (x - q)^2 / (q (1 - q))  (from ln t <= t - 1), i.e.
-  //     LR <= (sc Tk - sk Tc)^2 / (n Tc Tk).
-  // A row whose bound is below HALF the candidate cut cannot reach `p <= threshold`; it is
-  // dropped here for ~25 flops instead of a division and two logarithms.  The factor 2 and
-  // the host-side enabling conditions (fill_params) cover the rounding of the bound itself;
-  // rows that pass are evaluated exactly as before, so every exposed number is unchanged.
-  const double dsc = (double)st.sum_c, dsk = (double)st.sum_k;
-  const double a = dsc * P.dTk - dsk * P.dTc;
-  return st.valid && !(a * a < P.pf_cut * ((dsc + dsk) * P.dTcTk));
-}
-
-// The exact evaluation of rows that passed the pre-filter: likelihood ratio, candidate cut, tail
-// function, sign, compaction into the survivor sink.  Must be called by all 64 lanes of the wave
-// together (ballots inside); lanes without a row pass valid = false.
-__device__ __forceinline__ void evaluate_row(const filter_params& P, const double2* s_tab, const row_state& st)
-{
-  // table entry of each sum: { lf[k], log(k) }.  k = table_index(sum) (model.hpp:152-156);
-  // sums beyond the table (or >= 2^31, where k wraps to 0 but lambda does not) take the
-  // logarithm on the device.
-  const uint32_t kc = kmd::table_index(st.sum_c);
-  const uint32_t kk = kmd::table_index(st.sum_k);
-  double2 tc = make_double2(0.0, 0.0), tk = make_double2(0.0, 0.0);
-  if (kc < P.lds_n) tc = s_tab[kc]; else if (kc < P.lf_n) tc = P.tab[kc];
-  if (kk < P.lds_n) tk = s_tab[kk]; else if (kk < P.lf_n) tk = P.tab[kk];
-  const bool big_c = st.valid && st.sum_c >= P.lf_n;
-  const bool big_k = st.valid && st.sum_k >= P.lf_n;
-  if (big_c | big_k)                     // rare with the default 10000-entry table
-  {
-    if (big_c) { if (kc >= P.lf_n) tc.x = lf_beyond_table(kc); tc.y = ::log((double)st.sum_c); }
-    if (big_k) { if (kk >= P.lf_n) tk.x = lf_beyond_table(kk); tk.y = ::log((double)st.sum_k); }
-  }
-
-  const double lr = kmd::lr_from_sums(st.sum_c, st.sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
-  const bool cand = st.valid && (lr >= P.lr_cut);
-  const unsigned long long cand_mask = __ballot(cand);
-  if (cand_mask)
-  {
-    bool surv = false;
-    double p = 1.0, mean_control = 0.0;
-    int sign = KMD_SIGN_NO;
-    if (cand)
-    {
-      p = kmd::igamc_half(lr, P.lg_half);                   // model.hpp:161
-      surv = (p <= P.threshold);                            // merge.hpp:78
-      kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, mean_control, sign);
-    }
-    const unsigned long long surv_mask = __ballot(surv);
-    const unsigned long long ctrl_mask = __ballot(surv && sign == KMD_SIGN_CONTROL);
-    const int lane = __lane_id();
-    const int leader = __ffsll((long long)cand_mask) - 1;
-    unsigned long long base = 0;
-    if (lane == leader)
-    {
-      atomicAdd(&P.counters[KMD_CNT_CANDIDATES], (unsigned long long)__popcll(cand_mask));
-      if (surv_mask)
-      {
-        const unsigned long long ns = __popcll(surv_mask), nctl = __popcll(ctrl_mask);
-        base = atomicAdd(&P.counters[KMD_CNT_SIG], ns);                    // merge.hpp:101
-        if (nctl) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], nctl);       // merge.hpp:95-96
-        if (ns - nctl) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], ns - nctl);// merge.hpp:97-98
-      }
-    }
-    if (surv_mask)
-    {
-      base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
-             (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-      if (surv)
-      {
-        const unsigned long long slot =
-            base + __popcll(surv_mask & ((1ull << lane) - 1ull));
-        if (slot < P.out.capacity)
-        {
-          if (P.out.d_row) P.out.d_row[slot] = P.row_base + st.row;
-          if (P.out.d_kmer_lo && P.kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[st.row];
-          if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[st.row];
-          if (P.out.d_pvalue) P.out.d_pvalue[slot] = p;
-          if (P.out.d_sign) P.out.d_sign[slot] = sign;
-          if (P.out.d_mean_control) P.out.d_mean_control[slot] = mean_control;
-          if (P.out.d_mean_case) P.out.d_mean_case[slot] = (double)st.sum_k;
-        }
-      }
-    }
-  }
-}
 
 // One row from its two count sums to the survivor sink, at once.  Must be called by all 64 lanes
 // of the wave together.
@@ -271,6 +126,7 @@ __device__ __forceinline__ void queue_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int kRowMode = 0>
 __device__ __forceinline__ void defer_row(const filter_params& P, const double2* s_tab, const row_state& st,
                                           uint32_t& n_beyond, wave_queue& Q)
 {
@@ -296,10 +152,11 @@ __device__ __forceinline__ void defer_row(const filter_params& P, const double2*
     e.sum_c = Q.sc[Q.n + lane]; e.sum_k = Q.sk[Q.n + lane]; e.row = Q.row[Q.n + lane];
     e.valid = true;
     queue_fence();                                       // read before the next step overwrites
-    evaluate_row(P, s_tab, e);
+    evaluate_row<kRowMode>(P, s_tab, e);
   }
 }
 
+template <int kRowMode = 0>
 __device__ __forceinline__ void drain_queue(const filter_params& P, const double2* s_tab, wave_queue& Q)
 {
   if (Q.n == 0) return;
@@ -309,16 +166,9 @@ __device__ __forceinline__ void drain_queue(const filter_params& P, const double
   e.valid = lane < Q.n;
   e.sum_c = e.valid ? Q.sc[lane] : 0; e.sum_k = e.valid ? Q.sk[lane] : 0; e.row = e.valid ? Q.row[lane] : 0;
   Q.n = 0;
-  evaluate_row(P, s_tab, e);
+  evaluate_row<kRowMode>(P, s_tab, e);
 }
 
-// one atomic per wave per launch for the beyond-table row count
-__device__ __forceinline__ void flush_beyond(const filter_params& P, uint32_t n_beyond)
-{
-  for (int o = 32; o > 0; o >>= 1) n_beyond += __shfl_down(n_beyond, o, 64);
-  if (__lane_id() == 0 && n_beyond)
-    atomicAdd(&P.counters[KMD_CNT_DEFERRED], (unsigned long long)n_beyond);
-}
 
 __device__ __forceinline__ void stage_table(const filter_params& P, double2* s_tab)
 {
@@ -725,6 +575,38 @@ __global__ void __launch_bounds__(kBlock) k_filter_sums(const filter_params P, c
   flush_beyond(P, n_beyond);
   for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_down(n_valid, o, 64);
   if ((threadIdx.x & 63) == 0 && n_valid) atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)n_valid);   // merge.hpp:76
+}
+
+// ---- candidate rows of the fused merge (kmd_tilemerge.hip): a short device-resident list
+__global__ void __launch_bounds__(kBlock) k_filter_candidates(const filter_params P, const unsigned long long* __restrict__ sum_c,
+                                                              const unsigned long long* __restrict__ sum_k,
+                                                              unsigned long long rows_total, unsigned long long rows_beyond)
+{
+  extern __shared__ double2 s_lf[];
+  stage_table(P, s_lf);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    if (rows_total) atomicAdd(&P.counters[KMD_CNT_TOTAL], rows_total);                    // merge.hpp:76
+    if (rows_beyond) atomicAdd(&P.counters[KMD_CNT_DEFERRED], rows_beyond);
+  }
+  uint32_t n_beyond = 0;                                   // (counted by the merge kernel already: not flushed)
+  wave_queue Q;
+  {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s_lf + P.lds_n) + (size_t)(threadIdx.x >> 6) * kQueueCap * 3;
+    Q.sc = q; Q.sk = q + kQueueCap; Q.row = q + 2 * kQueueCap; Q.n = 0;
+  }
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n_round = (P.n_rows + stride - 1) / stride * stride;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
+  {
+    row_state st;
+    st.row = i;
+    st.valid = i < P.n_rows;
+    st.sum_c = st.valid ? sum_c[i] : 0ull;
+    st.sum_k = st.valid ? sum_k[i] : 0ull;
+    defer_row<1>(P, s_lf, st, n_beyond, Q);
+  }
+  drain_queue<1>(P, s_lf, Q);
 }
 
 // ---- row-major rows, 16-byte aligned pitch: wave-private staging -------------------------
@@ -1236,7 +1118,9 @@ __global__ void __launch_bounds__(256) k_process_all(const filter_params P, int 
   }
 }
 
-int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double threshold)
+} // namespace
+
+int kmd::fill_filter_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double threshold)
 {
   KMD_REQUIRE(m && t, "kmd: NULL model or tile");
   KMD_REQUIRE(t->count_bytes == 1 || t->count_bytes == 2 || t->count_bytes == 4,
@@ -1280,6 +1164,8 @@ int fill_params(filter_params& P, const kmd_model* m, const kmd_tile* t, double 
   P.out = kmd_survivors{};
   return KMD_OK;
 }
+
+namespace {
 
 template <typename K> int allow_big_lds(K kernel, size_t lds_bytes);
 
@@ -1519,7 +1405,7 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
                                   const kmd_survivors* out, uint64_t* d_counters, void* stream)
 {
   filter_params P;
-  int rc = fill_params(P, m, tile, threshold);
+  int rc = kmd::fill_filter_params(P, m, tile, threshold);
   if (rc != KMD_OK) return rc;
   KMD_REQUIRE(d_counters, "kmd_poisson_filter: NULL counters");
   P.counters = reinterpret_cast<unsigned long long*>(d_counters);
@@ -1568,7 +1454,7 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
   KMD_REQUIRE(n_rows == 0 || (d_sum_control && d_sum_case), "kmd_poisson_filter_sums: NULL sums");
   kmd_tile t { d_sum_control, 4, KMD_LAYOUT_SOA, n_rows, d_kmer, nullptr, n_rows, 0 };   // for the shared checks; counts are never read
   filter_params P;
-  int rc = fill_params(P, m, &t, threshold);
+  int rc = kmd::fill_filter_params(P, m, &t, threshold);
   if (rc != KMD_OK) return rc;
   P.counters = reinterpret_cast<unsigned long long*>(d_counters);
   if (out) P.out = *out;
@@ -1589,12 +1475,33 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
   return KMD_OK;
 }
 
+int kmd::launch_filter_candidates(const filter_params& P_in, const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_kmer_hi,
+                                  const uint64_t* d_sum_c, const uint64_t* d_sum_k, size_t n, uint64_t rows_total, uint64_t rows_beyond,
+                                  hipStream_t stream)
+{
+  filter_params P = P_in;
+  P.kmer_lo = d_kmer; P.kmer_hi = d_kmer_hi; P.row_base = 0; P.n_rows = n;
+  // a short table head in LDS (this kernel runs for microseconds; the table is read for candidates only)
+  const size_t want = std::min<size_t>(m->lf_n, 1024) * sizeof(double2);
+  const size_t queues = (size_t)(kBlock / 64) * kQueueBytesPerWave;
+  P.lds_n = (uint32_t)(want / sizeof(double2));
+  size_t grid = std::min<size_t>((size_t)m->n_cu, (n + kBlock - 1) / kBlock);
+  if (grid < 1) grid = 1;
+  const int rc = allow_big_lds(k_filter_candidates, want + queues);
+  if (rc != KMD_OK) return rc;
+  hipLaunchKernelGGL(k_filter_candidates, dim3((unsigned)grid), dim3(kBlock), want + queues, stream, P,
+                     reinterpret_cast<const unsigned long long*>(d_sum_c), reinterpret_cast<const unsigned long long*>(d_sum_k),
+                     (unsigned long long)rows_total, (unsigned long long)rows_beyond);
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
 extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, double* d_pvalue,
                                    int32_t* d_sign, double* d_mean_control, double* d_mean_case,
                                    void* stream)
 {
   filter_params P;
-  int rc = fill_params(P, m, tile, 1.0);
+  int rc = kmd::fill_filter_params(P, m, tile, 1.0);
   if (rc != KMD_OK) return rc;
   if (tile->n_rows == 0) return KMD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -914,205 +914,6 @@ struct scratch
   }
 };
 
-// ---- merge without a matrix: the two count sums of every distinct k-mer ------------------------
-// What the Poisson test needs of a row is (sum of its control counts, sum of its case counts).
-// Same buckets, same hash set per wave as k_bucket_merge; every record adds its count to its key's
-// control or case sum in LDS, and the bucket's distinct keys leave as (k-mer, sum_c, sum_k) triples
-// at positions a wave takes from one global counter, a chunk at a time: no ranking, no look-back
-// (the triples come in no particular order, with holes where a wave left a chunk unfinished: rows are
-// identified by their k-mer), no d x S block -- 24 bytes per row instead of 8 + 4 S.  One-limb k-mers.
-struct merge_sums_out
-{
-  uint32_t nc;                                          // samples [0, nc) are controls
-  unsigned long long* sum_c;
-  unsigned long long* sum_k;
-};
-
-template <uint32_t kWaveCap, int kWavesPerBlock>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
-k_bucket_sums(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ start,
-              uint32_t S, uint32_t nc, uint32_t nb, size_t row_capacity, uint64_t* __restrict__ kmer_out,
-              unsigned long long* __restrict__ sum_c_out, unsigned long long* __restrict__ sum_k_out,
-              unsigned long long* __restrict__ n_rows, uint32_t* __restrict__ overflow)
-{
-  constexpr uint32_t kMaxS = kWaveCap / 4, kPerLane = kWaveCap / 64;
-  constexpr int kSPL = kMaxS / 64;
-  __shared__ unsigned long long s_hash_all[kWavesPerBlock][kWaveCap];
-  __shared__ unsigned long long s_sc_all[kWavesPerBlock][kWaveCap];
-  __shared__ unsigned long long s_sk_all[kWavesPerBlock][kWaveCap];
-  __shared__ unsigned long long s_seg_all[kWavesPerBlock][kWaveCap];
-  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  unsigned long long* s_hash = s_hash_all[w];
-  unsigned long long* s_sc = s_sc_all[w];
-  unsigned long long* s_sk = s_sk_all[w];
-  uint32_t* s_beg = reinterpret_cast<uint32_t*>(s_seg_all[w]);
-  uint32_t* pref = s_beg + kMaxS;
-  uint16_t* smp_of = reinterpret_cast<uint16_t*>(s_seg_all[w] + kWaveCap / 2);
-  uint16_t* s_slot = reinterpret_cast<uint16_t*>(s_seg_all[w]);   // slots of the distinct keys (over the segment tables, read by then)
-  const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-  // Output positions: a wave takes kChunk entries at a time from the global counter (one atomic per
-  // chunk: one per bucket -- 400 k additions to ONE address -- cost 4 ms) and, at the end of the kernel,
-  // fills what it leaves unused with holes (sum_c = ~0, which no row can have); kmd_poisson_filter_sums
-  // skips them.
-  constexpr uint32_t kChunk = 1024;                   // >= the entries of one bucket: at most two pieces (256: 78 k atomics at 4v4, +0.35 ms)
-  unsigned long long chunk_at = 0;                      // next free entry of the wave's chunk (wave-uniform)
-  uint32_t chunk_left = 0;
-  auto fill_holes = [&]()
-  {
-    for (uint32_t t = lane; t < chunk_left; t += 64)
-      if (chunk_at + t < row_capacity) { kmer_out[chunk_at + t] = 0; sum_c_out[chunk_at + t] = ~0ull; sum_k_out[chunk_at + t] = 0; }
-    chunk_left = 0;
-  };
-  // segment bounds of the wave's first bucket; those of the next one are fetched while the current
-  // bucket is processed (one dependent global round trip less per bucket)
-  uint32_t nb_beg[kSPL], nb_end[kSPL];
-  {
-    const uint32_t j0 = blockIdx.x * kWavesPerBlock + w;
-#pragma unroll
-    for (int q = 0; q < kSPL; ++q)
-    {
-      const uint32_t s = lane * kSPL + q;
-      nb_beg[q] = 0; nb_end[q] = 0;
-      if (j0 < nb && s < S) { nb_beg[q] = start[(size_t)j0 * S + s]; nb_end[q] = start[(size_t)(j0 + 1) * S + s]; }
-    }
-  }
-  for (uint32_t j = blockIdx.x * kWavesPerBlock + w; j < nb; j += n_waves)
-  {
-    uint32_t len[kSPL], lsum = 0;
-#pragma unroll
-    for (int q = 0; q < kSPL; ++q)
-    {
-      const uint32_t s = lane * kSPL + q;
-      len[q] = 0;
-      if (s < S)
-      {
-        s_beg[s] = nb_beg[q];
-        len[q] = nb_end[q] - nb_beg[q];
-      }
-      lsum += len[q];
-    }
-    if (j + n_waves < nb)
-    {
-      const uint32_t jn = j + n_waves;
-#pragma unroll
-      for (int q = 0; q < kSPL; ++q)
-      {
-        const uint32_t s = lane * kSPL + q;
-        if (s < S) { nb_beg[q] = start[(size_t)jn * S + s]; nb_end[q] = start[(size_t)(jn + 1) * S + s]; }
-      }
-    }
-    uint32_t incl = lsum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
-    {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if ((int)lane >= o) incl += up;
-    }
-    uint32_t run = incl - lsum;
-    const uint32_t n = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
-    if (n > kWaveCap) { if (lane == 0) atomicAdd(overflow, 1u); continue; }      // the caller refines or gives up
-    if (n == 0) continue;
-#pragma unroll
-    for (int q = 0; q < kSPL; ++q)
-    {
-      const uint32_t s = lane * kSPL + q;
-      if (s < S)
-      {
-        pref[s] = run;
-        for (uint32_t t = 0; t < len[q]; ++t) smp_of[run + t] = (uint16_t)s;
-      }
-      run += len[q];
-    }
-    uint32_t slots = 64;
-    while (slots < 2 * n && slots < kWaveCap) slots <<= 1;
-    const uint32_t mask = slots - 1;
-    for (uint32_t t = lane; t < slots; t += 64) { s_hash[t] = kEmpty; s_sc[t] = 0; s_sk[t] = 0; }
-    wave_sync();
-    uint64_t key_r[kPerLane];
-    uint32_t cnt_r[kPerLane];
-    bool ctl_r[kPerLane];
-#pragma unroll
-    for (uint32_t r = 0; r < kPerLane; ++r)
-    {
-      const uint32_t f = r * 64 + lane;
-      key_r[r] = 0; cnt_r[r] = 0; ctl_r[r] = false;
-      if (r * 64 < n && f < n)
-      {
-        const uint32_t lo = smp_of[f];
-        const uint32_t i = s_beg[lo] + (f - pref[lo]);
-        key_r[r] = keys[i]; cnt_r[r] = counts[i]; ctl_r[r] = lo < nc;
-      }
-    }
-    uint32_t d = 0;
-    unsigned long long max_c = 0, max_k = 0;            // the all-ones key (the hash set's empty marker), per lane
-    bool has_max = false;
-#pragma unroll
-    for (uint32_t r = 0; r < kPerLane; ++r)
-    {
-      if (r * 64 >= n) continue;
-      const uint32_t f = r * 64 + lane;
-      bool fresh = false;
-      uint32_t my_slot = 0;
-      if (f < n)
-      {
-        const uint64_t k = key_r[r];
-        if (k == kEmpty) { has_max = true; if (ctl_r[r]) max_c += cnt_r[r]; else max_k += cnt_r[r]; }
-        else
-        {
-          uint32_t h = (hash_slot(k) >> 16) & mask;
-          for (;;)
-          {
-            const unsigned long long old = atomicCAS(&s_hash[h], kEmpty, (unsigned long long)k);
-            if (old == kEmpty) { fresh = true; break; }
-            if (old == k) break;
-            h = (h + 1) & mask;
-          }
-          atomicAdd(ctl_r[r] ? &s_sc[h] : &s_sk[h], (unsigned long long)cnt_r[r]);
-          if (fresh) my_slot = h;
-        }
-      }
-      // the lanes that claimed a slot list it (ballot prefix): the output below walks the bucket's
-      // d keys, not the whole hash table
-      const unsigned long long fm = __ballot(fresh);
-      if (fresh) s_slot[d + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint16_t)my_slot;
-      d += (uint32_t)__popcll(fm);
-    }
-    const bool any_max = __ballot(has_max) != 0;
-    if (any_max) { max_c = wave_sum64(max_c); max_k = wave_sum64(max_k); }
-    const uint32_t d_all = d + (any_max ? 1u : 0u);
-    wave_sync();
-    // the bucket's entries fill what is left of the wave's chunk and go on in a fresh one: the only
-    // holes are the chunks left unfinished at the end of the kernel
-    const uint32_t part_a = d_all <= chunk_left ? d_all : chunk_left;
-    const unsigned long long base_a = chunk_at;
-    unsigned long long base_b = 0;
-    chunk_at += part_a; chunk_left -= part_a;
-    if (part_a < d_all)
-    {
-      unsigned long long got = 0;
-      if (lane == 0) got = atomicAdd(n_rows, (unsigned long long)kChunk);
-      base_b = __shfl(got, 0, 64);
-      chunk_at = base_b + (d_all - part_a);
-      chunk_left = kChunk - (d_all - part_a);
-    }
-    if (base_a + part_a > row_capacity || (part_a < d_all && base_b + (d_all - part_a) > row_capacity))
-    {
-      if (lane == 0) atomicAdd(overflow + 1, 1u);
-      continue;
-    }
-    auto entry_of = [&](uint32_t t) -> unsigned long long { return t < part_a ? base_a + t : base_b + (t - part_a); };
-    for (uint32_t t = lane; t < d; t += 64)
-    {
-      const uint32_t h = s_slot[t];
-      const unsigned long long e = entry_of(t);
-      kmer_out[e] = s_hash[h]; sum_c_out[e] = s_sc[h]; sum_k_out[e] = s_sk[h];
-    }
-    if (any_max && lane == 0) { const unsigned long long e = entry_of(d); kmer_out[e] = kEmpty; sum_c_out[e] = max_c; sum_k_out[e] = max_k; }
-    wave_sync();                                        // the tables of the next bucket go into the same LDS
-  }
-  fill_holes();
-}
-
 // A bucket must hold a few whole rows (a row has up to S records: cap >= 4 S, the kernel's tables),
 // and the larger the buckets the smaller the [bucket][sample] start table that five passes read and
 // write -- against 2 and 1 waves per SIMD for the 512- and 1024-record kernels.  Measured
@@ -1137,7 +938,7 @@ template <typename CT>
 int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, const uint32_t* d_counts,
                const uint64_t* offsets, int layout, size_t ld, size_t row_capacity, CT* d_matrix,
                uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out, int n_cu, hipStream_t st,
-               bool* used, const merge_sums_out* sums = nullptr)
+               bool* used)
 {
   *used = false;
   const size_t n = (size_t)offsets[S];
@@ -1313,34 +1114,6 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
   // one run of the merge kernel over the current table; h_over / h_last are its verdict
   auto run_merge = [&]() -> int
   {
-    if (sums)                                                // (k-mer, sum_c, sum_k) triples instead of the matrix
-    {
-      void* p_n = nullptr;
-      KMD_HIP(sc.take(&p_n, 8));
-      unsigned long long* d_n = static_cast<unsigned long long*>(p_n);
-      KMD_HIP(hipMemsetAsync(d_n, 0, 8, st));
-      KMD_HIP(hipMemsetAsync(overflow, 0, 8, st));
-      auto launch_sums = [&](auto kernel, int wpb) -> int
-      {
-        int per_cu = 0;
-        KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, 0));
-        if (per_cu < 1) per_cu = 1;
-        const size_t grid = std::min((size_t)n_cu * (size_t)per_cu, (nb + wpb - 1) / wpb);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, st, d_kmers, d_counts, start, (uint32_t)S, sums->nc,
-                           (uint32_t)nb, row_capacity, d_kmer_out, sums->sum_c, sums->sum_k, d_n, overflow);
-        KMD_HIP(hipGetLastError());
-        return KMD_OK;
-      };
-      int rc_s;
-      if (cap == 256) rc_s = launch_sums(k_bucket_sums<256, 2>, 2);
-      else if (cap == 512) rc_s = launch_sums(k_bucket_sums<512, 2>, 2);
-      else rc_s = launch_sums(k_bucket_sums<1024, 1>, 1);
-      if (rc_s != KMD_OK) return rc_s;
-      KMD_HIP(hipMemcpyAsync(h_over, overflow, 8, hipMemcpyDeviceToHost, st));
-      KMD_HIP(hipMemcpyAsync(&h_last, d_n, 8, hipMemcpyDeviceToHost, st));
-      KMD_HIP(hipStreamSynchronize(st));
-      return KMD_OK;
-    }
     ng = (nb + 63) / 64;                                     // look-back groups
     const size_t status_bytes = ((nb * 8 + 127) / 128) * 128;
     void* p_status = nullptr;
@@ -1445,13 +1218,15 @@ int merge_fast(int S, const uint64_t* d_kmers_lo, const uint64_t* d_kmers_hi, co
 
 } // namespace
 
-// KmerSign::m_counts_ratio (merge.hpp:91-92) of survivors that came out of the sums path: there is no
+// KmerSign::m_counts_ratio (merge.hpp:91-92) of survivors that came out of the fused merge: there is no
 // matrix to gather from, so every (survivor, sample) pair looks its k-mer up in the sample's sorted
 // stream.  Survivors are few: n x S binary searches.
 namespace {
-__global__ void __launch_bounds__(256) k_gather_from_streams(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_gather_from_streams(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                             const uint32_t* __restrict__ counts,
                                                              const uint64_t* __restrict__ offs, uint32_t S,
                                                              const uint64_t* __restrict__ row_kmer,
+                                                             const uint64_t* __restrict__ row_kmer_hi,
                                                              const uint64_t* __restrict__ rows, size_t n,
                                                              double* __restrict__ out)
 {
@@ -1459,63 +1234,39 @@ __global__ void __launch_bounds__(256) k_gather_from_streams(const uint64_t* __r
   if (t >= n * S) return;
   const size_t i = t / S;
   const uint32_t s = (uint32_t)(t - i * S);
-  const uint64_t k = row_kmer[rows ? rows[i] : i];
+  const size_t at = rows ? rows[i] : i;
+  const uint64_t k = row_kmer[at], kh = keys_hi ? row_kmer_hi[at] : 0ull;
   size_t lo = (size_t)offs[s], hi = (size_t)offs[s + 1];
   const size_t end = hi;
   while (lo < hi)
   {
     const size_t mid = lo + ((hi - lo) >> 1);
-    if (keys[mid] < k) lo = mid + 1; else hi = mid;
+    const bool less = keys_hi ? (keys_hi[mid] < kh || (keys_hi[mid] == kh && keys[mid] < k)) : keys[mid] < k;
+    if (less) lo = mid + 1; else hi = mid;
   }
-  out[t] = (lo < end && keys[lo] == k) ? (double)counts[lo] : 0.0;
+  out[t] = (lo < end && keys[lo] == k && (!keys_hi || keys_hi[lo] == kh)) ? (double)counts[lo] : 0.0;
 }
 } // namespace
 
-extern "C" int kmd_survivors_gather_counts_streams(int n_samples, const uint64_t* d_kmers, const uint32_t* d_counts,
-                                                   const uint64_t* offsets, const uint64_t* d_row_kmer,
+extern "C" int kmd_survivors_gather_counts_streams(int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                                                   const uint32_t* d_counts, const uint64_t* offsets,
+                                                   const uint64_t* d_row_kmer, const uint64_t* d_row_kmer_hi,
                                                    const uint64_t* d_rows, size_t n, double* d_out, void* stream)
 {
   KMD_REQUIRE(n_samples > 0 && offsets, "kmd_survivors_gather_counts_streams: arguments");
   if (n == 0) return KMD_OK;
   KMD_REQUIRE(d_row_kmer && d_out && (offsets[n_samples] == 0 || (d_kmers && d_counts)), "kmd_survivors_gather_counts_streams: NULL device buffers");
+  KMD_REQUIRE(!d_kmers_hi || d_row_kmer_hi, "kmd_survivors_gather_counts_streams: two-limb streams need the survivors' high limbs");
   hipStream_t st = static_cast<hipStream_t>(stream);
   scratch sc;
   void* p_offs = nullptr;
   KMD_HIP(sc.take(&p_offs, ((size_t)n_samples + 1) * 8));
   KMD_HIP(hipMemcpyAsync(p_offs, offsets, ((size_t)n_samples + 1) * 8, hipMemcpyHostToDevice, st));
   const size_t cells = n * (size_t)n_samples;
-  hipLaunchKernelGGL(k_gather_from_streams, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_kmers, d_counts,
-                     static_cast<const uint64_t*>(p_offs), (uint32_t)n_samples, d_row_kmer, d_rows, n, d_out);
+  hipLaunchKernelGGL(k_gather_from_streams, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_kmers, d_kmers_hi, d_counts,
+                     static_cast<const uint64_t*>(p_offs), (uint32_t)n_samples, d_row_kmer, d_row_kmer_hi, d_rows, n, d_out);
   KMD_HIP(hipGetLastError());
   KMD_HIP(hipStreamSynchronize(st));                     // the offsets copy reads the caller's host array
-  return KMD_OK;
-}
-
-// The merge for a consumer that only needs each k-mer's two count sums (kmd_poisson_filter_sums):
-// no matrix is written.  One-limb k-mers, at most 256 samples (the bucketed path).
-extern "C" int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint32_t* d_counts,
-                              const uint64_t* offsets, size_t row_capacity, uint64_t* d_kmer_out,
-                              uint64_t* d_sum_control, uint64_t* d_sum_case, uint64_t* n_rows_out, void* stream)
-{
-  KMD_REQUIRE(n_samples > 0 && nb_controls >= 0 && nb_controls <= n_samples && offsets && n_rows_out, "kmd_merge_sums: arguments");
-  KMD_REQUIRE((uint32_t)n_samples <= kMaxFastSamples, "kmd_merge_sums: more than 256 samples");
-  const size_t n = (size_t)offsets[n_samples];
-  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_merge_sums: more than 2^32-1 records in one partition");
-  for (int s = 0; s < n_samples; ++s) KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_sums: offsets must be ascending");
-  *n_rows_out = 0;
-  if (n == 0) return KMD_OK;
-  KMD_REQUIRE(d_kmers && d_counts && d_kmer_out && d_sum_control && d_sum_case, "kmd_merge_sums: NULL device buffers");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  int dev = 0, n_cu = 256;
-  KMD_HIP(hipGetDevice(&dev));
-  KMD_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  merge_sums_out sums { (uint32_t)nb_controls, reinterpret_cast<unsigned long long*>(d_sum_control),
-                        reinterpret_cast<unsigned long long*>(d_sum_case) };
-  bool used = false;
-  const int rc = merge_fast<uint32_t>(n_samples, d_kmers, nullptr, d_counts, offsets, KMD_LAYOUT_ROWS, (size_t)n_samples, row_capacity,
-                                      nullptr, d_kmer_out, nullptr, n_rows_out, n_cu, st, &used, &sums);
-  if (rc != KMD_OK) return rc;
-  if (!used) { kmd::set_error("kmd_merge_sums: the k-mers cluster too densely for the bucketed merge (use kmd_merge_partition)"); return KMD_E_INVALID; }
   return KMD_OK;
 }
 

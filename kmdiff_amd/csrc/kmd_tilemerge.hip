@@ -1,0 +1,1071 @@
+// kmd_tilemerge.hip -- K2t: the k-way merge of one partition's per-sample k-mer streams, fused with
+// the Poisson test: streams in, survivors out, no matrix and no intermediate rows in HBM.
+//
+// Replaces km::KmerMerger<KSIZE,CMAX>::merge(diff_observer) as kmdiff drives it
+// (include/kmdiff/merge.hpp:265-289 with the observer of :68-103): every distinct k-mer of the S
+// sorted streams is one row; all the observer's model reads of a row are the sum of its control
+// counts and the sum of its case counts (include/kmdiff/model.hpp:144-145).
+//
+// Shape of the work (HBM-bound: 12 bytes per record are read once, nothing else is large):
+//   * k_tile_probe / k_tile_plan: how many records make a row here?  2048 records drawn uniformly, the
+//     number m of streams holding each one's k-mer; mean(1/m) = distinct k-mers / records (unbiased).
+//     The plan -- records per tile such that a tile's distinct k-mers fill ~1/3 of the hash table, the
+//     splitter stride, lanes per run -- stays on the device: no host round trip before the main kernel;
+//   * the key range of the partition is cut into TILES by splitters taken from the data (every r-th key
+//     of the longest stream); where each stream enters each tile: every 64th boundary by binary search
+//     over the stream, the 63 in between inside the short window those enclose (k_tile_coarse/_fine);
+//   * k_tile_sums: one WORKGROUP per tile on a persistent grid.  A tile is S contiguous runs of records,
+//     one per stream: sub-groups of G lanes stream a run each with coalesced loads (G fitted to the run
+//     length), the loads of the next round in flight while the current one is inserted; every record goes
+//     into a workgroup-wide LDS hash set keyed by the k-mer (64-bit compare-and-swap) and adds its count
+//     to that k-mer's control or case sum (64-bit LDS add);
+//   * after one barrier the table IS the tile's rows: every thread walks a few slots, a live slot goes
+//     through the chi-square pre-filter; the ~1 % that pass wait in a workgroup queue until a wave can
+//     evaluate 64 of them with every lane busy (likelihood ratio, tail function, compaction into the
+//     survivor sink -- kmd_eval.h, the same code K1 runs);
+//   * a tile whose k-mers do not fit the table (fewer records per row there than the plan assumed, or
+//     keys clustered where the longest stream has none) gives up and is listed; the host cuts the listed
+//     tiles into equal slices of the key range their records really span and runs the kernel again on
+//     those -- repeated until nothing is listed (every level divides a tile's key span).
+// Two-limb k-mers (32 < k <= 64): the same kernel keyed by the low limb, see k_tile_sums.
+#include "kmd_internal.h"
+#include "kmd_math.h"
+#include "kmd_eval.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace kmd::eval;
+
+#ifndef KMD_TILE_U
+#define KMD_TILE_U 2
+#endif
+#ifndef KMD_TILE_DEPTH
+#define KMD_TILE_DEPTH 4
+#endif
+#ifndef KMD_TILE_ABLATE
+#define KMD_TILE_ABLATE 0
+#endif
+
+namespace {
+
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile live in LDS (16 KB at 1024 streams)
+constexpr uint32_t kProbes = 2048;               // records sampled for the records-per-row estimate
+constexpr uint32_t kChunk = 64;                  // tile boundaries per coarse step of the start table
+constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
+
+// what k_tile_plan decides, on the device
+struct tile_plan
+{
+  uint32_t r;                                    // boundary j = key j * r of the longest stream
+  uint32_t nb;                                   // tiles
+  uint32_t g_shift;                              // lanes per run of records = 1 << g_shift
+  uint32_t fill;                                 // records per tile aimed at
+  float rho;                                     // records per row, estimated
+  uint32_t pad[3];
+};
+
+struct tile_job
+{
+  const uint64_t* keys;
+  const uint64_t* keys_hi;                       // two-limb k-mers, else NULL
+  const uint32_t* counts;
+  const uint32_t* start;                         // [rows][S]: row r = where every stream enters tile r; tile r ends at row r + 1
+  const uint8_t* todo;                           // NULL: every tile; else only tiles with todo[r] != 0
+  const tile_plan* plan;                         // n_tiles / g_shift when n_tiles == 0 (level 0: decided on the device)
+  uint32_t S, nc, n_tiles, g_shift, xcd_order;
+  // rows as (k-mer, control sum, case sum) triples instead of the test (kmd_merge_sums)
+  uint64_t* kmer_out;
+  uint64_t* kmer_hi_out;
+  unsigned long long* sum_c_out;
+  unsigned long long* sum_k_out;
+  unsigned long long row_capacity;
+  unsigned long long* n_rows;                    // entries written: rows (kmd_merge_sums) or candidate rows (kmd_merge_filter)
+  unsigned long long* row_total;                 // candidates mode: [0] distinct k-mers, [1] rows beyond the log-factorial table
+  // candidates mode: what the chi-square pre-filter needs of the model (kmd_eval.h, row_may_pass)
+  double dTc, dTk, dTcTk, pf_cut;
+  uint32_t lf_n;
+  uint32_t* over;                                // [0] tiles listed, [1 + i] tile, [1 + over_stride + i] its records (| kAbortBit)
+  uint32_t over_stride;
+};
+
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// first index in [lo, hi) whose key is >= (b, bh)
+__device__ __forceinline__ size_t lower_bound_key(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                  size_t lo, size_t hi, uint64_t b, uint64_t bh)
+{
+  if (keys_hi)
+    while (lo < hi)
+    {
+      const size_t mid = lo + ((hi - lo) >> 1);
+      const uint64_t kh = keys_hi[mid];
+      if (kh < bh || (kh == bh && keys[mid] < b)) lo = mid + 1; else hi = mid;
+    }
+  else
+    while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < b) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// mult[p] = number of streams that hold the k-mer of probe record p (records drawn uniformly from all
+// n, so mean(1 / mult) estimates rows / records without bias); one thread per (probe, stream)
+__global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                    const uint64_t* __restrict__ offs, uint32_t S, uint64_t n,
+                                                    uint32_t* __restrict__ mult)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= kProbes * S) return;
+  const uint32_t p = t / S, s = t - p * S;
+  const size_t i = (size_t)__umul64hi(mix64(p), n);
+  const uint64_t k = keys[i], kh = keys_hi ? keys_hi[i] : 0ull;
+  const size_t begin = offs[s], end = offs[s + 1];
+  const size_t at = lower_bound_key(keys, keys_hi, begin, end, k, kh);
+  if (at < end && keys[at] == k && (!keys_hi || keys_hi[at] == kh)) atomicAdd(&mult[p], 1u);
+}
+
+// the plan: records per tile such that its distinct k-mers fill `load` of the table
+__global__ void __launch_bounds__(256) k_tile_plan(const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t S,
+                                                   uint32_t slots, float load, uint32_t fill_fixed, uint32_t g_fixed,
+                                                   tile_plan* __restrict__ plan)
+{
+  __shared__ double s_part[256];
+  double acc = 0;
+  for (uint32_t p = threadIdx.x; p < kProbes; p += 256) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x != 0) return;
+  const double rho = (double)kProbes / s_part[0];                    // records per row
+  double fill = rho * (double)load * (double)slots;
+  const double fill_max = 24.0 * (double)slots;                      // ~0.6 MB of records per tile at most
+  if (fill > fill_max) fill = fill_max;
+  if (fill < 64.0) fill = 64.0;
+  if (fill_fixed) fill = (double)fill_fixed;
+  uint64_t r = (uint64_t)((double)n_l * fill / (double)n);           // every r-th key of the longest stream
+  if (r < 1) r = 1;
+  uint64_t nb = (n_l + r - 1) / r;
+  if (nb < 1) nb = 1;
+  // lanes per run: the power of two nearest the average run (one round of a sub-group takes most of it)
+  const double run = fill / (double)S;
+  uint32_t g = 3;
+  while (g < 6 && (double)(1u << g) < run * 0.75) ++g;
+  if (g_fixed) g = g_fixed;
+  plan->r = (uint32_t)r; plan->nb = (uint32_t)nb; plan->g_shift = g; plan->fill = (uint32_t)fill; plan->rho = (float)rho;
+}
+
+// where stream s enters tile j: boundary j = key j * r of the longest stream L (b_0 = -inf, b_nb = +inf).
+// Two steps: every kChunk-th boundary by binary search over the whole stream (coarse[c][s]) ...
+__global__ void __launch_bounds__(256) k_tile_coarse(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                     const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
+                                                     const tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse)
+{
+  const uint32_t nb = plan->nb, r = plan->r;
+  const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;               // coarse rows 0 .. n_chunks
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((size_t)n_chunks + 1) * S) return;
+  const size_t c = i / S;
+  const uint32_t s = (uint32_t)(i - c * S);
+  const size_t begin = offs[s], end = offs[s + 1], j = c * kChunk;
+  size_t pos;
+  if (j == 0) pos = begin;
+  else if (j >= nb) pos = end;
+  else
+  {
+    const size_t at = offs[L] + j * r;
+    pos = s == L ? at : lower_bound_key(keys, keys_hi, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
+  }
+  coarse[i] = (uint32_t)pos;
+}
+
+// ... the ones in between inside the window two coarse entries enclose: one wave per (chunk, stream),
+// its 64 lanes search the same few KB
+__global__ void __launch_bounds__(256) k_tile_fine(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                   const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
+                                                   const tile_plan* __restrict__ plan, const uint32_t* __restrict__ coarse,
+                                                   uint32_t* __restrict__ start)
+{
+  const uint32_t nb = plan->nb, r = plan->r;
+  const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // wave = (chunk, stream), stream fastest
+  const uint32_t lane = threadIdx.x & 63;
+  if (w >= (size_t)n_chunks * S) return;
+  const size_t c = w / S;
+  const uint32_t s = (uint32_t)(w - c * S);
+  const size_t j = c * kChunk + lane;
+  if (j <= nb)
+  {
+    size_t pos;
+    if (j == 0) pos = offs[s];
+    else if (j == nb) pos = offs[s + 1];
+    else
+    {
+      const size_t at = offs[L] + j * r;
+      if (s == L) pos = at;
+      else pos = lower_bound_key(keys, keys_hi, coarse[c * S + s], coarse[(c + 1) * S + s], keys[at], keys_hi ? keys_hi[at] : 0ull);
+    }
+    start[j * S + s] = (uint32_t)pos;
+  }
+  // row nb closes the last tile; when nb is a multiple of kChunk no lane above reaches it
+  if (c + 1 == n_chunks && lane == 0 && nb % kChunk == 0) start[(size_t)nb * S + s] = (uint32_t)offs[s + 1];
+}
+
+// A listed tile becomes m equal slices of the key range its records really span: rows first ..
+// first + m of the next table (the last one only closes slice m - 1).  One workgroup per listed tile.
+// Two-limb keys are cut on 64 bits chosen by `shift` from the 128 (the tile's keys agree above them).
+__device__ __forceinline__ uint64_t cut_bits(uint64_t lo, uint64_t hi, int shift)
+{
+  // bits [shift, shift + 64) of the 128-bit key
+  return shift == 0 ? lo : shift >= 64 ? (hi >> (shift - 64)) : ((hi << (64 - shift)) | (lo >> shift));
+}
+
+__global__ void __launch_bounds__(256) k_tile_refine(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                     const uint32_t* __restrict__ table, uint32_t S,
+                                                     const uint32_t* __restrict__ tile_of, const uint32_t* __restrict__ slices,
+                                                     const uint32_t* __restrict__ first, uint32_t* __restrict__ out,
+                                                     uint8_t* __restrict__ todo)
+{
+  __shared__ unsigned long long s_lo, s_hi, s_lo_h, s_hi_h;
+  __shared__ int s_shift;
+  const uint32_t i = blockIdx.x, s = threadIdx.x;
+  const uint32_t tile = tile_of[i], m = slices[i], row0 = first[i];
+  if (s == 0) { s_lo = ~0ull; s_hi = 0; s_lo_h = ~0ull; s_hi_h = 0; s_shift = 0; }
+  __syncthreads();
+  if (keys_hi)
+  {
+    // 128-bit span: first the high limbs' extremes, then the cut window
+    for (uint32_t q = s; q < S; q += blockDim.x)
+    {
+      const uint32_t b = table[(size_t)tile * S + q], e = table[((size_t)tile + 1) * S + q];
+      if (e > b) { atomicMin(&s_lo_h, (unsigned long long)keys_hi[b]); atomicMax(&s_hi_h, (unsigned long long)keys_hi[e - 1]); }
+    }
+    __syncthreads();
+    if (s == 0)
+    {
+      // the tile's keys agree on the bits above the highest bit in which its extreme HIGH limbs differ;
+      // cut on the 64 bits from there down (all of the low limb when the high limbs are equal)
+      const unsigned long long x = s_lo_h ^ s_hi_h;
+      s_shift = x ? 64 - __builtin_clzll(x) : 0;
+    }
+    __syncthreads();
+  }
+  const int shift = s_shift;
+  for (uint32_t q = s; q < S; q += blockDim.x)
+  {
+    const uint32_t b = table[(size_t)tile * S + q], e = table[((size_t)tile + 1) * S + q];
+    if (e > b)
+    {
+      const uint64_t kb = keys_hi ? cut_bits(keys[b], keys_hi[b], shift) : keys[b];
+      const uint64_t ke = keys_hi ? cut_bits(keys[e - 1], keys_hi[e - 1], shift) : keys[e - 1];
+      atomicMin(&s_lo, (unsigned long long)kb);
+      atomicMax(&s_hi, (unsigned long long)ke);
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = s; t <= m; t += blockDim.x) todo[row0 + t] = t < m ? 1 : 0;
+  const uint64_t k0 = s_lo, step = (s_hi - s_lo) / m + 1;           // m slices of this width cover [lo, hi]
+  for (uint32_t q = s; q < S; q += blockDim.x)
+  {
+    const uint32_t b = table[(size_t)tile * S + q], e = table[((size_t)tile + 1) * S + q];
+    out[(size_t)row0 * S + q] = b;
+    uint32_t lo = b;
+    for (uint32_t t = 1; t < m; ++t)
+    {
+      uint64_t bound = k0 + (uint64_t)t * step;
+      if (__umul64hi((uint64_t)t, step) != 0 || bound < k0) bound = ~0ull;     // saturate: past every key
+      uint32_t hi = e;                                                          // first record in [lo, e) with key >= bound
+      while (lo < hi)
+      {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint64_t k = keys_hi ? cut_bits(keys[mid], keys_hi[mid], shift) : keys[mid];
+        if (k < bound) lo = mid + 1; else hi = mid;
+      }
+      out[((size_t)row0 + t) * S + q] = lo;
+    }
+    out[((size_t)row0 + m) * S + q] = e;
+  }
+}
+
+constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+
+// LDS of one workgroup, carved from the dynamic allocation (the segment tables follow it)
+template <uint32_t kSlots, int kWaves, bool kTwo>
+struct tile_lds
+{
+  unsigned long long key[kSlots];
+  unsigned long long sc[kSlots];
+  unsigned long long sk[kSlots];
+  unsigned long long key_hi[kTwo ? kSlots : 1];
+  unsigned long long hi_min[kTwo ? kSlots : 1];          // see k_tile_sums: every record's high limb must agree with its slot's
+  unsigned long long maxsum[2];
+  unsigned long long max_hi[2];                          // kTwo: min / max high limb of the records whose low limb is all ones
+  unsigned long long base;
+  uint32_t n[2], fresh[2], abort[2];
+  uint32_t hasmax, bad;
+  uint32_t wcnt[kWaves];
+};
+
+// One workgroup per tile on a persistent grid.  Per tile:
+//   [segment table of the NEXT tile | walk of the table = rows of this tile] barrier [inserts of the next
+//   tile] barrier ...: two barriers per tile.
+// Tile order: each XCD (workgroup b runs on XCD b % 8) takes one contiguous eighth of the tiles and its
+// workgroups stride through it, so tiles that share cache lines at the ends of their runs meet in one L2.
+//
+// The table holds DISTINCT k-mers, and how many a tile has is not known beforehand (the plan sizes tiles
+// by an estimate of records per row): every wave adds the slots it claimed to a counter once per round,
+// and a probe sequence is bounded; past 3/4 full, or a probe sequence exhausted, the tile gives up -- its
+// slots are wiped, it is listed, the host cuts it.
+//
+// kTwo (32 < k <= 64): the table is keyed by the LOW limb.  Within a tile the high limbs (62 bits of a
+// k = 63 k-mer) almost always agree wherever the low limbs do -- they are the slowly varying part of a
+// sorted range -- but nothing guarantees it, so every record also folds its high limb into its slot's
+// minimum and maximum (two more LDS atomics); a slot whose minimum and maximum differ holds two k-mers
+// that share a low limb: the tile is then listed and cut again, which separates them (their high limbs
+// differ, so some slice boundary falls between them; at the latest when a slice is a single value of the
+// cut window).  A low limb of all ones (the empty marker) is kept apart the same way.
+template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo>
+__global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
+{
+  constexpr uint32_t kMask = kSlots - 1;
+  constexpr int kShift = 32 - ilog2_c(kSlots);
+  constexpr int kWaves = kThreads / 64;
+  constexpr int kWalk = kSlots / kThreads;               // table slots per thread in the walk
+  constexpr int kU = KMD_TILE_U;                         // records per lane and round
+  constexpr int kDepth = KMD_TILE_DEPTH;                 // rounds in flight per wave
+  constexpr uint32_t kFullAt = kSlots / 4 * 3;           // distinct k-mers at which a tile gives up
+  constexpr uint32_t kMaxProbe = 96;
+  static_assert((kSlots & kMask) == 0 && kSlots % kThreads == 0, "shape");
+  static_assert(kWalk <= 32, "walk bits");
+  using lds_t = tile_lds<kSlots, kWaves, kTwo>;
+  extern __shared__ unsigned long long s_raw[];
+  lds_t& M = *reinterpret_cast<lds_t*>(s_raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t S = J.S;
+  const uint32_t n_tiles = J.n_tiles ? J.n_tiles : J.plan->nb;
+  const uint32_t g_shift = J.n_tiles ? J.g_shift : J.plan->g_shift;
+  // segment tables of the current and the next tile, behind the fixed part: [2][begin[S] | length[S]]
+  uint32_t* const s_seg = reinterpret_cast<uint32_t*>(s_raw + (sizeof(lds_t) + 7) / 8);
+
+  // this workgroup's tiles: tile_first, tile_first + stride, ... below tile_end
+  uint32_t tile_first = blockIdx.x, tile_end = n_tiles, stride = gridDim.x;
+  if (J.xcd_order && (gridDim.x & 7u) == 0 && n_tiles >= gridDim.x)
+  {
+    const uint32_t x = blockIdx.x & 7u, per = gridDim.x >> 3, chunk = (n_tiles + 7u) >> 3;
+    tile_first = x * chunk + (blockIdx.x >> 3);
+    tile_end = (x + 1u) * chunk < n_tiles ? (x + 1u) * chunk : n_tiles;
+    stride = per;
+  }
+
+  for (uint32_t i = tid; i < kSlots; i += kThreads)
+  {
+    M.key[i] = kEmptyKey; M.sc[i] = 0; M.sk[i] = 0;
+    if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
+  }
+  if (tid == 0)
+  {
+    M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0;
+    M.hasmax = 0; M.bad = 0; M.maxsum[0] = 0; M.maxsum[1] = 0;
+    M.max_hi[0] = ~0ull; M.max_hi[1] = 0;
+  }
+  __syncthreads();
+  auto load_segments = [&](uint32_t tile, uint32_t buf)
+  {
+    if (tile >= tile_end) return;
+    uint32_t* beg = s_seg + (size_t)buf * 2 * S;
+    uint32_t mine = 0;
+    for (uint32_t s = tid; s < S; s += kThreads)
+    {
+      const uint32_t b = J.start[(size_t)tile * S + s], e = J.start[((size_t)tile + 1) * S + s];
+      beg[s] = b; beg[S + s] = e - b;
+      mine += e - b;
+    }
+    if (mine) atomicAdd(&M.n[buf], mine);
+  };
+  load_segments(tile_first, 0);
+  __syncthreads();
+
+  const uint32_t G = 1u << g_shift, sub = tid & (G - 1u), q0 = tid >> g_shift, Q = (uint32_t)kThreads >> g_shift;
+  uint32_t n_beyond = 0, rows_local = 0;
+  struct batch
+  {
+    uint64_t k[kU], kh[kTwo ? kU : 1];
+    uint32_t c[kU];
+    uint32_t valid, ctl;                                 // bit u: record u is there / is a control sample's
+  };
+
+  uint32_t it = 0;
+  for (uint32_t tile = tile_first; tile < tile_end; tile += stride, ++it)
+  {
+    const uint32_t buf = it & 1u;
+    const uint32_t n = M.n[buf];
+    const bool wanted = J.todo == nullptr || J.todo[tile] != 0;
+    const bool process = wanted && n > 0;
+    if (tid == 0) { M.n[buf ^ 1u] = 0; M.fresh[buf ^ 1u] = 0; M.abort[buf ^ 1u] = 0; }
+
+    // ---- inserts: sub-group q0 streams the runs q0, q0 + Q, ... of this tile
+    if (process)
+    {
+      const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
+      const uint32_t* len = beg + S;
+      uint32_t s = q0, pos = 0, end = 0;
+      // the lane's next record: `pos` in run `s`; a lane that has none left parks on record 0 (s >= S)
+      auto seek = [&]()
+      {
+        while (s < S)
+        {
+          const uint32_t b = beg[s];
+          pos = b + sub; end = b + len[s];
+          if (pos < end) return;
+          s += Q;
+        }
+        pos = 0; end = 0;
+      };
+      // the loads are unconditional (a lane without a record left reads record 0, its `valid` bit stays
+      // clear): a round is a fixed number of load instructions, so the ones of later rounds can stay in
+      // flight while an earlier round is inserted (the wait counts are static)
+      auto fetch = [&](batch& B)
+      {
+        B.valid = 0; B.ctl = 0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+          B.k[u] = __builtin_nontemporal_load(J.keys + pos);
+          B.c[u] = __builtin_nontemporal_load(J.counts + pos);
+          if constexpr (kTwo) B.kh[u] = __builtin_nontemporal_load(J.keys_hi + pos);
+          if (s < S)
+          {
+            B.valid |= 1u << u;
+            if (s < J.nc) B.ctl |= 1u << u;
+            pos += G;
+            if (pos >= end) { s += Q; seek(); }
+          }
+        }
+      };
+      // One round into the table; false: the tile gave up (table too full).
+      // What a wave pays for is the LONGEST probe sequence among its 64 x kU records, so the sequences
+      // must be short for all of them.  A k-mer has two home slots (two hashes); the sequence is
+      // home 0, home 1, home 1 + 1, home 1 + 2, ...  The first step looks at BOTH homes at once (plain
+      // 64-bit LDS reads -- most records find their k-mer already there: a row has rho records, only the
+      // first one claims a slot, with a compare-and-swap): at 1/3 load that settles ~97 % of the records;
+      // the few left walk on in a tail loop.  Everything is wave-uniform with per-lane state moved by
+      // selects: a divergent probe loop per record (a returning CAS per step) cost twice the instructions
+      // in exec-mask bookkeeping.  Slots are never released within a tile, so whichever record of a k-mer
+      // comes first, later ones walk the same sequence to the same slot.
+      auto insert = [&](const batch& A) -> bool
+      {
+        uint32_t slot[kU], nxt[kU];                      // where the k-mer is / next slot to look at
+        bool pend[kU];
+        uint32_t fresh_bits = 0;
+        bool special = false;
+        unsigned long long s0[kU], s1[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+          const bool v = (A.valid >> u) & 1u;
+          const uint32_t x = (uint32_t)A.k[u] ^ (uint32_t)(A.k[u] >> 29);
+          slot[u] = (x * 0x9E3779B1u) >> kShift;
+          nxt[u] = ((x ^ (x >> 15)) * 0x85EBCA6Bu) >> kShift;
+          pend[u] = v && A.k[u] != kEmptyKey;
+          special |= v && A.k[u] == kEmptyKey;
+          s0[u] = __hip_atomic_load(&M.key[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          s1[u] = __hip_atomic_load(&M.key[nxt[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (__ballot(special))
+        {
+          // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+            if (((A.valid >> u) & 1u) && A.k[u] == kEmptyKey)
+            {
+              atomicAdd(&M.maxsum[((A.ctl >> u) & 1u) ? 0 : 1], (unsigned long long)A.c[u]);
+              if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)A.kh[u]); atomicMax(&M.max_hi[1], (unsigned long long)A.kh[u]); }
+              M.hasmax = 1;
+            }
+        }
+        // step 1: both homes
+        bool want_cas = false;
+        bool claim[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+          const bool hit0 = s0[u] == A.k[u], hit1 = s1[u] == A.k[u];
+          const bool e0 = s0[u] == kEmptyKey, e1 = s1[u] == kEmptyKey;
+          const uint32_t home0 = slot[u], home1 = nxt[u];
+          const bool found = hit0 || hit1;
+          claim[u] = pend[u] && !found && (e0 || e1);        // the first empty home (home 1 only if home 0 is taken)
+          // found: there.  claiming: the slot to claim.  neither: on to home 1 + 1
+          slot[u] = (hit0 || (!hit1 && e0)) ? home0 : home1;
+          nxt[u] = (claim[u] && e0) ? home1 : ((home1 + 1u) & kMask);
+          pend[u] = pend[u] && !found;
+          want_cas |= claim[u];
+        }
+#if !(KMD_TILE_ABLATE & 1)
+        if (__ballot(want_cas))
+        {
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+            if (claim[u])
+            {
+              const unsigned long long old = atomicCAS(&M.key[slot[u]], (unsigned long long)kEmptyKey, (unsigned long long)A.k[u]);
+              if (old == kEmptyKey) { fresh_bits |= 1u << u; pend[u] = false; }
+              else if (old == A.k[u]) pend[u] = false;       // (another record of this k-mer was faster)
+            }                                                // else: lost the slot to another k-mer, walk on at nxt
+        }
+#else
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (claim[u]) { M.key[slot[u]] = A.k[u]; pend[u] = false; }
+#endif
+        // the tail: one slot per step from nxt on
+        bool gave_up = false;
+        for (uint32_t step = 0;; ++step)
+        {
+          bool any = false;
+#pragma unroll
+          for (int u = 0; u < kU; ++u) any |= pend[u];
+          if (!__ballot(any)) break;
+          if (step >= kMaxProbe) { gave_up = any; break; }
+          unsigned long long seen[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) seen[u] = __hip_atomic_load(&M.key[nxt[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          bool want = false;
+#pragma unroll
+          for (int u = 0; u < kU; ++u) want |= pend[u] && seen[u] == kEmptyKey;
+          if (__ballot(want))
+          {
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+              if (pend[u] && seen[u] == kEmptyKey)
+              {
+                seen[u] = atomicCAS(&M.key[nxt[u]], (unsigned long long)kEmptyKey, (unsigned long long)A.k[u]);
+                if (seen[u] == kEmptyKey) { seen[u] = A.k[u]; fresh_bits |= 1u << u; }
+              }
+          }
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+          {
+            const bool hit = pend[u] && seen[u] == A.k[u];
+            slot[u] = hit ? nxt[u] : slot[u];
+            pend[u] = pend[u] && !hit;
+            nxt[u] = (nxt[u] + 1u) & kMask;
+          }
+        }
+        uint32_t claimed = 0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+          const bool v = (A.valid >> u) & 1u;
+          if (v && A.k[u] != kEmptyKey && !pend[u])
+          {
+            const bool ctl = (A.ctl >> u) & 1u;
+#if KMD_TILE_ABLATE & 2   // dev: plain store instead of the 64-bit add (results wrong)
+            (ctl ? M.sc : M.sk)[slot[u]] = A.c[u];
+#else
+            atomicAdd(ctl ? &M.sc[slot[u]] : &M.sk[slot[u]], (unsigned long long)A.c[u]);
+#endif
+            if constexpr (kTwo)
+            {
+              atomicMax(&M.key_hi[slot[u]], (unsigned long long)A.kh[u]);
+              atomicMin(&M.hi_min[slot[u]], (unsigned long long)A.kh[u]);
+            }
+          }
+          claimed += (uint32_t)__popcll(__ballot(((fresh_bits >> u) & 1u) != 0));
+        }
+        // slots this wave claimed in the round -> the tile's count; a table 3/4 full gives up
+        if (lane == 0 && claimed)
+        {
+          const uint32_t before = atomicAdd(&M.fresh[buf], claimed);
+          if (before + claimed > kFullAt) M.abort[buf] = 1;
+        }
+        if (gave_up) M.abort[buf] = 1;
+        return M.abort[buf] == 0;                        // (LDS read, same for the whole wave)
+      };
+      // a ring of kDepth rounds: round i + kDepth is requested as soon as round i has been inserted
+      auto run_ring = [&](auto&& fetch)
+      {
+        batch R[kDepth];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) fetch(R[d]);
+        for (bool more = true; more;)
+        {
+#pragma unroll
+          for (int d = 0; d < kDepth; ++d)
+          {
+            if (!more) break;
+            if (!__ballot(R[d].valid != 0)) { more = false; break; }     // the runs are exhausted in order
+            if (!insert(R[d])) { more = false; break; }
+            fetch(R[d]);
+          }
+        }
+      };
+      if (g_shift == 6)
+      {
+        // Runs of a wave's worth of records and more (the usual case: a tile is sized to hold ~700 rows): a
+        // wave takes whole runs, one after the other -- runs wave, wave + kWaves, ... -- and walks a run
+        // 64 records at a time.  Everything about WHERE is wave-uniform and lives in scalar registers (the
+        // per-lane iterator of the general path cost more instructions than the inserts); a lane's address
+        // is the scalar position + its lane number.
+        uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);        // current run
+        uint32_t rb = 0, rl = 0, rc = 0;                                            // its first record, length, records done
+        auto next_run = [&]()
+        {
+          while (rs < S)
+          {
+            rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
+            rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)len[rs]);
+            rc = 0;
+            if (rl) return;
+            rs += kWaves;
+          }
+          rb = 0; rl = 0; rc = 0;
+        };
+        next_run();
+        auto fetch_wide = [&](batch& B)
+        {
+          B.valid = 0; B.ctl = 0;
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+          {
+            const uint32_t at = rb + rc + lane;                  // (exhausted: records 0 .. 63, never used)
+            B.k[u] = __builtin_nontemporal_load(J.keys + at);
+            B.c[u] = __builtin_nontemporal_load(J.counts + at);
+            if constexpr (kTwo) B.kh[u] = __builtin_nontemporal_load(J.keys_hi + at);
+            if (rc + lane < rl) B.valid |= 1u << u;
+            if (rs < J.nc) B.ctl |= 1u << u;                     // (wave-uniform)
+            rc += 64;
+            if (rc >= rl && rs < S) { rs += kWaves; next_run(); }
+          }
+        };
+        run_ring(fetch_wide);
+      }
+      else
+      {
+        seek();
+        run_ring(fetch);
+      }
+    }
+    __syncthreads();
+
+    // ---- the next tile's segment table; the table walk: this tile's rows
+    load_segments(tile + stride, buf ^ 1u);
+    if (process)
+    {
+      const bool aborted = M.abort[buf] != 0;
+      if constexpr (kTwo)
+      {
+        // two k-mers in one slot?  then this tile is cut again instead of emitted
+        bool bad = false;
+        if (!aborted)
+          for (uint32_t i = tid; i < kSlots; i += kThreads)
+            bad |= M.key[i] != kEmptyKey && M.key_hi[i] != M.hi_min[i];
+        if (tid == 0 && !aborted && M.hasmax && M.max_hi[0] != M.max_hi[1]) bad = true;
+        if (__ballot(bad) && lane == 0) M.bad = 1;
+        __syncthreads();
+      }
+      const bool bad_tile = aborted || (kTwo && M.bad != 0);
+      if constexpr (kTwo) { __syncthreads(); if (tid == 0) M.bad = 0; }     // everyone has read it
+      if (bad_tile && tid == 0)
+      {
+        const uint32_t at = atomicAdd(&J.over[0], 1u);
+        J.over[1 + at] = tile; J.over[1 + J.over_stride + at] = (n < kAbortBit ? n : kAbortBit - 1u) | kAbortBit;
+      }
+      // the walk: every thread owns kWalk slots.  Pass 1 counts the rows that leave (all of them, or --
+      // kFilter -- the ones the chi-square pre-filter lets through, ~1 %); the tile takes that many
+      // consecutive entries of the output with ONE global atomic; pass 2 writes them and wipes the slots.
+      uint32_t out_bits = 0, mine = 0;
+      bool special_out = false;
+      if (!bad_tile)
+      {
+#pragma unroll
+        for (int j = 0; j < kWalk; ++j)
+        {
+          const uint32_t i = tid + (uint32_t)j * kThreads;
+          const bool live = M.key[i] != kEmptyKey;
+          bool leaves = live;
+          if constexpr (kFilter)
+          {
+            row_state st; st.sum_c = live ? M.sc[i] : 0; st.sum_k = live ? M.sk[i] : 0; st.row = 0; st.valid = live;
+            leaves = row_may_pass(J, st, n_beyond);
+          }
+          rows_local += live ? 1u : 0u;
+          out_bits |= leaves ? 1u << j : 0u;
+          mine += leaves ? 1u : 0u;
+        }
+        if (tid == 0 && M.hasmax)                          // the all-ones k-mer, if this tile had it
+        {
+          special_out = true;
+          if constexpr (kFilter)
+          {
+            row_state st; st.sum_c = M.maxsum[0]; st.sum_k = M.maxsum[1]; st.row = 0; st.valid = true;
+            special_out = row_may_pass(J, st, n_beyond);
+          }
+          ++rows_local;
+          mine += special_out ? 1u : 0u;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+      if (lane == 0) M.wcnt[wave] = mine;
+      __syncthreads();
+      if (tid == 0)
+      {
+        uint32_t total = 0;
+        for (int w = 0; w < kWaves; ++w) total += M.wcnt[w];
+        M.base = total ? atomicAdd(J.n_rows, (unsigned long long)total) : 0ull;
+      }
+      __syncthreads();
+      unsigned long long out_at = M.base;
+      for (uint32_t w = 0; w < wave; ++w) out_at += M.wcnt[w];
+      if (special_out)                                     // (thread 0: the first entry of the tile)
+      {
+        if (out_at < J.row_capacity)
+        {
+          J.kmer_out[out_at] = kEmptyKey; J.sum_c_out[out_at] = M.maxsum[0]; J.sum_k_out[out_at] = M.maxsum[1];
+          if constexpr (kTwo) J.kmer_hi_out[out_at] = M.max_hi[1];
+        }
+      }
+      if (wave == 0) out_at += __shfl((unsigned long long)(special_out ? 1u : 0u), 0, 64);
+#pragma unroll
+      for (int j = 0; j < kWalk; ++j)
+      {
+        const uint32_t i = tid + (uint32_t)j * kThreads;
+        const uint64_t key = M.key[i];
+        const bool live = key != kEmptyKey;
+        const bool leaves = (out_bits >> j) & 1u;
+        const unsigned long long m = __ballot(leaves);
+        if (live)
+        {
+          if (leaves)
+          {
+            const unsigned long long e = out_at + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+            if (e < J.row_capacity)
+            {
+              J.kmer_out[e] = key; J.sum_c_out[e] = M.sc[i]; J.sum_k_out[e] = M.sk[i];
+              if constexpr (kTwo) J.kmer_hi_out[e] = M.key_hi[i];
+            }
+          }
+          M.key[i] = kEmptyKey; M.sc[i] = 0; M.sk[i] = 0;
+          if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
+        }
+        out_at += (unsigned long long)__popcll(m);
+      }
+      if (tid == 0 && M.hasmax) { M.hasmax = 0; M.maxsum[0] = 0; M.maxsum[1] = 0; M.max_hi[0] = ~0ull; M.max_hi[1] = 0; }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (kFilter)
+  {
+    // this workgroup's rows and rows beyond the log-factorial table (merge.hpp:76; kmd_filter.hip counts
+    // the same two for rows of a matrix)
+    for (int o = 32; o > 0; o >>= 1) { rows_local += __shfl_down(rows_local, o, 64); n_beyond += __shfl_down(n_beyond, o, 64); }
+    if (lane == 0 && rows_local) atomicAdd(&J.row_total[0], (unsigned long long)rows_local);
+    if (lane == 0 && n_beyond) atomicAdd(&J.row_total[1], (unsigned long long)n_beyond);
+  }
+}
+
+// kernel attribute (LDS beyond 64 KB) once per kernel and device
+template <typename K> int allow_lds(K kernel, size_t lds_bytes)
+{
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> allowed;
+  if (lds_bytes <= 64 * 1024) return KMD_OK;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = allowed[{ fn, dev }];
+  if (lds_bytes > have)
+  {
+    KMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    have = lds_bytes;
+  }
+  return KMD_OK;
+}
+
+struct scratch_set
+{
+  std::vector<void*> blocks;
+  hipError_t take(void** out, size_t bytes)
+  {
+    const hipError_t e = kmd::scratch_alloc(out, bytes ? bytes : 1);
+    if (e == hipSuccess) blocks.push_back(*out);
+    return e;
+  }
+  ~scratch_set() { for (void* b : blocks) kmd::scratch_free(b); }
+};
+
+struct tile_shape { int threads; uint32_t slots; };
+
+inline tile_shape pick_shape()
+{
+  tile_shape sh { 512, 2048 };
+  if (const char* e = std::getenv("KMD_TILE_SHAPE"))     // dev: "threads x slots" (A/B)
+  {
+    int t = 0; unsigned s = 0;
+    if (std::sscanf(e, "%dx%u", &t, &s) == 2) { sh.threads = t; sh.slots = s; }
+  }
+  return sh;
+}
+
+inline uint32_t env_u32(const char* name, uint32_t dflt)
+{
+  const char* e = std::getenv(name);
+  return e ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
+}
+
+// streams -> entries (k-mer, control sum, case sum): every row (pf == NULL, kmd_merge_sums) or the rows
+// the chi-square pre-filter of *pf lets through (kmd_merge_filter).  *n_entries = entries the run
+// produced (the first row_capacity of them written), totals[0] = distinct k-mers, totals[1] = rows with a
+// count sum beyond the log-factorial table (pre-filter mode).
+// Synchronous: the tiles that gave up are known only when the kernel has run.
+int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi, const uint32_t* d_counts,
+               const uint64_t* offsets, const filter_params* pf, uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out,
+               uint64_t* d_sum_c, uint64_t* d_sum_k, size_t row_capacity, uint64_t* n_entries, uint64_t totals[2], hipStream_t st)
+{
+  const bool fused = pf != nullptr;
+  const size_t n = (size_t)offsets[S];
+  const bool two = d_keys_hi != nullptr;
+  const bool dbg = std::getenv("KMD_DEBUG") != nullptr;
+  int dev = 0, n_cu = 256;
+  KMD_HIP(hipGetDevice(&dev));
+  KMD_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  const tile_shape sh = pick_shape();
+  const float load = (float)env_u32("KMD_TILE_LOAD_PCT", 33) / 100.0f;        // distinct k-mers per slot aimed at
+
+  uint32_t L = 0;
+  for (int s = 1; s < S; ++s) if (offsets[s + 1] - offsets[s] > offsets[L + 1] - offsets[L]) L = (uint32_t)s;
+  const uint64_t n_l = offsets[L + 1] - offsets[L];
+  // the most tiles the plan can ask for: every record its own row (rho = 1), or the dev override
+  uint32_t fill_min = (uint32_t)std::max(64.0f, load * (float)sh.slots);
+  if (const uint32_t f = env_u32("KMD_TILE_FILL", 0)) fill_min = std::min(fill_min, std::max(64u, f));
+  const uint64_t r_min = std::max<uint64_t>(1, (uint64_t)((double)n_l * (double)fill_min / (double)n));
+  const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min);
+  const uint32_t chunks_max = (nb_max + kChunk - 1) / kChunk;
+
+  scratch_set sc;
+  void *p_offs = nullptr, *p_table = nullptr, *p_coarse = nullptr, *p_over = nullptr, *p_small = nullptr;
+  KMD_HIP(sc.take(&p_offs, ((size_t)S + 1) * 8));
+  KMD_HIP(sc.take(&p_table, ((size_t)nb_max + 1) * (size_t)S * 4));
+  KMD_HIP(sc.take(&p_coarse, ((size_t)chunks_max + 1) * (size_t)S * 4));
+  KMD_HIP(sc.take(&p_small, 64 + (size_t)kProbes * 4));              // [plan | entries, rows, rows beyond the table | probe multiplicities]
+  tile_plan* d_plan = static_cast<tile_plan*>(p_small);
+  unsigned long long* d_rows = reinterpret_cast<unsigned long long*>(static_cast<char*>(p_small) + 32);
+  uint32_t* d_mult = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 64);
+  KMD_HIP(hipMemcpyAsync(p_offs, offsets, ((size_t)S + 1) * 8, hipMemcpyHostToDevice, st));
+  KMD_HIP(hipMemsetAsync(p_small, 0, 64 + (size_t)kProbes * 4, st));
+  const uint64_t* d_offs = static_cast<const uint64_t*>(p_offs);
+  {
+    hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S,
+                       (uint64_t)n, d_mult);
+    hipLaunchKernelGGL(k_tile_plan, dim3(1), dim3(256), 0, st, d_mult, (uint64_t)n, n_l, (uint32_t)S, sh.slots, load,
+                       env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0), d_plan);
+    const size_t cells_c = ((size_t)chunks_max + 1) * S;
+    hipLaunchKernelGGL(k_tile_coarse, dim3((unsigned)((cells_c + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
+                       d_plan, static_cast<uint32_t*>(p_coarse));
+    const size_t waves_f = (size_t)chunks_max * S;
+    hipLaunchKernelGGL(k_tile_fine, dim3((unsigned)((waves_f + 3) / 4)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
+                       d_plan, static_cast<const uint32_t*>(p_coarse), static_cast<uint32_t*>(p_table));
+    KMD_HIP(hipGetLastError());
+  }
+
+  tile_job J;
+  std::memset(&J, 0, sizeof J);
+  J.keys = d_keys; J.keys_hi = d_keys_hi; J.counts = d_counts;
+  J.S = (uint32_t)S; J.nc = (uint32_t)nc; J.plan = d_plan;
+  J.xcd_order = env_u32("KMD_TILE_XCD", 1);
+  J.kmer_out = d_kmer_out; J.kmer_hi_out = d_kmer_hi_out;
+  J.sum_c_out = reinterpret_cast<unsigned long long*>(d_sum_c); J.sum_k_out = reinterpret_cast<unsigned long long*>(d_sum_k);
+  J.row_capacity = row_capacity;
+  J.n_rows = d_rows;
+  J.row_total = d_rows + 1;
+  if (pf) { J.dTc = pf->dTc; J.dTk = pf->dTk; J.dTcTk = pf->dTcTk; J.pf_cut = pf->pf_cut; J.lf_n = pf->lf_n; }
+
+  auto launch = [&](auto kernel, int threads, size_t lds_fixed, uint32_t tiles_at_most) -> int
+  {
+    const size_t lds = (lds_fixed + 7) / 8 * 8 + 4 * (size_t)S * 4;        // + [2][begin | length] of S streams
+    int rc = allow_lds(kernel, lds);
+    if (rc != KMD_OK) return rc;
+    int per_cu = 0;
+    KMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+    if (per_cu < 1) per_cu = 1;
+    if (const uint32_t e = env_u32("KMD_TILE_BLOCKS_PER_CU", 0)) per_cu = (int)e;
+    size_t grid = (size_t)n_cu * (size_t)per_cu;
+    if (grid > tiles_at_most) grid = tiles_at_most;
+    if (dbg) std::fprintf(stderr, "[tile_merge] <= %u tiles, grid %zu x %d (%d per CU), lds %zu\n", tiles_at_most, grid, threads, per_cu, lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, J);
+    KMD_HIP(hipGetLastError());
+    return KMD_OK;
+  };
+  auto run = [&](uint32_t tiles_at_most) -> int
+  {
+#define KMD_TILE_CASE(T, SL)                                                                                                              \
+    if (sh.threads == T && sh.slots == SL)                                                                                                \
+    {                                                                                                                                     \
+      if (fused) return two ? launch(k_tile_sums<T, SL, true, true>, T, sizeof(tile_lds<SL, T / 64, true>), tiles_at_most)                \
+                            : launch(k_tile_sums<T, SL, true, false>, T, sizeof(tile_lds<SL, T / 64, false>), tiles_at_most);             \
+      return two ? launch(k_tile_sums<T, SL, false, true>, T, sizeof(tile_lds<SL, T / 64, true>), tiles_at_most)                          \
+                 : launch(k_tile_sums<T, SL, false, false>, T, sizeof(tile_lds<SL, T / 64, false>), tiles_at_most);                       \
+    }
+    KMD_TILE_CASE(512, 2048)
+    KMD_TILE_CASE(1024, 2048)
+    KMD_TILE_CASE(1024, 4096)
+    KMD_TILE_CASE(512, 4096)
+    KMD_TILE_CASE(256, 2048)
+    KMD_TILE_CASE(256, 1024)
+#undef KMD_TILE_CASE
+    kmd::set_error("kmd: KMD_TILE_SHAPE not built");
+    return KMD_E_INVALID;
+  };
+
+  // level 0: the planned table; further levels: the slices of the tiles that gave up
+  uint32_t n_tiles = 0;                                         // 0: the plan's (on the device)
+  uint32_t list_cap = nb_max;
+  const uint32_t* table = static_cast<const uint32_t*>(p_table);
+  const uint8_t* todo = nullptr;
+  tile_plan h_plan;
+  std::memset(&h_plan, 0, sizeof h_plan);
+  std::vector<uint32_t> h_over;
+  for (int level = 0;; ++level)
+  {
+    KMD_HIP(sc.take(&p_over, (1 + 2 * (size_t)list_cap) * 4));
+    KMD_HIP(hipMemsetAsync(p_over, 0, 4, st));
+    J.start = table; J.todo = todo; J.n_tiles = n_tiles;
+    J.over = static_cast<uint32_t*>(p_over); J.over_stride = list_cap;
+    int rc = run(list_cap);
+    if (rc != KMD_OK) return rc;
+    uint32_t n_over = 0;
+    KMD_HIP(hipMemcpyAsync(&n_over, p_over, 4, hipMemcpyDeviceToHost, st));
+    if (level == 0) KMD_HIP(hipMemcpyAsync(&h_plan, d_plan, sizeof h_plan, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    if (dbg)
+      std::fprintf(stderr, "[tile_merge] level %d: %u of %u tiles gave up (plan: %.2f records per row, %u records per tile, r %u, G %u)\n",
+                   level, n_over, level ? n_tiles : h_plan.nb, h_plan.rho, h_plan.fill, h_plan.r, 1u << h_plan.g_shift);
+    if (n_over == 0) break;
+    KMD_REQUIRE(level < 80, "kmd: tile refinement did not converge");
+    // cut the listed tiles by the key range they span: a tile that ran out of table is cut as if every
+    // record were a row of its own (its records per row are unknown but not what the plan assumed)
+    h_over.resize(2 * (size_t)n_over);
+    KMD_HIP(hipMemcpy(h_over.data(), static_cast<uint32_t*>(p_over) + 1, (size_t)n_over * 4, hipMemcpyDeviceToHost));
+    KMD_HIP(hipMemcpy(h_over.data() + n_over, static_cast<uint32_t*>(p_over) + 1 + list_cap, (size_t)n_over * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> h_ref(3 * (size_t)n_over);              // tile, slices, first row
+    const uint64_t per_slice = std::max<uint64_t>(64, (uint64_t)(load * (float)sh.slots));
+    uint64_t rows = 0;
+    for (uint32_t i = 0; i < n_over; ++i)
+    {
+      const uint64_t cnt = h_over[n_over + i] & ~kAbortBit;
+      uint64_t m = 2 * ((cnt + per_slice - 1) / per_slice);
+      if (m < 2) m = 2;
+      if (m > (1u << 20)) m = 1u << 20;
+      h_ref[i] = h_over[i]; h_ref[n_over + i] = (uint32_t)m; h_ref[2 * (size_t)n_over + i] = (uint32_t)rows;
+      rows += m + 1;
+    }
+    KMD_REQUIRE(rows < 0x7FFFFFFFull, "kmd: tile refinement table too large");
+    void *p_ref = nullptr, *p_sub = nullptr, *p_todo = nullptr;
+    KMD_HIP(sc.take(&p_ref, h_ref.size() * 4));
+    KMD_HIP(sc.take(&p_sub, (size_t)rows * (size_t)S * 4));
+    KMD_HIP(sc.take(&p_todo, (size_t)rows));
+    KMD_HIP(hipMemcpyAsync(p_ref, h_ref.data(), h_ref.size() * 4, hipMemcpyHostToDevice, st));
+    const uint32_t* d_ref = static_cast<const uint32_t*>(p_ref);
+    hipLaunchKernelGGL(k_tile_refine, dim3(n_over), dim3(256), 0, st, d_keys, d_keys_hi, table, (uint32_t)S, d_ref, d_ref + n_over,
+                       d_ref + 2 * (size_t)n_over, static_cast<uint32_t*>(p_sub), static_cast<uint8_t*>(p_todo));
+    KMD_HIP(hipGetLastError());
+    KMD_HIP(hipStreamSynchronize(st));                            // h_ref is read by the copy
+    table = static_cast<const uint32_t*>(p_sub);
+    todo = static_cast<const uint8_t*>(p_todo);
+    n_tiles = (uint32_t)(rows - 1);
+    list_cap = n_tiles;
+    // lanes per run for the slices: they hold ~per_slice / 2 records
+    uint32_t g = 3;
+    while (g < 6 && (double)(1u << g) < (double)per_slice * 0.5 / (double)S * 0.75) ++g;
+    J.g_shift = g;
+  }
+  unsigned long long h_rows[3] = { 0, 0, 0 };
+  KMD_HIP(hipMemcpy(h_rows, d_rows, sizeof h_rows, hipMemcpyDeviceToHost));
+  if (n_entries) *n_entries = (uint64_t)h_rows[0];
+  if (totals) { totals[0] = fused ? (uint64_t)h_rows[1] : (uint64_t)h_rows[0]; totals[1] = (uint64_t)h_rows[2]; }
+  return KMD_OK;
+}
+
+} // namespace
+
+// ---- C-ABI -------------------------------------------------------------------------------------
+
+extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                                const uint32_t* d_counts, const uint64_t* offsets, double threshold,
+                                const kmd_survivors* out, uint64_t* d_counters, uint64_t* n_rows_out, void* stream)
+{
+  KMD_REQUIRE(m && offsets && d_counters, "kmd_merge_filter: NULL model, offsets or counters");
+  KMD_REQUIRE(n_samples == m->nc + m->nk, "kmd_merge_filter: n_samples != controls + cases of the model");
+  KMD_REQUIRE((uint32_t)n_samples <= kMaxStreams, "kmd_merge_filter: more than 1024 samples");
+  const size_t n = (size_t)offsets[n_samples];
+  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_merge_filter: more than 2^32-1 records in one partition");
+  for (int s = 0; s < n_samples; ++s) KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_filter: offsets must be ascending");
+  if (n_rows_out) *n_rows_out = 0;
+  if (n == 0) return KMD_OK;
+  KMD_REQUIRE(d_kmers && d_counts, "kmd_merge_filter: NULL device buffers");
+  kmd_tile t { d_counts, 4, KMD_LAYOUT_SOA, n, nullptr, nullptr, n, 0 };      // for the shared checks; never read as a matrix
+  filter_params P;
+  int rc = kmd::fill_filter_params(P, m, &t, threshold);
+  if (rc != KMD_OK) return rc;
+  P.counters = reinterpret_cast<unsigned long long*>(d_counters);
+  if (out) P.out = *out;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // The merge leaves the rows the pre-filter lets through (~1 % of the rows; all of them when the
+  // pre-filter is off) in a scratch list; should the list prove too small, the merge runs again with
+  // the size it reported -- nothing of the first run has reached the caller's counters or sink.
+  const bool two = d_kmers_hi != nullptr;
+  size_t cap = std::max<size_t>((size_t)1 << 18, n / 8);
+  if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) cap = e;
+  uint64_t entries = 0, totals[2] = { 0, 0 };
+  scratch_set sc;
+  void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr;
+  for (int attempt = 0;; ++attempt)
+  {
+    KMD_HIP(sc.take(&p_k, cap * 8)); KMD_HIP(sc.take(&p_c, cap * 8)); KMD_HIP(sc.take(&p_s, cap * 8));
+    if (two) KMD_HIP(sc.take(&p_h, cap * 8));
+    rc = tile_merge(n_samples, m->nc, d_kmers, d_kmers_hi, d_counts, offsets, &P, static_cast<uint64_t*>(p_k), static_cast<uint64_t*>(p_h),
+                    static_cast<uint64_t*>(p_c), static_cast<uint64_t*>(p_s), cap, &entries, totals, st);
+    if (rc != KMD_OK) return rc;
+    if (entries <= cap) break;
+    KMD_REQUIRE(attempt == 0, "kmd_merge_filter: candidate list overflowed twice");
+    cap = (size_t)entries;
+  }
+  if (n_rows_out) *n_rows_out = totals[0];
+  rc = kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(p_k), static_cast<const uint64_t*>(p_h),
+                                     static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), (size_t)entries, totals[0], totals[1], st);
+  if (rc != KMD_OK) return rc;
+  KMD_HIP(hipStreamSynchronize(st));                            // the scratch list goes back to the cache
+  return KMD_OK;
+}
+
+// The same merge for a consumer that wants the rows themselves: every distinct k-mer leaves as
+// (k-mer, sum of its control counts, sum of its case counts), compact, in no particular order.
+extern "C" int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                              const uint32_t* d_counts, const uint64_t* offsets, size_t row_capacity, uint64_t* d_kmer_out,
+                              uint64_t* d_kmer_hi_out, uint64_t* d_sum_control, uint64_t* d_sum_case, uint64_t* n_rows_out,
+                              void* stream)
+{
+  KMD_REQUIRE(n_samples > 0 && nb_controls >= 0 && nb_controls <= n_samples && offsets && n_rows_out, "kmd_merge_sums: arguments");
+  KMD_REQUIRE((uint32_t)n_samples <= kMaxStreams, "kmd_merge_sums: more than 1024 samples");
+  const size_t n = (size_t)offsets[n_samples];
+  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_merge_sums: more than 2^32-1 records in one partition");
+  for (int s = 0; s < n_samples; ++s) KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_sums: offsets must be ascending");
+  *n_rows_out = 0;
+  if (n == 0) return KMD_OK;
+  KMD_REQUIRE(d_kmers && d_counts && d_kmer_out && d_sum_control && d_sum_case, "kmd_merge_sums: NULL device buffers");
+  KMD_REQUIRE(!d_kmers_hi || d_kmer_hi_out, "kmd_merge_sums: two-limb k-mers need d_kmer_hi_out");
+  const int rc = tile_merge(n_samples, nb_controls, d_kmers, d_kmers_hi, d_counts, offsets, nullptr, d_kmer_out, d_kmer_hi_out,
+                            d_sum_control, d_sum_case, row_capacity, n_rows_out, nullptr, static_cast<hipStream_t>(stream));
+  if (rc != KMD_OK) return rc;
+  if (*n_rows_out > row_capacity) { kmd::set_error("kmd_merge_sums: row capacity exceeded"); return KMD_E_OVERFLOW; }
+  return KMD_OK;
+}

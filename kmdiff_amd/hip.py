@@ -281,16 +281,20 @@ class SurvivorAccumulator:
         check(lib().kmd_stream_sync(None), "sync")
         return self.counters.to_host(np.uint64, N.NCOUNTERS)
 
-    def finish(self, sort=True):
-        """IAccumulator::finish: returns the number of survivors stored (sorted by row, the
-        reference's push order).  Raises KmdError(KMD_E_OVERFLOW) if records were dropped."""
+    def finish(self, sort=True, by_kmer=False):
+        """IAccumulator::finish: returns the number of survivors stored (sorted by row -- or by k-mer,
+        for survivors of merge_filter, which have no row index -- the reference's push order).
+        Raises KmdError(KMD_E_OVERFLOW) if records were dropped."""
         c = self.read_counters()
         n = int(c[N.CNT_SIG])
         if n > self.capacity:
             raise KmdError("survivor capacity exceeded: %d > %d (status %d)" % (n, self.capacity, N.KMD_E_OVERFLOW))
         if sort and n > 1:
             s = self.struct()
-            check(lib().kmd_survivors_sort_by_row(C.byref(s), n, None), "sort_by_row")
+            if by_kmer:
+                check(lib().kmd_survivors_sort_by_kmer(C.byref(s), n, None), "sort_by_kmer")
+            else:
+                check(lib().kmd_survivors_sort_by_row(C.byref(s), n, None), "sort_by_row")
         self._size = n
         return n
 
@@ -376,51 +380,91 @@ def merge_partition(streams, n_samples=None, count_bytes=4, layout=N.LAYOUT_TILE
     return m
 
 
-class RowSums:
-    """What kmd_merge_sums leaves on the device: n_rows entries (k-mer, control sum, case sum), unordered,
-    some of them holes (control sum = 2^64 - 1) that kmd_poisson_filter_sums skips."""
+class StreamSet:
+    """One partition's per-sample streams resident on the device, concatenated in sample order:
+    what km::KmerMerger opens (merge.hpp:265-266).  `streams` as in merge_partition."""
 
-    def __init__(self, capacity):
+    def __init__(self, streams):
+        self.n_samples = len(streams)
+        self.two = any(len(t) == 3 for t in streams)
+        self.offs = np.zeros(self.n_samples + 1, dtype=np.uint64)
+        for s, t in enumerate(streams):
+            self.offs[s + 1] = self.offs[s] + len(t[0])
+        self.total = int(self.offs[-1])
+        cat = lambda i, dt: (np.concatenate([np.asarray(t[i], dtype=dt) for t in streams]) if self.total else np.zeros(0, dt))
+        self.kmers, self.counts = DeviceBuffer.from_host(cat(0, np.uint64)), DeviceBuffer.from_host(cat(1, np.uint32))
+        self.kmers_hi = DeviceBuffer.from_host(cat(2, np.uint64)) if self.two else None
+
+    def ptrs(self):
+        t = self.total
+        return (self.kmers.ptr if t else None, self.kmers_hi.ptr if (self.two and t) else None, self.counts.ptr if t else None)
+
+
+class RowSums:
+    """What kmd_merge_sums leaves on the device: n_rows rows (k-mer, control sum, case sum), compact, in no
+    particular order."""
+
+    def __init__(self, capacity, two=False):
         self.kmers = DeviceBuffer(max(capacity, 1) * 8)
+        self.kmers_hi = DeviceBuffer(max(capacity, 1) * 8) if two else None
         self.sum_c = DeviceBuffer(max(capacity, 1) * 8)
         self.sum_k = DeviceBuffer(max(capacity, 1) * 8)
         self.capacity, self.n_rows = int(capacity), 0
 
     def to_host(self):
-        """(k-mers, control sums, case sums, entry index) of the rows, holes left out."""
+        """(k-mers, control sums, case sums, entry index) of the rows (+ high limbs last, two-limb k-mers)."""
         n = self.n_rows
         km, sc, sk = self.kmers.to_host(np.uint64, n), self.sum_c.to_host(np.uint64, n), self.sum_k.to_host(np.uint64, n)
-        rows = np.nonzero(sc != np.uint64(2 ** 64 - 1))[0]
-        return km[rows], sc[rows], sk[rows], rows
+        rows = np.arange(n)
+        if self.kmers_hi is not None:
+            return km, sc, sk, rows, self.kmers_hi.to_host(np.uint64, n)
+        return km, sc, sk, rows
 
 
 def merge_sums(streams, nb_controls, row_capacity=None):
     """The merge of one partition for a consumer that only needs every k-mer's two count sums
     (PoissonLikelihood::process reads nothing else of a row, model.hpp:144-145): no matrix."""
-    n_samples = len(streams)
-    offs = np.zeros(n_samples + 1, dtype=np.uint64)
-    for s, t in enumerate(streams):
-        offs[s + 1] = offs[s] + len(t[0])
-    total = int(offs[-1])
-    cat = lambda i, dt: (np.concatenate([np.asarray(t[i], dtype=dt) for t in streams]) if total else np.zeros(0, dt))
-    dk, dc = DeviceBuffer.from_host(cat(0, np.uint64)), DeviceBuffer.from_host(cat(1, np.uint32))
-    out = RowSums(total + (6 << 20) if row_capacity is None else int(row_capacity))   # room for the waves' unfinished chunks
+    ss = streams if isinstance(streams, StreamSet) else StreamSet(streams)
+    out = RowSums(max(ss.total, 1) if row_capacity is None else int(row_capacity), ss.two)
     n_rows = C.c_uint64(0)
-    check(lib().kmd_merge_sums(n_samples, int(nb_controls), dk.ptr if total else None, dc.ptr if total else None, offs.ctypes.data,
-                               out.capacity, out.kmers.ptr, out.sum_c.ptr, out.sum_k.ptr, C.byref(n_rows), None), "kmd_merge_sums")
+    dk, dh, dc = ss.ptrs()
+    rc = lib().kmd_merge_sums(ss.n_samples, int(nb_controls), dk, dh, dc, ss.offs.ctypes.data, out.capacity, out.kmers.ptr,
+                              out.kmers_hi.ptr if ss.two else None, out.sum_c.ptr, out.sum_k.ptr, C.byref(n_rows), None)
+    out.n_rows_needed = int(n_rows.value)
+    check(rc, "kmd_merge_sums")
     out.n_rows = int(n_rows.value)
-    out.streams = (n_samples, dk, dc, offs)                 # kept for gather_counts_streams
+    out.streams = ss                                         # kept for gather_counts_streams
     return out
 
 
-def gather_counts_streams(sums, rows_buf, n):
-    """KmerSign::m_counts_ratio for n survivors of the sums path (rows_buf: their `row` on the device):
-    host array [n][S] of doubles, every count looked up in the per-sample streams."""
-    n_samples, dk, dc, offs = sums.streams
-    out = DeviceBuffer(max(n, 1) * n_samples * 8)
-    check(lib().kmd_survivors_gather_counts_streams(n_samples, dk.ptr, dc.ptr, offs.ctypes.data, sums.kmers.ptr, rows_buf.ptr, n,
-                                                    out.ptr, None), "kmd_survivors_gather_counts_streams")
-    return out.to_host(np.float64, n * n_samples).reshape(n, n_samples)
+def merge_filter(streams, observer):
+    """km::KmerMerger::merge(diff_observer) for one partition (merge.hpp:265-289, 68-103): streams in,
+    survivors into the observer's accumulator; returns the number of distinct k-mers.  Survivor `row` =
+    low limb of the k-mer (SurvivorAccumulator.sort_by_kmer() gives the reference's order)."""
+    ss = streams if isinstance(streams, StreamSet) else StreamSet(streams)
+    n_rows = C.c_uint64(0)
+    s = observer.acc.struct()
+    dk, dh, dc = ss.ptrs()
+    check(lib().kmd_merge_filter(observer.model.handle, ss.n_samples, dk, dh, dc, ss.offs.ctypes.data, observer.threshold,
+                                 C.byref(s), observer.acc.counters.ptr, C.byref(n_rows), None), "kmd_merge_filter")
+    observer.acc._size = None
+    return int(n_rows.value)
+
+
+def gather_counts_streams(sums, rows_buf, n, row_kmers=None, row_kmers_hi=None):
+    """KmerSign::m_counts_ratio for n survivors of the fused paths: host array [n][S] of doubles, every
+    count looked up in the per-sample streams.  `sums`: a RowSums (rows_buf = the survivors' `row` on the
+    device) or a StreamSet with row_kmers(/_hi) = the survivors' own k-mer columns (rows_buf None)."""
+    ss = sums if isinstance(sums, StreamSet) else sums.streams
+    if row_kmers is None:
+        row_kmers, row_kmers_hi = sums.kmers, sums.kmers_hi
+    out = DeviceBuffer(max(n, 1) * ss.n_samples * 8)
+    dk, dh, dc = ss.ptrs()
+    check(lib().kmd_survivors_gather_counts_streams(ss.n_samples, dk, dh, dc, ss.offs.ctypes.data, row_kmers.ptr,
+                                                    row_kmers_hi.ptr if row_kmers_hi is not None else None,
+                                                    rows_buf.ptr if rows_buf is not None else None, n, out.ptr, None),
+          "kmd_survivors_gather_counts_streams")
+    return out.to_host(np.float64, n * ss.n_samples).reshape(n, ss.n_samples)
 
 
 class pop_strat_corrector:

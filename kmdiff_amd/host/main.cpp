@@ -395,8 +395,10 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   };
   device_input dset[2];
   dev_buf d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc, d_smk, d_sc;
-  dev_buf d_ekmer, d_esum_c, d_esum_k;                  // --no-matrix: the merge's (k-mer, control sum, case sum) entries
-  const bool use_sums = opt.no_matrix && !from_matrix && !two_limbs && !plugin && !run_pca && !opt.save_sk && S <= 256;
+  // --no-matrix: the streams go straight through merge + test (kmd_merge_filter); the count rows of the
+  // survivors (pop-strat, --keep-tmp, --save-sk) are looked up in the streams afterwards
+  const bool use_sums = opt.no_matrix && !from_matrix && !plugin && !run_pca && S <= 1024;
+  size_t fused_cap = (size_t)1 << 16;                    // survivor sink of the fused path (grows on demand)
   // a ring of staging sets: the partition being processed and `depth` more being decoded.  K-mer
   // files: one partition ahead, its S files on this worker's share of the -t threads (deeper
   // measured no gain: the decode is hidden already).  matrices/: one file = one LZ4 frame = one
@@ -468,7 +470,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   for (size_t p = wi; p < n_units; p += n_workers, ++turn)
   {
     kmd_tile tile {};
-    uint64_t n_rows = 0, n_entries = 0;
+    uint64_t n_rows = 0;
     bool sums_done = false;                              // --no-matrix took this partition
     // copies of this partition done: its page-locked slot goes to the decoder of turn + depth + 1,
     // and the next partition (decoded during the previous turn) is uploaded behind the kernels of this one
@@ -490,16 +492,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     else
     {
       const size_t n = D.n;
-      if (use_sums && n)
-      {
-        // kmd_merge_sums: no matrix; KMD_E_INVALID = k-mers too densely clustered for it -> the matrix path below
-        const size_t cap = n + ((size_t)6 << 20);            // distinct k-mers <= records, + the waves' unfinished chunks
-        d_ekmer.reserve(cap * 8); d_esum_c.reserve(cap * 8); d_esum_k.reserve(cap * 8);
-        const int rc = kmd_merge_sums((int)S, (int)opt.nb_controls, (const uint64_t*)D.kmers.p, (const uint32_t*)D.counts.p, D.offs.data(), cap,
-                                      (uint64_t*)d_ekmer.p, (uint64_t*)d_esum_c.p, (uint64_t*)d_esum_k.p, &n_entries, nullptr);
-        if (rc == KMD_OK) sums_done = true;
-        else if (rc != KMD_E_INVALID) ck(rc, "kmd_merge_sums");
-      }
+      if (use_sums && n) sums_done = true;               // merged and tested in one go below
       if (n && !sums_done)
       {
         d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
@@ -546,43 +539,48 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     }
     else if (sums_done)
     {
-      // the same observer over (k-mer, control sum, case sum) entries; the survivors come unordered and
-      // are put in ascending k-mer order (the reference's push order) here
+      // KmerMerger::merge(diff_observer) in one call: streams in, survivors out (k-mer order restored
+      // on the device); a sink that turns out too small is enlarged and the partition run again
       const device_input& D = dset[turn % 2];
-      d_srow.reserve(n_entries * 8); d_skmer.reserve(n_entries * 8); d_sp.reserve(n_entries * 8); d_ssign.reserve(n_entries * 4);
-      d_smc.reserve(n_entries * 8); d_smk.reserve(n_entries * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
-      ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
-      kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
-                         (double*)d_smc.p, (double*)d_smk.p, (size_t)n_entries };
-      ck(kmd_poisson_filter_sums(model, (const uint64_t*)d_ekmer.p, (const uint64_t*)d_esum_c.p, (const uint64_t*)d_esum_k.p, n_entries,
-                                 first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter_sums");
       uint64_t c[KMD_NCOUNTERS];
-      ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+      kmd_survivors sv {};
+      for (;;)
+      {
+        d_srow.reserve(fused_cap * 8); d_skmer.reserve(fused_cap * 8); d_sp.reserve(fused_cap * 8); d_ssign.reserve(fused_cap * 4);
+        d_smc.reserve(fused_cap * 8); d_smk.reserve(fused_cap * 8); d_cnt.reserve(KMD_NCOUNTERS * 8);
+        if (two_limbs) d_skmer_hi.reserve(fused_cap * 8);
+        ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
+        sv = kmd_survivors { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, two_limbs ? (uint64_t*)d_skmer_hi.p : nullptr, (double*)d_sp.p,
+                             (int32_t*)d_ssign.p, (double*)d_smc.p, (double*)d_smk.p, fused_cap };
+        ck(kmd_merge_filter(model, (int)S, (const uint64_t*)D.kmers.p, two_limbs ? (const uint64_t*)D.kmers_hi.p : nullptr,
+                            (const uint32_t*)D.counts.p, D.offs.data(), first_threshold, &sv, (uint64_t*)d_cnt.p, &n_rows, nullptr),
+           "kmd_merge_filter");
+        ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+        if (c[KMD_CNT_SIG] <= fused_cap) break;
+        fused_cap = (size_t)c[KMD_CNT_SIG] + (size_t)c[KMD_CNT_SIG] / 4;
+      }
       ns = (size_t)c[KMD_CNT_SIG];
+      ck(kmd_survivors_sort_by_kmer(&sv, ns, nullptr), "sort_by_kmer");                   // reference push order
+      sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
+      sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);
+      if (two_limbs) sv_all.kmer_hi.resize(base + ns);
       if (ns)
       {
-        std::vector<uint64_t> km(ns); std::vector<double> pv(ns), mc(ns), mk(ns), cnt; std::vector<int32_t> sg(ns);
-        ck(kmd_memcpy_d2h(km.data(), d_skmer.p, ns * 8, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(pv.data(), d_sp.p, ns * 8, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(sg.data(), d_ssign.p, ns * 4, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(mc.data(), d_smc.p, ns * 8, nullptr), "d2h");
-        ck(kmd_memcpy_d2h(mk.data(), d_smk.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.kmer.data() + base, d_skmer.p, ns * 8, nullptr), "d2h");
+        if (two_limbs) ck(kmd_memcpy_d2h(sv_all.kmer_hi.data() + base, d_skmer_hi.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.p.data() + base, d_sp.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.sign.data() + base, d_ssign.p, ns * 4, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.mean_control.data() + base, d_smc.p, ns * 8, nullptr), "d2h");
+        ck(kmd_memcpy_d2h(sv_all.mean_case.data() + base, d_smk.p, ns * 8, nullptr), "d2h");
         if (want_counts)                                                                  // merge.hpp:91-92, from the streams
         {
           d_sc.reserve(ns * S * 8);
-          ck(kmd_survivors_gather_counts_streams((int)S, (const uint64_t*)D.kmers.p, (const uint32_t*)D.counts.p, D.offs.data(),
-                                                 (const uint64_t*)d_ekmer.p, (const uint64_t*)d_srow.p, ns, (double*)d_sc.p, nullptr), "gather_counts_streams");
-          cnt.resize(ns * S);
-          ck(kmd_memcpy_d2h(cnt.data(), d_sc.p, ns * S * 8, nullptr), "d2h");
-        }
-        std::vector<size_t> order(ns);
-        for (size_t i = 0; i < ns; ++i) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return km[a] < km[b]; });
-        for (size_t i : order)
-        {
-          sv_all.kmer.push_back(km[i]); sv_all.p.push_back(pv[i]); sv_all.sign.push_back(sg[i]);
-          sv_all.mean_control.push_back(mc[i]); sv_all.mean_case.push_back(mk[i]);
-          if (want_counts) sv_all.counts.insert(sv_all.counts.end(), cnt.begin() + i * S, cnt.begin() + (i + 1) * S);
+          ck(kmd_survivors_gather_counts_streams((int)S, (const uint64_t*)D.kmers.p, two_limbs ? (const uint64_t*)D.kmers_hi.p : nullptr,
+                                                 (const uint32_t*)D.counts.p, D.offs.data(), (const uint64_t*)d_skmer.p,
+                                                 two_limbs ? (const uint64_t*)d_skmer_hi.p : nullptr, nullptr, ns, (double*)d_sc.p, nullptr),
+             "gather_counts_streams");
+          sv_all.counts.resize((base + ns) * S);
+          ck(kmd_memcpy_d2h(sv_all.counts.data() + base * S, d_sc.p, ns * S * 8, nullptr), "d2h");
         }
       }
       total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];

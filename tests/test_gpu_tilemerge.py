@@ -1,0 +1,194 @@
+"""Parity of the fused merge + test (kmd_merge_filter, kmd_merge_sums: kmdiff_amd/csrc/kmd_tilemerge.hip)
+with the CPU oracle: km::KmerMerger::merge(diff_observer) of one partition (merge.hpp:265-289, 68-103).
+The oracle side is kmdo_merge_partition[2] followed by kmdo_diff_partition on the merged matrix.
+Bars as in test_gpu_parity.py: k-mers, sums, sign, means, counters bit-exact; p within 1e-10 abs / 1e-9 rel.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as OL
+from test_gpu_parity import assert_p_close, totals_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kmdiff_amd as K
+    assert K.device_count() >= 1, "no GPU: the HIP path has no CPU fallback"
+    return K
+
+
+def make_streams(rng, universe, S, presence, count_hi=300, hi=None, empty=(), ones_in=()):
+    streams = []
+    for s in range(S):
+        pick = rng.random(len(universe)) < (presence[s] if hasattr(presence, "__len__") else presence)
+        if s in empty:
+            pick[:] = False
+        if len(ones_in):
+            pick[-1] = s in ones_in
+        cnt = rng.integers(1, count_hi, int(pick.sum())).astype(np.uint32)
+        streams.append((universe[pick], cnt) if hi is None else (universe[pick], cnt, hi[pick]))
+    return streams
+
+
+def run_fused(K, oracle, streams, nc, thr, two=False, lf_n=10000):
+    """device: streams -> survivors; oracle: merge, then diff_partition on the merged matrix"""
+    S = len(streams)
+    if two:
+        want, wlo, whi = oracle.merge_partition2(streams)
+    else:
+        want, wlo = oracle.merge_partition(streams)
+        whi = None
+    tcs, tks = totals_of(want, nc)
+    ref = oracle.diff_partition(want, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(lf_n), thr)
+    model = K.PoissonLikelihood(nc, S - nc, tcs, tks, lf_n)
+    acc = K.SurvivorAccumulator(max(want.shape[0], 1), kmer_limbs=2 if two else 1)
+    obs = K.diff_observer(model, acc, thr)
+    ss = K.StreamSet(streams)
+    n_rows = K.merge_filter(ss, obs)
+    n = acc.finish(by_kmer=True)
+    got = acc.get()
+    c = acc.read_counters()
+    assert n_rows == want.shape[0] and int(c[0]) == want.shape[0]
+    assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == ref["counters"]
+    rr = ref["row"].astype(np.int64)
+    assert n == len(rr)
+    assert got["kmer_lo"].tolist() == wlo[rr].tolist()
+    if two:
+        assert got["kmer_hi"].tolist() == whi[rr].tolist()
+    else:
+        assert got["row"].tolist() == wlo[rr].tolist()
+    assert got["sign"].tolist() == ref["sign"].tolist()
+    assert got["mean_control"].tolist() == ref["mean_control"].tolist()
+    assert got["mean_case"].tolist() == ref["mean_case"].tolist()
+    assert_p_close(got["pvalue"], ref["pvalue"])
+    if n:
+        counts = K.gather_counts_streams(ss, None, n, acc.bufs["kmer_lo"], acc.bufs["kmer_hi"] if two else None)
+        assert (counts == want[rr].astype(np.float64)).all()
+    return want, ref
+
+
+@pytest.mark.parametrize("S,nc,presence", [(9, 4, 0.5), (40, 20, 0.65), (40, 20, 0.05), (33, 1, 0.3), (64, 63, 0.2), (105, 50, 0.4),
+                                           (200, 100, 0.1), (256, 128, 0.02), (300, 100, 0.03), (2, 1, 0.9), (3, 2, 1.0)])
+def test_merge_filter_equals_merge_then_diff(K, oracle, S, nc, presence):
+    """Random k-mers over the 62-bit range, every sample present with its own probability, a sample
+    without k-mers, the all-ones k-mer (the table's empty marker) in a third of the samples."""
+    rng = np.random.default_rng(7000 + S)
+    universe = np.unique(np.concatenate([rng.integers(0, 1 << 62, int(150_000 / (S * presence)) + 3000, dtype=np.uint64),
+                                         np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
+    pres = np.clip(presence * rng.uniform(0.5, 1.5, S), 0.01, 1.0)
+    streams = make_streams(rng, universe, S, pres, empty=(2,) if S > 3 else (), ones_in=tuple(range(0, S, 3)))
+    want, ref = run_fused(K, oracle, streams, nc, 0.01)
+    assert len(ref["row"]) > 20 or S <= 2
+
+
+def test_merge_sums_rows_are_compact_and_exact(K, oracle):
+    """kmd_merge_sums: exactly one entry per distinct k-mer, no holes; KMD_E_OVERFLOW reports the rows needed."""
+    rng = np.random.default_rng(99)
+    S, nc = 24, 11
+    universe = np.unique(rng.integers(0, 1 << 60, 90_000, dtype=np.uint64))
+    streams = make_streams(rng, universe, S, 0.3, count_hi=2 ** 32 - 1)
+    want, kmers = oracle.merge_partition(streams)
+    sums = K.merge_sums(streams, nc)
+    km, sc, sk, _ = sums.to_host()
+    assert sums.n_rows == want.shape[0] == len(km)
+    order = np.argsort(km, kind="stable")
+    assert (km[order] == kmers).all()
+    assert (sc[order] == want[:, :nc].sum(axis=1, dtype=np.uint64)).all()
+    assert (sk[order] == want[:, nc:].sum(axis=1, dtype=np.uint64)).all()
+    with pytest.raises(K.KmdError):
+        K.merge_sums(streams, nc, row_capacity=want.shape[0] - 5)
+
+
+@pytest.mark.parametrize("kind", ["gap", "dense", "runs", "dup-heavy"])
+def test_merge_filter_clustered_keys(K, oracle, kind):
+    """Key distributions the data splitters (every r-th key of the LONGEST stream) cannot balance: the
+    tiles over capacity are cut again on the device, level by level -- no fallback, same results.
+      gap      : the other samples hold 60 k consecutive k-mers where the longest one has none
+      dense    : everything inside a few thousand consecutive integers (slices end at single k-mers)
+      runs     : 200 dense runs scattered over the range
+      dup-heavy: 40 samples, every k-mer in every sample"""
+    rng = np.random.default_rng({"gap": 1, "dense": 2, "runs": 3, "dup-heavy": 4}[kind])
+    if kind == "gap":
+        S, nc = 12, 6
+        base = np.unique(rng.integers(0, 1 << 62, 60_000, dtype=np.uint64))
+        gap = (np.uint64(1) << np.uint64(61)) + np.arange(60_000, dtype=np.uint64) * np.uint64(5)
+        base = base[(base < gap[0]) | (base > gap[-1])]
+        streams = []
+        for s in range(S):
+            if s == 0:
+                km = base                                           # the longest stream: nothing in the gap
+            else:
+                km = np.unique(np.concatenate([base[rng.random(len(base)) < 0.3], gap[rng.random(len(gap)) < 0.8]]))
+            streams.append((km, rng.integers(1, 200 if s < nc else 30, len(km)).astype(np.uint32)))
+    elif kind == "dense":
+        S, nc = 20, 10
+        universe = np.uint64(123456789) + np.arange(6000, dtype=np.uint64)
+        streams = make_streams(rng, universe, S, 0.9)
+    elif kind == "runs":
+        S, nc = 16, 8
+        starts = np.sort(rng.integers(0, 1 << 61, 200, dtype=np.uint64))
+        universe = np.unique((starts[:, None] + np.arange(400, dtype=np.uint64)[None, :] * np.uint64(3)).ravel())
+        streams = make_streams(rng, universe, S, rng.uniform(0.2, 0.9, S))
+    else:
+        S, nc = 40, 20
+        universe = np.unique(rng.integers(0, 1 << 62, 9000, dtype=np.uint64))
+        streams = make_streams(rng, universe, S, 1.0)
+    run_fused(K, oracle, streams, nc, 1e-3)
+
+
+@pytest.mark.parametrize("S,nc,hi_bits", [(6, 3, 6), (40, 20, 62), (100, 50, 30)])
+def test_merge_filter_two_limb_kmers(K, oracle, S, nc, hi_bits):
+    """32 < k <= 64: (hi, lo) pairs.  Families of k-mers that share a LOW limb under different high limbs
+    (one table slot would take both: the tile must be cut until they part), low limbs of all ones, the
+    all-ones k-mer."""
+    rng = np.random.default_rng(8000 + S)
+    n = 60_000
+    hi = rng.integers(0, 1 << hi_bits, n, dtype=np.uint64)
+    lo = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    lo[:2000] = lo[2000:4000]                                        # same low limb ...
+    hi[:2000] = hi[2000:4000] + np.uint64(1)                         # ... next high limb: neighbours in the order
+    lo[4000:4020] = np.uint64(2 ** 64 - 1)                           # low limb = the empty marker, assorted high limbs
+    hi[4019] = np.uint64((1 << hi_bits) - 1)                          # the largest k-mer there is at this width
+    order = np.lexsort((lo, hi))
+    hi, lo = hi[order], lo[order]
+    keep = np.ones(n, dtype=bool)
+    keep[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+    hi, lo = hi[keep], lo[keep]
+    streams = make_streams(rng, lo, S, rng.uniform(0.1, 0.6, S), hi=hi)
+    run_fused(K, oracle, streams, nc, 1e-2, two=True)
+    # the rows themselves
+    want, wlo, whi = oracle.merge_partition2(streams)
+    sums = K.merge_sums(streams, nc)
+    km, sc, sk, _, kh = sums.to_host()
+    order = np.lexsort((km, kh))
+    assert len(km) == want.shape[0]
+    assert (km[order] == wlo).all() and (kh[order] == whi).all()
+    assert (sc[order] == want[:, :nc].sum(axis=1, dtype=np.uint64)).all()
+    assert (sk[order] == want[:, nc:].sum(axis=1, dtype=np.uint64)).all()
+
+
+def test_merge_filter_tiny_and_empty_inputs(K, oracle):
+    tcs, tks = np.array([10], np.uint64), np.array([10, 10], np.uint64)
+    model = K.PoissonLikelihood(1, 2, tcs, tks, 100)
+    acc = K.SurvivorAccumulator(16)
+    obs = K.diff_observer(model, acc, 1.0)
+    assert K.merge_filter([(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * 3, obs) == 0
+    streams = [(np.array([5, 9], np.uint64), np.array([2, 3], np.uint32)), (np.array([9], np.uint64), np.array([7], np.uint32)),
+               (np.zeros(0, np.uint64), np.zeros(0, np.uint32))]
+    assert K.merge_filter(streams, obs) == 2
+    assert acc.finish(by_kmer=True) == 2                             # threshold 1: every row survives
+    got = acc.get()
+    assert got["kmer_lo"].tolist() == [5, 9] and got["mean_case"].tolist() == [0.0, 7.0]
+
+
+@pytest.mark.parametrize("thr", [1.0, 0.5, 1e-30, 0.0])
+def test_merge_filter_thresholds_without_prefilter(K, oracle, thr):
+    """Thresholds at which the chi-square pre-filter is off (every row is evaluated exactly; the
+    workgroup queue overflows into immediate evaluation) and at which nothing survives."""
+    rng = np.random.default_rng(5)
+    S, nc = 10, 5
+    universe = np.unique(rng.integers(0, 1 << 62, 30_000, dtype=np.uint64))
+    streams = make_streams(rng, universe, S, 0.5)
+    run_fused(K, oracle, streams, nc, thr)

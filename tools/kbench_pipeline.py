@@ -19,6 +19,8 @@ ap.add_argument("--nk", type=int, default=20)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--keys", default="random")
 ap.add_argument("--sparse", type=float, default=1.0, help="keep each record with this probability (rows of few records)")
+ap.add_argument("--fused-only", action="store_true", help="only kmd_merge_filter (no matrix path beside it, no cross-check)")
+ap.add_argument("--triples", action="store_true", help="also time kmd_merge_sums + kmd_poisson_filter_sums")
 a = ap.parse_args()
 S = a.nc + a.nk
 lib = K._native.lib()
@@ -48,41 +50,58 @@ for s in range(S):
 kmers = np.concatenate(ks); counts = np.concatenate(cs).astype(np.uint32)
 n = len(kmers)
 dk, dc = K.DeviceBuffer.from_host(kmers), K.DeviceBuffer.from_host(counts)
-out = K.CountMatrix(a.rows, S, 4, K.LAYOUT_TILED, with_kmers=True)
 tot = host.sum(axis=0, dtype=np.uint64)
 model = K.PoissonLikelihood(a.nc, a.nk, tot[:a.nc], tot[a.nc:], 10000)
 acc = K.SurvivorAccumulator(max(1 << 16, a.rows // 100))
 obs = K.diff_observer(model, acc, 5e-7)
 nr = C.c_uint64(0)
-best = 1e9
+best, sig_matrix, rows_matrix = 1e9, None, None
+if not a.fused_only:
+    out = K.CountMatrix(a.rows, S, 4, K.LAYOUT_TILED, with_kmers=True)
+    for _ in range(a.iters + 1):
+        acc.counters.zero()
+        lib.kmd_stream_sync(None)
+        t0 = time.perf_counter()
+        K._native.check(lib.kmd_merge_partition(S, dk.ptr, None, dc.ptr, offs.ctypes.data, 4, K.LAYOUT_TILED, out.ld, a.rows,
+                                                out.counts.ptr, out.kmer_lo.ptr, None, C.byref(nr), None))
+        out.n_rows = int(nr.value)
+        obs.process(out)
+        lib.kmd_stream_sync(None)
+        best = min(best, time.perf_counter() - t0)
+    sig_matrix, rows_matrix = int(acc.read_counters()[1]), out.n_rows
+# the same partition without the matrix or any rows in HBM: merge + test in one kernel (kmd_merge_filter)
+ss = K.StreamSet([(k_, c_) for k_, c_ in zip(ks, cs)])
+best_f, ev0, ev1 = 1e9, K.Event(), K.Event()
 for _ in range(a.iters + 1):
     acc.counters.zero()
     lib.kmd_stream_sync(None)
     t0 = time.perf_counter()
-    K._native.check(lib.kmd_merge_partition(S, dk.ptr, None, dc.ptr, offs.ctypes.data, 4, K.LAYOUT_TILED, out.ld, a.rows,
-                                            out.counts.ptr, out.kmer_lo.ptr, None, C.byref(nr), None))
-    out.n_rows = int(nr.value)
-    obs.process(out)
+    rows_f = K.merge_filter(ss, obs)
     lib.kmd_stream_sync(None)
-    best = min(best, time.perf_counter() - t0)
-sig_matrix = int(acc.read_counters()[1])
-# the same partition without the matrix: (k-mer, control sum, case sum) per row, then the test on the sums
-sums = K.RowSums(a.rows + (6 << 20))        # rows + the waves' unfinished chunks (holes)
-best_s = 1e9
-for _ in range(a.iters + 1):
-    acc.counters.zero()
-    lib.kmd_stream_sync(None)
-    t0 = time.perf_counter()
-    K._native.check(lib.kmd_merge_sums(S, a.nc, dk.ptr, dc.ptr, offs.ctypes.data, sums.capacity, sums.kmers.ptr, sums.sum_c.ptr, sums.sum_k.ptr,
-                                       C.byref(nr), None))
-    sums.n_rows = int(nr.value)
-    obs.process_sums(sums)
-    lib.kmd_stream_sync(None)
-    best_s = min(best_s, time.perf_counter() - t0)
-sig_sums = int(acc.read_counters()[1])
-assert int(acc.read_counters()[0]) == out.n_rows and sig_sums == sig_matrix, (int(acc.read_counters()[0]), out.n_rows, sig_sums, sig_matrix)
-print("pipeline keys=%s S=%d records=%d rows=%d  sums path (no matrix) %.2f ms  %.3e rows/s  %.3e records/s  sig=%d"
-      % (a.keys, S, n, out.n_rows, best_s * 1e3, out.n_rows / best_s, n / best_s, sig_sums))
-c = acc.read_counters()
-print("pipeline keys=%s S=%d records=%d rows=%d  merge+filter %.2f ms  %.3e rows/s  %.3e records/s  sig=%d"
-      % (a.keys, S, n, out.n_rows, best * 1e3, out.n_rows / best, n / best, sig_matrix))
+    best_f = min(best_f, time.perf_counter() - t0)
+cf = acc.read_counters()
+sig_fused = int(cf[1])
+assert rows_f == int(cf[0]) and (a.fused_only or (rows_f == rows_matrix and sig_fused == sig_matrix)), (rows_f, rows_matrix, int(cf[0]), sig_fused, sig_matrix)
+print("pipeline keys=%s S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of 12 B/record  sig=%d"
+      % (a.keys, S, n, rows_f, best_f * 1e3, rows_f / best_f, n / best_f, 12e-9 * n / best_f, sig_fused))
+if a.triples:
+    # rows as (k-mer, control sum, case sum), then the test on the sums
+    sums = K.RowSums(a.rows)
+    best_s = 1e9
+    for _ in range(a.iters + 1):
+        acc.counters.zero()
+        lib.kmd_stream_sync(None)
+        t0 = time.perf_counter()
+        K._native.check(lib.kmd_merge_sums(S, a.nc, dk.ptr, None, dc.ptr, offs.ctypes.data, sums.capacity, sums.kmers.ptr, None, sums.sum_c.ptr, sums.sum_k.ptr,
+                                           C.byref(nr), None))
+        sums.n_rows = int(nr.value)
+        obs.process_sums(sums)
+        lib.kmd_stream_sync(None)
+        best_s = min(best_s, time.perf_counter() - t0)
+    sig_sums = int(acc.read_counters()[1])
+    assert int(acc.read_counters()[0]) == rows_f and sig_sums == sig_fused, (int(acc.read_counters()[0]), rows_f, sig_sums, sig_fused)
+    print("pipeline keys=%s S=%d records=%d rows=%d  rows as sums + test on the sums %.2f ms  %.3e rows/s  %.3e records/s  sig=%d"
+          % (a.keys, S, n, rows_f, best_s * 1e3, rows_f / best_s, n / best_s, sig_sums))
+if not a.fused_only:
+  print("pipeline keys=%s S=%d records=%d rows=%d  merge+filter %.2f ms  %.3e rows/s  %.3e records/s  sig=%d"
+        % (a.keys, S, n, out.n_rows, best * 1e3, out.n_rows / best, n / best, sig_matrix))
