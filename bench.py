@@ -18,7 +18,12 @@ The JSON line also carries
                  8 TB/s HBM3E peak;
   cpu_baseline : the reference's own arithmetic (oracle/_ref, kind "reference") or the C
                  restatement (kind "port") on the host cores, on a bounded sample of the same
-                 workload, tail function evaluated for every row as the reference does.
+                 workload, tail function evaluated for every row as the reference does;
+  pipeline     : (N = 1) the kmtricks-side input of the same path: one partition's per-sample k-mer
+                 streams resident in HBM -> survivors (kmd_merge_filter: k-way merge fused with the test),
+                 12 algorithmic bytes per record, HIP events around back-to-back calls;
+  h2d_inclusive: (N = 1) the headline step with the host-to-device copy of the partition (from page-locked
+                 memory) inside the timed loop -- never `value`.
 """
 import argparse
 import ctypes as C
@@ -42,12 +47,35 @@ BYTES_PER_ROW = 8 * ((K_SIZE + 31) // 32) + (NC + NK) * COUNT_BYTES       # 168
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def usable_cpus():
+    """CPUs this process may really run on: the affinity mask, capped by the cgroup's CPU quota (a lease
+    can show 256 CPUs in /proc and grant a fraction of them: threads beyond the grant only time-share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = "affinity mask %d" % n
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.999))
+                note += ", cgroup quota %d" % q
+                n = min(n, q)
+            break
+        except Exception:
+            continue
+    return max(1, n), note
+
+
 def cpu_baseline(rows_per_part, tc, tk):
-    """Host-core baseline on a bounded sample (one partition per thread)."""
+    """Host-core baseline on a bounded sample (one partition per thread): first ONE thread alone
+    (`per_thread`), then one thread per usable CPU."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as OL
     o = OL.load()
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cpus()
     thr = THRESHOLD / CUTOFF
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libkmdiff_ref.so")
     if os.path.exists(ref_path):
@@ -70,20 +98,81 @@ def cpu_baseline(rows_per_part, tc, tk):
                                    mc.ctypes.data, mk.ctypes.data)
             nsig[t] = int((p <= thr).sum())
             secs[t] = time.perf_counter() - t0
+        work(0)                                            # one thread alone
+        per_thread = n / secs[0]
         th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
         [t.start() for t in th]
         [t.join() for t in th]
         return {"value": cores * n / max(secs), "unit": "k-mers/s", "cores": cores, "kind": "reference",
+                "per_thread": per_thread, "cores_from": cores_note,
                 "sample": "%d partitions x %d rows (20v20, u32), one per thread, row-major, reference "
-                          "LogFactorialTable + alglib chisquarecdistribution for every row; %d survivors"
+                          "LogFactorialTable + alglib chisquarecdistribution for every row (oracle/_ref: -O2, no "
+                          "-march); per_thread = one thread alone; %d survivors"
                           % (cores, n, sum(nsig))}
     n = 2_000_000
     c = OL.Counters()
     s = o.L.kmdo_bench_partitions(SEED, cores, n, NC, NK, COUNT_BYTES, tc, tk, LOG_FACTORIAL, thr, cores,
                                   C.byref(c))
-    return {"value": cores * n / s, "unit": "k-mers/s", "cores": cores, "kind": "port",
+    return {"value": cores * n / s, "unit": "k-mers/s", "cores": cores, "kind": "port", "cores_from": cores_note,
             "sample": "%d partitions x %d rows (20v20, u32), one per thread, row-major, C restatement "
                       "with the tail function for every row; %d survivors" % (cores, n, c.n_sig)}
+
+
+def pipeline_leg(K, lib, rows=4_000_000, iters=6):
+    """Streams -> survivors on one partition: the per-sample (k-mer, count) streams kmtricks writes
+    (records of sample s = the rows with a non-zero count in column s), resident in HBM, through
+    kmd_merge_filter.  12 algorithmic bytes per record (8-byte k-mer + 4-byte count, each read once)."""
+    mat = K.synth_matrix(SEED, 0, rows, NC, NK, COUNT_BYTES, K.LAYOUT_ROWS)
+    host, lo = mat.to_host(), mat.kmers_to_host()[0]
+    streams = []
+    for s in range(NC + NK):
+        sel = host[:, s] > 0
+        streams.append((lo[sel], host[sel, s]))
+    tot = host.sum(axis=0, dtype=np.uint64)
+    del mat
+    ss = K.StreamSet(streams)
+    model = K.PoissonLikelihood(NC, NK, tot[:NC], tot[NC:], LOG_FACTORIAL)
+    acc = K.SurvivorAccumulator(max(1 << 16, rows // 100))
+    obs = K.diff_observer(model, acc, THRESHOLD / CUTOFF, NC, NK)
+    n_rows = K.merge_filter(ss, obs)                       # warm-up (first-use costs)
+    acc.counters.zero()
+    e0, e1 = K.Event(), K.Event()
+    e0.record()
+    for _ in range(iters):
+        n_rows = K.merge_filter(ss, obs)
+    e1.record()
+    ms = e0.elapsed_ms(e1) / iters
+    c = acc.read_counters()
+    assert int(c[0]) == iters * n_rows == iters * rows, (int(c[0]), n_rows, rows)
+    gbs = 12.0 * ss.total / (ms * 1e-3) / 1e9
+    return {"what": "one partition's per-sample k-mer streams resident in HBM -> survivors (kmd_merge_filter: k-way merge "
+                    "fused with the Poisson test; tile plan + boundary search + merge kernel + candidate evaluation, host "
+                    "round trip included)",
+            "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),
+            "records_per_s": ss.total / (ms * 1e-3), "bytes_algorithmic": 12 * ss.total,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+            "n_sig": int(c[1]) // iters}
+
+
+def h2d_leg(K, lib, obs, mat, steps=3):
+    """The headline step with the partition's host-to-device copy (page-locked source) in the loop."""
+    nbytes = mat.counts.nbytes
+    h = C.c_void_p()
+    K._native.check(lib.kmd_malloc_host(C.byref(h), nbytes), "kmd_malloc_host")
+    try:
+        K._native.check(lib.kmd_memcpy_d2h(h, mat.counts.ptr, nbytes, None), "d2h")
+        K._native.check(lib.kmd_stream_sync(None))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            K._native.check(lib.kmd_memcpy_h2d(mat.counts.ptr, h, nbytes, None), "h2d")
+            obs.process(mat)
+        K._native.check(lib.kmd_stream_sync(None))
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        lib.kmd_free_host(h)
+    return {"value": mat.n_rows / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3, "h2d_GBs": nbytes / dt / 1e9,
+            "what": "kmd_memcpy_h2d of the partition's %d-byte count matrix from page-locked memory + kmd_poisson_filter, "
+                    "serial, per step" % nbytes}
 
 
 def main():
@@ -96,6 +185,7 @@ def main():
     ap.add_argument("--correction", default="bonferroni")
     ap.add_argument("--layout", default="tiled", choices=["tiled", "soa", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the streams -> survivors and H2D-inclusive legs (N = 1 extras)")
     args = ap.parse_args()
 
     import torch
@@ -198,11 +288,13 @@ def main():
             a.free(); b.free()
         except Exception:
             pass
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic.json (static: %s; not measured by this run)" % tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
             except Exception:
                 traffic = None
         out = {
@@ -221,9 +313,15 @@ def main():
                                     "kept_after_correction": int(kept[0])},
                        "copy_probe_GBs": copy_gbs, "read_probe_GBs": read_gbs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_filter_%s<u32>" % ("rows" if args.layout == "rows" else "soa"), "avg_kernel_ms": avg_kernel_ms},
         }
+        if world == 1 and not args.no_pipeline:
+            try:
+                out["h2d_inclusive"] = h2d_leg(K, lib, obs, mats[0])
+            except Exception as e:                          # (a box without room for the page-locked copy)
+                out["h2d_inclusive"] = {"error": str(e)}
+            out["pipeline"] = pipeline_leg(K, lib)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.rows, int(totals[:NC].sum()), int(totals[NC:].sum()))
         print(json.dumps(out), flush=True)

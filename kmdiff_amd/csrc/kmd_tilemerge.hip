@@ -50,6 +50,9 @@ using namespace kmd::eval;
 #ifndef KMD_TILE_ABLATE
 #define KMD_TILE_ABLATE 0
 #endif
+#ifndef KMD_TILE_RING
+#define KMD_TILE_RING 8
+#endif
 
 namespace {
 
@@ -90,7 +93,8 @@ struct tile_job
   // candidates mode: what the chi-square pre-filter needs of the model (kmd_eval.h, row_may_pass)
   double dTc, dTk, dTcTk, pf_cut;
   uint32_t lf_n;
-  uint32_t* over;                                // [0] tiles listed, [1 + i] tile, [1 + over_stride + i] its records (| kAbortBit)
+  uint32_t* over_n;                              // tiles listed
+  uint32_t* over;                                // [i] tile, [over_stride + i] its records (| kAbortBit)
   uint32_t over_stride;
 };
 
@@ -333,7 +337,7 @@ struct tile_lds
 // that share a low limb: the tile is then listed and cut again, which separates them (their high limbs
 // differ, so some slice boundary falls between them; at the latest when a slice is a single value of the
 // cut window).  A low limb of all ones (the empty marker) is kept apart the same way.
-template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo>
+template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo, bool kWide>
 __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
 {
   constexpr uint32_t kMask = kSlots - 1;
@@ -353,6 +357,10 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
   const uint32_t S = J.S;
   const uint32_t n_tiles = J.n_tiles ? J.n_tiles : J.plan->nb;
   const uint32_t g_shift = J.n_tiles ? J.g_shift : J.plan->g_shift;
+  // two instantiations, both launched at level 0 where the plan is on the device: the one whose way of
+  // streaming a tile (kWide: whole waves per run, g_shift 6; else sub-groups of lanes) the plan did
+  // not choose returns at once
+  if ((g_shift == 6) != kWide) return;
   // segment tables of the current and the next tile, behind the fixed part: [2][begin[S] | length[S]]
   uint32_t* const s_seg = reinterpret_cast<uint32_t*>(s_raw + (sizeof(lds_t) + 7) / 8);
 
@@ -412,8 +420,154 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
     const bool process = wanted && n > 0;
     if (tid == 0) { M.n[buf ^ 1u] = 0; M.fresh[buf ^ 1u] = 0; M.abort[buf ^ 1u] = 0; }
 
-    // ---- inserts: sub-group q0 streams the runs q0, q0 + Q, ... of this tile
-    if (process)
+    // ---- inserts, kWide: runs of a wave's worth of records and more (the usual case: a tile is sized to
+    // hold ~700 rows).  A wave takes whole runs, one after the other -- runs wave, wave + kWaves, ... --
+    // 64 records at a time, one per lane.  Everything about WHERE is wave-uniform and lives in scalar
+    // registers: the position in the run, how many of the 64 lanes hold a record, whether the run is a
+    // control sample's; a lane's address is a scalar base + its lane number.  kRing rounds are in flight.
+    if constexpr (kWide)
+    {
+      if (process)
+      {
+        constexpr int kRing = KMD_TILE_RING;
+        const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
+        const uint32_t* len = beg + S;
+        uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);          // current run
+        uint32_t rb = 0, rl = 0, rc = 0;                                              // its first record, length, records done
+        auto next_run = [&]()
+        {
+          while (rs < S)
+          {
+            rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
+            rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)len[rs]);
+            rc = 0;
+            if (rl) return;
+            rs += kWaves;
+          }
+          rb = 0; rl = 0; rc = 0;
+        };
+        next_run();
+        uint64_t rk[kRing], rkh[kTwo ? kRing : 1];
+        uint32_t rcnt[kRing], rrem[kRing], rctl[kRing];                               // rrem / rctl: scalar
+        uint32_t claimed = 0;                                                         // slots this wave claimed (scalar)
+        bool stop = false;
+        auto fetch_w = [&](const int d)
+        {
+          const uint32_t rem = rs < S ? rl - rc : 0u;
+          // lanes past the end of the run re-read its last record (never used): nothing is read out of bounds
+          const uint32_t l = lane < rem ? lane : (rem ? rem - 1u : 0u);
+          const size_t base = (size_t)rb + rc;
+          rk[d] = __builtin_nontemporal_load(J.keys + base + l);
+          rcnt[d] = __builtin_nontemporal_load(J.counts + base + l);
+          if constexpr (kTwo) rkh[d] = __builtin_nontemporal_load(J.keys_hi + base + l);
+          rrem[d] = rem;
+          rctl[d] = rs < J.nc ? 1u : 0u;
+          rc += 64;
+          if (rc >= rl && rs < S)
+          {
+            // end of a run: this wave's claims so far go to the tile's count; a table 3/4 full gives up
+            if (claimed)
+            {
+              if (lane == 0) { const uint32_t before = atomicAdd(&M.fresh[buf], claimed); if (before + claimed > kFullAt) M.abort[buf] = 1; }
+              claimed = 0;
+            }
+            rs += kWaves; next_run();
+          }
+        };
+        auto insert_w = [&](const int d)
+        {
+          const uint64_t k = rk[d];
+          const bool v = lane < rrem[d];
+          const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
+          const uint32_t h0 = (x * 0x9E3779B1u) >> kShift;
+          const uint32_t h1 = ((x ^ (x >> 15)) * 0x85EBCA6Bu) >> kShift;
+          const unsigned long long s0 = __hip_atomic_load(&M.key[h0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const unsigned long long s1 = __hip_atomic_load(&M.key[h1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const bool is_marker = k == kEmptyKey;
+          if (__ballot(v && is_marker))
+          {
+            // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
+            if (v && is_marker)
+            {
+              atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)rcnt[d]);
+              if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d]); }
+              M.hasmax = 1;
+            }
+          }
+          const bool usable = v && !is_marker;
+          const bool hit0 = s0 == k, hit1 = s1 == k, e0 = s0 == kEmptyKey, e1 = s1 == kEmptyKey;
+          const bool found = hit0 || hit1;
+          const bool claim = usable && !found && (e0 || e1);                          // the first empty home
+          uint32_t slot = (hit0 || (!hit1 && e0)) ? h0 : h1;
+          uint32_t nxt = (claim && e0) ? h1 : ((h1 + 1u) & kMask);
+          bool pend = usable && !found;
+          if (__ballot(claim))
+          {
+            bool fresh = false;
+            if (claim)
+            {
+              const unsigned long long old = atomicCAS(&M.key[slot], (unsigned long long)kEmptyKey, (unsigned long long)k);
+              fresh = old == kEmptyKey;
+              if (fresh || old == k) pend = false;                                    // else: lost the slot to another k-mer
+            }
+            claimed += (uint32_t)__popcll(__ballot(fresh));
+          }
+          // the tail: one slot per step from nxt on (about 3 % of the records get here)
+          for (uint32_t step = 0; __ballot(pend); ++step)
+          {
+            if (step >= kMaxProbe) { M.abort[buf] = 1; break; }
+            unsigned long long seen = __hip_atomic_load(&M.key[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool want = pend && seen == kEmptyKey;
+            if (__ballot(want))
+            {
+              bool fresh = false;
+              if (want)
+              {
+                seen = atomicCAS(&M.key[nxt], (unsigned long long)kEmptyKey, (unsigned long long)k);
+                fresh = seen == kEmptyKey;
+                if (fresh) seen = k;
+              }
+              claimed += (uint32_t)__popcll(__ballot(fresh));
+            }
+            const bool hit = pend && seen == k;
+            slot = hit ? nxt : slot;
+            pend = pend && !hit;
+            nxt = (nxt + 1u) & kMask;
+          }
+          if (usable && !pend)
+          {
+            unsigned long long* sums = rctl[d] ? M.sc : M.sk;                         // (scalar choice)
+            atomicAdd(&sums[slot], (unsigned long long)rcnt[d]);
+            if constexpr (kTwo)
+            {
+              atomicMax(&M.key_hi[slot], (unsigned long long)rkh[d]);
+              atomicMin(&M.hi_min[slot], (unsigned long long)rkh[d]);
+            }
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < kRing; ++d) fetch_w(d);
+        while (!stop)
+        {
+#pragma unroll
+          for (int d = 0; d < kRing; ++d)
+          {
+            if (stop) break;
+            if (rrem[d] == 0) { stop = true; break; }                                 // the runs are exhausted in order
+            insert_w(d);
+            fetch_w(d);
+            if ((d & 3) == 3 && M.abort[buf]) { stop = true; break; }                 // (LDS read, same for the whole wave)
+          }
+        }
+        if (claimed && lane == 0)
+        {
+          const uint32_t before = atomicAdd(&M.fresh[buf], claimed);
+          if (before + claimed > kFullAt) M.abort[buf] = 1;
+        }
+      }
+    }
+    // ---- inserts, general: sub-group q0 (G lanes) streams the runs q0, q0 + Q, ... of this tile
+    if (!kWide && process)
     {
       const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
       const uint32_t* len = beg + S;
@@ -607,47 +761,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           }
         }
       };
-      if (g_shift == 6)
-      {
-        // Runs of a wave's worth of records and more (the usual case: a tile is sized to hold ~700 rows): a
-        // wave takes whole runs, one after the other -- runs wave, wave + kWaves, ... -- and walks a run
-        // 64 records at a time.  Everything about WHERE is wave-uniform and lives in scalar registers (the
-        // per-lane iterator of the general path cost more instructions than the inserts); a lane's address
-        // is the scalar position + its lane number.
-        uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);        // current run
-        uint32_t rb = 0, rl = 0, rc = 0;                                            // its first record, length, records done
-        auto next_run = [&]()
-        {
-          while (rs < S)
-          {
-            rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
-            rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)len[rs]);
-            rc = 0;
-            if (rl) return;
-            rs += kWaves;
-          }
-          rb = 0; rl = 0; rc = 0;
-        };
-        next_run();
-        auto fetch_wide = [&](batch& B)
-        {
-          B.valid = 0; B.ctl = 0;
-#pragma unroll
-          for (int u = 0; u < kU; ++u)
-          {
-            const uint32_t at = rb + rc + lane;                  // (exhausted: records 0 .. 63, never used)
-            B.k[u] = __builtin_nontemporal_load(J.keys + at);
-            B.c[u] = __builtin_nontemporal_load(J.counts + at);
-            if constexpr (kTwo) B.kh[u] = __builtin_nontemporal_load(J.keys_hi + at);
-            if (rc + lane < rl) B.valid |= 1u << u;
-            if (rs < J.nc) B.ctl |= 1u << u;                     // (wave-uniform)
-            rc += 64;
-            if (rc >= rl && rs < S) { rs += kWaves; next_run(); }
-          }
-        };
-        run_ring(fetch_wide);
-      }
-      else
+      if constexpr (!kWide)
       {
         seek();
         run_ring(fetch);
@@ -675,8 +789,8 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
       if constexpr (kTwo) { __syncthreads(); if (tid == 0) M.bad = 0; }     // everyone has read it
       if (bad_tile && tid == 0)
       {
-        const uint32_t at = atomicAdd(&J.over[0], 1u);
-        J.over[1 + at] = tile; J.over[1 + J.over_stride + at] = (n < kAbortBit ? n : kAbortBit - 1u) | kAbortBit;
+        const uint32_t at = atomicAdd(J.over_n, 1u);
+        J.over[at] = tile; J.over[J.over_stride + at] = (n < kAbortBit ? n : kAbortBit - 1u) | kAbortBit;
       }
       // the walk: every thread owns kWalk slots.  Pass 1 counts the rows that leave (all of them, or --
       // kFilter -- the ones the chi-square pre-filter lets through, ~1 %); the tile takes that many
@@ -859,6 +973,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   KMD_HIP(sc.take(&p_small, 64 + (size_t)kProbes * 4));              // [plan | entries, rows, rows beyond the table | probe multiplicities]
   tile_plan* d_plan = static_cast<tile_plan*>(p_small);
   unsigned long long* d_rows = reinterpret_cast<unsigned long long*>(static_cast<char*>(p_small) + 32);
+  uint32_t* d_over_n = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 56);
   uint32_t* d_mult = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 64);
   KMD_HIP(hipMemcpyAsync(p_offs, offsets, ((size_t)S + 1) * 8, hipMemcpyHostToDevice, st));
   KMD_HIP(hipMemsetAsync(p_small, 0, 64 + (size_t)kProbes * 4, st));
@@ -910,17 +1025,28 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
 #define KMD_TILE_CASE(T, SL)                                                                                                              \
     if (sh.threads == T && sh.slots == SL)                                                                                                \
     {                                                                                                                                     \
-      if (fused) return two ? launch(k_tile_sums<T, SL, true, true>, T, sizeof(tile_lds<SL, T / 64, true>), tiles_at_most)                \
-                            : launch(k_tile_sums<T, SL, true, false>, T, sizeof(tile_lds<SL, T / 64, false>), tiles_at_most);             \
-      return two ? launch(k_tile_sums<T, SL, false, true>, T, sizeof(tile_lds<SL, T / 64, true>), tiles_at_most)                          \
-                 : launch(k_tile_sums<T, SL, false, false>, T, sizeof(tile_lds<SL, T / 64, false>), tiles_at_most);                       \
+      int rc_ = KMD_OK;                                                                                                                   \
+      for (int wide_ = 1; wide_ >= 0 && rc_ == KMD_OK; --wide_)                                                                            \
+      {                                                                                                                                   \
+        if (J.n_tiles && (J.g_shift == 6) != (wide_ == 1)) continue;          /* way known on the host: launch that one only */           \
+        const size_t lds_ = two ? sizeof(tile_lds<SL, T / 64, true>) : sizeof(tile_lds<SL, T / 64, false>);                              \
+        if (wide_)                                                                                                                        \
+          rc_ = fused ? (two ? launch(k_tile_sums<T, SL, true, true, true>, T, lds_, tiles_at_most)                                      \
+                             : launch(k_tile_sums<T, SL, true, false, true>, T, lds_, tiles_at_most))                                    \
+                      : (two ? launch(k_tile_sums<T, SL, false, true, true>, T, lds_, tiles_at_most)                                     \
+                             : launch(k_tile_sums<T, SL, false, false, true>, T, lds_, tiles_at_most));                                  \
+        else                                                                                                                              \
+          rc_ = fused ? (two ? launch(k_tile_sums<T, SL, true, true, false>, T, lds_, tiles_at_most)                                     \
+                             : launch(k_tile_sums<T, SL, true, false, false>, T, lds_, tiles_at_most))                                   \
+                      : (two ? launch(k_tile_sums<T, SL, false, true, false>, T, lds_, tiles_at_most)                                    \
+                             : launch(k_tile_sums<T, SL, false, false, false>, T, lds_, tiles_at_most));                                 \
+      }                                                                                                                                   \
+      return rc_;                                                                                                                         \
     }
     KMD_TILE_CASE(512, 2048)
     KMD_TILE_CASE(1024, 2048)
     KMD_TILE_CASE(1024, 4096)
-    KMD_TILE_CASE(512, 4096)
     KMD_TILE_CASE(256, 2048)
-    KMD_TILE_CASE(256, 1024)
 #undef KMD_TILE_CASE
     kmd::set_error("kmd: KMD_TILE_SHAPE not built");
     return KMD_E_INVALID;
@@ -933,19 +1059,21 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   const uint8_t* todo = nullptr;
   tile_plan h_plan;
   std::memset(&h_plan, 0, sizeof h_plan);
+  alignas(8) char h_small[64];
   std::vector<uint32_t> h_over;
   for (int level = 0;; ++level)
   {
-    KMD_HIP(sc.take(&p_over, (1 + 2 * (size_t)list_cap) * 4));
-    KMD_HIP(hipMemsetAsync(p_over, 0, 4, st));
+    KMD_HIP(sc.take(&p_over, 2 * (size_t)list_cap * 4));
+    if (level > 0) KMD_HIP(hipMemsetAsync(d_over_n, 0, 4, st));
     J.start = table; J.todo = todo; J.n_tiles = n_tiles;
-    J.over = static_cast<uint32_t*>(p_over); J.over_stride = list_cap;
+    J.over_n = d_over_n; J.over = static_cast<uint32_t*>(p_over); J.over_stride = list_cap;
     int rc = run(list_cap);
     if (rc != KMD_OK) return rc;
-    uint32_t n_over = 0;
-    KMD_HIP(hipMemcpyAsync(&n_over, p_over, 4, hipMemcpyDeviceToHost, st));
-    if (level == 0) KMD_HIP(hipMemcpyAsync(&h_plan, d_plan, sizeof h_plan, hipMemcpyDeviceToHost, st));
+    // one read-back per level: [plan | entries, rows, rows beyond the table | tiles listed]
+    KMD_HIP(hipMemcpyAsync(h_small, p_small, 64, hipMemcpyDeviceToHost, st));
     KMD_HIP(hipStreamSynchronize(st));
+    std::memcpy(&h_plan, h_small, sizeof h_plan);
+    const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h_small + 56);
     if (dbg)
       std::fprintf(stderr, "[tile_merge] level %d: %u of %u tiles gave up (plan: %.2f records per row, %u records per tile, r %u, G %u)\n",
                    level, n_over, level ? n_tiles : h_plan.nb, h_plan.rho, h_plan.fill, h_plan.r, 1u << h_plan.g_shift);
@@ -954,8 +1082,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     // cut the listed tiles by the key range they span: a tile that ran out of table is cut as if every
     // record were a row of its own (its records per row are unknown but not what the plan assumed)
     h_over.resize(2 * (size_t)n_over);
-    KMD_HIP(hipMemcpy(h_over.data(), static_cast<uint32_t*>(p_over) + 1, (size_t)n_over * 4, hipMemcpyDeviceToHost));
-    KMD_HIP(hipMemcpy(h_over.data() + n_over, static_cast<uint32_t*>(p_over) + 1 + list_cap, (size_t)n_over * 4, hipMemcpyDeviceToHost));
+    KMD_HIP(hipMemcpy(h_over.data(), static_cast<uint32_t*>(p_over), (size_t)n_over * 4, hipMemcpyDeviceToHost));
+    KMD_HIP(hipMemcpy(h_over.data() + n_over, static_cast<uint32_t*>(p_over) + list_cap, (size_t)n_over * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> h_ref(3 * (size_t)n_over);              // tile, slices, first row
     const uint64_t per_slice = std::max<uint64_t>(64, (uint64_t)(load * (float)sh.slots));
     uint64_t rows = 0;
@@ -988,8 +1116,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     while (g < 6 && (double)(1u << g) < (double)per_slice * 0.5 / (double)S * 0.75) ++g;
     J.g_shift = g;
   }
-  unsigned long long h_rows[3] = { 0, 0, 0 };
-  KMD_HIP(hipMemcpy(h_rows, d_rows, sizeof h_rows, hipMemcpyDeviceToHost));
+  unsigned long long h_rows[3];
+  std::memcpy(h_rows, h_small + 32, sizeof h_rows);               // (read back with the last level)
   if (n_entries) *n_entries = (uint64_t)h_rows[0];
   if (totals) { totals[0] = fused ? (uint64_t)h_rows[1] : (uint64_t)h_rows[0]; totals[1] = (uint64_t)h_rows[2]; }
   return KMD_OK;
