@@ -65,10 +65,12 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   int device = 0, devices = 1, verbose = 1;   // first GPU, number of GPUs (0 = all): partition p on GPU (device + p % devices)
 };
 
+// Errors travel as exceptions: a GPU worker thread reports through its worker_result (run_gpu_worker), the
+// main thread prints and exits from main() -- nobody calls exit() while other workers, decoder tasks or
+// copies from page-locked memory are still alive.
 [[noreturn]] void die(const std::string& msg)
 {
-  std::fprintf(stderr, "[kmdiff-hip] error: %s\n", msg.c_str());
-  std::exit(1);
+  throw std::runtime_error(msg);
 }
 
 void ck(int rc, const char* what)
@@ -138,8 +140,14 @@ diff_options parse(int argc, char** argv)
     else if (a == "--ploidy") o.ploidy = std::stoull(need(i));
     else if (a == "--random-seed") o.seed = std::stoull(need(i));
     else if (a == "-t" || a == "--threads") o.threads = std::max<size_t>(1, std::stoull(need(i)));
-    else if (a == "-v" || a == "--verbose" ||
-             a == "--gender" || a == "--learning-rate" || a == "--epsilon") (void)need(i);
+    else if (a == "--epsilon")
+    {
+      // popstrat.hpp:162-175 forwards it to pop_strat_corrector::s_epsilon, which the reference never reads
+      // (the clamp of the likelihood ratio, popstrat.hpp:321, is the literal 1e-30): accepted, no effect
+      (void)need(i);
+      std::fprintf(stderr, "[kmdiff-hip] note: --epsilon is accepted for compatibility; like the reference's it has no effect\n");
+    }
+    else if (a == "-v" || a == "--verbose" || a == "--gender" || a == "--learning-rate") (void)need(i);
     else if (a == "-f" || a == "--kff-output")
       std::fprintf(stderr, "[kmdiff-hip] warning: KFF output is not part of this build (kff-cpp-api is an un-vendored, un-pinned "
                            "dependency of the reference); writing FASTA\n");
@@ -164,17 +172,47 @@ int correction_type(const std::string& c)
          c == "sidak" ? KMD_CORR_SIDAK : c == "holm" ? KMD_CORR_HOLM : KMD_CORR_NOTHING;
 }
 
-// fmt's "{}" for a double: shortest representation that round-trips (aggregator.hpp:51-55 formats
-// m_mean_case with it)
+// fmt's "{}" for a double (aggregator.hpp:51-55 formats m_mean_case with it): the shortest digits
+// that round-trip, written in fixed notation -- without a trailing ".0" -- when the decimal exponent is
+// in [-4, 16), in exponent notation (at least two exponent digits) outside; 10 -> "10", 1200 -> "1200",
+// 1e16 -> "1e+16", 0.5 -> "0.5".  (fmt's write_float with the default exponent thresholds; the pinned
+// fmt commit is not in the tree, 7.0+ behaviour assumed.)
 std::string shortest(double v)
 {
+  if (v == 0) return std::signbit(v) ? "-0" : "0";
+  if (!std::isfinite(v)) return std::isnan(v) ? "nan" : (v < 0 ? "-inf" : "inf");
   char buf[64];
-  for (int prec = 1; prec <= 17; ++prec)
+  int prec = 1;
+  for (; prec <= 17; ++prec)
   {
-    std::snprintf(buf, sizeof buf, "%.*g", prec, v);
+    std::snprintf(buf, sizeof buf, "%.*e", prec - 1, v);
     if (std::strtod(buf, nullptr) == v) break;
   }
-  return buf;
+  // buf = [-]d[.ddd]e[+-]XX
+  std::string t(buf);
+  const bool neg = t[0] == '-';
+  if (neg) t.erase(0, 1);
+  const size_t e = t.find('e');
+  const int exp10 = std::atoi(t.c_str() + e + 1);
+  std::string digits = t.substr(0, e);
+  digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  std::string out;
+  if (exp10 >= -4 && exp10 < 16)
+  {
+    if (exp10 < 0) out = "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+    else if ((size_t)exp10 + 1 >= digits.size()) out = digits + std::string((size_t)exp10 + 1 - digits.size(), '0');
+    else out = digits.substr(0, (size_t)exp10 + 1) + "." + digits.substr((size_t)exp10 + 1);
+  }
+  else
+  {
+    out = digits.substr(0, 1);
+    if (digits.size() > 1) out += "." + digits.substr(1);
+    char eb[16];
+    std::snprintf(eb, sizeof eb, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10));
+    out += eb;
+  }
+  return neg ? "-" + out : out;
 }
 
 // Timer (src/time.cpp:8-49): wall time of a stage, logged like cmd/diff.hpp:158,197,221,372

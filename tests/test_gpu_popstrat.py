@@ -1,0 +1,144 @@
+"""Pop-strat re-test (K3, kmd_popstrat_apply) against the oracle's restatement of pop_strat_corrector::apply
+(popstrat.hpp:249-333) and glm_irls (linear_model.cpp:297-410) at the edges the reference code has:
+the iteration limit (break before the weights are copied), a singular and a NaN Hessian, rows that all
+fail g_i > 1e-305, both likelihoods underflowing to zero, no standardisation, 2 .. 10 principal components,
+--epsilon.  (The oracle's IRLS itself is held against an independent Newton-Raphson in test_irls_cases.py.)
+Bars: |p_dev - p_ref| <= 1e-10 absolute and 1e-7 relative (FP64 pow / log / exp of ocml vs glibc)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kmdiff_amd as K
+    assert K.device_count() >= 1, "no GPU: the HIP path has no CPU fallback"
+    return K
+
+
+def oracle_setup(oracle, nc, nk, tc, tk, Z, npc, stand, max_iter, Y):
+    n, fn = nc + nk, 2 + npc
+    nul, alt, tot = np.zeros((n, fn)), np.zeros((n, fn + 1)), np.zeros(n)
+    oracle.L.kmdo_popstrat_features(nc, nk, tc.ctypes.data, tk.ctypes.data, Z.ctypes.data, Z.shape[1], npc, int(stand),
+                                    nul.ctypes.data, alt.ctypes.data, tot.ctypes.data)
+    w = np.zeros(fn)
+    oracle.L.kmdo_glm_irls(nul.ctypes.data, Y.ctypes.data, n, fn, max_iter, w.ctypes.data, None, None)
+    return alt, w, tot
+
+
+def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_scale=1.0, seed=3, want_spread=True):
+    S = nc + nk
+    rng = np.random.default_rng(seed)
+    if Z is None:
+        Z = rng.normal(0, 0.1, size=(S, 10))
+        Z[:nc, 0] += 0.05
+    Z = np.ascontiguousarray(Z, dtype=np.float64)
+    tc = (rng.integers(8_000_000, 12_000_000, nc) * totals_scale).astype(np.uint64)
+    tk = (rng.integers(8_000_000, 12_000_000, nk) * totals_scale).astype(np.uint64)
+    Yv = np.concatenate([np.ones(nc), np.zeros(nk)]) if Y is None else np.ascontiguousarray(Y, dtype=np.float64)
+    it = max_iter if max_iter > 0 else 100
+    pop = K.pop_strat_corrector(nc, nk, tc, tk, npc, Z, Y=Yv, stand=stand, max_iter=max_iter)
+    alt_o, null_o, tot_o = oracle_setup(oracle, nc, nk, tc, tk, Z, npc, stand, it, Yv)
+    alt_d, null_d, _ = pop.info()
+    assert alt_d.tolist() == alt_o.tolist()
+    both_nan = np.isnan(null_d) & np.isnan(null_o)
+    assert (np.abs(null_d - null_o)[~both_nan] <= 1e-9 * max(1.0, np.abs(null_o[~both_nan]).max(initial=0.0))).all()
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    n = len(rows)
+    p_dev = pop.apply(K.DeviceBuffer.from_host(rows), n)
+    p_ref = np.array([oracle.L.kmdo_popstrat_pvalue(alt_o.ctypes.data, S, alt_o.shape[1], Yv.ctypes.data, tot_o.ctypes.data,
+                                                    r.ctypes.data, null_o.ctypes.data, it) for r in rows])
+    assert np.isfinite(p_dev).all() == np.isfinite(p_ref).all()
+    ok = np.isfinite(p_ref)
+    assert np.abs(p_dev[ok] - p_ref[ok]).max(initial=0.0) <= 1e-10
+    nz = ok & (p_ref > 1e-300)
+    assert (np.abs(p_dev[nz] - p_ref[nz]) / p_ref[nz]).max(initial=0.0) <= 1e-7
+    if want_spread:
+        assert len(np.unique(p_ref[ok])) > min(10, n // 4)
+    return p_ref
+
+
+def count_rows(rng, n, nc, nk, effect=3.0):
+    """count vectors of survivors: a case / control effect of random size and direction, plus noise"""
+    S = nc + nk
+    base = rng.gamma(2.0, 30.0, (n, 1))
+    eff = np.where(rng.random((n, 1)) < 0.5, effect, 1.0 / effect)
+    lam = np.repeat(base, S, axis=1)
+    lam[:, nc:] *= eff
+    return rng.poisson(lam).astype(np.float64)
+
+
+@pytest.mark.parametrize("max_iter", [1, 2, 3, 4, 7])
+def test_iteration_limit_drops_the_last_update(K, oracle, max_iter):
+    """linear_model.cpp:386-395: the iteration that reaches max_iters leaves before `weight` is copied."""
+    rng = np.random.default_rng(max_iter)
+    # (limit 1: the weights stay at 1, every sigmoid saturates, both likelihoods are 0 -> one p-value for all)
+    check(K, oracle, 12, 12, 2, True, max_iter, count_rows(rng, 300, 12, 12), want_spread=max_iter > 1)
+
+
+@pytest.mark.parametrize("npc", [2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("stand", [True, False])
+def test_principal_components_and_standardisation(K, oracle, npc, stand):
+    rng = np.random.default_rng(100 + npc)
+    nc, nk = (20, 20) if npc < 8 else (35, 30)
+    # unstandardised totals of 1e7 make the Hessian wildly scaled: the no-pivot LU still has to agree
+    check(K, oracle, nc, nk, npc, stand, 0, count_rows(rng, 400, nc, nk), want_spread=stand)
+
+
+def test_singular_hessian_leaves_the_weights_at_one(K, oracle):
+    """A survivor whose count vector is all zero has a zero k-mer column: last pivot 0, det == 0
+    (linear_model.cpp:182-186, 366-372) -> the fit stops before its first update."""
+    rng = np.random.default_rng(5)
+    rows = count_rows(rng, 64, 10, 10)
+    rows[::3] = 0.0
+    check(K, oracle, 10, 10, 2, True, 0, rows)
+
+
+def test_nan_hessian(K, oracle):
+    """A principal component that is zero for every sample, unstandardised: a zero pivot in the middle of the
+    no-pivot LU, 0/0, det is NaN -> both the null fit and every survivor's fit stop at once."""
+    rng = np.random.default_rng(6)
+    Z = rng.normal(0, 0.1, size=(20, 10))
+    Z[:, 0] = 0.0
+    check(K, oracle, 10, 10, 2, False, 0, count_rows(rng, 100, 10, 10), Z=Z, want_spread=False)
+
+
+def test_rows_that_all_fail_the_variance_filter(K, oracle):
+    """g_i = mu_i (1 - mu_i) > 1e-305 fails for every sample (linear_model.cpp:336, 343) when the phenotypes
+    put mu outside (0, 1) on entry: the fit returns its initial weights."""
+    rng = np.random.default_rng(7)
+    check(K, oracle, 8, 8, 2, True, 0, count_rows(rng, 50, 8, 8), Y=np.full(16, 2.0), want_spread=False)
+
+
+def test_both_likelihoods_zero_fixup(K, oracle):
+    """popstrat.hpp:312-316: null and alternative likelihood both underflow to 0 -> (0.001, 1).  Unstandardised
+    totals of 1e9 under weights left at 1 (iteration limit 1) saturate every sigmoid."""
+    rng = np.random.default_rng(8)
+    p = check(K, oracle, 10, 10, 2, False, 1, count_rows(rng, 80, 10, 10), totals_scale=100.0, want_spread=False)
+    # LLR = -2 ln(0.001 / 1) = 13.8155...: one and the same p-value for every survivor
+    assert len(np.unique(p)) == 1 and p[0] == oracle.chisqc(1, -2.0 * np.log(0.001 / 1.0))
+
+
+def test_perfect_separation(K, oracle):
+    """Counts that separate cases from controls perfectly: the weights grow until the MSE stops changing."""
+    rng = np.random.default_rng(9)
+    rows = np.zeros((40, 20))
+    rows[:, 10:] = rng.integers(200, 400, (40, 10))
+    rows[:, :10] = rng.integers(0, 3, (40, 10))
+    check(K, oracle, 10, 10, 2, True, 0, rows, want_spread=False)
+
+
+def test_large_batch_matches_small_batches(K, oracle):
+    """The answer of a survivor does not depend on who shares its wave or launch."""
+    rng = np.random.default_rng(10)
+    nc = nk = 20
+    rows = count_rows(rng, 5000, nc, nk)
+    Z = rng.normal(0, 0.1, size=(40, 10))
+    tc = rng.integers(8_000_000, 12_000_000, nc).astype(np.uint64)
+    tk = rng.integers(8_000_000, 12_000_000, nk).astype(np.uint64)
+    pop = K.pop_strat_corrector(nc, nk, tc, tk, 2, Z)
+    p_all = pop.apply(K.DeviceBuffer.from_host(rows), len(rows))
+    for a, b in [(0, 1), (1, 64), (64, 129), (129, 1000), (1000, 5000)]:
+        p = pop.apply(K.DeviceBuffer.from_host(rows[a:b]), b - a)
+        assert (p == p_all[a:b]).all()
