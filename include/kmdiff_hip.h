@@ -282,6 +282,9 @@ int kmd_popstrat_create(kmd_popstrat** out, int nb_controls, int nb_cases,
                         const double* Z, int z_cols, int npc, const double* Y,
                         int standardize, int max_iter);
 int kmd_popstrat_destroy(kmd_popstrat* ps);
+/* --epsilon (src/cli.cpp:336-339 -> pop_strat_corrector::set_params, popstrat.hpp:162-175): a non-zero value
+ * replaces the default 1e-30 below which |LLR| counts as zero (popstrat.hpp:321) */
+int kmd_popstrat_set_epsilon(kmd_popstrat* ps, double epsilon);
 /* introspection for tests: any output may be NULL.  alt_global is n x n_features_alt. */
 int kmd_popstrat_info(const kmd_popstrat* ps, int* n_samples, int* n_features_alt, double* alt_global,
                       double* null_model, double* null_likelihood);

@@ -11,8 +11,11 @@
 // X^T S X accumulated sample by sample, no-pivot LU, per-column substitutions); keeping a
 // whole fit inside one lane preserves that order exactly, and the parallelism comes from
 // the number of survivors (10^5..10^6 per run).  The shared design columns are wave-uniform
-// (scalar loads); per-sample state (eta, mu) is recomputed on the fly from the current
-// weights instead of being stored, so a fit needs F*F*2 + O(F) doubles of registers.
+// (staged once per wave in LDS: n x (F + 1) doubles; from global memory when that does not fit);
+// per-sample state (eta, mu) is recomputed on the fly from the current weights instead of being
+// stored; the inverse of the Hessian is never stored either (its columns go into the weight update as
+// they are solved), so a fit needs F*F + O(F) doubles of registers.  The survivors' own column -- their
+// count in every sample -- is fetched one sample ahead.
 //
 // Several reference quirks are behaviour and are reproduced: the
 // standardisation divides column sums by ncols and scales ROW i by the deviation of
@@ -36,6 +39,7 @@ struct kmd_popstrat
   std::vector<double> h_null_model;
   double null_likelihood;
   double lg_half;
+  double epsilon;   // pop_strat_corrector::s_epsilon (popstrat.hpp:154,172-173,321)
   double* d_alt;    // device copies
   double* d_y;
   double* d_totals;
@@ -46,18 +50,32 @@ namespace {
 
 constexpr double kE = 2.718281828459045235360287471352662498;   // M_E
 
-__device__ __forceinline__ double sigmoid_ref(double x)           // linear_model.cpp:191-195
+// linear_model.cpp:191-195: 1 / (1 + pow(e, -x)) with e = M_E, the double nearest to e.  ln(M_E) rounds to
+// exactly 1.0 in double precision (it is 1 - 5.3e-17), so pow(M_E, -x) = exp(-x) (1 + 5.3e-17 x): evaluated
+// as exp(-x) -- a third of pow's instructions, and the sigmoid is on the critical path of every sample of
+// every iteration -- it stays within 4e-14 relative of the reference's value over the whole range where the
+// result is not 0 or 1 anyway (|x| < 745); the p-values keep the 1e-7 relative bar of the parity tests.
+#ifndef KMD_SIGMOID_POW
+#define KMD_SIGMOID_POW 0
+#endif
+__device__ __forceinline__ double sigmoid_ref(double x)
 {
+#if KMD_SIGMOID_POW
   return 1.0 / (1.0 + ::pow(kE, -x));
+#else
+  return 1.0 / (1.0 + ::exp(-x));
+#endif
 }
 
-// no-pivot Doolittle LU in place (linear_model.cpp:94-132) + per-column solves
-// (:134-189).  a: F x F (destroyed: L below the diagonal, U on and above).  inv out.
-// Returns 1 singular (det == 0), 2 NaN det, 0 ok.  The sums skip the structural zeros of
-// the reference's full-width loops (lower[r][c>=r] * y[c] with y[c] still 0): adding +0.0
-// terms does not change a sum.
+// no-pivot Doolittle LU in place (linear_model.cpp:94-132) + per-column solves (:134-189) + the weight
+// update w = H^-1 (X^T S z) (:381).  a: F x F (destroyed: L below the diagonal, U on and above).
+// Column c of the inverse is used the moment it is solved: w[p] = sum over c, ascending, of
+// inv[p][c] * b[c] -- the order multiply() adds them in (:77-86) -- so the inverse is never stored.
+// Returns 1 singular (det == 0), 2 NaN det, 0 ok (w valid).  The sums skip the structural zeros of the
+// reference's full-width loops (lower[r][c >= r] * y[c] with y[c] still 0): adding +0.0 terms does not
+// change a sum.
 template <int F>
-__device__ __forceinline__ int lu_inverse(double (&a)[F][F], double (&inv)[F][F])
+__device__ __forceinline__ int lu_solve(double (&a)[F][F], const double (&b)[F], double (&w)[F])
 {
 #pragma unroll
   for (int i = 0; i < F; ++i)
@@ -80,6 +98,8 @@ __device__ __forceinline__ int lu_inverse(double (&a)[F][F], double (&inv)[F][F]
     }
   }
   double det = 1;
+#pragma unroll
+  for (int p = 0; p < F; ++p) w[p] = 0.0;
 #pragma unroll
   for (int c = 0; c < F; ++c)
   {
@@ -105,7 +125,7 @@ __device__ __forceinline__ int lu_inverse(double (&a)[F][F], double (&inv)[F][F]
       det *= a[row][row];
     }
 #pragma unroll
-    for (int j = 0; j < F; ++j) inv[j][c] = x[j];
+    for (int p = 0; p < F; ++p) w[p] = w[p] + x[p] * b[c];          // inv[p][c] * b[c]
   }
   if (det == 0) return 1;
   if (det != det) return 2;
@@ -124,11 +144,24 @@ struct irls_args
   int max_iter;
 };
 
+// The shared part of a sample's design row: features 0 .. F-2, phenotype, total.  LDSD: staged in LDS
+// as [n][F + 1] (feature 0 .. F-2 | y | total); else read from global memory (wave-uniform addresses).
+template <int F, bool LDSD>
+struct design_rows
+{
+  const irls_args& A;
+  const double* s_d;
+  __device__ __forceinline__ double x(int i, int j) const { return LDSD ? s_d[i * (F + 1) + j] : A.alt[i * A.stride + j]; }
+  __device__ __forceinline__ double y(int i) const { return LDSD ? s_d[i * (F + 1) + F - 1] : A.y[i]; }
+  __device__ __forceinline__ double total(int i) const { return LDSD ? s_d[i * (F + 1) + F] : A.totals[i]; }
+};
+
 // glm_irls (linear_model.cpp:297-410) over F features.  KMER: feature F-1 of each sample is
 // counts/totals (popstrat.hpp:254-257), else all F features come from `alt`.
-template <int F, bool KMER>
-__device__ __forceinline__ void irls_fit(const irls_args& A, size_t surv, double (&weight)[F])
+template <int F, bool KMER, bool LDSD>
+__device__ __forceinline__ void irls_fit(const irls_args& A, const double* s_d, size_t surv, double (&weight)[F])
 {
+  const design_rows<F, LDSD> D { A, s_d };
   double w[F];
 #pragma unroll
   for (int j = 0; j < F; ++j) { weight[j] = 1; w[j] = 1; }
@@ -144,13 +177,13 @@ __device__ __forceinline__ void irls_fit(const irls_args& A, size_t surv, double
       for (int q = 0; q < F; ++q) H[p][q] = 0.0; }
     double error = 0.0;
     int ng = 0;
-    for (int i = 0; i < A.n; ++i)
+    auto sample = [&](int i, double count)
     {
       double x[F];
 #pragma unroll
-      for (int j = 0; j < F; ++j) x[j] = A.alt[i * A.stride + j];
-      if (KMER) x[F - 1] = A.counts[(size_t)i * A.ld + surv] / A.totals[i];
-      const double yi = A.y[i];
+      for (int j = 0; j < F - 1; ++j) x[j] = D.x(i, j);
+      x[F - 1] = KMER ? count / D.total(i) : A.alt[i * A.stride + F - 1];
+      const double yi = D.y(i);
       double eta, mu;
       if (first)
       {
@@ -178,22 +211,23 @@ __device__ __forceinline__ void irls_fit(const irls_args& A, size_t surv, double
         }
       }
       error += (yi - mu) * (yi - mu);                            // :341
+    };
+    {
+      // the count of the next sample is requested before this one is worked on
+      double c_next = KMER ? A.counts[surv] : 0.0;
+      for (int i = 0; i < A.n; ++i)
+      {
+        const double c = c_next;
+        if (KMER) c_next = A.counts[(size_t)(i + 1 < A.n ? i + 1 : i) * A.ld + surv];
+        sample(i, c);
+      }
     }
     first = false;
     if (ng == 0) break;                                          // :343
     error /= A.n;
     if (::fabs(error - prev_error) < 1e-6) break;                // :349
     prev_error = error;
-    double inv[F][F];
-    if (lu_inverse<F>(H, inv)) break;                            // :366-373
-#pragma unroll
-    for (int p = 0; p < F; ++p)
-    {
-      double r = 0.0;
-#pragma unroll
-      for (int q = 0; q < F; ++q) r = r + inv[p][q] * b[q];      // :381
-      w[p] = r;
-    }
+    if (lu_solve<F>(H, b, w)) break;                             // :366-381 (w is dead on this way out)
     iter += 1;
     if (iter >= A.max_iter) break;                               // :386-389 (weight NOT updated)
     prev_error = error;
@@ -203,33 +237,55 @@ __device__ __forceinline__ void irls_fit(const irls_args& A, size_t surv, double
 }
 
 // pop_strat_corrector::apply(KmerSign&) (popstrat.hpp:249-333) for one survivor per lane
-template <int F>
+template <int F, bool LDSD>
 __global__ void __launch_bounds__(64) k_popstrat_apply(irls_args A, size_t n_surv, double null_likelihood,
-                                                       double lg_half, double* __restrict__ out_p)
+                                                       double lg_half, double epsilon, double* __restrict__ out_p)
 {
-  const size_t surv = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (surv >= n_surv) return;
-  double model[F];
-  irls_fit<F, true>(A, surv, model);
-  double alt_l = 1.0;                                            // :263-287
-  for (int i = 0; i < A.n; ++i)
+  extern __shared__ double s_d[];
+  if constexpr (LDSD)
   {
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < F; ++j)
+    // the shared design, once per wave: [n][feature 0 .. F-2 | y | total]
+    for (int t = threadIdx.x; t < A.n * (F + 1); t += 64)
     {
-      const double xj = (j == F - 1) ? A.counts[(size_t)i * A.ld + surv] / A.totals[i] : A.alt[i * A.stride + j];
-      s += model[j] * xj;
+      const int i = t / (F + 1), j = t - i * (F + 1);
+      s_d[t] = j < F - 1 ? A.alt[i * A.stride + j] : j == F - 1 ? A.y[i] : A.totals[i];
     }
-    const double p = sigmoid_ref(s);
-    if (A.y[i] == 1) alt_l = alt_l * p; else alt_l *= 1.0 - p;
+    __syncthreads();
+  }
+  size_t surv = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = surv < n_surv;
+  if (!live) surv = n_surv - 1;                                  // (keeps the wave together; result dropped)
+  const design_rows<F, LDSD> D { A, s_d };
+  double model[F];
+  irls_fit<F, true, LDSD>(A, s_d, surv, model);
+  double alt_l = 1.0;                                            // :263-287
+  {
+    auto sample = [&](int i, double count)
+    {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < F; ++j)
+      {
+        const double xj = (j == F - 1) ? count / D.total(i) : D.x(i, j);
+        s += model[j] * xj;
+      }
+      const double p = sigmoid_ref(s);
+      if (D.y(i) == 1) alt_l = alt_l * p; else alt_l *= 1.0 - p;
+    };
+    double c_next = A.counts[surv];
+    for (int i = 0; i < A.n; ++i)
+    {
+      const double c = c_next;
+      c_next = A.counts[(size_t)(i + 1 < A.n ? i + 1 : i) * A.ld + surv];
+      sample(i, c);
+    }
   }
   double null_l = null_likelihood;                               // :289-310 (same for every k-mer)
   if (null_l == 0.0 && alt_l == 0.0) { null_l = 0.001; alt_l = 1.0; }     // :312-316
   const double ratio = null_l / alt_l;
   double llr = -2.0 * ::log(ratio);                              // :318-319
-  if (::fabs(llr) < 1e-30 || llr < 0.0 || alt_l != alt_l) llr = 0.0;     // :321-326
-  out_p[surv] = kmd::igamc_half(llr / 2.0, lg_half);             // :328 chisquarecdistribution(1, llr)
+  if (::fabs(llr) < epsilon || llr < 0.0 || alt_l != alt_l) llr = 0.0;    // :321-326
+  if (live) out_p[surv] = kmd::igamc_half(llr / 2.0, lg_half);   // :328 chisquarecdistribution(1, llr)
 }
 
 // the null model: glm_irls(null features, Y) (popstrat.cpp:316-324) and its likelihood
@@ -238,7 +294,7 @@ __global__ void k_popstrat_null(irls_args A, double* __restrict__ out_model, dou
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double model[F];
-  irls_fit<F, false>(A, 0, model);
+  irls_fit<F, false, false>(A, nullptr, 0, model);
   double l = 1.0;
   for (int i = 0; i < A.n; ++i)
   {
@@ -265,9 +321,15 @@ __global__ void __launch_bounds__(256) k_transpose_counts(const double* __restri
 }
 
 template <int F>
-void launch_apply(const irls_args& A, size_t n, double null_like, double lg_half, double* d_p, hipStream_t st)
+void launch_apply(const irls_args& A, size_t n, double null_like, double lg_half, double epsilon, double* d_p, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_popstrat_apply<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, A, n, null_like, lg_half, d_p);
+  // the shared design in LDS when it fits comfortably (n x (F + 1) doubles per wave; 11 KB at 100v100)
+  const size_t lds = (size_t)A.n * (F + 1) * sizeof(double);
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  if (lds <= 40 * 1024)
+    hipLaunchKernelGGL((k_popstrat_apply<F, true>), dim3(grid), dim3(64), lds, st, A, n, null_like, lg_half, epsilon, d_p);
+  else
+    hipLaunchKernelGGL((k_popstrat_apply<F, false>), dim3(grid), dim3(64), 0, st, A, n, null_like, lg_half, epsilon, d_p);
 }
 
 template <int F>
@@ -296,6 +358,7 @@ int kmd_popstrat_create(kmd_popstrat** out, int nb_controls, int nb_cases,
   if (!ps) return KMD_E_NOMEM;
   ps->n = n; ps->f = fa; ps->max_iter = max_iter > 0 ? max_iter : 100;    // popstrat.hpp:151,162-178
   ps->lg_half = kmd::lngamma_half_host();
+  ps->epsilon = 1e-30;                                                      // popstrat.hpp:154
   ps->d_alt = ps->d_y = ps->d_totals = ps->d_null_model = nullptr;
   std::vector<double> totals(n);
   for (int i = 0; i < nb_controls; ++i) totals[i] = (double)total_controls[i];           // popstrat.cpp:144-145
@@ -384,6 +447,15 @@ int kmd_popstrat_destroy(kmd_popstrat* ps)
   return KMD_OK;
 }
 
+// pop_strat_corrector::set_params' epsilon (popstrat.hpp:162-175: only a non-zero value replaces the
+// default 1e-30): the bound below which |LLR| counts as zero (popstrat.hpp:321)
+int kmd_popstrat_set_epsilon(kmd_popstrat* ps, double epsilon)
+{
+  KMD_REQUIRE(ps, "kmd_popstrat_set_epsilon: NULL");
+  if (epsilon) ps->epsilon = epsilon;
+  return KMD_OK;
+}
+
 int kmd_popstrat_info(const kmd_popstrat* ps, int* n_samples, int* n_features_alt, double* alt_global,
                       double* null_model, double* null_likelihood)
 {
@@ -417,17 +489,17 @@ int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sampl
   irls_args A { ps->d_alt, ps->f, ps->d_y, ps->d_totals, counts, ld, ps->n, ps->max_iter };
   switch (ps->f)
   {
-    case 3: launch_apply<3>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 4: launch_apply<4>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 5: launch_apply<5>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 6: launch_apply<6>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 7: launch_apply<7>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 8: launch_apply<8>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 9: launch_apply<9>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 10: launch_apply<10>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 11: launch_apply<11>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    case 12: launch_apply<12>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
-    default: launch_apply<13>(A, n, ps->null_likelihood, ps->lg_half, d_pvalue, st); break;
+    case 3: launch_apply<3>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 4: launch_apply<4>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 5: launch_apply<5>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 6: launch_apply<6>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 7: launch_apply<7>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 8: launch_apply<8>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 9: launch_apply<9>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 10: launch_apply<10>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 11: launch_apply<11>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    case 12: launch_apply<12>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
+    default: launch_apply<13>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;
   }
   hipError_t e = hipGetLastError();
   if (d_t)
