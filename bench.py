@@ -258,7 +258,8 @@ def main():
     elapsed = D.max_over_ranks(elapsed)
 
     avg_kernel_ms = D.max_over_ranks(ev0.elapsed_ms(ev1) / args.steps)    # back-to-back launches
-    kept = D.allreduce_counters([int(keep.sum()), n_ctrl, n_case])
+    near = int(acc.read_counters()[K._native.CNT_NEAR_THRESHOLD])    # rows decided with correctly rounded log / exp
+    kept = D.allreduce_counters([int(keep.sum()), n_ctrl, n_case, near])
 
     if rank == 0:
         total_rows = float(args.rows) * args.steps * world
@@ -310,7 +311,8 @@ def main():
                        "resident_partitions": n_res, "device": K.device_name(),
                        "counters": {"total": int(g_counters[0]), "n_sig": int(g_counters[1]),
                                     "n_sig_control": int(g_counters[2]), "n_sig_case": int(g_counters[3]),
-                                    "kept_after_correction": int(kept[0])},
+                                    "kept_after_correction": int(kept[0]),
+                                    "near_threshold": int(kept[3])},
                        "copy_probe_GBs": copy_gbs, "read_probe_GBs": read_gbs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

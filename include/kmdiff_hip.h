@@ -59,6 +59,13 @@ enum { KMD_LAYOUT_ROWS = 0, KMD_LAYOUT_SOA = 1, KMD_LAYOUT_TILED = 2 };
 const char* kmd_status_string(int status);
 const char* kmd_last_error(void);
 int kmd_abi_version(void);
+/* test hooks: the correctly rounded log / exp (and Cephes igamc(1/2, x) over them) that decide rows whose
+ * p-value lies within 1e-8 of the threshold (KMD_CNT_NEAR_THRESHOLD), evaluated on the host */
+double kmd_test_log_rounded(double x);
+double kmd_test_exp_rounded(double x);
+double kmd_test_igamc_half_rounded(double x);
+struct kmd_model;
+double kmd_test_row_pvalue_rounded(const struct kmd_model* m, uint64_t sum_control, uint64_t sum_case);
 
 /* ---- device plumbing (so that a C/C++ host needs nothing but this library) ----------- */
 int kmd_device_count(int* n);
@@ -141,7 +148,9 @@ typedef struct {
 enum { KMD_CNT_TOTAL = 0, KMD_CNT_SIG = 1, KMD_CNT_SIG_CONTROL = 2, KMD_CNT_SIG_CASE = 3,
        KMD_CNT_CANDIDATES = 4,   /* rows whose tail function was evaluated                 */
        KMD_CNT_DEFERRED = 5,     /* rows with a count sum >= log_factorial_size            */
-       KMD_CNT_RESERVED6 = 6, KMD_CNT_RESERVED7 = 7, KMD_NCOUNTERS = 8 };
+       KMD_CNT_NEAR_THRESHOLD = 6, /* candidates with |p / threshold - 1| <= 1e-8: decided with correctly rounded
+                                      log / exp, so that no libm's last bit can move them across (kmd_ddmath.h) */
+       KMD_CNT_RESERVED7 = 7, KMD_NCOUNTERS = 8 };
 
 typedef struct {
   const void*     d_counts;   /* count matrix tile                                         */

@@ -16,7 +16,7 @@ SIGN_CONTROL, SIGN_CASE, SIGN_NO = 0, 1, 2
 CORR_NOTHING, CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM = 0, 1, 2, 3, 4
 LAYOUT_ROWS, LAYOUT_SOA, LAYOUT_TILED = 0, 1, 2
 NCOUNTERS = 8
-(CNT_TOTAL, CNT_SIG, CNT_SIG_CONTROL, CNT_SIG_CASE, CNT_CANDIDATES, CNT_DEFERRED) = range(6)
+(CNT_TOTAL, CNT_SIG, CNT_SIG_CONTROL, CNT_SIG_CASE, CNT_CANDIDATES, CNT_DEFERRED, CNT_NEAR_THRESHOLD) = range(7)
 
 
 class KmdError(RuntimeError):
@@ -42,6 +42,10 @@ SIGNATURES = {
     "kmd_status_string": (C.c_char_p, [_i]),
     "kmd_last_error": (C.c_char_p, []),
     "kmd_abi_version": (_i, []),
+    "kmd_test_log_rounded": (_d, [_d]),
+    "kmd_test_exp_rounded": (_d, [_d]),
+    "kmd_test_igamc_half_rounded": (_d, [_d]),
+    "kmd_test_row_pvalue_rounded": (_d, [_vp, _u64, _u64]),
     "kmd_device_count": (_i, [C.POINTER(_i)]),
     "kmd_set_device": (_i, [_i]),
     "kmd_device_name": (_i, [C.c_char_p, _sz]),

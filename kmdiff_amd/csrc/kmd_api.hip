@@ -114,6 +114,21 @@ const char* kmd_status_string(int status)
 const char* kmd_last_error(void) { return g_last_error.c_str(); }
 int kmd_abi_version(void) { return KMD_ABI_VERSION; }
 
+// test hooks (host side of kmd_ddmath.h / kmd_math.h, the code the device runs for rows within 1e-8 of the
+// threshold): tests/test_rounded_math.py holds them against mpmath
+double kmd_test_log_rounded(double x) { return kmd::libm_rounded::log(x); }
+double kmd_test_exp_rounded(double x) { return kmd::libm_rounded::exp(x); }
+double kmd_test_igamc_half_rounded(double x) { return kmd::igamc_half<kmd::libm_rounded>(x, kmd::lngamma_half_host()); }
+// the p-value of a row with these two count sums the way the device decides a near-threshold row: table terms
+// as the model holds them, the four libm calls correctly rounded (sums inside the table only)
+double kmd_test_row_pvalue_rounded(const kmd_model* m, uint64_t sum_c, uint64_t sum_k)
+{
+  if (!m || sum_c >= m->lf_n || sum_k >= m->lf_n) return -1.0;
+  const double lc = sum_c ? ::log((double)sum_c) : 0.0, lk = sum_k ? ::log((double)sum_k) : 0.0;   // the table's second column
+  const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, m->h_lf[sum_c], m->h_lf[sum_k], lc, lk, m->dT, m->dTc, m->dTk);
+  return kmd::igamc_half<kmd::libm_rounded>(lr, m->lg_half);
+}
+
 int kmd_device_count(int* n)
 {
   KMD_REQUIRE(n, "kmd_device_count: NULL");

@@ -119,12 +119,25 @@ __device__ __forceinline__ void evaluate_row(const filter_params& P, const doubl
     bool surv = false;
     double p = 1.0, mean_control = 0.0;
     int sign = KMD_SIGN_NO;
+    bool near = false;
     if (cand)
     {
       p = kmd::igamc_half(lr, P.lg_half);                   // model.hpp:161
+      // the guard of the decision: a p-value within 1e-8 (relative) of the threshold is ~10 x closer than
+      // the device's and a host's libm can move it apart; such a row (KMD_CNT_NEAR_THRESHOLD counts
+      // them) repeats its four libm calls with correctly rounded log / exp (kmd_ddmath.h).  Sums
+      // beyond the log-factorial table keep the ordinary result: their table term is Stirling's, not
+      // the reference's running sum, so there is no reference bit pattern to match
+      near = fabs(p - P.threshold) <= 1e-8 * P.threshold && !(big_c | big_k);
+      if (near)
+      {
+        const double lr2 = kmd::lr_from_sums<kmd::libm_rounded>(st.sum_c, st.sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
+        p = kmd::igamc_half<kmd::libm_rounded>(lr2, P.lg_half);
+      }
       surv = (p <= P.threshold);                            // merge.hpp:78
       kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, mean_control, sign);
     }
+    const unsigned long long near_mask = __ballot(near);
     const unsigned long long surv_mask = __ballot(surv);
     const unsigned long long ctrl_mask = __ballot(surv && sign == KMD_SIGN_CONTROL);
     const int lane = __lane_id();
@@ -133,6 +146,7 @@ __device__ __forceinline__ void evaluate_row(const filter_params& P, const doubl
     if (lane == leader)
     {
       atomicAdd(&P.counters[KMD_CNT_CANDIDATES], (unsigned long long)__popcll(cand_mask));
+      if (near_mask) atomicAdd(&P.counters[KMD_CNT_NEAR_THRESHOLD], (unsigned long long)__popcll(near_mask));
       if (surv_mask)
       {
         const unsigned long long ns = __popcll(surv_mask), nctl = __popcll(ctrl_mask);

@@ -11,6 +11,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "kmd_ddmath.h"
+
 #define KMD_HD __host__ __device__ __forceinline__
 
 namespace kmd {
@@ -48,24 +50,38 @@ constexpr double kIgamBig = 4503599627370496.0;
 constexpr double kIgamBigInv = 2.22044604925031308085 * 0.0000000000000001;
 constexpr double kIgamMinLog = -709.78271289338399;
 
+// The two libm functions of the path: the platform's (glibc on the host, ocml on the device) or the
+// correctly rounded ones of kmd_ddmath.h (rows within 1e-8 of the threshold, kmd_eval.h).
+struct libm_native
+{
+  static KMD_HD double log(double x) { return ::log(x); }
+  static KMD_HD double exp(double x) { return ::exp(x); }
+};
+struct libm_rounded
+{
+  static KMD_HD double log(double x) { return (x > 2.3e-308 && x < 1.7e308) ? ddm::log_cr(x) : ::log(x); }
+  static KMD_HD double exp(double x) { return (x > -708.0 && x < 708.0) ? ddm::exp_cr(x) : ::exp(x); }
+};
+
 // igamc(1/2, x) -- continued fraction for x >= 1, 1 - power series below.
 // lg_half = lngamma_half_host().
+template <class M = libm_native>
 KMD_HD double igamc_half(double x, double lg_half)
 {
   const double a = 0.5;
   if (x <= 0) return 1;
-  double ax = a * ::log(x) - x - lg_half;
+  double ax = a * M::log(x) - x - lg_half;
   if (x < 1)   // (x < 1 || x < a) with a = 1/2
   {
     // igam(a, x): specialfunctions.cpp:4596-4617 (x > 1 && x > a cannot hold here)
     if (ax < kIgamMinLog) return 1 - 0.0;
-    ax = ::exp(ax);
+    ax = M::exp(ax);
     double r = a, c = 1, ans = 1;
     do { r = r + 1; c = c * x / r; ans = ans + c; } while (c / ans > kIgamEps);
     return 1 - ans * ax / a;
   }
   if (ax < kIgamMinLog) return 0;
-  ax = ::exp(ax);
+  ax = M::exp(ax);
   double y = 1 - a, z = x + y + 1, c = 0;
   double pkm2 = 1, qkm2 = x, pkm1 = x + 1, qkm1 = z * x;
   double ans = pkm1 / qkm1, t;
@@ -89,10 +105,11 @@ KMD_HD double igamc_half(double x, double lg_half)
 // PoissonLikelihood::poisson_prob (include/kmdiff/model.hpp:133-138) with the table value
 // lf[k] already looked up.
 #define KMD_LOG(x) ::log(x)
+template <class M = libm_native>
 KMD_HD double poisson_prob(double k, double lambda, double lf_k)
 {
   if (lambda <= 0) return 0;
-  return (-lambda + (k * KMD_LOG(lambda) - lf_k));
+  return (-lambda + (k * M::log(lambda) - lf_k));
 }
 
 // `int k = mean_control` (model.hpp:152-156): double -> int truncation.  Sums >= 2^31 are
@@ -111,6 +128,7 @@ struct lrt_result { double lr; double mean_control; int sign; };
 // built on the host with the same libm call the reference makes (so they are the reference's
 // own values), only the two null-hypothesis logarithms are evaluated per row.
 // dT = double(Tc + Tk), dTc = double(Tc), dTk = double(Tk).
+template <class M = libm_native>
 KMD_HD double lr_from_sums(uint64_t sum_c, uint64_t sum_k, double lf_c, double lf_k,
                            double log_sc, double log_sk, double dT, double dTc, double dTk)
 {
@@ -120,8 +138,8 @@ KMD_HD double lr_from_sums(uint64_t sum_c, uint64_t sum_k, double lf_c, double l
   double alt = 0, nul = 0;
   alt += (sc <= 0) ? 0.0 : (-sc + (kc * log_sc - lf_c));                     // :152 (poisson_prob :133-138)
   alt += (sk <= 0) ? 0.0 : (-sk + (kk * log_sk - lf_k));                     // :153
-  nul += poisson_prob(kc, mean * dTc, lf_c);                                 // :155
-  nul += poisson_prob(kk, mean * dTk, lf_k);                                 // :156
+  nul += poisson_prob<M>(kc, mean * dTc, lf_c);                              // :155
+  nul += poisson_prob<M>(kk, mean * dTk, lf_k);                              // :156
   double lr = alt - nul;                                                     // :158
   if (lr < 0) lr = 0;                                                        // :160
   return lr;

@@ -23,6 +23,7 @@
 // accepted and FASTA is written), progress bars.
 #include <algorithm>
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -254,6 +255,7 @@ struct survivors_of_run
   survivor_set sv_all;                                   // survivors of all partitions, partition after partition
   std::vector<size_t> part_begin;                        // [nb_partitions + 1] into sv_all
   uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+  uint64_t n_near = 0;                               // rows decided with correctly rounded log / exp (KMD_CNT_NEAR_THRESHOLD)
   std::vector<double> Z_device;                          // [S][10] when the device PCA ran
 };
 
@@ -388,7 +390,7 @@ struct worker_result
 {
   survivor_set sv;
   std::vector<std::pair<size_t, size_t>> span;     // per partition of this worker: (begin, count) in sv
-  uint64_t total = 0, n_sig = 0, n_ctrl = 0, n_case = 0, n_sampled = 0;
+  uint64_t total = 0, n_sig = 0, n_ctrl = 0, n_case = 0, n_sampled = 0, n_near = 0;
   std::vector<double> xtx;                         // the worker's PCA Gram matrix
   std::string error;
 };
@@ -422,6 +424,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   sv_all.n_counts = want_counts ? S : 0;
   sv_all.kmer_bytes = two_limbs ? 16 : 8;
   uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
+  uint64_t n_near = 0;                               // rows decided with correctly rounded log / exp (KMD_CNT_NEAR_THRESHOLD)
   // what a partition brings to the device, twice: the set of partition t + 1 is filled by the copy
   // stream while the kernels of partition t read the other one.  K-mer feed: the S streams one after
   // the other (the input of K2); matrices/ feed: the rows themselves (the tile K1 reads).
@@ -622,6 +625,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
         }
       }
       total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
+      n_near += c[KMD_CNT_NEAR_THRESHOLD];
     }
     else if (n_rows)
     {
@@ -657,6 +661,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
         }
       }
       total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
+      n_near += c[KMD_CNT_NEAR_THRESHOLD];
     }
     t_device += t_dev.seconds();
     if (turn > depth) t_steady += t_wait.seconds();       // decoder wait + device work of this partition
@@ -671,7 +676,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       write_matrix_file(opt.output_directory + "/positive_kmer_matrix/matrices/matrix_" + std::to_string(p) + ".count.lz4", sk);
     }
   }
-  R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case;
+  R.total = total_kmers; R.n_sig = n_sig; R.n_ctrl = n_sig_control; R.n_case = n_sig_case; R.n_near = n_near;
   if (opt.verbose_timing)
   {
     std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder (%.3f s of it for the first %zu partitions, whose staging arrays "
@@ -762,7 +767,7 @@ void do_diff(const run_context& C, survivors_of_run& O, const bool run_pca)
       if (want_counts) sv_all.counts.insert(sv_all.counts.end(), R.sv.counts.begin() + b * S, R.sv.counts.begin() + (b + cnt) * S);
       part_begin[p + 1] = sv_all.size();
     }
-    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; }
+    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; O.n_near += R.n_near; }
   }
   for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
   if (run_pca)                                                                             // run_eigenstrat_smartpca
@@ -988,7 +993,8 @@ void do_correction(const run_context& C, survivors_of_run& O)
   std::ofstream js(opt.output_directory + "/summary.json");
   js << "{\"total_kmers\": " << total_kmers << ", \"n_sig\": " << n_sig << ", \"n_sig_control\": " << n_sig_control
      << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
-     << ", \"kept_case\": " << c_cases << ", \"kmer_size\": " << cfg.kmer_size << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
+     << ", \"kept_case\": " << c_cases << ", \"near_threshold\": " << O.n_near << ", \"kmer_size\": " << cfg.kmer_size
+     << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
 }
 
 } // namespace

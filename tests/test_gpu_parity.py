@@ -802,6 +802,7 @@ def test_full_size_config2_properties(K, oracle):
     ns = acc.finish()
     c = acc.read_counters()
     assert int(c[0]) == n and int(c[1]) == ns and int(c[2]) + int(c[3]) == ns
+    assert int(c[6]) == 0                                                 # no p-value within 1e-8 of the threshold
     got = acc.get()
     assert (np.diff(got["row"].astype(np.int64)) > 0).all()               # ascending, no duplicates
     assert (np.diff(got["kmer_lo"].astype(np.int64)) > 0).all()           # ascending k-mers
@@ -867,7 +868,7 @@ def test_full_size_config3_256_partitions(K, oracle):
     model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
     rng = np.random.default_rng(99)
     check_parts = {0, 255} | set(int(x) for x in rng.integers(1, 255, 4))
-    total = n_sig = n_ctrl = n_case = 0
+    total = n_sig = n_ctrl = n_case = n_near = 0
     per_part = []
     for p in range(parts):
         K._native.check(lib.kmd_synth_fill(SEED, p, 0, rows, nc, nk, 4, K.LAYOUT_TILED, mat.ld, mat.counts.ptr,
@@ -876,6 +877,7 @@ def test_full_size_config3_256_partitions(K, oracle):
         K.diff_observer(model, acc, THR).process(mat)
         c = acc.read_counters()
         assert int(c[0]) == rows and int(c[1]) == int(c[2]) + int(c[3]) and int(c[1]) < rows // 500
+        n_near += int(c[6])
         total += int(c[0]); n_sig += int(c[1]); n_ctrl += int(c[2]); n_case += int(c[3])
         per_part.append(int(c[1]))
         if p in check_parts:
@@ -886,6 +888,7 @@ def test_full_size_config3_256_partitions(K, oracle):
             starts = np.concatenate([[0, rows - 2048], rng.integers(0, rows - 2048, 6)])
             replay_windows(K, oracle, p, rows, nc, nk, 1, tot, got, starts)
     assert total == 10_000_000_000 and n_sig == n_ctrl + n_case == sum(per_part)
+    assert n_near == 0            # KMD_CNT_NEAR_THRESHOLD: in 10^10 rows no p-value within 1e-8 of the threshold
     assert 0.5e-4 < n_sig / total < 5e-4
     assert max(per_part) < 1.5 * (n_sig / parts) and min(per_part) > 0.6 * (n_sig / parts)     # partitions look alike
 
@@ -901,7 +904,7 @@ def test_full_size_config4_k63_50v50(K, oracle):
     obs.process(mat)
     ns = acc.finish()
     c = acc.read_counters()
-    assert int(c[0]) == rows and ns == int(c[2]) + int(c[3]) and ns > 100
+    assert int(c[0]) == rows and ns == int(c[2]) + int(c[3]) and ns > 100 and int(c[6]) == 0
     got = acc.get()
     assert (np.diff(got["kmer_hi"].astype(np.int64)) > 0).all()      # 128-bit k-mers ascending (hi limb strictly)
     assert int(c[5]) > 0                                             # 50-sample sums do leave the 10000-entry table
@@ -919,7 +922,7 @@ def test_full_size_config5_popstrat_100v100(K, oracle):
     K.diff_observer(model, acc, THR).process(mat)
     ns = acc.finish()
     got = acc.get()
-    assert ns > 100
+    assert ns > 100 and int(acc.read_counters()[6]) == 0
     rng = np.random.default_rng(8)
     Z = rng.normal(0, 0.1, size=(nc + nk, 10))
     pop = K.pop_strat_corrector(nc, nk, tot[:nc], tot[nc:], npc, Z)

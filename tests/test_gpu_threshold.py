@@ -1,0 +1,84 @@
+"""The guard of `p <= threshold` (include/kmdiff/merge.hpp:78; SURVEY 7, hard part 2): a bit-identical survivor set
+cannot rest on two libms agreeing in the last bit.  Rows whose p-value lies within 1e-8 (relative) of the
+threshold are counted (KMD_CNT_NEAR_THRESHOLD) and decided with correctly rounded log / exp (kmd_ddmath.h),
+i.e. with the value a glibc-built reference computes wherever glibc's own four calls were correctly rounded
+(> 98 % of rows, tests/test_rounded_math.py).  Here the threshold is put ON a row's p-value, and one ulp to
+either side, and the device's survivor set is held against the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as OL
+from test_gpu_parity import totals_of
+
+pytestmark = pytest.mark.gpu
+SEED = 0x6B6D64696666
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kmdiff_amd as K
+    assert K.device_count() >= 1, "no GPU: the HIP path has no CPU fallback"
+    return K
+
+
+def survivors(K, model, mat, n, thr):
+    acc = K.SurvivorAccumulator(n)
+    K.diff_observer(model, acc, thr).process(mat)
+    ns = acc.finish()
+    got = acc.get()
+    return got["row"].astype(np.int64), got["pvalue"], acc.read_counters()
+
+
+def test_threshold_placed_on_a_p_value(K, oracle):
+    n, nc, nk = 60_000, 6, 6
+    host, _, _ = oracle.synth_rows(SEED, 3, 0, n, nc, nk, 4)
+    tcs, tks = totals_of(host, nc)
+    lf = oracle.lf_table(10000)
+    ref = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), lf, 1e-3)
+    rows, ps = ref["row"].astype(np.int64), ref["pvalue"]
+    assert len(rows) > 200
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, 10000)
+    mat = K.CountMatrix.from_host(host, K.LAYOUT_ROWS)
+    lib = K._native.lib()
+    # every reference p-value as the device would compute it for a near-threshold row: correctly rounded libm
+    sc = host[rows][:, :nc].sum(axis=1, dtype=np.uint64)
+    sk = host[rows][:, nc:].sum(axis=1, dtype=np.uint64)
+    p_rounded = np.array([lib.kmd_test_row_pvalue_rounded(C.c_void_p(model.handle), int(a), int(b)) for a, b in zip(sc, sk)])
+    inside = p_rounded >= 0                                          # (sums inside the log-factorial table)
+    agree = inside & (p_rounded == ps)
+    assert agree.sum() >= 0.95 * inside.sum()                        # glibc gave the rounded value itself
+    order = np.argsort(ps)
+    picks = [i for i in order[:: max(1, len(order) // 40)] if inside[i] and ps[i] > 1e-300][:40]
+    n_checked = 0
+    for i in picks:
+        for thr in (ps[i], np.nextafter(ps[i], 0.0), np.nextafter(ps[i], 1.0)):
+            got_rows, got_p, c = survivors(K, model, mat, n, float(thr))
+            assert int(c[K._native.CNT_NEAR_THRESHOLD]) >= 1         # the row on the threshold was seen
+            # what the device must do: decide near rows by the rounded value, everything else is far away
+            want_rounded = set(rows[(np.where(inside, p_rounded, ps) <= thr)].tolist())
+            assert set(got_rows.tolist()) == want_rounded
+            if agree[i]:
+                # ... which is the reference's own decision wherever glibc returned the rounded value
+                near_band = np.abs(ps - thr) <= 1e-8 * thr
+                if agree[near_band].all():
+                    assert set(got_rows.tolist()) == set(rows[ps <= thr].tolist())
+                    n_checked += 1
+            # and the p-value reported for the row on the threshold is the rounded one, bit for bit
+            k = np.nonzero(got_rows == rows[i])[0]
+            if len(k):
+                assert got_p[k[0]] == p_rounded[i]
+    assert n_checked >= 0.9 * 3 * len(picks)
+
+
+def test_no_near_threshold_rows_in_an_ordinary_partition(K, oracle):
+    """10^7 synthetic rows at the default threshold: the counter stays at zero (nothing to resolve)."""
+    n, nc, nk = 10_000_000, 20, 20
+    mat = K.synth_matrix(SEED, 1, n, nc, nk, 4, K.LAYOUT_TILED)
+    tot = K.column_sums(mat)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(n // 100)
+    K.diff_observer(model, acc, 0.05 / 100000).process(mat)
+    c = acc.read_counters()
+    assert int(c[K._native.CNT_SIG]) > 100 and int(c[K._native.CNT_NEAR_THRESHOLD]) == 0
