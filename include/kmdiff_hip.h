@@ -325,6 +325,11 @@ void kmd_pca_destroy(kmd_pca* pca);
 /* Sampler::sample over one tile (merge.hpp:150-152): records the presence pattern of the
  * sampled rows, in row order.  The tile needs its k-mer column. */
 int kmd_pca_sample(kmd_pca* pca, const kmd_tile* tile, void* stream);
+/* The same sampling for the fused merge (kmd_merge_filter: no matrix, no tile): the sampled k-mers are found
+ * in the per-sample streams (arguments as kmd_merge_filter), in ascending k-mer order -- the rows, their
+ * order and every sum over them are those kmd_pca_sample records from the merged matrix.  Synchronous. */
+int kmd_pca_sample_streams(kmd_pca* pca, int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                           const uint32_t* d_counts, const uint64_t* offsets, void* stream);
 int kmd_pca_count(const kmd_pca* pca, uint64_t* n_sampled);
 /* xtx_host[S*S] (row-major, host) = sum over this object's sampled rows of x x^T, summed in a
  * fixed order.  Ranks add their matrices (rank order) before kmd_pca_eigen. */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "kmd_pca_create": (_i, [C.POINTER(C.c_void_p), _i, C.c_double, _u64, _i, _sz]),
     "kmd_pca_destroy": (None, [_vp]),
     "kmd_pca_sample": (_i, [_vp, _vp, _vp]),
+    "kmd_pca_sample_streams": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "kmd_pca_count": (_i, [_vp, C.POINTER(_u64)]),
     "kmd_pca_gram": (_i, [_vp, _vp, _vp]),
     "kmd_pca_eigen": (_i, [_i, _vp, _i, _vp, _vp]),

@@ -268,30 +268,9 @@ __global__ void __launch_bounds__(1024) k_jacobi(double* __restrict__ A, double*
   if (tid == 0) *sweeps_done = sweep;
 }
 
-template <typename CT>
-int pca_sample_tile(kmd_pca* P, const kmd_tile* tile, hipStream_t st)
+// room for `extra` more sampled rows (the store grows by doubling)
+int pca_reserve(kmd_pca* P, size_t total, hipStream_t st)
 {
-  const size_t n_rows = tile->n_rows;
-  const size_t n_tiles = (n_rows + 63) / 64;
-  void *p_cnt = nullptr, *p_off = nullptr, *p_tmp = nullptr;
-  struct guard { void** p; ~guard() { if (*p) kmd::scratch_free(*p); } } g1{ &p_cnt }, g2{ &p_off }, g3{ &p_tmp };
-  KMD_HIP(kmd::scratch_alloc(&p_cnt, (n_tiles + 1) * 4));
-  KMD_HIP(kmd::scratch_alloc(&p_off, (n_tiles + 1) * 4));
-  uint32_t* cnt = static_cast<uint32_t*>(p_cnt);
-  uint32_t* off = static_cast<uint32_t*>(p_off);
-  KMD_HIP(hipMemsetAsync(cnt + n_tiles, 0, 4, st));
-  size_t grid = (n_tiles + 3) / 4;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_pca_count, dim3((unsigned)grid), dim3(256), 0, st, tile->d_kmer_lo, tile->d_kmer_hi, n_rows, P->seed,
-                     P->thresh, P->all_rows, cnt);
-  KMD_HIP(hipGetLastError());
-  size_t tmp = 0;
-  KMD_HIP(rocprim::exclusive_scan(nullptr, tmp, cnt, off, 0u, n_tiles + 1, rocprim::plus<uint32_t>(), st));
-  KMD_HIP(kmd::scratch_alloc(&p_tmp, tmp ? tmp : 1));
-  KMD_HIP(rocprim::exclusive_scan(p_tmp, tmp, cnt, off, 0u, n_tiles + 1, rocprim::plus<uint32_t>(), st));
-  uint32_t total = 0;
-  KMD_HIP(hipMemcpyAsync(&total, off + n_tiles, 4, hipMemcpyDeviceToHost, st));
-  KMD_HIP(hipStreamSynchronize(st));
   if (P->n + total > P->cap)                             // grow: at least double
   {
     const size_t want = std::max(P->cap * 2, P->n + (size_t)total);
@@ -317,6 +296,122 @@ int pca_sample_tile(kmd_pca* P, const kmd_tile* tile, hipStream_t st)
     (void)hipFree(P->d_bits); (void)hipFree(P->d_f); (void)hipFree(P->d_mu);
     P->d_bits = nb; P->d_f = nf; P->d_mu = nm; P->cap = want;
   }
+  return KMD_OK;
+}
+
+// ---- sampling without a matrix (the fused merge, kmd_tilemerge.hip): the sampled k-mers are found in
+// the per-sample streams themselves.  A record is kept when its k-mer is sampled (the same hash of
+// (seed, k-mer) as k_pca_count); the kept k-mers are sorted and de-duplicated (a k-mer has a record in
+// every sample that holds it) -- ascending k-mer order IS the row order of the merged matrix, so the
+// sampled rows, their order and every sum over them are those of the matrix path; the presence pattern
+// of a sampled k-mer is one binary search per sample.
+__global__ void __launch_bounds__(256) k_pca_scan_streams(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, size_t n,
+                                                          uint64_t seed, uint64_t thresh, bool all_rows,
+                                                          uint64_t* __restrict__ out_lo, uint64_t* __restrict__ out_hi, size_t cap,
+                                                          unsigned long long* __restrict__ counter)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n_round = (n + stride - 1) / stride * stride;
+  const uint32_t lane = threadIdx.x & 63;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
+  {
+    const bool in = i < n;
+    const uint64_t k = in ? lo[i] : 0ull, kh = (in && hi) ? hi[i] : 0ull;
+    const bool s = in && pca_sampled(seed, thresh, all_rows, k, kh);
+    const unsigned long long m = __ballot(s);
+    if (!m) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
+    const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    if (s && out_lo && at < cap) { out_lo[at] = k; if (out_hi) out_hi[at] = kh; }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pca_heads(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, size_t n,
+                                                   uint32_t* __restrict__ flag)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || lo[i] != lo[i - 1] || (hi && hi[i] != hi[i - 1])) ? 1u : 0u;
+}
+
+// one wave per distinct sampled k-mer: its presence pattern (binary search in every stream), mu and f
+__global__ void __launch_bounds__(256) k_pca_presence(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                      const uint64_t* __restrict__ offs, int S, int W,
+                                                      const uint64_t* __restrict__ s_lo, const uint64_t* __restrict__ s_hi,
+                                                      const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos,
+                                                      size_t n_sorted, int diploid, size_t base, size_t cap,
+                                                      uint32_t* __restrict__ bits, double* __restrict__ out_f, double* __restrict__ out_mu)
+{
+  const size_t n_waves = (size_t)gridDim.x * 4;
+  const uint32_t lane = threadIdx.x & 63;
+  for (size_t j = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < n_sorted; j += n_waves)
+  {
+    if (!flag[j]) continue;                               // (wave-uniform) a repeat of the k-mer before it
+    const size_t slot = base + pos[j];
+    if (slot >= cap) continue;
+    const uint64_t k = s_lo[j], kh = s_hi ? s_hi[j] : 0ull;
+    uint32_t present = 0;
+    for (int w64 = 0; w64 * 64 < S; ++w64)
+    {
+      const int smp = w64 * 64 + (int)lane;
+      bool g = false;
+      if (smp < S)
+      {
+        size_t lo = (size_t)offs[smp], hi = (size_t)offs[smp + 1];
+        const size_t end = hi;
+        while (lo < hi)
+        {
+          const size_t mid = lo + ((hi - lo) >> 1);
+          const bool less = keys_hi ? (keys_hi[mid] < kh || (keys_hi[mid] == kh && keys[mid] < k)) : keys[mid] < k;
+          if (less) lo = mid + 1; else hi = mid;
+        }
+        g = lo < end && keys[lo] == k && (!keys_hi || keys_hi[lo] == kh);     // a record = a count > 0 (fvadjust: cc = cc > 0)
+      }
+      const unsigned long long pm = __ballot(g);
+      present += (uint32_t)__popcll(pm);
+      if (lane == 0)
+      {
+        bits[slot * W + 2 * w64] = (uint32_t)pm;
+        if (2 * w64 + 1 < W) bits[slot * W + 2 * w64 + 1] = (uint32_t)(pm >> 32);
+      }
+    }
+    if (lane == 0)
+    {
+      const double mu = (double)present / (double)S;                  // ymean
+      const double p = diploid ? 1.0 - sqrt(1.0 - mu) : mu;           // smartpca.c:1784-1791
+      const double y = p * (1.0 - p);
+      out_mu[slot] = mu;
+      out_f[slot] = y > 0.0 ? 1.0 / sqrt(y) : 1.0;                    // yfancy (x is all zero when y == 0)
+    }
+  }
+}
+
+template <typename CT>
+int pca_sample_tile(kmd_pca* P, const kmd_tile* tile, hipStream_t st)
+{
+  const size_t n_rows = tile->n_rows;
+  const size_t n_tiles = (n_rows + 63) / 64;
+  void *p_cnt = nullptr, *p_off = nullptr, *p_tmp = nullptr;
+  struct guard { void** p; ~guard() { if (*p) kmd::scratch_free(*p); } } g1{ &p_cnt }, g2{ &p_off }, g3{ &p_tmp };
+  KMD_HIP(kmd::scratch_alloc(&p_cnt, (n_tiles + 1) * 4));
+  KMD_HIP(kmd::scratch_alloc(&p_off, (n_tiles + 1) * 4));
+  uint32_t* cnt = static_cast<uint32_t*>(p_cnt);
+  uint32_t* off = static_cast<uint32_t*>(p_off);
+  KMD_HIP(hipMemsetAsync(cnt + n_tiles, 0, 4, st));
+  size_t grid = (n_tiles + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pca_count, dim3((unsigned)grid), dim3(256), 0, st, tile->d_kmer_lo, tile->d_kmer_hi, n_rows, P->seed,
+                     P->thresh, P->all_rows, cnt);
+  KMD_HIP(hipGetLastError());
+  size_t tmp = 0;
+  KMD_HIP(rocprim::exclusive_scan(nullptr, tmp, cnt, off, 0u, n_tiles + 1, rocprim::plus<uint32_t>(), st));
+  KMD_HIP(kmd::scratch_alloc(&p_tmp, tmp ? tmp : 1));
+  KMD_HIP(rocprim::exclusive_scan(p_tmp, tmp, cnt, off, 0u, n_tiles + 1, rocprim::plus<uint32_t>(), st));
+  uint32_t total = 0;
+  KMD_HIP(hipMemcpyAsync(&total, off + n_tiles, 4, hipMemcpyDeviceToHost, st));
+  KMD_HIP(hipStreamSynchronize(st));
+  { const int rc_g = pca_reserve(P, total, st); if (rc_g != KMD_OK) return rc_g; }
   if (total)
   {
     hipLaunchKernelGGL((k_pca_emit<CT>), dim3((unsigned)grid), dim3(256), 0, st, static_cast<const CT*>(tile->d_counts),
@@ -384,6 +479,85 @@ int kmd_pca_sample(kmd_pca* P, const kmd_tile* tile, void* stream)
     case 4: return pca_sample_tile<uint32_t>(P, tile, st);
     default: kmd::set_error("kmd_pca_sample: count_bytes must be 1, 2 or 4"); return KMD_E_INVALID;
   }
+}
+
+// Sampler::sample for the fused merge (no matrix): the same rows, found in the streams (see k_pca_scan_streams).
+int kmd_pca_sample_streams(kmd_pca* P, int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
+                           const uint32_t* d_counts, const uint64_t* offsets, void* stream)
+{
+  (void)d_counts;                                          // a record means count > 0: the keys are all that is read
+  KMD_REQUIRE(P && offsets && n_samples == P->S, "kmd_pca_sample_streams: arguments");
+  const size_t n = (size_t)offsets[n_samples];
+  if (n == 0) return KMD_OK;
+  KMD_REQUIRE(d_kmers, "kmd_pca_sample_streams: NULL k-mers");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<void*> held;
+  struct guard { std::vector<void*>& h; ~guard() { for (void* q : h) kmd::scratch_free(q); } } g{ held };
+  auto take = [&](void** p, size_t bytes) -> hipError_t { const hipError_t e = kmd::scratch_alloc(p, bytes ? bytes : 1); if (e == hipSuccess) held.push_back(*p); return e; };
+  void *p_cnt = nullptr, *p_offs = nullptr;
+  KMD_HIP(take(&p_cnt, 8));
+  KMD_HIP(take(&p_offs, ((size_t)n_samples + 1) * 8));
+  KMD_HIP(hipMemsetAsync(p_cnt, 0, 8, st));
+  KMD_HIP(hipMemcpyAsync(p_offs, offsets, ((size_t)n_samples + 1) * 8, hipMemcpyHostToDevice, st));
+  unsigned long long* d_cnt = static_cast<unsigned long long*>(p_cnt);
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+  // pass 1: how many records are sampled; pass 2: list them
+  hipLaunchKernelGGL(k_pca_scan_streams, dim3(grid), dim3(256), 0, st, d_kmers, d_kmers_hi, n, P->seed, P->thresh, P->all_rows,
+                     (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)0, d_cnt);
+  unsigned long long n_rec = 0;
+  KMD_HIP(hipMemcpyAsync(&n_rec, d_cnt, 8, hipMemcpyDeviceToHost, st));
+  KMD_HIP(hipStreamSynchronize(st));
+  if (n_rec == 0) return KMD_OK;
+  KMD_REQUIRE(n_rec < 0xFFFFFFFFull, "kmd_pca_sample_streams: too many sampled records");
+  const bool two = d_kmers_hi != nullptr;
+  void *p_lo = nullptr, *p_hi = nullptr, *p_lo2 = nullptr, *p_hi2 = nullptr, *p_flag = nullptr, *p_pos = nullptr, *p_tmp = nullptr;
+  KMD_HIP(take(&p_lo, n_rec * 8)); KMD_HIP(take(&p_lo2, n_rec * 8));
+  if (two) { KMD_HIP(take(&p_hi, n_rec * 8)); KMD_HIP(take(&p_hi2, n_rec * 8)); }
+  KMD_HIP(take(&p_flag, (n_rec + 1) * 4)); KMD_HIP(take(&p_pos, (n_rec + 1) * 4));
+  KMD_HIP(hipMemsetAsync(p_cnt, 0, 8, st));
+  hipLaunchKernelGGL(k_pca_scan_streams, dim3(grid), dim3(256), 0, st, d_kmers, d_kmers_hi, n, P->seed, P->thresh, P->all_rows,
+                     static_cast<uint64_t*>(p_lo), static_cast<uint64_t*>(p_hi), (size_t)n_rec, d_cnt);
+  KMD_HIP(hipGetLastError());
+  // ascending (hi, lo): LSD -- by the low limb carrying the high one, then stably by the high limb
+  uint64_t *lo = static_cast<uint64_t*>(p_lo), *hi = static_cast<uint64_t*>(p_hi), *lo2 = static_cast<uint64_t*>(p_lo2), *hi2 = static_cast<uint64_t*>(p_hi2);
+  size_t tmp = 0, tmp2 = 0;
+  if (!two)
+  {
+    KMD_HIP(rocprim::radix_sort_keys(nullptr, tmp, lo, lo2, (size_t)n_rec, 0, 64, st));
+    KMD_HIP(take(&p_tmp, tmp));
+    KMD_HIP(rocprim::radix_sort_keys(p_tmp, tmp, lo, lo2, (size_t)n_rec, 0, 64, st));
+    lo = lo2;
+  }
+  else
+  {
+    KMD_HIP(rocprim::radix_sort_pairs(nullptr, tmp, lo, lo2, hi, hi2, (size_t)n_rec, 0, 64, st));
+    KMD_HIP(take(&p_tmp, tmp));
+    KMD_HIP(rocprim::radix_sort_pairs(p_tmp, tmp, lo, lo2, hi, hi2, (size_t)n_rec, 0, 64, st));
+    KMD_HIP(rocprim::radix_sort_pairs(nullptr, tmp2, hi2, hi, lo2, lo, (size_t)n_rec, 0, 64, st));
+    void* p_tmp2 = nullptr;
+    KMD_HIP(take(&p_tmp2, tmp2));
+    KMD_HIP(rocprim::radix_sort_pairs(p_tmp2, tmp2, hi2, hi, lo2, lo, (size_t)n_rec, 0, 64, st));
+  }
+  uint32_t* flag = static_cast<uint32_t*>(p_flag);
+  uint32_t* pos = static_cast<uint32_t*>(p_pos);
+  hipLaunchKernelGGL(k_pca_heads, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, lo, two ? hi : nullptr, (size_t)n_rec, flag);
+  KMD_HIP(hipMemsetAsync(flag + n_rec, 0, 4, st));
+  size_t tmp3 = 0;
+  void* p_tmp3 = nullptr;
+  KMD_HIP(rocprim::exclusive_scan(nullptr, tmp3, flag, pos, 0u, (size_t)n_rec + 1, rocprim::plus<uint32_t>(), st));
+  KMD_HIP(take(&p_tmp3, tmp3));
+  KMD_HIP(rocprim::exclusive_scan(p_tmp3, tmp3, flag, pos, 0u, (size_t)n_rec + 1, rocprim::plus<uint32_t>(), st));
+  uint32_t total = 0;
+  KMD_HIP(hipMemcpyAsync(&total, pos + n_rec, 4, hipMemcpyDeviceToHost, st));
+  KMD_HIP(hipStreamSynchronize(st));
+  { const int rc_g = pca_reserve(P, total, st); if (rc_g != KMD_OK) return rc_g; }
+  const unsigned grid_p = (unsigned)std::min<size_t>(((size_t)n_rec + 3) / 4, 8192);
+  hipLaunchKernelGGL(k_pca_presence, dim3(grid_p), dim3(256), 0, st, d_kmers, d_kmers_hi, static_cast<const uint64_t*>(p_offs), P->S, P->W,
+                     lo, two ? hi : nullptr, flag, pos, (size_t)n_rec, P->diploid, P->n, P->cap, P->d_bits, P->d_f, P->d_mu);
+  KMD_HIP(hipGetLastError());
+  KMD_HIP(hipStreamSynchronize(st));
+  P->n += total;
+  return KMD_OK;
 }
 
 int kmd_pca_count(const kmd_pca* P, uint64_t* n_sampled)

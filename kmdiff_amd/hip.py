@@ -588,6 +588,15 @@ class PopulationPCA:
         t = mat.tile()
         check(lib().kmd_pca_sample(self.handle, C.byref(t), None), "kmd_pca_sample")
 
+    def sample_streams(self, streams):
+        """The same rows for the fused merge (no matrix): sampled k-mers are looked up in the per-sample
+        streams (a StreamSet, or a list of streams as merge_partition takes)."""
+        ss = streams if isinstance(streams, StreamSet) else StreamSet(streams)
+        if ss.n_samples != self.n_samples:
+            raise ValueError("%d streams, the PCA has %d samples" % (ss.n_samples, self.n_samples))
+        dk, dh, dc = ss.ptrs()
+        check(lib().kmd_pca_sample_streams(self.handle, ss.n_samples, dk, dh, dc, ss.offs.ctypes.data, None), "kmd_pca_sample_streams")
+
     def count(self):
         n = C.c_uint64(0)
         check(lib().kmd_pca_count(self.handle, C.byref(n)), "kmd_pca_count")

@@ -578,3 +578,71 @@ std::string kmer_to_string(uint64_t kmer, size_t k)
 }
 
 } // namespace kmd_host
+
+
+namespace kmd_host {
+
+// ---- KFF 1.0 (see kmtricks_io.hpp) -------------------------------------------------------------
+namespace {
+void put_be(std::FILE* f, uint64_t v, int bytes)
+{
+  unsigned char b[8];
+  for (int i = 0; i < bytes; ++i) b[i] = (unsigned char)(v >> (8 * (bytes - 1 - i)));
+  if (std::fwrite(b, 1, (size_t)bytes, f) != (size_t)bytes) throw std::runtime_error("KFF: write failed");
+}
+void put_var(std::FILE* f, const char* name, uint64_t value)
+{
+  if (std::fwrite(name, 1, std::strlen(name) + 1, f) != std::strlen(name) + 1) throw std::runtime_error("KFF: write failed");
+  put_be(f, value, 8);
+}
+}
+
+kff_writer::kff_writer(const std::string& path, size_t kmer_size) : m_k(kmer_size)
+{
+  m_f = std::fopen(path.c_str(), "wb");
+  if (!m_f) throw std::runtime_error("cannot write " + path);
+  m_open = true;
+  std::fputs("KFF", m_f);
+  put_be(m_f, 1, 1); put_be(m_f, 0, 1);                   // version 1.0
+  put_be(m_f, (0u << 6) | (1u << 4) | (3u << 2) | 2u, 1); // write_encoding({0, 1, 3, 2}): A C G T
+  put_be(m_f, 0, 1); put_be(m_f, 0, 1);                   // k-mers not declared unique / canonical
+  put_be(m_f, 0, 4);                                      // no free block
+  std::fputc('v', m_f);                                   // Section_GV: k, max, data_size (kff_utils.hpp:43-47)
+  put_be(m_f, 3, 8);
+  put_var(m_f, "k", m_k); put_var(m_f, "max", 1); put_var(m_f, "data_size", 0);
+  std::fputc('r', m_f);                                   // Section_Raw
+  m_count_at = std::ftell(m_f);
+  put_be(m_f, 0, 8);                                      // number of blocks: patched by close()
+}
+
+void kff_writer::write(uint64_t kmer_lo, uint64_t kmer_hi)
+{
+  const size_t nbytes = (m_k + 3) / 4;                    // write_compacted_sequence(encoded, k, nullptr)
+  unsigned char b[16];
+  for (size_t i = 0; i < nbytes; ++i)
+  {
+    const size_t shift = 8 * (nbytes - 1 - i);            // byte i holds bits [shift, shift + 8) of the 2k-bit value
+    b[i] = (unsigned char)(shift >= 64 ? (kmer_hi >> (shift - 64)) : shift == 0 ? kmer_lo : ((kmer_lo >> shift) | (shift > 56 ? (kmer_hi << (64 - shift)) : 0)));
+  }
+  if (std::fwrite(b, 1, nbytes, m_f) != nbytes) throw std::runtime_error("KFF: write failed");
+  ++m_blocks;
+}
+
+void kff_writer::close()
+{
+  if (!m_open) return;
+  m_open = false;
+  const long end = std::ftell(m_f);
+  std::fseek(m_f, m_count_at, SEEK_SET);
+  put_be(m_f, m_blocks, 8);
+  std::fseek(m_f, end, SEEK_SET);
+  std::fputc('v', m_f);                                   // footer
+  put_be(m_f, 2, 8);
+  put_var(m_f, "first_index", 0);
+  put_var(m_f, "footer_size", 9 + 2 * (12 + 8));
+  std::fputs("KFF", m_f);
+  std::fclose(m_f);
+  m_f = nullptr;
+}
+
+} // namespace kmd_host

@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,34 @@ struct matrix_rows
 };
 matrix_rows read_matrix_file(const std::string& path);
 void write_matrix_file(const std::string& path, const matrix_rows& m);
+
+// KffWriter (include/kmdiff/kff_utils.hpp:32-107) over kff-cpp-api's Kff_file / Section_GV / Section_Raw, written
+// out by hand from the KFF 1.0 format description (kff-cpp-api is an un-vendored dependency of the reference;
+// its pinned commit is not recoverable -- this writer is UNPINNED against it):
+//   header   "KFF" | version 1.0 | encoding byte (A C G T -> 2 bits each; the reference passes {0, 1, 3, 2}:
+//            0b00011110) | uniqueness 0 | canonicity 0 | free block size 0 (u32, big endian)
+//   'v'      3 variables (u64 count, then name\0 + u64 value, big endian): k, max = 1, data_size = 0
+//   'r'      u64 number of blocks; one block per k-mer: with max = 1 there is no count field, the sequence is
+//            ceil(k / 4) bytes, 2 bits per nucleotide, first nucleotide most significant, right-aligned (the
+//            FIRST byte holds the k % 4 leading nucleotides), no data bytes
+//   footer   'v' with first_index = 0 and footer_size, then "KFF"
+// The reference's codes (A 0, C 1, G 3, T 2) are kmtricks' own 2-bit codes, so a k-mer's compacted sequence is
+// its packed value, big endian.
+class kff_writer
+{
+ public:
+  kff_writer(const std::string& path, size_t kmer_size);
+  void write(uint64_t kmer_lo, uint64_t kmer_hi = 0);     // kmer_hi: bits 64.. for 32 < k <= 64
+  void close();
+  ~kff_writer() { if (m_open) close(); }
+ private:
+  struct impl;
+  std::FILE* m_f = nullptr;
+  size_t m_k = 0;
+  uint64_t m_blocks = 0;
+  long m_count_at = 0;
+  bool m_open = false;
+};
 std::vector<std::string> matrix_paths(const std::string& run_dir);    // sorted; empty when there is no matrices/ content
 
 // ---- survivor files: <out>/partitions/p<i>_uncorrected and p<i>_popstrat_uncorrected

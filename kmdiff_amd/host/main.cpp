@@ -36,6 +36,7 @@
 #include <thread>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -57,8 +58,8 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   std::string model_lib_path, model_config;          // --cmodel / --config: a user's IModel plugin (cli.cpp:246-262)
   size_t nb_controls = 0, nb_cases = 0, cutoff = 100000, log_size = 10000, npc = 2, max_iteration = 0;
   double threshold = 0.05;
-  bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false;
-  bool no_matrix = std::getenv("KMD_HOST_SUMS") != nullptr;   // --no-matrix: merge to (k-mer, control sum, case sum) where that is all stage 1 needs
+  bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false, kff = false;
+  bool matrix_path = std::getenv("KMD_HOST_MATRIX") != nullptr;   // --matrix-path: k-way merge into the count matrix, then K1 (default: merge fused with the test)
   double kmer_pca = 0.001;                  // proportion of k-mers sampled for the PCA (cli.cpp:286-289)
   size_t ploidy = 2, seed = 0;              // cli.cpp:298-302, :349-351
   size_t threads = std::max(1u, std::thread::hardware_concurrency());   // -t: host threads decoding the k-mer files (cli.cpp:72-76)
@@ -104,10 +105,11 @@ void usage()
             "  --devices INT      number of GPUs, 0 = all: partition p goes to GPU p mod N {1}\n"
             "  --keep-tmp         keep partitions/p<i>_uncorrected (+ options.bin): a later run resumes from them\n"
             "  --save-sk          write the significant rows to positive_kmer_matrix/matrices/matrix_<p>.count.lz4\n"
-            "  --no-matrix        (k <= 32, <= 256 samples, no device PCA / --save-sk / --cmodel) merge the streams straight to each\n"
-            "                     k-mer's control and case count sums instead of the count matrix; same output\n"
+            "  --matrix-path      k-way merge into the count matrix, then the test (default: merge fused with the test, no\n"
+            "                     matrix -- same output; --cmodel and the matrices/ feed always take the matrix path)\n"
             "  -t/--threads INT   host threads decoding the per-sample k-mer files {all}\n"
-            "  -f, -m, -r: accepted for compatibility, ignored");
+            "  -f/--kff-output    control_kmers.kff / case_kmers.kff (k-mers only) instead of the two FASTA files\n"
+            "  -m, -r: accepted for compatibility, ignored");
 }
 
 diff_options parse(int argc, char** argv)
@@ -136,7 +138,8 @@ diff_options parse(int argc, char** argv)
     else if (a == "--devices") o.devices = std::stoi(need(i));
     else if (a == "--keep-tmp") o.keep_tmp = true;
     else if (a == "--save-sk") o.save_sk = true;
-    else if (a == "--no-matrix") o.no_matrix = true;
+    else if (a == "--no-matrix") {}                       // (the default now)
+    else if (a == "--matrix-path") o.matrix_path = true;
     else if (a == "--kmer-pca") o.kmer_pca = std::stod(need(i));
     else if (a == "--ploidy") o.ploidy = std::stoull(need(i));
     else if (a == "--random-seed") o.seed = std::stoull(need(i));
@@ -149,9 +152,7 @@ diff_options parse(int argc, char** argv)
       std::fprintf(stderr, "[kmdiff-hip] note: --epsilon is accepted for compatibility; like the reference's it has no effect\n");
     }
     else if (a == "-v" || a == "--verbose" || a == "--gender" || a == "--learning-rate") (void)need(i);
-    else if (a == "-f" || a == "--kff-output")
-      std::fprintf(stderr, "[kmdiff-hip] warning: KFF output is not part of this build (kff-cpp-api is an un-vendored, un-pinned "
-                           "dependency of the reference); writing FASTA\n");
+    else if (a == "-f" || a == "--kff-output") o.kff = true;          // cli.cpp: control_kmers.kff / case_kmers.kff
     else if (a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
              a == "--stand" || a == "--irls") {}
     else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
@@ -438,7 +439,9 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   dev_buf d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc, d_smk, d_sc;
   // --no-matrix: the streams go straight through merge + test (kmd_merge_filter); the count rows of the
   // survivors (pop-strat, --keep-tmp, --save-sk) are looked up in the streams afterwards
-  const bool use_sums = opt.no_matrix && !from_matrix && !plugin && !run_pca && S <= 1024;
+  // (the default; --matrix-path keeps the k-way merge into the count matrix + K1, which a --cmodel plugin and
+  // the matrices/ feed need anyway)
+  const bool use_sums = !opt.matrix_path && !from_matrix && !plugin && S <= 1024;
   size_t fused_cap = (size_t)1 << 16;                    // survivor sink of the fused path (grows on demand)
   // a ring of staging sets: the partition being processed and `depth` more being decoded.  K-mer
   // files: one partition ahead, its S files on this worker's share of the -t threads (deeper
@@ -549,7 +552,13 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     }
     size_t ns = 0;
     const size_t base = sv_all.size();
-    if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");             // merge.hpp:150-152
+    if (pca && sums_done)                                                                     // merge.hpp:150-152, from the streams
+    {
+      const device_input& Dp = dset[turn % 2];
+      ck(kmd_pca_sample_streams(pca, (int)S, (const uint64_t*)Dp.kmers.p, two_limbs ? (const uint64_t*)Dp.kmers_hi.p : nullptr,
+                                (const uint32_t*)Dp.counts.p, Dp.offs.data(), nullptr), "kmd_pca_sample_streams");
+    }
+    else if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");        // merge.hpp:150-152
     if (n_rows && plugin)
     {
       // diff_observer::process with the user's model (merge.hpp:68-103): the merged rows come
@@ -975,7 +984,15 @@ void do_correction(const run_context& C, survivors_of_run& O)
   for (size_t i = 0; i < n; ++i) order[i] = i;
   if (opt.correction == "benjamini" || opt.correction == "holm")
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return s_p[a] < s_p[b]; });
-  std::ofstream fc(opt.output_directory + "/control_kmers.fasta"), fk(opt.output_directory + "/case_kmers.fasta");
+  // aggregator.hpp:197: ".kff" or ".fasta"; a KFF file holds the k-mers only (kff_utils.hpp:49-56)
+  std::unique_ptr<kff_writer> kc, kk;
+  std::ofstream fc, fk;
+  if (opt.kff)
+  {
+    kc = std::make_unique<kff_writer>(opt.output_directory + "/control_kmers.kff", cfg.kmer_size);
+    kk = std::make_unique<kff_writer>(opt.output_directory + "/case_kmers.kff", cfg.kmer_size);
+  }
+  else { fc.open(opt.output_directory + "/control_kmers.fasta"); fk.open(opt.output_directory + "/case_kmers.fasta"); }
   size_t ic = 0, ik = 0;
   for (size_t i : order)
   {
@@ -983,11 +1000,18 @@ void do_correction(const run_context& C, survivors_of_run& O)
     const bool control = s_sign[i] == KMD_SIGN_CONTROL;                                     // aggregator.hpp:155-162
     std::ofstream& f = control ? fc : fk;
     size_t& idx = control ? ic : ik;
+    if (opt.kff)
+    {
+      (control ? kc : kk)->write(s_kmer[i], two_limbs ? sv_all.kmer_hi[i] : 0);
+      ++idx;
+      continue;
+    }
     char pv[64]; std::snprintf(pv, sizeof pv, "%g", s_p[i]);                               // {:g}
     f << '>' << idx << "_pval=" << pv << "_control=" << (uint64_t)s_mc[i] << "_case=" << shortest(s_mk[i]) << '\n'
       << (two_limbs ? kmer_to_string(sv_all.kmer_hi[i], s_kmer[i], cfg.kmer_size) : kmer_to_string(s_kmer[i], cfg.kmer_size)) << '\n';
     ++idx;
   }
+  if (opt.kff) { kc->close(); kk->close(); }
   std::fprintf(stderr, "[kmdiff-hip] Significant k-mers: %" PRIu64 " (control), %" PRIu64 " (case).\n", c_controls, c_cases);   // cmd/diff.hpp:259
   // machine-readable summary for tests and scripts
   std::ofstream js(opt.output_directory + "/summary.json");

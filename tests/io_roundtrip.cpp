@@ -1,7 +1,7 @@
 // Test harness (no GPU): reads a file with the host readers of kmdiff_amd/host/kmtricks_io.cpp and
 // writes it back with the host writers, so that tests/test_host_io.py can compare both directions
 // with the independent Python reader/writer of tests/kmtricks_files.py.
-//   io_roundtrip matrix <in> <out> | survivors <in> <out> | survivors16 <in> <out> | options <in> <out> | kmers <in> <out>
+//   io_roundtrip matrix <in> <out> | survivors <in> <out> | survivors16 <in> <out> | options <in> <out> | kmers <in> <out> | kff <in> <out>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -76,6 +76,20 @@ int main(int argc, char** argv)
       if (f.slots == 2) std::fwrite(kh.data(), 8, f.records, o);
       std::fwrite(ct.data(), 4, f.records, o);
       std::fclose(o);
+    }
+    else if (what == "kff")
+    {
+      // <in>: text, first line k, then one "lo hi" pair (decimal) per k-mer; <out>: the KFF file
+      std::FILE* i = std::fopen(in.c_str(), "r");
+      if (!i) return 1;
+      unsigned long long k = 0, lo = 0, hi = 0;
+      if (std::fscanf(i, "%llu", &k) != 1) return 1;
+      kmd_host::kff_writer w(out, (size_t)k);
+      size_t n = 0;
+      while (std::fscanf(i, "%llu %llu", &lo, &hi) == 2) { w.write(lo, hi); ++n; }
+      std::fclose(i);
+      w.close();
+      std::printf("kmers=%zu k=%llu\n", n, k);
     }
     else if (what == "options")
     {

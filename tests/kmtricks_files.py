@@ -219,3 +219,43 @@ def kmer_to_string2(hi, lo, k):
 
 def kmer_to_string(v, k):
     return "".join("ACTG"[(int(v) >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def read_kff(path):
+    """A KFF 1.0 file as kmdiff writes it (include/kmdiff/kff_utils.hpp:32-107: one global-variable section
+    with k / max / data_size, one raw section, max = 1 and data_size = 0): (variables, encoding byte, k-mers
+    as strings).  Written from the format description -- kff-cpp-api is not in the tree: UNPINNED."""
+    with open(path, "rb") as f:
+        b = f.read()
+    assert b[:3] == b"KFF" and b[-3:] == b"KFF", "signature"
+    major, minor, enc, uniq, canon = b[3], b[4], b[5], b[6], b[7]
+    assert (major, minor) == (1, 0) and uniq == 0 and canon == 0
+    free = struct.unpack(">I", b[8:12])[0]
+    pos = 12 + free
+    letters = [None] * 4
+    for nt, shift in zip("ACGT", (6, 4, 2, 0)):
+        letters[(enc >> shift) & 3] = nt
+    assert None not in letters, "encoding is not a permutation"
+    variables, kmers = {}, []
+    while pos < len(b) - 3:
+        kind = chr(b[pos]); pos += 1
+        if kind == "v":
+            nv = struct.unpack(">Q", b[pos:pos + 8])[0]; pos += 8
+            for _ in range(nv):
+                end = b.index(b"\0", pos)
+                name = b[pos:end].decode(); pos = end + 1
+                variables[name] = struct.unpack(">Q", b[pos:pos + 8])[0]; pos += 8
+        elif kind == "r":
+            k, mx, ds = variables["k"], variables["max"], variables["data_size"]
+            assert mx == 1 and ds == 0
+            nb = struct.unpack(">Q", b[pos:pos + 8])[0]; pos += 8
+            nbytes = (k + 3) // 4
+            for _ in range(nb):
+                v = int.from_bytes(b[pos:pos + nbytes], "big"); pos += nbytes
+                assert v >> (2 * k) == 0, "bits above the sequence"
+                kmers.append("".join(letters[(v >> (2 * (k - 1 - i))) & 3] for i in range(k)))
+        else:
+            raise AssertionError("unknown section %r at %d" % (kind, pos - 1))
+    assert pos == len(b) - 3
+    assert variables.get("first_index") == 0 and variables.get("footer_size") == 9 + 2 * (12 + 8)
+    return variables, enc, kmers

@@ -32,11 +32,13 @@ def read_fasta(path):
 
 
 def fmt_shortest(v):
-    for prec in range(1, 18):
-        s = "%.*g" % (prec, v)
-        if float(s) == v:
-            return s
-    return repr(v)
+    """fmt's {} for a double: shortest round-trip digits, fixed notation for 1e-4 <= |v| < 1e16 (no trailing .0)"""
+    r = repr(float(v))                                     # shortest round-trip digits (David Gay), like fmt
+    if "e" in r or "inf" in r or "nan" in r:
+        m, e = r.split("e")
+        digits = m.replace(".", "").replace("-", "").rstrip("0") or "0"
+        return ("-" if v < 0 else "") + digits[0] + ("." + digits[1:] if len(digits) > 1 else "") + "e%s%02d" % ("-" if int(e) < 0 else "+", abs(int(e)))
+    return r[:-2] if r.endswith(".0") else r
 
 
 def test_cli_on_reference_fixture(tmp_path):
@@ -104,6 +106,23 @@ def test_cli_matches_oracle_pipeline(synth_run, tmp_path, correction):
             assert f[0] == str(j) and f[2] == "control=%d" % int(surv["mc"][i]) and f[3] == "case=" + fmt_shortest(surv["mk"][i])
             pv = float(f[1].split("=")[1])
             assert abs(pv - surv["p"][i]) <= 1e-5 * surv["p"][i] + 1e-300          # %g keeps 6 digits
+
+
+def test_cli_kff_output_holds_the_fasta_kmers(synth_run, tmp_path):
+    """-f / --kff-output (aggregator.hpp:197, kff_utils.hpp:32-107): control_kmers.kff / case_kmers.kff hold the
+    k-mers of the two FASTA files, in the same order; the case sum in a FASTA header is rendered like fmt's {}
+    (plain digits for integral sums: 1200, not 1.2e+03)."""
+    run_dir, nc, nk, k, mats, kms = synth_run
+    run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000], tmp_path / "a")
+    run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-f"], tmp_path / "b")
+    for name in ("control", "case"):
+        fasta = read_fasta(tmp_path / "a" / ("%s_kmers.fasta" % name))
+        variables, enc, kmers = KF.read_kff(tmp_path / "b" / ("%s_kmers.kff" % name))
+        assert variables["k"] == k and enc == 0x1E and kmers == [seq for _, seq in fasta] and len(kmers) >= 3
+        assert not os.path.exists(tmp_path / "b" / ("%s_kmers.fasta" % name))
+        for hdr, _ in fasta:
+            case = hdr.split("_case=")[1]
+            assert case.isdigit(), hdr                    # integral sums below 1e16 print as integers
 
 
 def test_cli_matrix_feed_equals_kmer_file_feed(synth_run, tmp_path):
@@ -345,24 +364,35 @@ def test_cli_empty_sample_files_and_an_empty_partition(tmp_path):
     assert s["n_sig"] == len(surv["p"]) > 0 and s["kept"] == int(keep.sum())
 
 
-def test_cli_no_matrix_equals_matrix_path(synth_run, tmp_path):
-    """--no-matrix (kmd_merge_sums + kmd_poisson_filter_sums: the streams are merged straight to each k-mer's
-    control and case count sums) writes what the matrix path writes: summary, both FASTA files, and -- the
-    survivors' count rows then come from the streams -- the --keep-tmp survivor files byte for byte; also
-    with BH (ascending-p order) and on the reference's fixture."""
+def test_cli_fused_path_equals_matrix_path(synth_run, tmp_path):
+    """The default path (kmd_merge_filter: streams merged and tested in one go, no matrix) writes what
+    --matrix-path (k-way merge into the count matrix, then K1) writes: summary, both FASTA files, the --keep-tmp
+    survivor files byte for byte (the survivors' count rows then come from the streams), the --save-sk matrices,
+    and with --pop-correction the sampled rows, pcs.evec and the re-tested p-values; also with BH
+    (ascending-p order) and on the reference's fixture."""
     import shutil
     run_dir, nc, nk, k, mats, kms = synth_run
-    for extra in (["-c", "bonferroni"], ["-c", "benjamini", "--keep-tmp"]):
-        a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3] + extra, tmp_path / "a")
-        b, err = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3, "--no-matrix"] + extra, tmp_path / "b")
+    for extra in (["-c", "bonferroni"], ["-c", "benjamini", "--keep-tmp"], ["--save-sk"],
+                  ["--pop-correction", "--kmer-pca", "0.05", "-c", "disabled", "--keep-tmp"]):
+        a, _ = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3, "--matrix-path"] + extra, tmp_path / "a")
+        b, err = run_cli(["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-t", 3] + extra, tmp_path / "b")
         assert a == b and a["n_sig"] > 10
         for name in ("control_kmers.fasta", "case_kmers.fasta"):
             assert open(tmp_path / "a" / name).read() == open(tmp_path / "b" / name).read()
         if "--keep-tmp" in extra:
+            suffix = "_popstrat_uncorrected" if "--pop-correction" in extra else "_uncorrected"
             for p in range(3):
-                fa = KF.lz4_frame_decode(open(tmp_path / "a" / "partitions" / ("p%d_uncorrected" % p), "rb").read())
-                fb = KF.lz4_frame_decode(open(tmp_path / "b" / "partitions" / ("p%d_uncorrected" % p), "rb").read())
+                fa = KF.lz4_frame_decode(open(tmp_path / "a" / "partitions" / ("p%d%s" % (p, suffix)), "rb").read())
+                fb = KF.lz4_frame_decode(open(tmp_path / "b" / "partitions" / ("p%d%s" % (p, suffix)), "rb").read())
                 assert fa == fb and len(fa) > 0
+        if "--save-sk" in extra:
+            for p in range(3):
+                name = os.path.join("positive_kmer_matrix", "matrices", "matrix_%d.count.lz4" % p)
+                assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read()
+        if "--pop-correction" in extra:
+            assert open(tmp_path / "a" / "popstrat" / "pcs.evec").read() == open(tmp_path / "b" / "popstrat" / "pcs.evec").read()
         shutil.rmtree(tmp_path / "a"); shutil.rmtree(tmp_path / "b")
-    s, _ = run_cli(["-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", 1, "-2", 1, "-u", 10000, "--no-matrix"], tmp_path / "f")
-    assert (s["total_kmers"], s["n_sig"], s["kept"]) == (320, 0, 0)
+    for extra in ([], ["--matrix-path"]):
+        s, _ = run_cli(["-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", 1, "-2", 1, "-u", 10000] + extra, tmp_path / "f")
+        assert (s["total_kmers"], s["n_sig"], s["kept"]) == (320, 0, 0)
+        shutil.rmtree(tmp_path / "f")

@@ -192,3 +192,24 @@ def test_merge_filter_thresholds_without_prefilter(K, oracle, thr):
     universe = np.unique(rng.integers(0, 1 << 62, 30_000, dtype=np.uint64))
     streams = make_streams(rng, universe, S, 0.5)
     run_fused(K, oracle, streams, nc, thr)
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_pca_sampling_from_the_streams_equals_sampling_the_matrix(K, oracle, two):
+    """kmd_pca_sample_streams (the fused path has no matrix): the same sampled rows, in the same order, hence
+    bit for bit the same Gram matrix as kmd_pca_sample over the merged matrix."""
+    rng = np.random.default_rng(21 + two)
+    S = 23
+    n = 40_000
+    lo = np.unique(rng.integers(0, 1 << 62, n, dtype=np.uint64))
+    hi = np.sort(rng.integers(0, 50, len(lo), dtype=np.uint64)) if two else None
+    if two:
+        order = np.lexsort((lo, hi)); lo, hi = lo[order], hi[order]
+    streams = make_streams(rng, lo, S, rng.uniform(0.2, 0.8, S), hi=hi)
+    mat = K.merge_partition(streams, count_bytes=4, layout=K.LAYOUT_TILED)
+    a = K.PopulationPCA(S, 0.02, seed=7)
+    a.sample(mat)
+    b = K.PopulationPCA(S, 0.02, seed=7)
+    b.sample_streams(streams)
+    assert a.count() == b.count() and a.count() > 200
+    assert (a.gram() == b.gram()).all()

@@ -149,3 +149,24 @@ def test_streaming_kmer_reader_rejects_a_truncated_frame(tmp_path):
     open(tmp_path / "nomark.kmer.lz4", "wb").write(whole[:-4])          # the 4-byte end mark cut off
     rc, out, err = tool("kmers", tmp_path / "nomark.kmer.lz4", tmp_path / "dump")
     assert rc == 1 and "truncated LZ4 frame" in err
+
+
+@pytest.mark.parametrize("k", [20, 31, 32, 33, 47, 63, 64])
+def test_kff_writer_round_trip(tmp_path, k):
+    """-f / --kff-output (KffWriter, include/kmdiff/kff_utils.hpp:32-107): header, encoding {0, 1, 3, 2} = 0x1e,
+    the k / max = 1 / data_size = 0 variables, one raw section of 2-bit sequences, footer -- read back by the
+    independent Python reader.  UNPINNED against kff-cpp-api (absent from the reference tree)."""
+    rng = np.random.default_rng(k)
+    n = 200
+    bits = 2 * k
+    vals = [int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62) | (int(rng.integers(0, 16)) << 124) for _ in range(n)]
+    vals = [v & ((1 << bits) - 1) for v in vals] + [0, (1 << bits) - 1]
+    src = tmp_path / "kmers.txt"
+    src.write_text("%d\n" % k + "".join("%d %d\n" % (v & (2 ** 64 - 1), v >> 64) for v in vals))
+    rc, out, err = tool("kff", src, tmp_path / "out.kff")
+    assert rc == 0, err
+    variables, enc, kmers = KF.read_kff(tmp_path / "out.kff")
+    assert enc == 0b00011110 and variables["k"] == k and variables["max"] == 1 and variables["data_size"] == 0
+    want = [KF.kmer_to_string2(v >> 64, v & (2 ** 64 - 1), k) if k > 32 else KF.kmer_to_string(v, k) for v in vals]
+    assert kmers == want
+    assert os.path.getsize(tmp_path / "out.kff") == 12 + (1 + 8 + (2 + 8) + (4 + 8) + (10 + 8)) + (1 + 8) + len(vals) * ((k + 3) // 4) + 49 + 3
