@@ -88,6 +88,7 @@ SIGNATURES = {
     "kmd_poisson_filter_sums": (_i, [_vp, _vp, _vp, _vp, _sz, _d, C.POINTER(Survivors), _vp, _vp]),
     "kmd_popstrat_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i]),
     "kmd_popstrat_destroy": (_i, [_vp]),
+    "kmd_popstrat_set_epsilon": (_i, [_vp, _d]),
     "kmd_popstrat_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), _vp, _vp, C.POINTER(_d)]),
     "kmd_popstrat_apply": (_i, [_vp, _vp, _i, _sz, _sz, _vp, _vp]),
     "kmd_pca_create": (_i, [C.POINTER(C.c_void_p), _i, C.c_double, _u64, _i, _sz]),

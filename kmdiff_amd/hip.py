@@ -473,7 +473,7 @@ class pop_strat_corrector:
     controls / 0.0 for cases)."""
 
     def __init__(self, nb_controls, nb_cases, control_totals, case_totals, npc, Z, Y=None,
-                 stand=True, max_iter=0):
+                 stand=True, max_iter=0, epsilon=0.0):
         _require_device()
         n = nb_controls + nb_cases
         tc = np.ascontiguousarray(control_totals, dtype=np.uint64)
@@ -489,6 +489,8 @@ class pop_strat_corrector:
                                         Z.ctypes.data, Z.shape[1], int(npc), Y.ctypes.data, int(bool(stand)),
                                         int(max_iter)), "kmd_popstrat_create")
         self.handle, self.n = h.value, n
+        if epsilon:                                             # set_params (popstrat.hpp:162-175): only a non-zero value counts
+            check(lib().kmd_popstrat_set_epsilon(self.handle, float(epsilon)), "kmd_popstrat_set_epsilon")
         nf = C.c_int(0)
         check(lib().kmd_popstrat_info(self.handle, None, C.byref(nf), None, None, None), "popstrat_info")
         self.n_features = nf.value

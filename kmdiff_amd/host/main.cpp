@@ -57,7 +57,7 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   std::string kmtricks_dir, output_directory = "./kmdiff_output", correction = "bonferroni", pcs;
   std::string model_lib_path, model_config;          // --cmodel / --config: a user's IModel plugin (cli.cpp:246-262)
   size_t nb_controls = 0, nb_cases = 0, cutoff = 100000, log_size = 10000, npc = 2, max_iteration = 0;
-  double threshold = 0.05;
+  double threshold = 0.05, epsilon = 0.0;
   bool pop_correction = false, stand = true, keep_tmp = false, save_sk = false, kff = false;
   bool matrix_path = std::getenv("KMD_HOST_MATRIX") != nullptr;   // --matrix-path: k-way merge into the count matrix, then K1 (default: merge fused with the test)
   double kmer_pca = 0.001;                  // proportion of k-mers sampled for the PCA (cli.cpp:286-289)
@@ -144,13 +144,7 @@ diff_options parse(int argc, char** argv)
     else if (a == "--ploidy") o.ploidy = std::stoull(need(i));
     else if (a == "--random-seed") o.seed = std::stoull(need(i));
     else if (a == "-t" || a == "--threads") o.threads = std::max<size_t>(1, std::stoull(need(i)));
-    else if (a == "--epsilon")
-    {
-      // popstrat.hpp:162-175 forwards it to pop_strat_corrector::s_epsilon, which the reference never reads
-      // (the clamp of the likelihood ratio, popstrat.hpp:321, is the literal 1e-30): accepted, no effect
-      (void)need(i);
-      std::fprintf(stderr, "[kmdiff-hip] note: --epsilon is accepted for compatibility; like the reference's it has no effect\n");
-    }
+    else if (a == "--epsilon") o.epsilon = std::stod(need(i));         // -> pop_strat_corrector::s_epsilon (popstrat.hpp:162-175,321)
     else if (a == "-v" || a == "--verbose" || a == "--gender" || a == "--learning-rate") (void)need(i);
     else if (a == "-f" || a == "--kff-output") o.kff = true;          // cli.cpp: control_kmers.kff / case_kmers.kff
     else if (a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
@@ -939,6 +933,7 @@ void do_pop(const run_context& C, survivors_of_run& O, const bool run_stage2)
     kmd_popstrat* ps = nullptr;
     ck(kmd_popstrat_create(&ps, (int)opt.nb_controls, (int)opt.nb_cases, total_controls.data(), total_cases.data(), Z.data(), 10,
                            (int)opt.npc, Y.data(), opt.stand ? 1 : 0, (int)opt.max_iteration), "kmd_popstrat_create");
+    ck(kmd_popstrat_set_epsilon(ps, opt.epsilon), "kmd_popstrat_set_epsilon");             // cmd/diff.hpp:356
     dev_buf d_c, d_p; d_c.reserve(n * S * 8); d_p.reserve(n * 8);
     ck(kmd_memcpy_h2d(d_c.p, s_counts.data(), n * S * 8, nullptr), "h2d");
     ck(kmd_popstrat_apply(ps, (const double*)d_c.p, 0, 0, n, (double*)d_p.p, nullptr), "kmd_popstrat_apply");
@@ -1026,9 +1021,9 @@ void do_correction(const run_context& C, survivors_of_run& O)
 int main(int argc, char** argv)
 {
   run_context C;
-  C.opt = parse(argc, argv);
   try
   {
+    C.opt = parse(argc, argv);
     const stopwatch whole_time;
     open_run(C);
     const diff_options& opt = C.opt;
@@ -1071,6 +1066,10 @@ int main(int argc, char** argv)
     kmd_model_destroy(C.model0);
     std::fprintf(stderr, "[kmdiff-hip] Done in %.3f s.\n", whole_time.seconds());                                   // cmd/diff.hpp:372-376
   }
-  catch (const std::exception& e) { die(e.what()); }                                          // src/main.cc:93-102 logs and exits
+  catch (const std::exception& e)                                                             // src/main.cc:93-102 logs and exits
+  {
+    std::fprintf(stderr, "[kmdiff-hip] error: %s\n", e.what());
+    return 1;
+  }
   return 0;
 }

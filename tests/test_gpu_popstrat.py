@@ -142,3 +142,22 @@ def test_large_batch_matches_small_batches(K, oracle):
     for a, b in [(0, 1), (1, 64), (64, 129), (129, 1000), (1000, 5000)]:
         p = pop.apply(K.DeviceBuffer.from_host(rows[a:b]), b - a)
         assert (p == p_all[a:b]).all()
+
+
+def test_epsilon_clamps_small_likelihood_ratios(K, oracle):
+    """--epsilon (cli.cpp:336-339 -> set_params -> s_epsilon, popstrat.hpp:162-175): |LLR| below it counts as 0,
+    i.e. p = 1 (popstrat.hpp:321-326); 0 keeps the default 1e-30."""
+    rng = np.random.default_rng(12)
+    nc = nk = 10
+    rows = count_rows(rng, 300, nc, nk, effect=1.05)                 # hardly any effect: small likelihood ratios
+    Z = rng.normal(0, 0.1, size=(20, 10))
+    tc = rng.integers(8_000_000, 12_000_000, nc).astype(np.uint64)
+    tk = rng.integers(8_000_000, 12_000_000, nk).astype(np.uint64)
+    buf = K.DeviceBuffer.from_host(rows)
+    p0 = K.pop_strat_corrector(nc, nk, tc, tk, 2, Z).apply(buf, len(rows))
+    p_same = K.pop_strat_corrector(nc, nk, tc, tk, 2, Z, epsilon=0.0).apply(buf, len(rows))
+    p_big = K.pop_strat_corrector(nc, nk, tc, tk, 2, Z, epsilon=0.5).apply(buf, len(rows))
+    assert (p0 == p_same).all()
+    llr_small = p0 > oracle.chisqc(1, 0.5)                            # LLR < 0.5  <=>  p above the tail at 0.5
+    assert llr_small.any() and (~llr_small).any()
+    assert (p_big[llr_small] == 1.0).all() and (p_big[~llr_small] == p0[~llr_small]).all()
