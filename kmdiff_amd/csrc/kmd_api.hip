@@ -34,8 +34,18 @@ constexpr size_t kMaxParked = 8ull << 30;                   // beyond this, free
 
 hipError_t kmd::scratch_alloc(void** p, size_t bytes)
 {
+  // size classes: powers of two up to 64 MB; above, eighths of an octave (at most 12.5 % over the request --
+  // a plain power of two nearly doubled the footprint of the sort path's n x 8-byte arrays -- and still few
+  // enough classes that the blocks of one partition are found again by the next)
   size_t cls = 256;
-  while (cls < bytes) cls <<= 1;
+  while (cls < bytes && cls < ((size_t)64 << 20)) cls <<= 1;
+  if (cls < bytes)
+  {
+    size_t octave = cls;
+    while ((octave << 1) <= bytes) octave <<= 1;          // largest power of two <= bytes
+    const size_t step = octave >> 3;
+    cls = (bytes + step - 1) / step * step;
+  }
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;

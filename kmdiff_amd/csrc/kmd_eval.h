@@ -28,7 +28,10 @@ struct filter_params
   uint32_t lds_n;           // table entries held in LDS
   kmd_survivors out;
   unsigned long long* counters;
+  unsigned long long* near;   // rows within 1e-8 of the threshold: [0] count, then kNearCap x { sum_c, sum_k, row, slot } (or NULL)
 };
+
+constexpr unsigned long long kNearCap = 4096;
 
 // LogFactorialTable::operator[] for k >= table size (log_factorial_table.hpp:14-18 falls back
 // to the O(k) loop log(k) + log(k-1) + ... + log(2), src/log_factorial_table.cpp:13-22).
@@ -86,14 +89,18 @@ __device__ __forceinline__ bool row_may_pass(const PP& P, const row_state& st, u
   return st.valid && !(a * a < P.pf_cut * ((dsc + dsk) * P.dTcTk));
 }
 
+// What the exact evaluation of one row decides (per lane).
+struct row_result
+{
+  bool cand, surv, near;
+  double p, mean_control;
+  int sign;
+};
+
 // The exact evaluation of rows that passed the pre-filter: likelihood ratio, candidate cut, tail
-// function, sign, compaction into the survivor sink.  Must be called by all 64 lanes of the wave
-// together (ballots inside); lanes without a row pass valid = false.
-// kRowMode 0: st.row is the row's index in the tile (survivor `row` = row_base + index).
-// kRowMode 1: st.row indexes a list of candidate rows that have no index of their own (rows that come
-//             out of the fused merge, kmd_tilemerge.hip): the survivor's `row` is the k-mer's low limb.
-template <int kRowMode = 0>
-__device__ __forceinline__ void evaluate_row(const filter_params& P, const double2* s_tab, const row_state& st)
+// function, decision.  Must be called by all 64 lanes of the wave together (a ballot skips the tail
+// function when no lane needs it); lanes without a row pass valid = false.
+__device__ __forceinline__ row_result evaluate_core(const filter_params& P, const double2* s_tab, const row_state& st)
 {
   // table entry of each sum: { lf[k], log(k) }.  k = table_index(sum) (model.hpp:152-156);
   // sums beyond the table (or >= 2^31, where k wraps to 0 but lambda does not) take the
@@ -112,34 +119,51 @@ __device__ __forceinline__ void evaluate_row(const filter_params& P, const doubl
   }
 
   const double lr = kmd::lr_from_sums(st.sum_c, st.sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
-  const bool cand = st.valid && (lr >= P.lr_cut);
-  const unsigned long long cand_mask = __ballot(cand);
+  row_result R;
+  R.cand = st.valid && (lr >= P.lr_cut);
+  R.surv = false; R.near = false; R.p = 1.0; R.mean_control = 0.0; R.sign = KMD_SIGN_NO;
+  if (__ballot(R.cand) && R.cand)
+  {
+    R.p = kmd::igamc_half(lr, P.lg_half);                   // model.hpp:161
+    // the guard of the decision: a p-value within 1e-8 (relative) of the threshold is ~10 x closer than
+    // the device's and a host's libm can move it apart.  Such a row is only FLAGGED here (and listed by the
+    // caller, note_near_rows); k_resolve_near, a one-wave kernel behind every filter launch, repeats its
+    // four libm calls with correctly rounded log / exp (kmd_ddmath.h) and corrects the sink if the
+    // decision changes.  (Inlined here, that arithmetic cost every kernel that evaluates rows registers:
+    // K1 spilled and lost 4 % at 20v20, 24 % at 4v4.)  Sums beyond the log-factorial table are left
+    // alone: their table term is Stirling's, not the reference's running sum -- no bit pattern to match
+    R.near = fabs(R.p - P.threshold) <= 1e-8 * P.threshold && !(big_c | big_k);
+    R.surv = (R.p <= P.threshold);                          // merge.hpp:78
+    kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, R.mean_control, R.sign);
+  }
+  return R;
+}
+
+// A flagged row goes on the launch's near list with the sink slot its (ocml) decision gave it, -1 if none.
+__device__ __forceinline__ void note_near_row(const filter_params& P, const row_state& st, long long slot)
+{
+  if (!P.near) return;
+  const unsigned long long at = atomicAdd(&P.near[0], 1ull);
+  if (at >= kNearCap) return;                             // (counted by KMD_CNT_NEAR_THRESHOLD all the same)
+  unsigned long long* e = P.near + 1 + 4 * at;
+  e[0] = st.sum_c; e[1] = st.sum_k; e[2] = st.row; e[3] = (unsigned long long)slot;
+}
+
+// kRowMode 0: st.row is the row's index in the tile (survivor `row` = row_base + index).
+// kRowMode 1: st.row indexes a list of candidate rows that have no index of their own (rows that come
+//             out of the fused merge, kmd_tilemerge.hip): the survivor's `row` is the k-mer's low limb.
+// Evaluation + compaction into the survivor sink (a ballot, one atomic per counter and wave).
+template <int kRowMode = 0>
+__device__ __forceinline__ void evaluate_row(const filter_params& P, const double2* s_tab, const row_state& st)
+{
+  const row_result R = evaluate_core(P, s_tab, st);
+  const unsigned long long cand_mask = __ballot(R.cand);
   if (cand_mask)
   {
-    bool surv = false;
-    double p = 1.0, mean_control = 0.0;
-    int sign = KMD_SIGN_NO;
-    bool near = false;
-    if (cand)
-    {
-      p = kmd::igamc_half(lr, P.lg_half);                   // model.hpp:161
-      // the guard of the decision: a p-value within 1e-8 (relative) of the threshold is ~10 x closer than
-      // the device's and a host's libm can move it apart; such a row (KMD_CNT_NEAR_THRESHOLD counts
-      // them) repeats its four libm calls with correctly rounded log / exp (kmd_ddmath.h).  Sums
-      // beyond the log-factorial table keep the ordinary result: their table term is Stirling's, not
-      // the reference's running sum, so there is no reference bit pattern to match
-      near = fabs(p - P.threshold) <= 1e-8 * P.threshold && !(big_c | big_k);
-      if (near)
-      {
-        const double lr2 = kmd::lr_from_sums<kmd::libm_rounded>(st.sum_c, st.sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
-        p = kmd::igamc_half<kmd::libm_rounded>(lr2, P.lg_half);
-      }
-      surv = (p <= P.threshold);                            // merge.hpp:78
-      kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, mean_control, sign);
-    }
-    const unsigned long long near_mask = __ballot(near);
+    const bool surv = R.surv;
+    const unsigned long long near_mask = __ballot(R.near);
     const unsigned long long surv_mask = __ballot(surv);
-    const unsigned long long ctrl_mask = __ballot(surv && sign == KMD_SIGN_CONTROL);
+    const unsigned long long ctrl_mask = __ballot(surv && R.sign == KMD_SIGN_CONTROL);
     const int lane = __lane_id();
     const int leader = __ffsll((long long)cand_mask) - 1;
     unsigned long long base = 0;
@@ -156,9 +180,12 @@ __device__ __forceinline__ void evaluate_row(const filter_params& P, const doubl
       }
     }
     if (surv_mask)
-    {
       base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
              (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    if (near_mask && R.near)
+      note_near_row(P, st, surv ? (long long)(base + __popcll(surv_mask & ((1ull << lane) - 1ull))) : -1ll);
+    if (surv_mask)
+    {
       if (surv)
       {
         const unsigned long long slot =
@@ -168,9 +195,9 @@ __device__ __forceinline__ void evaluate_row(const filter_params& P, const doubl
           if (P.out.d_row) P.out.d_row[slot] = kRowMode == 1 ? P.kmer_lo[st.row] : P.row_base + st.row;
           if (P.out.d_kmer_lo && P.kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[st.row];
           if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[st.row];
-          if (P.out.d_pvalue) P.out.d_pvalue[slot] = p;
-          if (P.out.d_sign) P.out.d_sign[slot] = sign;
-          if (P.out.d_mean_control) P.out.d_mean_control[slot] = mean_control;
+          if (P.out.d_pvalue) P.out.d_pvalue[slot] = R.p;
+          if (P.out.d_sign) P.out.d_sign[slot] = R.sign;
+          if (P.out.d_mean_control) P.out.d_mean_control[slot] = R.mean_control;
           if (P.out.d_mean_case) P.out.d_mean_case[slot] = (double)st.sum_k;
         }
       }
@@ -195,6 +222,10 @@ int fill_filter_params(eval::filter_params& P, const kmd_model* m, const kmd_til
 // The exact evaluation of the candidate rows the fused merge (kmd_tilemerge.hip) left in a device list:
 // n entries (k-mer, control sum, case sum).  They passed the pre-filter there; `rows_total` (distinct
 // k-mers of the partition) and `rows_beyond` (rows past the log-factorial table) are added to the counters.
+// The near list of one filter launch (stream-ordered allocation) and the kernel that resolves it; both no-ops
+// when the device has no memory pools.  begin: before the filter kernel (fills P.near); end: right after it.
+int near_list_begin(eval::filter_params& P, hipStream_t stream);
+int near_list_end(const eval::filter_params& P, int row_mode, hipStream_t stream);
 int launch_filter_candidates(const eval::filter_params& P, const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_kmer_hi,
                              const uint64_t* d_sum_c, const uint64_t* d_sum_k, size_t n, uint64_t rows_total, uint64_t rows_beyond,
                              hipStream_t stream);

@@ -577,24 +577,54 @@ __global__ void __launch_bounds__(kBlock) k_filter_sums(const filter_params P, c
   if ((threadIdx.x & 63) == 0 && n_valid) atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)n_valid);   // merge.hpp:76
 }
 
-// ---- candidate rows of the fused merge (kmd_tilemerge.hip): a short device-resident list
-__global__ void __launch_bounds__(kBlock) k_filter_candidates(const filter_params P, const unsigned long long* __restrict__ sum_c,
-                                                              const unsigned long long* __restrict__ sum_k,
-                                                              unsigned long long rows_total, unsigned long long rows_beyond)
+// ---- candidate rows of the fused merge (kmd_tilemerge.hip): a device-resident list of rows that passed the
+// pre-filter.  Unlike the rows K1 sees, a good part of these are survivors -- on data where k-mers are rare
+// and sample-specific, millions per partition -- and one atomic per counter and 64-row step on the same
+// four addresses then IS the kernel's time (measured: 4.6 ms for 36 M rows).  So a wave parks its survivors
+// in an LDS staging area of its own and sends ~200 of them off at a time: one atomic on the sink's cursor,
+// consecutive records written by consecutive lanes; the other counters stay in registers until the wave
+// is done.
+constexpr int kCandBlock = 256;
+constexpr uint32_t kCandStage = 256;                     // staged survivors per wave (flushed at >= 192: room for 64 more)
+
+__global__ void __launch_bounds__(kCandBlock) k_filter_candidates(const filter_params P, const unsigned long long* __restrict__ sum_c,
+                                                                  const unsigned long long* __restrict__ sum_k,
+                                                                  unsigned long long rows_total, unsigned long long rows_beyond)
 {
-  extern __shared__ double2 s_lf[];
-  stage_table(P, s_lf);
+  __shared__ unsigned long long s_row[kCandBlock / 64][kCandStage];
+  __shared__ double s_p[kCandBlock / 64][kCandStage], s_mc[kCandBlock / 64][kCandStage], s_mk[kCandBlock / 64][kCandStage];
+  __shared__ int s_sign[kCandBlock / 64][kCandStage];
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     if (rows_total) atomicAdd(&P.counters[KMD_CNT_TOTAL], rows_total);                    // merge.hpp:76
     if (rows_beyond) atomicAdd(&P.counters[KMD_CNT_DEFERRED], rows_beyond);
   }
-  uint32_t n_beyond = 0;                                   // (counted by the merge kernel already: not flushed)
-  wave_queue Q;
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t staged = 0, n_cand = 0, n_near = 0, n_ctrl = 0, n_case = 0;                    // wave-uniform
+  auto flush = [&]()
   {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(s_lf + P.lds_n) + (size_t)(threadIdx.x >> 6) * kQueueCap * 3;
-    Q.sc = q; Q.sk = q + kQueueCap; Q.row = q + 2 * kQueueCap; Q.n = 0;
-  }
+    if (staged == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&P.counters[KMD_CNT_SIG], (unsigned long long)staged);   // merge.hpp:101
+    base = __shfl(base, 0, 64);
+    for (uint32_t t = lane; t < staged; t += 64)
+    {
+      const unsigned long long slot = base + t;
+      if (slot < P.out.capacity)
+      {
+        const unsigned long long row = s_row[w][t];
+        if (P.out.d_row) P.out.d_row[slot] = P.kmer_lo[row];
+        if (P.out.d_kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[row];
+        if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[row];
+        if (P.out.d_pvalue) P.out.d_pvalue[slot] = s_p[w][t];
+        if (P.out.d_sign) P.out.d_sign[slot] = s_sign[w][t];
+        if (P.out.d_mean_control) P.out.d_mean_control[slot] = s_mc[w][t];
+        if (P.out.d_mean_case) P.out.d_mean_case[slot] = s_mk[w][t];
+      }
+    }
+    staged = 0;
+    queue_fence();
+  };
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n_round = (P.n_rows + stride - 1) / stride * stride;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
@@ -604,9 +634,57 @@ __global__ void __launch_bounds__(kBlock) k_filter_candidates(const filter_param
     st.valid = i < P.n_rows;
     st.sum_c = st.valid ? sum_c[i] : 0ull;
     st.sum_k = st.valid ? sum_k[i] : 0ull;
-    defer_row<1>(P, s_lf, st, n_beyond, Q);
+    const row_result R = evaluate_core(P, nullptr, st);
+    const unsigned long long cm = __ballot(R.cand);
+    if (!cm) continue;
+    const unsigned long long sm = __ballot(R.surv);
+    n_cand += (uint32_t)__popcll(cm);
+    const unsigned long long nm = __ballot(R.near);
+    if (nm)
+    {
+      // a row on the threshold (never, in practice): its sink slot must be known now -- what is staged goes
+      // out first, then this step's survivors, then the list entry
+      n_near += (uint32_t)__popcll(nm);
+      flush();
+      unsigned long long base = 0;
+      if (lane == 0 && sm) base = atomicAdd(&P.counters[KMD_CNT_SIG], (unsigned long long)__popcll(sm));
+      base = __shfl(base, 0, 64);
+      const unsigned long long slot = base + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
+      if (R.surv && slot < P.out.capacity)
+      {
+        if (P.out.d_row) P.out.d_row[slot] = P.kmer_lo[i];
+        if (P.out.d_kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[i];
+        if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[i];
+        if (P.out.d_pvalue) P.out.d_pvalue[slot] = R.p;
+        if (P.out.d_sign) P.out.d_sign[slot] = R.sign;
+        if (P.out.d_mean_control) P.out.d_mean_control[slot] = R.mean_control;
+        if (P.out.d_mean_case) P.out.d_mean_case[slot] = (double)st.sum_k;
+      }
+      if (R.near) note_near_row(P, st, R.surv ? (long long)slot : -1ll);
+      const uint32_t nctl2 = (uint32_t)__popcll(__ballot(R.surv && R.sign == KMD_SIGN_CONTROL));
+      n_ctrl += nctl2; n_case += (uint32_t)__popcll(sm) - nctl2;
+      continue;
+    }
+    if (!sm) continue;
+    const uint32_t nctl = (uint32_t)__popcll(__ballot(R.surv && R.sign == KMD_SIGN_CONTROL));
+    n_ctrl += nctl; n_case += (uint32_t)__popcll(sm) - nctl;                             // merge.hpp:95-98
+    if (R.surv)
+    {
+      const uint32_t at = staged + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+      s_row[w][at] = i; s_p[w][at] = R.p; s_sign[w][at] = R.sign; s_mc[w][at] = R.mean_control; s_mk[w][at] = (double)st.sum_k;
+    }
+    staged += (uint32_t)__popcll(sm);
+    queue_fence();
+    if (staged >= kCandStage - 64) flush();
   }
-  drain_queue<1>(P, s_lf, Q);
+  flush();
+  if (lane == 0)
+  {
+    if (n_cand) atomicAdd(&P.counters[KMD_CNT_CANDIDATES], (unsigned long long)n_cand);
+    if (n_near) atomicAdd(&P.counters[KMD_CNT_NEAR_THRESHOLD], (unsigned long long)n_near);
+    if (n_ctrl) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], (unsigned long long)n_ctrl);
+    if (n_case) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], (unsigned long long)n_case);
+  }
 }
 
 // ---- row-major rows, 16-byte aligned pitch: wave-private staging -------------------------
@@ -1162,6 +1240,7 @@ int kmd::fill_filter_params(filter_params& P, const kmd_model* m, const kmd_tile
   P.lds_n = 0;
   P.counters = nullptr;
   P.out = kmd_survivors{};
+  P.near = nullptr;
   return KMD_OK;
 }
 
@@ -1412,6 +1491,8 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
   if (out) P.out = *out;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tile->n_rows == 0) return KMD_OK;
+  rc = kmd::near_list_begin(P, st);                     // rows within 1e-8 of the threshold: listed, resolved behind the kernel
+  if (rc != KMD_OK) return rc;
 
   // LDS budget: the table head; two workgroups per CU when it fits in half of the LDS
   const size_t lds_cap = m->lds_per_block_max;          // 160 KiB on gfx950
@@ -1428,20 +1509,22 @@ extern "C" int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, doub
     P.lds_n = (uint32_t)(want / sizeof(double2));
     switch (tile->count_bytes)
     {
-      case 1: return launch_soa<uint8_t>(P, m, want + queues, blocks_per_cu, tiled, st);
-      case 2: return launch_soa<uint16_t>(P, m, want + queues, blocks_per_cu, tiled, st);
-      default: return launch_soa<uint32_t>(P, m, want + queues, blocks_per_cu, tiled, st);
+      case 1: rc = launch_soa<uint8_t>(P, m, want + queues, blocks_per_cu, tiled, st); break;
+      case 2: rc = launch_soa<uint16_t>(P, m, want + queues, blocks_per_cu, tiled, st); break;
+      default: rc = launch_soa<uint32_t>(P, m, want + queues, blocks_per_cu, tiled, st); break;
     }
   }
   else
   {
     switch (tile->count_bytes)
     {
-      case 1: return launch_rows<uint8_t>(P, m, st);
-      case 2: return launch_rows<uint16_t>(P, m, st);
-      default: return launch_rows<uint32_t>(P, m, st);
+      case 1: rc = launch_rows<uint8_t>(P, m, st); break;
+      case 2: rc = launch_rows<uint16_t>(P, m, st); break;
+      default: rc = launch_rows<uint32_t>(P, m, st); break;
     }
   }
+  const int rc_near = kmd::near_list_end(P, 0, st);
+  return rc != KMD_OK ? rc : rc_near;
 }
 
 // kmd_poisson_filter for rows that come as (k-mer, control sum, case sum): what kmd_merge_sums
@@ -1469,9 +1552,135 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
   if (grid > (n_rows + kBlock - 1) / kBlock) grid = (n_rows + kBlock - 1) / kBlock;
   rc = allow_big_lds(k_filter_sums, want + queues);
   if (rc != KMD_OK) return rc;
+  rc = kmd::near_list_begin(P, st);
+  if (rc != KMD_OK) return rc;
   hipLaunchKernelGGL(k_filter_sums, dim3((unsigned)grid), dim3(kBlock), want + queues, st, P,
                      reinterpret_cast<const unsigned long long*>(d_sum_control), reinterpret_cast<const unsigned long long*>(d_sum_case));
   KMD_HIP(hipGetLastError());
+  return kmd::near_list_end(P, 0, st);
+}
+
+// ---- the rows within 1e-8 of the threshold (kmd_eval.h: evaluate_core flags them, note_near_row lists them).
+// One wave behind every filter launch: the listed rows are re-evaluated with correctly rounded log / exp
+// (kmd_ddmath.h), and where that decision differs from the one the filter made with the device's libm the
+// survivor sink is corrected: a record that should not be there is struck out (and the sink compacted), one
+// that is missing is appended; survivors that stay get the rounded p-value.  The list is empty in practice
+// (0 rows in 10^10 synthetic ones): the kernel then reads one word and leaves.
+template <int kRowMode>
+__global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
+{
+  const unsigned long long listed = P.near[0] < kNearCap ? P.near[0] : kNearCap;
+  if (listed == 0) return;
+  const int lane = (int)threadIdx.x;
+  unsigned long long struck = 0;
+  for (unsigned long long e0 = 0; e0 < listed; e0 += 64)
+  {
+    const bool have = e0 + lane < listed;
+    const unsigned long long* e = P.near + 1 + 4 * (e0 + (have ? lane : 0));
+    const uint64_t sum_c = e[0], sum_k = e[1], row = e[2];
+    const long long slot = (long long)e[3];
+    bool now = false;
+    double p = 1.0, mean_control = 0.0;
+    int sign = KMD_SIGN_NO;
+    if (have)
+    {
+      const double2 tc = P.tab[kmd::table_index(sum_c)], tk = P.tab[kmd::table_index(sum_k)];     // (inside the table: flagged rows are)
+      const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
+      p = kmd::igamc_half<kmd::libm_rounded>(lr, P.lg_half);
+      now = p <= P.threshold;                                                              // merge.hpp:78
+      kmd::sign_of(sum_c, sum_k, P.dTc, P.dTk, mean_control, sign);
+    }
+    const bool was = have && slot >= 0;
+    // stays: the rounded p-value; goes: struck out (p = -1 marks the record until the sink is compacted)
+    if (was && (unsigned long long)slot < P.out.capacity && P.out.d_pvalue) P.out.d_pvalue[slot] = now ? p : -1.0;
+    const unsigned long long go_ctrl = __ballot(was && !now && sign == KMD_SIGN_CONTROL), go = __ballot(was && !now);
+    const unsigned long long come_ctrl = __ballot(have && !was && now && sign == KMD_SIGN_CONTROL), come = __ballot(have && !was && now);
+    struck += (unsigned long long)__popcll(go);
+    unsigned long long base = 0;
+    if (lane == 0)
+    {
+      if (go_ctrl) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], 0ull - (unsigned long long)__popcll(go_ctrl));
+      if (go & ~go_ctrl) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], 0ull - (unsigned long long)__popcll(go & ~go_ctrl));
+      if (come_ctrl) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], (unsigned long long)__popcll(come_ctrl));
+      if (come & ~come_ctrl) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], (unsigned long long)__popcll(come & ~come_ctrl));
+      if (come) base = atomicAdd(&P.counters[KMD_CNT_SIG], (unsigned long long)__popcll(come));
+    }
+    base = __shfl(base, 0, 64);
+    if (have && !was && now)
+    {
+      const unsigned long long at = base + (unsigned long long)__popcll(come & ((1ull << lane) - 1ull));
+      if (at < P.out.capacity)
+      {
+        if (P.out.d_row) P.out.d_row[at] = kRowMode == 1 ? P.kmer_lo[row] : P.row_base + row;
+        if (P.out.d_kmer_lo && P.kmer_lo) P.out.d_kmer_lo[at] = P.kmer_lo[row];
+        if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[at] = P.kmer_hi[row];
+        if (P.out.d_pvalue) P.out.d_pvalue[at] = p;
+        if (P.out.d_sign) P.out.d_sign[at] = sign;
+        if (P.out.d_mean_control) P.out.d_mean_control[at] = mean_control;
+        if (P.out.d_mean_case) P.out.d_mean_case[at] = (double)sum_k;
+      }
+    }
+  }
+  if (struck == 0 || !P.out.d_pvalue) return;
+  // compact the sink in place (this wave alone, behind the filter kernel on its stream): records marked
+  // p = -1 leave, the others close ranks in order
+  __threadfence();
+  const unsigned long long n = P.counters[KMD_CNT_SIG] < P.out.capacity ? P.counters[KMD_CNT_SIG] : P.out.capacity;
+  unsigned long long w = 0;
+  for (unsigned long long r0 = 0; r0 < n; r0 += 64)
+  {
+    const unsigned long long r = r0 + lane;
+    const bool keep = r < n && P.out.d_pvalue[r] >= 0.0;
+    const unsigned long long km = __ballot(keep);
+    const unsigned long long to = w + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull));
+    // (reads of this step happen before its writes: every lane loads first)
+    unsigned long long v_row = 0, v_lo = 0, v_hi = 0; double v_p = 0, v_mc = 0, v_mk = 0; int v_s = 0;
+    if (keep)
+    {
+      if (P.out.d_row) v_row = P.out.d_row[r];
+      if (P.out.d_kmer_lo) v_lo = P.out.d_kmer_lo[r];
+      if (P.out.d_kmer_hi) v_hi = P.out.d_kmer_hi[r];
+      v_p = P.out.d_pvalue[r];
+      if (P.out.d_sign) v_s = P.out.d_sign[r];
+      if (P.out.d_mean_control) v_mc = P.out.d_mean_control[r];
+      if (P.out.d_mean_case) v_mk = P.out.d_mean_case[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (keep && to != r)
+    {
+      if (P.out.d_row) P.out.d_row[to] = v_row;
+      if (P.out.d_kmer_lo) P.out.d_kmer_lo[to] = v_lo;
+      if (P.out.d_kmer_hi) P.out.d_kmer_hi[to] = v_hi;
+      P.out.d_pvalue[to] = v_p;
+      if (P.out.d_sign) P.out.d_sign[to] = v_s;
+      if (P.out.d_mean_control) P.out.d_mean_control[to] = v_mc;
+      if (P.out.d_mean_case) P.out.d_mean_case[to] = v_mk;
+    }
+    w += (unsigned long long)__popcll(km);
+    __threadfence();
+  }
+  if (lane == 0) P.counters[KMD_CNT_SIG] = w;             // (= the old count - struck, when nothing was truncated)
+}
+
+int kmd::near_list_begin(filter_params& P, hipStream_t stream)
+{
+  P.near = nullptr;
+  static const bool off = std::getenv("KMD_NO_GUARD") != nullptr;      // dev: the filter without its guard
+  if (off) return KMD_OK;
+  void* p = nullptr;
+  if (hipMallocAsync(&p, (1 + 4 * kNearCap) * sizeof(unsigned long long), stream) != hipSuccess) { (void)hipGetLastError(); return KMD_OK; }
+  P.near = static_cast<unsigned long long*>(p);
+  KMD_HIP(hipMemsetAsync(P.near, 0, sizeof(unsigned long long), stream));
+  return KMD_OK;
+}
+
+int kmd::near_list_end(const filter_params& P, int row_mode, hipStream_t stream)
+{
+  if (!P.near) return KMD_OK;
+  if (row_mode == 1) hipLaunchKernelGGL(k_resolve_near<1>, dim3(1), dim3(64), 0, stream, P);
+  else hipLaunchKernelGGL(k_resolve_near<0>, dim3(1), dim3(64), 0, stream, P);
+  KMD_HIP(hipGetLastError());
+  KMD_HIP(hipFreeAsync(P.near, stream));
   return KMD_OK;
 }
 
@@ -1481,19 +1690,16 @@ int kmd::launch_filter_candidates(const filter_params& P_in, const kmd_model* m,
 {
   filter_params P = P_in;
   P.kmer_lo = d_kmer; P.kmer_hi = d_kmer_hi; P.row_base = 0; P.n_rows = n;
-  // a short table head in LDS (this kernel runs for microseconds; the table is read for candidates only)
-  const size_t want = std::min<size_t>(m->lf_n, 1024) * sizeof(double2);
-  const size_t queues = (size_t)(kBlock / 64) * kQueueBytesPerWave;
-  P.lds_n = (uint32_t)(want / sizeof(double2));
-  size_t grid = std::min<size_t>((size_t)m->n_cu, (n + kBlock - 1) / kBlock);
+  P.lds_n = 0;                                            // the table is read for candidates only: from L2
+  size_t grid = std::min<size_t>((size_t)m->n_cu * 8, (n + kCandBlock - 1) / kCandBlock);
   if (grid < 1) grid = 1;
-  const int rc = allow_big_lds(k_filter_candidates, want + queues);
+  int rc = near_list_begin(P, stream);
   if (rc != KMD_OK) return rc;
-  hipLaunchKernelGGL(k_filter_candidates, dim3((unsigned)grid), dim3(kBlock), want + queues, stream, P,
+  hipLaunchKernelGGL(k_filter_candidates, dim3((unsigned)grid), dim3(kCandBlock), 0, stream, P,
                      reinterpret_cast<const unsigned long long*>(d_sum_c), reinterpret_cast<const unsigned long long*>(d_sum_k),
                      (unsigned long long)rows_total, (unsigned long long)rows_beyond);
   KMD_HIP(hipGetLastError());
-  return KMD_OK;
+  return near_list_end(P, 1, stream);
 }
 
 extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, double* d_pvalue,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev tool (GPU box): FP64 instruction counts of the K3 pop-strat kernel (per launch, whole grid).
 # usage: bash tools/pmc_popstrat.sh [kbench_popstrat args]
-repo=$GRAFT_REPO_ROOT
+repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
