@@ -138,8 +138,8 @@ struct irls_args
   int stride;             // FA
   const double* y;
   const double* totals;
-  const double* counts;   // [n_samples][ld] (sample-major): counts[i*ld + survivor]
-  size_t ld;
+  const double* counts;   // count of sample i for survivor v: counts[i * si + v * ss]
+  size_t si, ss;          // sample-major [S][ld]: (ld, 1) -- what a lane per survivor reads coalesced; survivor-major [n][S]: (1, S)
   int n;
   int max_iter;
 };
@@ -214,11 +214,11 @@ __device__ __forceinline__ void irls_fit(const irls_args& A, const double* s_d, 
     };
     {
       // the count of the next sample is requested before this one is worked on
-      double c_next = KMER ? A.counts[surv] : 0.0;
+      double c_next = KMER ? A.counts[surv * A.ss] : 0.0;
       for (int i = 0; i < A.n; ++i)
       {
         const double c = c_next;
-        if (KMER) c_next = A.counts[(size_t)(i + 1 < A.n ? i + 1 : i) * A.ld + surv];
+        if (KMER) c_next = A.counts[(size_t)(i + 1 < A.n ? i + 1 : i) * A.si + surv * A.ss];
         sample(i, c);
       }
     }
@@ -272,11 +272,11 @@ __global__ void __launch_bounds__(64) k_popstrat_apply(irls_args A, size_t n_sur
       const double p = sigmoid_ref(s);
       if (D.y(i) == 1) alt_l = alt_l * p; else alt_l *= 1.0 - p;
     };
-    double c_next = A.counts[surv];
+    double c_next = A.counts[surv * A.ss];
     for (int i = 0; i < A.n; ++i)
     {
       const double c = c_next;
-      c_next = A.counts[(size_t)(i + 1 < A.n ? i + 1 : i) * A.ld + surv];
+      c_next = A.counts[(size_t)(i + 1 < A.n ? i + 1 : i) * A.si + surv * A.ss];
       sample(i, c);
     }
   }
@@ -286,6 +286,284 @@ __global__ void __launch_bounds__(64) k_popstrat_apply(irls_args A, size_t n_sur
   double llr = -2.0 * ::log(ratio);                              // :318-319
   if (::fabs(llr) < epsilon || llr < 0.0 || alt_l != alt_l) llr = 0.0;    // :321-326
   if (live) out_p[surv] = kmd::igamc_half(llr / 2.0, lg_half);   // :328 chisquarecdistribution(1, llr)
+}
+
+// ---- the same fit with a GROUP of lanes per survivor ---------------------------------------------------
+// One lane per survivor runs ~2 x 10^5 dependent instructions per fit: a small batch of survivors (one
+// partition's: 10^3..10^4) leaves most SIMDs with one wave or none, and beyond 7 features the F x F Hessian
+// does not fit a lane's registers any more (npc = 10: 1.3 KB of scratch per lane, 42 ms for 22 k survivors).
+// Here L lanes (32 up to 5 features, else 64) share a survivor:
+//   * samples are PREPARED L at a time, one per lane (design row, dot product, sigmoid, g, g z: the long
+//     dependent chains, now L-wide) into an LDS chunk;
+//   * the F x F + F + 1 running sums -- Hessian entries, X^T S z entries, the squared error -- are spread over
+//     the lanes, and every lane adds its entries' terms sample after sample IN SAMPLE ORDER, exactly the sums
+//     the reference forms (multiply(), linear_model.cpp:77-86);
+//   * the no-pivot LU runs in LDS, one row / column of entries per step across the lanes, the F column solves
+//     of inverse() one per lane; det is formed by every lane in the reference's order.
+// Every value is computed by the same operations in the same order as in irls_fit above: the two kernels
+// return the same bits (tests/test_gpu_popstrat.py::test_group_kernel_equals_lane_kernel).
+__device__ __forceinline__ void group_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int F> struct group_shape
+{
+  static constexpr int kEntries = F * F + F + 1;          // H, X^T S z, squared error
+  static constexpr int L = kEntries <= 32 ? 32 : 64;       // lanes per survivor
+  static constexpr int kPerLane = (kEntries + L - 1) / L;
+  static constexpr int kSample = 2 * F + 3;                // chunk entry: x[F], g x[F], g z, (y - mu)^2, good
+  // doubles of LDS per survivor: chunk | H | b | w | weight | inverse columns | scalars
+  static constexpr int kLds = L * kSample + F * F + 3 * F + F * F + 8;
+};
+
+template <int F>
+__global__ void __launch_bounds__(64) k_popstrat_group(irls_args A, size_t n_surv, double null_likelihood,
+                                                       double lg_half, double epsilon, double* __restrict__ out_p)
+{
+  using G = group_shape<F>;
+  constexpr int L = G::L, kGroups = 64 / L;
+  extern __shared__ double s_all[];
+  const int lane = (int)threadIdx.x, grp = lane / L, l = lane % L;
+  double* const base = s_all + (size_t)grp * G::kLds;
+  double* const chunk = base;                              // [L][kSample]
+  double* const Hm = chunk + L * G::kSample;               // [F][F]
+  double* const bv = Hm + F * F;                           // [F]
+  double* const wv = bv + F;                               // [F]  new weights
+  double* const weight = wv + F;                           // [F]  returned weights
+  double* const xc = weight + F;                           // [F][F] inverse, column-major: xc[c][p]
+  double* const sc = xc + F * F;                           // [0] squared error, [1] rows with g > 1e-305
+  size_t surv = (size_t)blockIdx.x * kGroups + grp;
+  const bool live = surv < n_surv;
+  if (!live) surv = n_surv - 1;
+
+  // the entries this lane owns: e = l + m L
+  int ep[G::kPerLane], eq[G::kPerLane], ek[G::kPerLane];   // kind 0 H[p][q], 1 b[p], 2 error, -1 none
+#pragma unroll
+  for (int m = 0; m < G::kPerLane; ++m)
+  {
+    const int e = l + m * L;
+    ek[m] = e < F * F ? 0 : e < F * F + F ? 1 : e == F * F + F ? 2 : -1;
+    ep[m] = e < F * F ? e / F : e - F * F;
+    eq[m] = e < F * F ? e % F : 0;
+  }
+  double w[F];
+#pragma unroll
+  for (int j = 0; j < F; ++j) w[j] = 1;
+  if (l < F) weight[l] = 1;
+  double prev_error = 1e18;
+  int iter = 0;
+  bool first = true, active = true;
+  const double* cnt = A.counts;
+
+  // one sample's design row, the k-mer column from the survivor's count
+  auto row_of = [&](int i, double (&x)[F])
+  {
+#pragma unroll
+    for (int j = 0; j < F - 1; ++j) x[j] = A.alt[i * A.stride + j];
+    x[F - 1] = cnt[(size_t)i * A.si + surv * A.ss] / A.totals[i];
+  };
+
+  while (__ballot(active))
+  {
+    double acc[G::kPerLane];
+    int ng = 0;
+#pragma unroll
+    for (int m = 0; m < G::kPerLane; ++m) acc[m] = 0.0;
+    for (int c0 = 0; c0 < A.n; c0 += L)
+    {
+      const int i = c0 + l;
+      if (active && i < A.n)
+      {
+        double x[F];
+        row_of(i, x);
+        const double yi = A.y[i];
+        double eta, mu;
+        if (first)
+        {
+          mu = (yi + 0.5) / 2;                                     // :314
+          eta = ::log(mu / (1 - mu));                              // :315
+        }
+        else
+        {
+          eta = 0;                                                 // :400-405
+#pragma unroll
+          for (int j = 0; j < F; ++j) eta += x[j] * w[j];
+          mu = sigmoid_ref(eta);
+        }
+        const double g = mu * (1.0 - mu);                          // :333
+        const double z = eta + (yi - mu) / (g + 1e-305);           // :338
+        double* s = chunk + l * G::kSample;
+#pragma unroll
+        for (int j = 0; j < F; ++j) { s[j] = x[j]; s[F + j] = g * x[j]; }
+        s[2 * F] = g * z;
+        s[2 * F + 1] = (yi - mu) * (yi - mu);
+        s[2 * F + 2] = g > 1e-305 ? 1.0 : 0.0;
+      }
+      group_sync();
+      const int tn = A.n - c0 < L ? A.n - c0 : L;
+      if (active)
+      {
+        // the two factors of every term sit at fixed offsets of a chunk entry: left = x[p] (or (y - mu)^2 for the
+        // error entry, times 1), right = g x[q] / g z (or 1); four samples' worth are fetched before the four
+        // dependent additions (an LDS round trip per addition made this loop the kernel's time); kU samples at a time
+        int off_a[G::kPerLane], off_b[G::kPerLane];
+#pragma unroll
+        for (int m = 0; m < G::kPerLane; ++m)
+        {
+          off_a[m] = ek[m] == 2 ? 2 * F + 1 : ep[m];
+          off_b[m] = ek[m] == 0 ? F + eq[m] : 2 * F;
+        }
+        constexpr int kU = G::kPerLane == 1 ? 8 : 4;
+        for (int t0 = 0; t0 < tn; t0 += kU)
+        {
+          double fa[kU][G::kPerLane], fb[kU][G::kPerLane], fg[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+          {
+            const double* s = chunk + (t0 + u < tn ? t0 + u : tn - 1) * G::kSample;
+            fg[u] = s[2 * F + 2];
+#pragma unroll
+            for (int m = 0; m < G::kPerLane; ++m) { fa[u][m] = s[off_a[m]]; fb[u][m] = s[off_b[m]]; }
+          }
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+          {
+            if (t0 + u >= tn) break;
+            const bool good = fg[u] != 0.0;
+#pragma unroll
+            for (int m = 0; m < G::kPerLane; ++m)
+            {
+              if (ek[m] == 2) { acc[m] += fa[u][m]; ng += good ? 1 : 0; }                    // :341
+              else if (ek[m] >= 0 && good) acc[m] = acc[m] + fa[u][m] * fb[u][m];             // :357-364, :376-380
+            }
+          }
+        }
+      }
+      group_sync();
+    }
+    first = false;
+    // the sums to where every lane can read them
+#pragma unroll
+    for (int m = 0; m < G::kPerLane; ++m)
+    {
+      if (ek[m] == 0) Hm[ep[m] * F + eq[m]] = acc[m];
+      else if (ek[m] == 1) bv[ep[m]] = acc[m];
+      else if (ek[m] == 2) { sc[0] = acc[m]; sc[1] = (double)ng; }
+    }
+    group_sync();
+    if (active)
+    {
+      double error = sc[0];
+      if (sc[1] == 0.0) active = false;                            // :343
+      else
+      {
+        error /= A.n;
+        if (::fabs(error - prev_error) < 1e-6) active = false;     // :349
+        else prev_error = error;
+      }
+    }
+    // no-pivot Doolittle LU in place (:94-132): row i of U across the lanes, then column i of L
+    for (int i = 0; i < F; ++i)
+    {
+      if (active && l >= i && l < F)
+      {
+        const int k = l;
+        double sum = 0.0;
+        for (int j = 0; j < i; ++j) sum += Hm[i * F + j] * Hm[j * F + k];
+        Hm[i * F + k] = Hm[i * F + k] - sum;
+      }
+      group_sync();
+      if (active && l > i && l < F)
+      {
+        const int k = l;
+        double sum = 0;
+        for (int j = 0; j < i; ++j) sum += Hm[k * F + j] * Hm[j * F + i];
+        Hm[k * F + i] = (Hm[k * F + i] - sum) / Hm[i * F + i];
+      }
+      group_sync();
+    }
+    // inverse() (:134-189): lane c solves column c; det is the running product over every column solve
+    if (active && l < F)
+    {
+      const int c = l;
+      double y[F], x[F];
+      y[0] = (c == 0) ? 1.0 : 0.0;
+#pragma unroll
+      for (int row = 1; row < F; ++row)
+      {
+        double sum = 0;
+        for (int col = 0; col < row; ++col) sum += Hm[row * F + col] * y[col];
+        y[row] = ((c == row) ? 1.0 : 0.0) - sum;
+      }
+      x[F - 1] = y[F - 1] / Hm[(F - 1) * F + (F - 1)];
+#pragma unroll
+      for (int row = F - 2; row > -1; --row)
+      {
+        double sum = 0;
+        for (int col = row + 1; col < F; ++col) sum += Hm[row * F + col] * x[col];
+        x[row] = (y[row] - sum) / Hm[row * F + row];
+      }
+#pragma unroll
+      for (int p = 0; p < F; ++p) xc[c * F + p] = x[p];
+    }
+    group_sync();
+    if (active)
+    {
+      double det = 1;
+      for (int c = 0; c < F; ++c)
+        for (int row = F - 1; row > -1; --row) det *= Hm[row * F + row];
+      if (det == 0 || det != det) active = false;                  // :366-373
+    }
+    if (active && l < F)
+    {
+      double r = 0.0;
+      for (int c = 0; c < F; ++c) r = r + xc[c * F + l] * bv[c];   // :381
+      wv[l] = r;
+    }
+    group_sync();
+    if (active)
+    {
+#pragma unroll
+      for (int j = 0; j < F; ++j) w[j] = wv[j];
+      iter += 1;
+      if (iter >= A.max_iter) active = false;                      // :386-389 (weight NOT updated)
+      else if (l < F) weight[l] = w[l];                            // :394-395
+    }
+    group_sync();
+  }
+
+  // the alternative likelihood (popstrat.hpp:263-287): factors prepared L at a time, multiplied in sample order
+  double model[F];
+#pragma unroll
+  for (int j = 0; j < F; ++j) model[j] = weight[j];
+  double alt_l = 1.0;
+  for (int c0 = 0; c0 < A.n; c0 += L)
+  {
+    const int i = c0 + l;
+    if (i < A.n)
+    {
+      double x[F];
+      row_of(i, x);
+      double sdot = 0.0;
+#pragma unroll
+      for (int j = 0; j < F; ++j) sdot += model[j] * x[j];
+      const double p = sigmoid_ref(sdot);
+      chunk[l] = A.y[i] == 1 ? p : 1.0 - p;
+    }
+    group_sync();
+    const int tn = A.n - c0 < L ? A.n - c0 : L;
+    for (int t = 0; t < tn; ++t) alt_l = alt_l * chunk[t];
+    group_sync();
+  }
+  double null_l = null_likelihood;                               // :289-310 (same for every k-mer)
+  if (null_l == 0.0 && alt_l == 0.0) { null_l = 0.001; alt_l = 1.0; }     // :312-316
+  const double ratio = null_l / alt_l;
+  double llr = -2.0 * ::log(ratio);                              // :318-319
+  if (::fabs(llr) < epsilon || llr < 0.0 || alt_l != alt_l) llr = 0.0;    // :321-326
+  if (live && l == 0) out_p[surv] = kmd::igamc_half(llr / 2.0, lg_half);  // :328
 }
 
 // the null model: glm_irls(null features, Y) (popstrat.cpp:316-324) and its likelihood
@@ -320,9 +598,28 @@ __global__ void __launch_bounds__(256) k_transpose_counts(const double* __restri
   out[(size_t)s * ld + i] = in[t];
 }
 
+// Which kernel: measured at 100v100 (tools/kbench_popstrat.py, KMD_POPSTRAT_KERNEL=lane|group) -- 22 k survivors:
+// F = 5: 0.98 (group) / 1.44 ms (lane), F = 7: 1.72 / 1.77, F = 9: 2.56 / 2.06, F = 13: 4.3 / 6.4; 68 k survivors,
+// F = 5: 2.65 / 1.93; 364 k: 25 / 5.7 (F = 5), 66 / 28 (F = 13).  A lane per survivor is the throughput design; the
+// group kernel is for batches that cannot fill the chip (one partition's survivors).
+inline bool use_group_kernel(int F, size_t n)
+{
+  if (const char* e = std::getenv("KMD_POPSTRAT_KERNEL")) return e[0] == 'g';   // tests, A/B
+  return (F <= 7 && n < 32768) || (F >= 12 && n < 65536);
+}
+
 template <int F>
 void launch_apply(const irls_args& A, size_t n, double null_like, double lg_half, double epsilon, double* d_p, hipStream_t st)
 {
+  using G = group_shape<F>;
+  const bool group = use_group_kernel(F, n);
+  if (group)
+  {
+    const size_t lds = (size_t)(64 / G::L) * G::kLds * sizeof(double);
+    const unsigned grid = (unsigned)((n + 64 / G::L - 1) / (64 / G::L));
+    hipLaunchKernelGGL((k_popstrat_group<F>), dim3(grid), dim3(64), lds, st, A, n, null_like, lg_half, epsilon, d_p);
+    return;
+  }
   // the shared design in LDS when it fits comfortably (n x (F + 1) doubles per wave; 11 KB at 100v100)
   const size_t lds = (size_t)A.n * (F + 1) * sizeof(double);
   const unsigned grid = (unsigned)((n + 63) / 64);
@@ -404,7 +701,7 @@ int kmd_popstrat_create(kmd_popstrat** out, int nb_controls, int nb_cases,
   {
     // null model on the device: same code, fn features read with the alt stride (the null
     // design is the first fn columns of the alt design, popstrat.cpp:279-311)
-    irls_args A { ps->d_alt, fa, ps->d_y, ps->d_totals, nullptr, 0, n, ps->max_iter };
+    irls_args A { ps->d_alt, fa, ps->d_y, ps->d_totals, nullptr, 0, 0, n, ps->max_iter };
     double* d_like = ps->d_null_model + fn;
     switch (fn)
     {
@@ -474,19 +771,32 @@ int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sampl
   KMD_REQUIRE(ps && (n == 0 || (d_counts && d_pvalue)), "kmd_popstrat_apply: NULL");
   if (n == 0) return KMD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // which kernel (launch_apply): a lane per survivor for large batches of few features, a group of lanes per
+  // survivor otherwise; the first reads counts sample-major (coalesced across survivors), the second
+  // survivor-major (a group reads consecutive samples of its survivor)
+  const bool group = use_group_kernel(ps->f, n);
   const double* counts = d_counts;
   double* d_t = nullptr;
+  size_t si, ss;
   if (!sample_major)
   {
-    // [n][S] as gathered for KmerSign::m_counts_ratio -> sample-major so lanes read coalesced
     KMD_REQUIRE(ld == 0 || ld == (size_t)ps->n, "kmd_popstrat_apply: survivor-major counts must be dense [n][S]");
-    KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_t), n * (size_t)ps->n * sizeof(double)));
-    const size_t total = n * (size_t)ps->n;
-    hipLaunchKernelGGL(k_transpose_counts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_counts, n, ps->n, n, d_t);
-    counts = d_t; ld = n;
+    si = 1; ss = (size_t)ps->n;
+    if (!group)
+    {
+      // [n][S] as gathered for KmerSign::m_counts_ratio -> sample-major so lanes read coalesced
+      KMD_HIP(kmd::scratch_alloc(reinterpret_cast<void**>(&d_t), n * (size_t)ps->n * sizeof(double)));
+      const size_t total = n * (size_t)ps->n;
+      hipLaunchKernelGGL(k_transpose_counts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_counts, n, ps->n, n, d_t);
+      counts = d_t; si = n; ss = 1;
+    }
   }
-  else KMD_REQUIRE(ld >= n, "kmd_popstrat_apply: ld < n");
-  irls_args A { ps->d_alt, ps->f, ps->d_y, ps->d_totals, counts, ld, ps->n, ps->max_iter };
+  else
+  {
+    KMD_REQUIRE(ld >= n, "kmd_popstrat_apply: ld < n");
+    si = ld; ss = 1;
+  }
+  irls_args A { ps->d_alt, ps->f, ps->d_y, ps->d_totals, counts, si, ss, ps->n, ps->max_iter };
   switch (ps->f)
   {
     case 3: launch_apply<3>(A, n, ps->null_likelihood, ps->lg_half, ps->epsilon, d_pvalue, st); break;

@@ -161,3 +161,28 @@ def test_epsilon_clamps_small_likelihood_ratios(K, oracle):
     llr_small = p0 > oracle.chisqc(1, 0.5)                            # LLR < 0.5  <=>  p above the tail at 0.5
     assert llr_small.any() and (~llr_small).any()
     assert (p_big[llr_small] == 1.0).all() and (p_big[~llr_small] == p0[~llr_small]).all()
+
+
+@pytest.mark.parametrize("nc,nk,npc,stand,max_iter", [(10, 10, 2, True, 0), (20, 20, 2, False, 0), (33, 31, 4, True, 3), (50, 50, 5, True, 0),
+                                                      (100, 100, 2, True, 0), (40, 40, 10, True, 0), (6, 5, 2, True, 1)])
+def test_group_kernel_equals_lane_kernel(K, oracle, monkeypatch, nc, nk, npc, stand, max_iter):
+    """The two K3 kernels -- one lane per survivor, a group of lanes per survivor (small batches, many features) --
+    perform the same operations in the same order: bit-identical p-values, both layouts of the counts; and both
+    meet the oracle (every other test of this file runs under whichever kernel the batch size selects)."""
+    rng = np.random.default_rng(nc * 100 + npc)
+    S = nc + nk
+    rows = count_rows(rng, 700, nc, nk)
+    rows[5] = 0.0                                                      # a singular fit among them
+    Z = rng.normal(0, 0.1, size=(S, 10))
+    tc = rng.integers(8_000_000, 12_000_000, nc).astype(np.uint64)
+    tk = rng.integers(8_000_000, 12_000_000, nk).astype(np.uint64)
+    pop = K.pop_strat_corrector(nc, nk, tc, tk, npc, Z, stand=stand, max_iter=max_iter)
+    buf = K.DeviceBuffer.from_host(rows)
+    buf_t = K.DeviceBuffer.from_host(np.ascontiguousarray(rows.T))
+    out = {}
+    for kind in ("lane", "group"):
+        monkeypatch.setenv("KMD_POPSTRAT_KERNEL", kind)
+        out[kind] = pop.apply(buf, len(rows))
+        assert (pop.apply(buf_t, len(rows), sample_major=True, ld=len(rows)) == out[kind]).all()
+    assert (out["lane"] == out["group"]).all()
+    assert len(np.unique(out["lane"])) > 50 or max_iter == 1
