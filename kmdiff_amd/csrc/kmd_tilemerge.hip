@@ -57,8 +57,15 @@ using namespace kmd::eval;
 namespace {
 
 constexpr uint64_t kEmptyKey = ~0ull;
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u64x2 lds_u64x2;        // a bucket of two slots, read with one ds_read_b128
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kRsrcFlags = 0x00020000;           // buffer descriptor, dword 3: raw 32-bit data, no swizzle (gfx9 family)
+constexpr int kAuxNt = 2;                        // buffer load: non-temporal
+// the lanes' predicate as a mask, straight from the compare (HIP's __ballot takes an int: a select and a second compare)
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile live in LDS (16 KB at 1024 streams)
-constexpr uint32_t kProbes = 2048;               // records sampled for the records-per-row estimate
+constexpr uint32_t kProbes = 512;                // records sampled for the records-per-row estimate (+-5 % at worst; 2048 cost 39 us, 4x this)
 constexpr uint32_t kChunk = 64;                  // tile boundaries per coarse step of the start table
 constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
 
@@ -106,7 +113,9 @@ __host__ __device__ inline uint64_t mix64(uint64_t x)
   return x ^ (x >> 31);
 }
 
-// first index in [lo, hi) whose key is >= (b, bh)
+// first index in [lo, hi) whose key is >= (b, bh).  (An 8-ary version -- 7 pivots loaded per step, a third of the
+// dependent round trips -- was measured: k_tile_probe 39 -> 61 us, k_tile_fine 38 -> 62 us.  These searches are bound
+// by the number of distinct cache lines and pages they touch, not by the length of the chain.)
 __device__ __forceinline__ size_t lower_bound_key(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                   size_t lo, size_t hi, uint64_t b, uint64_t bh)
 {
@@ -433,115 +442,118 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
         const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
         const uint32_t* len = beg + S;
         uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);          // current run
-        uint32_t rb = 0, rl = 0, rc = 0;                                              // its first record, length, records done
+        uint32_t rl = 0, rc = 0;                                                      // its length, records done
+        const uint64_t* run_k = J.keys;                                               // its first record (scalar pointers)
+        const uint64_t* run_kh = J.keys_hi;
+        const uint32_t* run_c = J.counts;
         auto next_run = [&]()
         {
+          rc = 0;
           while (rs < S)
           {
-            rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
+            const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
             rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)len[rs]);
-            rc = 0;
+            run_k = J.keys + rb; run_c = J.counts + rb;
+            if constexpr (kTwo) run_kh = J.keys_hi + rb;
             if (rl) return;
             rs += kWaves;
           }
-          rb = 0; rl = 0; rc = 0;
+          rl = 0;
         };
         next_run();
         uint64_t rk[kRing], rkh[kTwo ? kRing : 1];
         uint32_t rcnt[kRing], rrem[kRing], rctl[kRing];                               // rrem / rctl: scalar
-        uint32_t claimed = 0;                                                         // slots this wave claimed (scalar)
         bool stop = false;
+        // A round's 64 records are read through a buffer descriptor made for the round: base = the run's first
+        // record, scalar offset = records done, extent = records left.  The hardware's range check returns 0
+        // to the lanes past the end of the run (no clamped index, no address arithmetic in vector registers --
+        // a lane's offset is 8 x its number, always), and nothing is read once the runs are exhausted.
+        const uint32_t lane8 = lane * 8u, lane4 = lane * 4u;
         auto fetch_w = [&](const int d)
         {
           const uint32_t rem = rs < S ? rl - rc : 0u;
-          // lanes past the end of the run re-read its last record (never used): nothing is read out of bounds
-          const uint32_t l = lane < rem ? lane : (rem ? rem - 1u : 0u);
-          const size_t base = (size_t)rb + rc;
-          rk[d] = __builtin_nontemporal_load(J.keys + base + l);
-          rcnt[d] = __builtin_nontemporal_load(J.counts + base + l);
-          if constexpr (kTwo) rkh[d] = __builtin_nontemporal_load(J.keys_hi + base + l);
+          const uint32_t ext = rem < 64u ? rem : 64u;
+          const auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(run_k), (short)0, (int)(ext * 8u), kRsrcFlags);
+          const auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(run_c), (short)0, (int)(ext * 4u), kRsrcFlags);
+          const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(dk, (int)lane8, (int)(rc * 8u), kAuxNt);
+          rk[d] = ((uint64_t)kk.y << 32) | kk.x;
+          rcnt[d] = __builtin_amdgcn_raw_buffer_load_b32(dc, (int)lane4, (int)(rc * 4u), kAuxNt);
+          if constexpr (kTwo)
+          {
+            const auto dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(run_kh), (short)0, (int)(ext * 8u), kRsrcFlags);
+            const u32x2 hh = __builtin_amdgcn_raw_buffer_load_b64(dh, (int)lane8, (int)(rc * 8u), kAuxNt);
+            rkh[d] = ((uint64_t)hh.y << 32) | hh.x;
+          }
           rrem[d] = rem;
           rctl[d] = rs < J.nc ? 1u : 0u;
           rc += 64;
-          if (rc >= rl && rs < S)
-          {
-            // end of a run: this wave's claims so far go to the tile's count; a table 3/4 full gives up
-            if (claimed)
-            {
-              if (lane == 0) { const uint32_t before = atomicAdd(&M.fresh[buf], claimed); if (before + claimed > kFullAt) M.abort[buf] = 1; }
-              claimed = 0;
-            }
-            rs += kWaves; next_run();
-          }
+          if (rc >= rl && rs < S) { rs += kWaves; next_run(); }
         };
         auto insert_w = [&](const int d)
         {
           const uint64_t k = rk[d];
           const bool v = lane < rrem[d];
-          const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
-          const uint32_t h0 = (x * 0x9E3779B1u) >> kShift;
-          const uint32_t h1 = ((x ^ (x >> 15)) * 0x85EBCA6Bu) >> kShift;
-          const unsigned long long s0 = __hip_atomic_load(&M.key[h0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const unsigned long long s1 = __hip_atomic_load(&M.key[h1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const bool is_marker = k == kEmptyKey;
-          if (__ballot(v && is_marker))
+          if (v & is_marker)
           {
             // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
-            if (v && is_marker)
-            {
-              atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)rcnt[d]);
-              if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d]); }
-              M.hasmax = 1;
-            }
+            atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)rcnt[d]);
+            if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d]); }
+            M.hasmax = 1;
           }
-          const bool usable = v && !is_marker;
-          const bool hit0 = s0 == k, hit1 = s1 == k, e0 = s0 == kEmptyKey, e1 = s1 == kEmptyKey;
-          const bool found = hit0 || hit1;
-          const bool claim = usable && !found && (e0 || e1);                          // the first empty home
-          uint32_t slot = (hit0 || (!hit1 && e0)) ? h0 : h1;
-          uint32_t nxt = (claim && e0) ? h1 : ((h1 + 1u) & kMask);
-          bool pend = usable && !found;
-          if (__ballot(claim))
+          // A k-mer's probe sequence: the two slots of its home bucket 0, the two of its home bucket 1, then one
+          // slot after the other from there.  The first step reads both buckets (two 16-byte LDS reads, four
+          // candidates): at 1/3 load ~0.3 % of the k-mers live beyond them, so the loop below runs in one
+          // round of seven (with two single-slot homes it ran in nine of ten: a wave pays for the longest
+          // sequence among its 64 records).  The first of the four that holds the k-mer OR is empty is the
+          // one: slots are never released within a tile, so a k-mer is never behind an empty slot.
+          // No count of claimed slots is kept: a table that fills up shows as a sequence that does not end.
+          if (v & !is_marker)
           {
-            bool fresh = false;
-            if (claim)
+            const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
+            const uint32_t b0 = ((x * 0x9E3779B1u) >> (kShift + 1)) << 1;
+            const uint32_t b1 = (((x ^ (x >> 15)) * 0x85EBCA6Bu) >> (kShift + 1)) << 1;
+            const u64x2 q0 = *(const lds_u64x2*)(&M.key[b0]), q1 = *(const lds_u64x2*)(&M.key[b1]);
+            // (bitwise operators on purpose: the short-circuit forms become a branch per term)
+            const bool e0 = q0.x == kEmptyKey, e1 = q0.y == kEmptyKey, e2 = q1.x == kEmptyKey, e3 = q1.y == kEmptyKey;
+            const bool m0 = e0 | (q0.x == k), m1 = e1 | (q0.y == k), m2 = e2 | (q1.x == k), m3 = e3 | (q1.y == k);
+            uint32_t slot = b1 + 1u;
+            slot = m2 ? b1 : slot;
+            slot = m1 ? b0 + 1u : slot;
+            slot = m0 ? b0 : slot;
+            bool placed = m0 | m1 | m2 | m3;
+            const bool p2m = m0 | m1, p3m = p2m | m2;
+            uint32_t pos = 4;                                                         // where in the sequence to go on, if at all
+            if (e0 | (e1 & !m0) | (e2 & !p2m) | (e3 & !p3m))                          // the first of them is an empty one: claim it
             {
               const unsigned long long old = atomicCAS(&M.key[slot], (unsigned long long)kEmptyKey, (unsigned long long)k);
-              fresh = old == kEmptyKey;
-              if (fresh || old == k) pend = false;                                    // else: lost the slot to another k-mer
+              if ((old != kEmptyKey) & (old != k)) { placed = false; pos = 0; }       // another k-mer took it: once more, slot by slot
             }
-            claimed += (uint32_t)__popcll(__ballot(fresh));
-          }
-          // the tail: one slot per step from nxt on (about 3 % of the records get here)
-          for (uint32_t step = 0; __ballot(pend); ++step)
-          {
-            if (step >= kMaxProbe) { M.abort[buf] = 1; break; }
-            unsigned long long seen = __hip_atomic_load(&M.key[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool want = pend && seen == kEmptyKey;
-            if (__ballot(want))
+            if (!placed)
             {
-              bool fresh = false;
-              if (want)
+              // the rest of the sequence, one slot per step (position 0, 1: bucket 0; from 2 on: bucket 1 and behind it)
+              for (uint32_t step = 0;; ++step, ++pos)
               {
-                seen = atomicCAS(&M.key[nxt], (unsigned long long)kEmptyKey, (unsigned long long)k);
-                fresh = seen == kEmptyKey;
-                if (fresh) seen = k;
+                if (step >= kMaxProbe) { M.abort[buf] = 1; break; }
+                const uint32_t nxt = pos < 2u ? b0 + pos : (b1 + pos - 2u) & kMask;
+                unsigned long long seen = __hip_atomic_load(&M.key[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (seen == kEmptyKey)
+                {
+                  seen = atomicCAS(&M.key[nxt], (unsigned long long)kEmptyKey, (unsigned long long)k);
+                  if (seen == kEmptyKey) seen = k;
+                }
+                if (seen == k) { slot = nxt; placed = true; break; }
               }
-              claimed += (uint32_t)__popcll(__ballot(fresh));
             }
-            const bool hit = pend && seen == k;
-            slot = hit ? nxt : slot;
-            pend = pend && !hit;
-            nxt = (nxt + 1u) & kMask;
-          }
-          if (usable && !pend)
-          {
-            unsigned long long* sums = rctl[d] ? M.sc : M.sk;                         // (scalar choice)
-            atomicAdd(&sums[slot], (unsigned long long)rcnt[d]);
-            if constexpr (kTwo)
+            if (placed)
             {
-              atomicMax(&M.key_hi[slot], (unsigned long long)rkh[d]);
-              atomicMin(&M.hi_min[slot], (unsigned long long)rkh[d]);
+              unsigned long long* sums = rctl[d] ? M.sc : M.sk;                       // (scalar choice)
+              atomicAdd(&sums[slot], (unsigned long long)rcnt[d]);
+              if constexpr (kTwo)
+              {
+                atomicMax(&M.key_hi[slot], (unsigned long long)rkh[d]);
+                atomicMin(&M.hi_min[slot], (unsigned long long)rkh[d]);
+              }
             }
           }
         };
@@ -558,11 +570,6 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
             fetch_w(d);
             if ((d & 3) == 3 && M.abort[buf]) { stop = true; break; }                 // (LDS read, same for the whole wave)
           }
-        }
-        if (claimed && lane == 0)
-        {
-          const uint32_t before = atomicAdd(&M.fresh[buf], claimed);
-          if (before + claimed > kFullAt) M.abort[buf] = 1;
         }
       }
     }
@@ -634,7 +641,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           s0[u] = __hip_atomic_load(&M.key[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           s1[u] = __hip_atomic_load(&M.key[nxt[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (__ballot(special))
+        if (ballot(special))
         {
           // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
 #pragma unroll
@@ -664,7 +671,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           want_cas |= claim[u];
         }
 #if !(KMD_TILE_ABLATE & 1)
-        if (__ballot(want_cas))
+        if (ballot(want_cas))
         {
 #pragma unroll
           for (int u = 0; u < kU; ++u)
@@ -686,7 +693,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           bool any = false;
 #pragma unroll
           for (int u = 0; u < kU; ++u) any |= pend[u];
-          if (!__ballot(any)) break;
+          if (!ballot(any)) break;
           if (step >= kMaxProbe) { gave_up = any; break; }
           unsigned long long seen[kU];
 #pragma unroll
@@ -694,7 +701,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           bool want = false;
 #pragma unroll
           for (int u = 0; u < kU; ++u) want |= pend[u] && seen[u] == kEmptyKey;
-          if (__ballot(want))
+          if (ballot(want))
           {
 #pragma unroll
             for (int u = 0; u < kU; ++u)
@@ -732,7 +739,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
               atomicMin(&M.hi_min[slot[u]], (unsigned long long)A.kh[u]);
             }
           }
-          claimed += (uint32_t)__popcll(__ballot(((fresh_bits >> u) & 1u) != 0));
+          claimed += (uint32_t)__popcll(ballot(((fresh_bits >> u) & 1u) != 0));
         }
         // slots this wave claimed in the round -> the tile's count; a table 3/4 full gives up
         if (lane == 0 && claimed)
@@ -755,7 +762,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           for (int d = 0; d < kDepth; ++d)
           {
             if (!more) break;
-            if (!__ballot(R[d].valid != 0)) { more = false; break; }     // the runs are exhausted in order
+            if (!ballot(R[d].valid != 0)) { more = false; break; }     // the runs are exhausted in order
             if (!insert(R[d])) { more = false; break; }
             fetch(R[d]);
           }
@@ -782,7 +789,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           for (uint32_t i = tid; i < kSlots; i += kThreads)
             bad |= M.key[i] != kEmptyKey && M.key_hi[i] != M.hi_min[i];
         if (tid == 0 && !aborted && M.hasmax && M.max_hi[0] != M.max_hi[1]) bad = true;
-        if (__ballot(bad) && lane == 0) M.bad = 1;
+        if (ballot(bad) && lane == 0) M.bad = 1;
         __syncthreads();
       }
       const bool bad_tile = aborted || (kTwo && M.bad != 0);
@@ -854,7 +861,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
         const uint64_t key = M.key[i];
         const bool live = key != kEmptyKey;
         const bool leaves = (out_bits >> j) & 1u;
-        const unsigned long long m = __ballot(leaves);
+        const unsigned long long m = ballot(leaves);
         if (live)
         {
           if (leaves)
