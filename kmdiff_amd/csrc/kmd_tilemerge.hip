@@ -464,15 +464,17 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
         uint64_t rk[kRing], rkh[kTwo ? kRing : 1];
         uint32_t rcnt[kRing], rrem[kRing], rctl[kRing];                               // rrem / rctl: scalar
         bool stop = false;
-        // A round's 64 records are read through a buffer descriptor made for the round: base = the run's first
-        // record, scalar offset = records done, extent = records left.  The hardware's range check returns 0
-        // to the lanes past the end of the run (no clamped index, no address arithmetic in vector registers --
-        // a lane's offset is 8 x its number, always), and nothing is read once the runs are exhausted.
+        // A round's 64 records are read through a buffer descriptor of the run: base = the run's first record,
+        // extent = the run, scalar offset = records done, a lane's offset = 8 x its number, always.  The
+        // hardware's range check (on gfx950 it covers the scalar offset too: measured, a per-round extent with
+        // the scalar offset on top returned zeros from the second round on) gives 0 to the lanes past the end
+        // of the run: no clamped index and no address arithmetic in vector registers, and nothing is read
+        // once the runs are exhausted (extent 0).
         const uint32_t lane8 = lane * 8u, lane4 = lane * 4u;
         auto fetch_w = [&](const int d)
         {
           const uint32_t rem = rs < S ? rl - rc : 0u;
-          const uint32_t ext = rem < 64u ? rem : 64u;
+          const uint32_t ext = rs < S ? rl : 0u;
           const auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(run_k), (short)0, (int)(ext * 8u), kRsrcFlags);
           const auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(run_c), (short)0, (int)(ext * 4u), kRsrcFlags);
           const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(dk, (int)lane8, (int)(rc * 8u), kAuxNt);
