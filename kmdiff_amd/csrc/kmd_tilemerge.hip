@@ -441,55 +441,58 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
         constexpr int kRing = KMD_TILE_RING;
         const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
         const uint32_t* len = beg + S;
+        // A round's 64 records are read through buffer descriptors of the run: base = the run's first record,
+        // extent = the run, scalar offset = records done, a lane's offset = 8 x its number, always.  The
+        // hardware's range check (on gfx950 it covers the scalar offset too: measured, a per-round extent with
+        // the scalar offset on top returned zeros from the second round on) gives 0 to the lanes past the end
+        // of the run: no clamped index and no address arithmetic in vector registers, and nothing is read
+        // once the runs are exhausted (extent 0).  The descriptors are made once per run; a round costs the
+        // scalar unit a subtraction, two shifts, an addition and a compare.
         uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);          // current run
-        uint32_t rl = 0, rc = 0;                                                      // its length, records done
-        const uint64_t* run_k = J.keys;                                               // its first record (scalar pointers)
-        const uint64_t* run_kh = J.keys_hi;
-        const uint32_t* run_c = J.counts;
+        uint32_t rl = 0, rc = 0, ctl_now = 0;                                         // its length (0: no run left), records done, control sample?
+        auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys), (short)0, 0, kRsrcFlags);
+        auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts), (short)0, 0, kRsrcFlags);
+        auto dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(kTwo ? J.keys_hi : J.keys), (short)0, 0, kRsrcFlags);
         auto next_run = [&]()
         {
-          rc = 0;
+          rc = 0; rl = 0;
           while (rs < S)
           {
             const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
             rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)len[rs]);
-            run_k = J.keys + rb; run_c = J.counts + rb;
-            if constexpr (kTwo) run_kh = J.keys_hi + rb;
-            if (rl) return;
+            if (rl) 
+            {
+              dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
+              dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts + rb), (short)0, (int)(rl * 4u), kRsrcFlags);
+              if constexpr (kTwo) dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys_hi + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
+              ctl_now = rs < J.nc ? 1u : 0u;
+              return;
+            }
             rs += kWaves;
           }
-          rl = 0;
+          // no run left: extent 0, every further load returns 0 without touching memory
+          dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys), (short)0, 0, kRsrcFlags);
+          dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts), (short)0, 0, kRsrcFlags);
+          if constexpr (kTwo) dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys_hi), (short)0, 0, kRsrcFlags);
         };
         next_run();
         uint64_t rk[kRing], rkh[kTwo ? kRing : 1];
         uint32_t rcnt[kRing], rrem[kRing], rctl[kRing];                               // rrem / rctl: scalar
         bool stop = false;
-        // A round's 64 records are read through a buffer descriptor of the run: base = the run's first record,
-        // extent = the run, scalar offset = records done, a lane's offset = 8 x its number, always.  The
-        // hardware's range check (on gfx950 it covers the scalar offset too: measured, a per-round extent with
-        // the scalar offset on top returned zeros from the second round on) gives 0 to the lanes past the end
-        // of the run: no clamped index and no address arithmetic in vector registers, and nothing is read
-        // once the runs are exhausted (extent 0).
         const uint32_t lane8 = lane * 8u, lane4 = lane * 4u;
         auto fetch_w = [&](const int d)
         {
-          const uint32_t rem = rs < S ? rl - rc : 0u;
-          const uint32_t ext = rs < S ? rl : 0u;
-          const auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(run_k), (short)0, (int)(ext * 8u), kRsrcFlags);
-          const auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(run_c), (short)0, (int)(ext * 4u), kRsrcFlags);
           const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(dk, (int)lane8, (int)(rc * 8u), kAuxNt);
           rk[d] = ((uint64_t)kk.y << 32) | kk.x;
           rcnt[d] = __builtin_amdgcn_raw_buffer_load_b32(dc, (int)lane4, (int)(rc * 4u), kAuxNt);
           if constexpr (kTwo)
           {
-            const auto dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(run_kh), (short)0, (int)(ext * 8u), kRsrcFlags);
             const u32x2 hh = __builtin_amdgcn_raw_buffer_load_b64(dh, (int)lane8, (int)(rc * 8u), kAuxNt);
             rkh[d] = ((uint64_t)hh.y << 32) | hh.x;
           }
-          rrem[d] = rem;
-          rctl[d] = rs < J.nc ? 1u : 0u;
-          rc += 64;
-          if (rc >= rl && rs < S) { rs += kWaves; next_run(); }
+          rrem[d] = rl - rc;                                                          // (0 when no run is left: rl = rc = 0)
+          rctl[d] = ctl_now;
+          if (rc + 64u >= rl) { rs += kWaves; next_run(); } else rc += 64u;
         };
         auto insert_w = [&](const int d)
         {
