@@ -228,5 +228,6 @@ int near_list_begin(eval::filter_params& P, hipStream_t stream);
 int near_list_end(const eval::filter_params& P, int row_mode, hipStream_t stream);
 int launch_filter_candidates(const eval::filter_params& P, const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_kmer_hi,
                              const uint64_t* d_sum_c, const uint64_t* d_sum_k, size_t n, uint64_t rows_total, uint64_t rows_beyond,
-                             hipStream_t stream);
+                             hipStream_t stream, const uint64_t* d_gate = nullptr, const uint32_t* d_gate_over = nullptr,
+                             size_t gate_cap = 0);
 }

@@ -587,10 +587,22 @@ __global__ void __launch_bounds__(kBlock) k_filter_sums(const filter_params P, c
 constexpr int kCandBlock = 256;
 constexpr uint32_t kCandStage = 256;                     // staged survivors per wave (flushed at >= 192: room for 64 more)
 
+// `gate` (may be NULL): the launch was enqueued BEHIND the merge that fills the list, before the host knew how
+// the merge went -- gate[0..2] = entries, distinct k-mers, rows beyond the table as the merge left them on the
+// device, *gate_over = tiles it could not finish.  If any tile is unfinished or the list overflowed, the kernel
+// does nothing at all (the host then goes the long way and launches it again without a gate).
 __global__ void __launch_bounds__(kCandBlock) k_filter_candidates(const filter_params P, const unsigned long long* __restrict__ sum_c,
                                                                   const unsigned long long* __restrict__ sum_k,
-                                                                  unsigned long long rows_total, unsigned long long rows_beyond)
+                                                                  unsigned long long rows_total, unsigned long long rows_beyond,
+                                                                  const unsigned long long* __restrict__ gate,
+                                                                  const uint32_t* __restrict__ gate_over, unsigned long long gate_cap)
 {
+  size_t n_rows = P.n_rows;
+  if (gate)
+  {
+    if (*gate_over != 0 || gate[0] > gate_cap) return;
+    n_rows = (size_t)gate[0]; rows_total = gate[1]; rows_beyond = gate[2];
+  }
   __shared__ unsigned long long s_row[kCandBlock / 64][kCandStage];
   __shared__ double s_p[kCandBlock / 64][kCandStage], s_mc[kCandBlock / 64][kCandStage], s_mk[kCandBlock / 64][kCandStage];
   __shared__ int s_sign[kCandBlock / 64][kCandStage];
@@ -626,12 +638,12 @@ __global__ void __launch_bounds__(kCandBlock) k_filter_candidates(const filter_p
     queue_fence();
   };
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t n_round = (P.n_rows + stride - 1) / stride * stride;
+  const size_t n_round = (n_rows + stride - 1) / stride * stride;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
   {
     row_state st;
     st.row = i;
-    st.valid = i < P.n_rows;
+    st.valid = i < n_rows;
     st.sum_c = st.valid ? sum_c[i] : 0ull;
     st.sum_k = st.valid ? sum_k[i] : 0ull;
     const row_result R = evaluate_core(P, nullptr, st);
@@ -1686,18 +1698,20 @@ int kmd::near_list_end(const filter_params& P, int row_mode, hipStream_t stream)
 
 int kmd::launch_filter_candidates(const filter_params& P_in, const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_kmer_hi,
                                   const uint64_t* d_sum_c, const uint64_t* d_sum_k, size_t n, uint64_t rows_total, uint64_t rows_beyond,
-                                  hipStream_t stream)
+                                  hipStream_t stream, const uint64_t* d_gate, const uint32_t* d_gate_over, size_t gate_cap)
 {
   filter_params P = P_in;
   P.kmer_lo = d_kmer; P.kmer_hi = d_kmer_hi; P.row_base = 0; P.n_rows = n;
   P.lds_n = 0;                                            // the table is read for candidates only: from L2
-  size_t grid = std::min<size_t>((size_t)m->n_cu * 8, (n + kCandBlock - 1) / kCandBlock);
+  // gated: the number of entries is on the device, the grid is the full one (idle workgroups leave at once)
+  size_t grid = d_gate ? (size_t)m->n_cu * 8 : std::min<size_t>((size_t)m->n_cu * 8, (n + kCandBlock - 1) / kCandBlock);
   if (grid < 1) grid = 1;
   int rc = near_list_begin(P, stream);
   if (rc != KMD_OK) return rc;
   hipLaunchKernelGGL(k_filter_candidates, dim3((unsigned)grid), dim3(kCandBlock), 0, stream, P,
                      reinterpret_cast<const unsigned long long*>(d_sum_c), reinterpret_cast<const unsigned long long*>(d_sum_k),
-                     (unsigned long long)rows_total, (unsigned long long)rows_beyond);
+                     (unsigned long long)rows_total, (unsigned long long)rows_beyond,
+                     reinterpret_cast<const unsigned long long*>(d_gate), d_gate_over, (unsigned long long)gate_cap);
   KMD_HIP(hipGetLastError());
   return near_list_end(P, 1, stream);
 }

@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -817,11 +818,15 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           const uint32_t i = tid + (uint32_t)j * kThreads;
           const bool live = M.key[i] != kEmptyKey;
           bool leaves = live;
+#if KMD_TILE_ABLATE & 4   // dev: no pre-filter evaluation, nothing leaves (results wrong)
+          leaves = false;
+#else
           if constexpr (kFilter)
           {
             row_state st; st.sum_c = live ? M.sc[i] : 0; st.sum_k = live ? M.sk[i] : 0; st.row = 0; st.valid = live;
             leaves = row_may_pass(J, st, n_beyond);
           }
+#endif
           rows_local += live ? 1u : 0u;
           out_bits |= leaves ? 1u << j : 0u;
           mine += leaves ? 1u : 0u;
@@ -838,6 +843,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           mine += special_out ? 1u : 0u;
         }
       }
+#if !(KMD_TILE_ABLATE & 8)   // dev: no reservation (and its two barriers)
       for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
       if (lane == 0) M.wcnt[wave] = mine;
       __syncthreads();
@@ -848,6 +854,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
         M.base = total ? atomicAdd(J.n_rows, (unsigned long long)total) : 0ull;
       }
       __syncthreads();
+#endif
       unsigned long long out_at = M.base;
       for (uint32_t w = 0; w < wave; ++w) out_at += M.wcnt[w];
       if (special_out)                                     // (thread 0: the first entry of the tile)
@@ -953,9 +960,15 @@ inline uint32_t env_u32(const char* name, uint32_t dflt)
 // produced (the first row_capacity of them written), totals[0] = distinct k-mers, totals[1] = rows with a
 // count sum beyond the log-factorial table (pre-filter mode).
 // Synchronous: the tiles that gave up are known only when the kernel has run.
+// `behind_level0` (may be empty): work the caller wants enqueued right behind the first pass, BEFORE the host
+// learns how that pass went -- it is given the device addresses of [entries, distinct k-mers, rows beyond the
+// table] and of the count of unfinished tiles, and must gate itself on them (k_filter_candidates does).
+// *clean = the first pass finished every tile (the gated work was live if the list did not overflow either).
+using level0_hook = std::function<int(const uint64_t* d_live, const uint32_t* d_over_n)>;
 int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi, const uint32_t* d_counts,
                const uint64_t* offsets, const filter_params* pf, uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out,
-               uint64_t* d_sum_c, uint64_t* d_sum_k, size_t row_capacity, uint64_t* n_entries, uint64_t totals[2], hipStream_t st)
+               uint64_t* d_sum_c, uint64_t* d_sum_k, size_t row_capacity, uint64_t* n_entries, uint64_t totals[2], hipStream_t st,
+               const level0_hook& behind_level0 = level0_hook(), bool* clean = nullptr)
 {
   const bool fused = pf != nullptr;
   const size_t n = (size_t)offsets[S];
@@ -965,7 +978,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   KMD_HIP(hipGetDevice(&dev));
   KMD_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   const tile_shape sh = pick_shape();
-  const float load = (float)env_u32("KMD_TILE_LOAD_PCT", 33) / 100.0f;        // distinct k-mers per slot aimed at
+  const float load = (float)env_u32("KMD_TILE_LOAD_PCT", 50) / 100.0f;        // distinct k-mers per slot aimed at
 
   uint32_t L = 0;
   for (int s = 1; s < S; ++s) if (offsets[s + 1] - offsets[s] > offsets[L + 1] - offsets[L]) L = (uint32_t)s;
@@ -1081,6 +1094,11 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     J.over_n = d_over_n; J.over = static_cast<uint32_t*>(p_over); J.over_stride = list_cap;
     int rc = run(list_cap);
     if (rc != KMD_OK) return rc;
+    if (level == 0 && behind_level0)
+    {
+      rc = behind_level0(reinterpret_cast<const uint64_t*>(d_rows), d_over_n);
+      if (rc != KMD_OK) return rc;
+    }
     // one read-back per level: [plan | entries, rows, rows beyond the table | tiles listed]
     KMD_HIP(hipMemcpyAsync(h_small, p_small, 64, hipMemcpyDeviceToHost, st));
     KMD_HIP(hipStreamSynchronize(st));
@@ -1089,6 +1107,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     if (dbg)
       std::fprintf(stderr, "[tile_merge] level %d: %u of %u tiles gave up (plan: %.2f records per row, %u records per tile, r %u, G %u)\n",
                    level, n_over, level ? n_tiles : h_plan.nb, h_plan.rho, h_plan.fill, h_plan.r, 1u << h_plan.g_shift);
+    if (level == 0 && clean) *clean = n_over == 0;
     if (n_over == 0) break;
     KMD_REQUIRE(level < 80, "kmd: tile refinement did not converge");
     // cut the listed tiles by the key range they span: a tile that ran out of table is cut as if every
@@ -1172,14 +1191,29 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   {
     KMD_HIP(sc.take(&p_k, cap * 8)); KMD_HIP(sc.take(&p_c, cap * 8)); KMD_HIP(sc.take(&p_s, cap * 8));
     if (two) KMD_HIP(sc.take(&p_h, cap * 8));
+    // The exact evaluation of the list is enqueued right behind the first pass of the merge, gated on the device
+    // by "every tile finished and the list did not overflow" (almost always): one host round trip per call.
+    bool clean = false;
+    const size_t cap_now = cap;
+    auto speculate = [&](const uint64_t* d_live, const uint32_t* d_over_n) -> int
+    {
+      return kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(p_k), static_cast<const uint64_t*>(p_h),
+                                           static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), 0, 0, 0, st,
+                                           d_live, d_over_n, cap_now);
+    };
     rc = tile_merge(n_samples, m->nc, d_kmers, d_kmers_hi, d_counts, offsets, &P, static_cast<uint64_t*>(p_k), static_cast<uint64_t*>(p_h),
-                    static_cast<uint64_t*>(p_c), static_cast<uint64_t*>(p_s), cap, &entries, totals, st);
+                    static_cast<uint64_t*>(p_c), static_cast<uint64_t*>(p_s), cap, &entries, totals, st, speculate, &clean);
     if (rc != KMD_OK) return rc;
-    if (entries <= cap) break;
+    if (entries <= cap)
+    {
+      if (n_rows_out) *n_rows_out = totals[0];
+      if (clean) return KMD_OK;                               // the gated launch did the work; tile_merge has synchronised behind it
+      break;
+    }
     KMD_REQUIRE(attempt == 0, "kmd_merge_filter: candidate list overflowed twice");
     cap = (size_t)entries;
   }
-  if (n_rows_out) *n_rows_out = totals[0];
+  // the long way (tiles were cut again after the first pass): the list is complete only now
   rc = kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(p_k), static_cast<const uint64_t*>(p_h),
                                      static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), (size_t)entries, totals[0], totals[1], st);
   if (rc != KMD_OK) return rc;
