@@ -1633,6 +1633,8 @@ __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
       }
     }
   }
+  // the list is handed back empty: it belongs to the stream and serves the next filter launch on it as it is
+  if (lane == 0) P.near[0] = 0;
   if (struck == 0 || !P.out.d_pvalue) return;
   // compact the sink in place (this wave alone, behind the filter kernel on its stream): records marked
   // p = -1 leave, the others close ranks in order
@@ -1674,13 +1676,40 @@ __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
   if (lane == 0) P.counters[KMD_CNT_SIG] = w;             // (= the old count - struck, when nothing was truncated)
 }
 
+// The list of a launch: one per (device, stream), made at the first filter launch on that stream and kept; it is
+// empty whenever no filter work is in flight on the stream (k_resolve_near hands it back empty), so a launch costs
+// neither an allocation nor a memset.  Launches on one stream are ordered, launches on different streams have
+// different lists.
+namespace {
+std::mutex g_near_mu;
+std::map<std::pair<int, hipStream_t>, unsigned long long*> g_near_lists;
+constexpr size_t kNearListsMax = 256;                   // streams served with a kept list; beyond: allocated per launch
+}
+
 int kmd::near_list_begin(filter_params& P, hipStream_t stream)
 {
   P.near = nullptr;
   static const bool off = std::getenv("KMD_NO_GUARD") != nullptr;      // dev: the filter without its guard
   if (off) return KMD_OK;
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
+  const size_t bytes = (1 + 4 * kNearCap) * sizeof(unsigned long long);
+  {
+    std::lock_guard<std::mutex> lock(g_near_mu);
+    auto it = g_near_lists.find({ dev, stream });
+    if (it != g_near_lists.end()) { P.near = it->second; return KMD_OK; }
+    if (g_near_lists.size() < kNearListsMax)
+    {
+      void* p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return KMD_OK; }
+      if (hipMemset(p, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return KMD_OK; }
+      g_near_lists[{ dev, stream }] = static_cast<unsigned long long*>(p);
+      P.near = static_cast<unsigned long long*>(p);
+      return KMD_OK;
+    }
+  }
   void* p = nullptr;
-  if (hipMallocAsync(&p, (1 + 4 * kNearCap) * sizeof(unsigned long long), stream) != hipSuccess) { (void)hipGetLastError(); return KMD_OK; }
+  if (hipMallocAsync(&p, bytes, stream) != hipSuccess) { (void)hipGetLastError(); return KMD_OK; }
   P.near = static_cast<unsigned long long*>(p);
   KMD_HIP(hipMemsetAsync(P.near, 0, sizeof(unsigned long long), stream));
   return KMD_OK;
@@ -1692,7 +1721,15 @@ int kmd::near_list_end(const filter_params& P, int row_mode, hipStream_t stream)
   if (row_mode == 1) hipLaunchKernelGGL(k_resolve_near<1>, dim3(1), dim3(64), 0, stream, P);
   else hipLaunchKernelGGL(k_resolve_near<0>, dim3(1), dim3(64), 0, stream, P);
   KMD_HIP(hipGetLastError());
-  KMD_HIP(hipFreeAsync(P.near, stream));
+  bool kept = false;
+  {
+    int dev = 0;
+    KMD_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_near_mu);
+    auto it = g_near_lists.find({ dev, stream });
+    kept = it != g_near_lists.end() && it->second == P.near;
+  }
+  if (!kept) KMD_HIP(hipFreeAsync(P.near, stream));
   return KMD_OK;
 }
 

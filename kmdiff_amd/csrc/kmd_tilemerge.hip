@@ -7,26 +7,29 @@
 // counts and the sum of its case counts (include/kmdiff/model.hpp:144-145).
 //
 // Shape of the work (HBM-bound: 12 bytes per record are read once, nothing else is large):
-//   * k_tile_probe / k_tile_plan: how many records make a row here?  2048 records drawn uniformly, the
-//     number m of streams holding each one's k-mer; mean(1/m) = distinct k-mers / records (unbiased).
-//     The plan -- records per tile such that a tile's distinct k-mers fill ~1/3 of the hash table, the
-//     splitter stride, lanes per run -- stays on the device: no host round trip before the main kernel;
+//   * k_tile_probe: how many records make a row here?  512 records drawn uniformly, the number m of
+//     streams holding each one's k-mer; mean(1/m) = distinct k-mers / records (unbiased).  The plan --
+//     records per tile such that a tile's distinct k-mers fill half of the hash table, the splitter
+//     stride, lanes per run -- stays on the device: no host round trip before the main kernel;
 //   * the key range of the partition is cut into TILES by splitters taken from the data (every r-th key
-//     of the longest stream); where each stream enters each tile: every 64th boundary by binary search
-//     over the stream, the 63 in between inside the short window those enclose (k_tile_coarse/_fine);
+//     of the longest stream); where each stream enters each tile: every 64th boundary by a search over
+//     the stream, the 63 in between inside the short window those enclose (k_tile_coarse/_fine);
 //   * k_tile_sums: one WORKGROUP per tile on a persistent grid.  A tile is S contiguous runs of records,
-//     one per stream: sub-groups of G lanes stream a run each with coalesced loads (G fitted to the run
-//     length), the loads of the next round in flight while the current one is inserted; every record goes
-//     into a workgroup-wide LDS hash set keyed by the k-mer (64-bit compare-and-swap) and adds its count
-//     to that k-mer's control or case sum (64-bit LDS add);
+//     one per stream.  A wave takes whole runs, 64 records a round (one per lane) through a buffer
+//     descriptor of the run, 8 rounds in flight (kWide; for runs shorter than a wave: sub-groups of G
+//     lanes per run).  Every record goes into a workgroup-wide LDS hash set keyed by the k-mer -- two
+//     home buckets of two slots, both read in the first step, a compare-and-swap only to claim an empty
+//     slot -- and adds its count to that k-mer's control or case sum (64-bit LDS add);
 //   * after one barrier the table IS the tile's rows: every thread walks a few slots, a live slot goes
-//     through the chi-square pre-filter; the ~1 % that pass wait in a workgroup queue until a wave can
-//     evaluate 64 of them with every lane busy (likelihood ratio, tail function, compaction into the
-//     survivor sink -- kmd_eval.h, the same code K1 runs);
+//     through the chi-square pre-filter; the ~1 % that pass leave as (k-mer, control sum, case sum) for
+//     a list in HBM (one global atomic per tile).  k_filter_candidates (kmd_filter.hip; kmd_eval.h, the
+//     code K1 runs) evaluates the list exactly -- likelihood ratio, tail function, compaction into the
+//     survivor sink.  It is enqueued right behind this kernel, gated on the device (below);
 //   * a tile whose k-mers do not fit the table (fewer records per row there than the plan assumed, or
-//     keys clustered where the longest stream has none) gives up and is listed; the host cuts the listed
-//     tiles into equal slices of the key range their records really span and runs the kernel again on
-//     those -- repeated until nothing is listed (every level divides a tile's key span).
+//     keys clustered where the longest stream has none) notices by a probe sequence that does not end,
+//     gives up and is listed; the host cuts the listed tiles into equal slices of the key range their
+//     records really span and runs the kernel again on those -- repeated until nothing is listed (every
+//     level divides a tile's key span).
 // Two-limb k-mers (32 < k <= 64): the same kernel keyed by the low limb, see k_tile_sums.
 #include "kmd_internal.h"
 #include "kmd_math.h"
@@ -114,9 +117,10 @@ __host__ __device__ inline uint64_t mix64(uint64_t x)
   return x ^ (x >> 31);
 }
 
-// first index in [lo, hi) whose key is >= (b, bh).  (An 8-ary version -- 7 pivots loaded per step, a third of the
-// dependent round trips -- was measured: k_tile_probe 39 -> 61 us, k_tile_fine 38 -> 62 us.  These searches are bound
-// by the number of distinct cache lines and pages they touch, not by the length of the chain.)
+// first index in [lo, hi) whose key is >= (b, bh).  (Multi-way versions were measured -- 7 pivots per step, a third
+// of the dependent round trips: k_tile_probe 39 -> 61 us, k_tile_fine 38 -> 62 us; 3 pivots per step with a quarter
+// of the probes: k_tile_probe 23 -> 29 us, k_tile_coarse 12 -> 15 us.  These searches are bound by the number of
+// distinct lines and pages they touch in ~1 GB of keys, not by the length of the chain.)
 __device__ __forceinline__ size_t lower_bound_key(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                   size_t lo, size_t hi, uint64_t b, uint64_t bh)
 {
@@ -148,18 +152,18 @@ __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__
   if (at < end && keys[at] == k && (!keys_hi || keys_hi[at] == kh)) atomicAdd(&mult[p], 1u);
 }
 
-// the plan: records per tile such that its distinct k-mers fill `load` of the table
-__global__ void __launch_bounds__(256) k_tile_plan(const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t S,
-                                                   uint32_t slots, float load, uint32_t fill_fixed, uint32_t g_fixed,
-                                                   tile_plan* __restrict__ plan)
+// the plan: records per tile such that its distinct k-mers fill `load` of the table.  Every workgroup of
+// k_tile_coarse works it out for itself from the probe's 512 counts (the first one writes it down for the
+// kernels behind): no launch of its own.
+__device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t S,
+                                               uint32_t slots, float load, uint32_t fill_fixed, uint32_t g_fixed, double* s_part)
 {
-  __shared__ double s_part[256];
   double acc = 0;
-  for (uint32_t p = threadIdx.x; p < kProbes; p += 256) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
+  for (uint32_t p = threadIdx.x; p < kProbes; p += blockDim.x) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
+  // (a fixed order of the sum: every workgroup must arrive at the same plan)
   s_part[threadIdx.x] = acc;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x != 0) return;
+  for (uint32_t o = blockDim.x >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
   const double rho = (double)kProbes / s_part[0];                    // records per row
   double fill = rho * (double)load * (double)slots;
   const double fill_max = 24.0 * (double)slots;                      // ~0.6 MB of records per tile at most
@@ -175,16 +179,24 @@ __global__ void __launch_bounds__(256) k_tile_plan(const uint32_t* __restrict__ 
   uint32_t g = 3;
   while (g < 6 && (double)(1u << g) < run * 0.75) ++g;
   if (g_fixed) g = g_fixed;
-  plan->r = (uint32_t)r; plan->nb = (uint32_t)nb; plan->g_shift = g; plan->fill = (uint32_t)fill; plan->rho = (float)rho;
+  tile_plan pl;
+  pl.r = (uint32_t)r; pl.nb = (uint32_t)nb; pl.g_shift = g; pl.fill = (uint32_t)fill; pl.rho = (float)rho;
+  pl.pad[0] = pl.pad[1] = pl.pad[2] = 0;
+  return pl;
 }
 
 // where stream s enters tile j: boundary j = key j * r of the longest stream L (b_0 = -inf, b_nb = +inf).
-// Two steps: every kChunk-th boundary by binary search over the whole stream (coarse[c][s]) ...
+// Two steps: every kChunk-th boundary by a search over the whole stream (coarse[c][s]) ...
 __global__ void __launch_bounds__(256) k_tile_coarse(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                      const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
-                                                     const tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse)
+                                                     const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
+                                                     uint32_t fill_fixed, uint32_t g_fixed,
+                                                     tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse)
 {
-  const uint32_t nb = plan->nb, r = plan->r;
+  __shared__ double s_part[256];
+  const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, s_part);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *plan = pl;
+  const uint32_t nb = pl.nb, r = pl.r;
   const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;               // coarse rows 0 .. n_chunks
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ((size_t)n_chunks + 1) * S) return;
@@ -1006,10 +1018,9 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   {
     hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S,
                        (uint64_t)n, d_mult);
-    hipLaunchKernelGGL(k_tile_plan, dim3(1), dim3(256), 0, st, d_mult, (uint64_t)n, n_l, (uint32_t)S, sh.slots, load,
-                       env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0), d_plan);
     const size_t cells_c = ((size_t)chunks_max + 1) * S;
     hipLaunchKernelGGL(k_tile_coarse, dim3((unsigned)((cells_c + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
+                       d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
                        d_plan, static_cast<uint32_t*>(p_coarse));
     const size_t waves_f = (size_t)chunks_max * S;
     hipLaunchKernelGGL(k_tile_fine, dim3((unsigned)((waves_f + 3) / 4)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
@@ -1045,6 +1056,10 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     KMD_HIP(hipGetLastError());
     return KMD_OK;
   };
+  // level 0: which way of streaming a tile the plan takes is decided on the device -- except that with few
+  // samples every plan takes whole waves per run (a tile holds >= load x slots records, a run >= that / S)
+  const bool wide_for_sure = !env_u32("KMD_TILE_FILL", 0) && !env_u32("KMD_TILE_G", 0) &&
+                             (double)std::max(64.0f, load * (float)sh.slots) / (double)S * 0.75 > 32.0;
   auto run = [&](uint32_t tiles_at_most) -> int
   {
 #define KMD_TILE_CASE(T, SL)                                                                                                              \
@@ -1054,6 +1069,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
       for (int wide_ = 1; wide_ >= 0 && rc_ == KMD_OK; --wide_)                                                                            \
       {                                                                                                                                   \
         if (J.n_tiles && (J.g_shift == 6) != (wide_ == 1)) continue;          /* way known on the host: launch that one only */           \
+        if (!J.n_tiles && wide_ == 0 && wide_for_sure) continue;                                                                          \
         const size_t lds_ = two ? sizeof(tile_lds<SL, T / 64, true>) : sizeof(tile_lds<SL, T / 64, false>);                              \
         if (wide_)                                                                                                                        \
           rc_ = fused ? (two ? launch(k_tile_sums<T, SL, true, true, true>, T, lds_, tiles_at_most)                                      \
