@@ -55,7 +55,15 @@ using namespace kmd::eval;
 #define KMD_TILE_ABLATE 0
 #endif
 #ifndef KMD_TILE_RING
-#define KMD_TILE_RING 8
+#define KMD_TILE_RING 4              // rounds of loads in flight per wave (8, 12, 16 measured: no faster, more registers)
+#endif
+// waves per SIMD the register allocator is held to: 16 bytes per slot (32-bit sums) let four workgroups of 8 waves
+// share a CU's LDS -- if a wave keeps to 64 VGPRs
+#ifndef KMD_TILE_WAVES
+#define KMD_TILE_WAVES(sum32, two, wide) ((sum32) && !(two) && (wide) ? 8 : 1)
+#endif
+#ifndef KMD_TILE_ABORT_EVERY
+#define KMD_TILE_ABORT_EVERY 4       // rounds between two looks at the tile's give-up flag (a power of two <= KMD_TILE_RING)
 #endif
 
 namespace {
@@ -72,6 +80,8 @@ constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile liv
 constexpr uint32_t kProbes = 512;                // records sampled for the records-per-row estimate (+-5 % at worst; 2048 cost 39 us, 4x this)
 constexpr uint32_t kChunk = 64;                  // tile boundaries per coarse step of the start table
 constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
+constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a count too large for 32-bit sums
+constexpr uint32_t kBigCount = 1u << 22;         // 1024 samples of counts below this cannot overflow a 32-bit sum
 
 // what k_tile_plan decides, on the device
 struct tile_plan
@@ -325,18 +335,21 @@ __global__ void __launch_bounds__(256) k_tile_refine(const uint64_t* __restrict_
 constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 
 // LDS of one workgroup, carved from the dynamic allocation (the segment tables follow it)
-template <uint32_t kSlots, int kWaves, bool kTwo>
+// kSum32: a slot's two sums are 32-bit halves of one word (16 bytes per slot with the key: four workgroups per CU
+// instead of three, half the bytes per atomic add); kmd_tilemerge keeps 64-bit sums for the tiles that need them.
+template <uint32_t kSlots, int kWaves, bool kTwo, bool kSum32>
 struct tile_lds
 {
   unsigned long long key[kSlots];
-  unsigned long long sc[kSlots];
-  unsigned long long sk[kSlots];
+  unsigned long long sc[kSum32 ? 1 : kSlots];
+  unsigned long long sk[kSum32 ? 1 : kSlots];
+  uint32_t s32[kSum32 ? 2 * kSlots : 2];                 // [2 i] control sum, [2 i + 1] case sum of slot i
   unsigned long long key_hi[kTwo ? kSlots : 1];
   unsigned long long hi_min[kTwo ? kSlots : 1];          // see k_tile_sums: every record's high limb must agree with its slot's
   unsigned long long maxsum[2];
   unsigned long long max_hi[2];                          // kTwo: min / max high limb of the records whose low limb is all ones
   unsigned long long base;
-  uint32_t n[2], fresh[2], abort[2];
+  uint32_t n[2], fresh[2], abort[2], big[2];
   uint32_t hasmax, bad;
   uint32_t wcnt[kWaves];
 };
@@ -359,8 +372,9 @@ struct tile_lds
 // that share a low limb: the tile is then listed and cut again, which separates them (their high limbs
 // differ, so some slice boundary falls between them; at the latest when a slice is a single value of the
 // cut window).  A low limb of all ones (the empty marker) is kept apart the same way.
-template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo, bool kWide>
-__global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
+template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo, bool kWide, bool kSum32>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(KMD_TILE_WAVES(kSum32, kTwo, kWide))))
+k_tile_sums(const tile_job J)
 {
   constexpr uint32_t kMask = kSlots - 1;
   constexpr int kShift = 32 - ilog2_c(kSlots);
@@ -372,7 +386,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
   constexpr uint32_t kMaxProbe = 96;
   static_assert((kSlots & kMask) == 0 && kSlots % kThreads == 0, "shape");
   static_assert(kWalk <= 32, "walk bits");
-  using lds_t = tile_lds<kSlots, kWaves, kTwo>;
+  using lds_t = tile_lds<kSlots, kWaves, kTwo, kSum32>;
   extern __shared__ unsigned long long s_raw[];
   lds_t& M = *reinterpret_cast<lds_t*>(s_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -396,14 +410,25 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
     stride = per;
   }
 
+  // a slot's sums: two 64-bit words, or (kSum32) the halves of one
+  auto wipe_sums = [&](uint32_t i)
+  {
+    if constexpr (kSum32) *reinterpret_cast<unsigned long long*>(&M.s32[2 * i]) = 0ull;
+    else { M.sc[i] = 0; M.sk[i] = 0; }
+  };
+  auto read_sums = [&](uint32_t i, unsigned long long& c, unsigned long long& k)
+  {
+    if constexpr (kSum32) { const unsigned long long w = *reinterpret_cast<const unsigned long long*>(&M.s32[2 * i]); c = w & 0xFFFFFFFFull; k = w >> 32; }
+    else { c = M.sc[i]; k = M.sk[i]; }
+  };
   for (uint32_t i = tid; i < kSlots; i += kThreads)
   {
-    M.key[i] = kEmptyKey; M.sc[i] = 0; M.sk[i] = 0;
+    M.key[i] = kEmptyKey; wipe_sums(i);
     if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
   }
   if (tid == 0)
   {
-    M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0;
+    M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0; M.big[0] = 0; M.big[1] = 0;
     M.hasmax = 0; M.bad = 0; M.maxsum[0] = 0; M.maxsum[1] = 0;
     M.max_hi[0] = ~0ull; M.max_hi[1] = 0;
   }
@@ -440,7 +465,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
     const uint32_t n = M.n[buf];
     const bool wanted = J.todo == nullptr || J.todo[tile] != 0;
     const bool process = wanted && n > 0;
-    if (tid == 0) { M.n[buf ^ 1u] = 0; M.fresh[buf ^ 1u] = 0; M.abort[buf ^ 1u] = 0; }
+    if (tid == 0) { M.n[buf ^ 1u] = 0; M.fresh[buf ^ 1u] = 0; M.abort[buf ^ 1u] = 0; M.big[buf ^ 1u] = 0; }
 
     // ---- inserts, kWide: runs of a wave's worth of records and more (the usual case: a tile is sized to
     // hold ~700 rows).  A wave takes whole runs, one after the other -- runs wave, wave + kWaves, ... --
@@ -565,8 +590,16 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
             }
             if (placed)
             {
-              unsigned long long* sums = rctl[d] ? M.sc : M.sk;                       // (scalar choice)
-              atomicAdd(&sums[slot], (unsigned long long)rcnt[d]);
+              if constexpr (kSum32)
+              {
+                if (rcnt[d] >= kBigCount) M.big[buf] = 1;                             // (never, in practice: the tile is redone with 64-bit sums)
+                atomicAdd(&M.s32[2u * slot + (rctl[d] ? 0u : 1u)], rcnt[d]);          // (scalar choice of the half)
+              }
+              else
+              {
+                unsigned long long* sums = rctl[d] ? M.sc : M.sk;                     // (scalar choice)
+                atomicAdd(&sums[slot], (unsigned long long)rcnt[d]);
+              }
               if constexpr (kTwo)
               {
                 atomicMax(&M.key_hi[slot], (unsigned long long)rkh[d]);
@@ -586,7 +619,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
             if (rrem[d] == 0) { stop = true; break; }                                 // the runs are exhausted in order
             insert_w(d);
             fetch_w(d);
-            if ((d & 3) == 3 && M.abort[buf]) { stop = true; break; }                 // (LDS read, same for the whole wave)
+            if ((d & (KMD_TILE_ABORT_EVERY - 1)) == KMD_TILE_ABORT_EVERY - 1 && M.abort[buf]) { stop = true; break; }   // (LDS read, same for the whole wave)
           }
         }
       }
@@ -746,11 +779,12 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
           if (v && A.k[u] != kEmptyKey && !pend[u])
           {
             const bool ctl = (A.ctl >> u) & 1u;
-#if KMD_TILE_ABLATE & 2   // dev: plain store instead of the 64-bit add (results wrong)
-            (ctl ? M.sc : M.sk)[slot[u]] = A.c[u];
-#else
-            atomicAdd(ctl ? &M.sc[slot[u]] : &M.sk[slot[u]], (unsigned long long)A.c[u]);
-#endif
+            if constexpr (kSum32)
+            {
+              if (A.c[u] >= kBigCount) M.big[buf] = 1;
+              atomicAdd(&M.s32[2u * slot[u] + (ctl ? 0u : 1u)], A.c[u]);
+            }
+            else atomicAdd(ctl ? &M.sc[slot[u]] : &M.sk[slot[u]], (unsigned long long)A.c[u]);
             if constexpr (kTwo)
             {
               atomicMax(&M.key_hi[slot[u]], (unsigned long long)A.kh[u]);
@@ -798,7 +832,8 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
     load_segments(tile + stride, buf ^ 1u);
     if (process)
     {
-      const bool aborted = M.abort[buf] != 0;
+      const bool big = kSum32 && M.big[buf] != 0;
+      const bool aborted = M.abort[buf] != 0 || big;
       if constexpr (kTwo)
       {
         // two k-mers in one slot?  then this tile is cut again instead of emitted
@@ -815,7 +850,7 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
       if (bad_tile && tid == 0)
       {
         const uint32_t at = atomicAdd(J.over_n, 1u);
-        J.over[at] = tile; J.over[J.over_stride + at] = (n < kAbortBit ? n : kAbortBit - 1u) | kAbortBit;
+        J.over[at] = tile; J.over[J.over_stride + at] = (n < kBigBit ? n : kBigBit - 1u) | kAbortBit | (big ? kBigBit : 0u);
       }
       // the walk: every thread owns kWalk slots.  Pass 1 counts the rows that leave (all of them, or --
       // kFilter -- the ones the chi-square pre-filter lets through, ~1 %); the tile takes that many
@@ -835,7 +870,9 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
 #else
           if constexpr (kFilter)
           {
-            row_state st; st.sum_c = live ? M.sc[i] : 0; st.sum_k = live ? M.sk[i] : 0; st.row = 0; st.valid = live;
+            unsigned long long sum_c, sum_k;
+            read_sums(i, sum_c, sum_k);
+            row_state st; st.sum_c = live ? sum_c : 0; st.sum_k = live ? sum_k : 0; st.row = 0; st.valid = live;
             leaves = row_may_pass(J, st, n_beyond);
           }
 #endif
@@ -893,11 +930,13 @@ __global__ void __launch_bounds__(kThreads) k_tile_sums(const tile_job J)
             const unsigned long long e = out_at + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
             if (e < J.row_capacity)
             {
-              J.kmer_out[e] = key; J.sum_c_out[e] = M.sc[i]; J.sum_k_out[e] = M.sk[i];
+              unsigned long long sum_c, sum_k;
+              read_sums(i, sum_c, sum_k);
+              J.kmer_out[e] = key; J.sum_c_out[e] = sum_c; J.sum_k_out[e] = sum_k;
               if constexpr (kTwo) J.kmer_hi_out[e] = M.key_hi[i];
             }
           }
-          M.key[i] = kEmptyKey; M.sc[i] = 0; M.sk[i] = 0;
+          M.key[i] = kEmptyKey; wipe_sums(i);
           if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
         }
         out_at += (unsigned long long)__popcll(m);
@@ -949,6 +988,7 @@ struct scratch_set
 };
 
 struct tile_shape { int threads; uint32_t slots; };
+template <int kT, uint32_t kS> struct shape_tag { static constexpr int threads = kT; static constexpr uint32_t slots = kS; };
 
 inline tile_shape pick_shape()
 {
@@ -1060,35 +1100,40 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   // samples every plan takes whole waves per run (a tile holds >= load x slots records, a run >= that / S)
   const bool wide_for_sure = !env_u32("KMD_TILE_FILL", 0) && !env_u32("KMD_TILE_G", 0) &&
                              (double)std::max(64.0f, load * (float)sh.slots) / (double)S * 0.75 > 32.0;
+  bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
   auto run = [&](uint32_t tiles_at_most) -> int
   {
-#define KMD_TILE_CASE(T, SL)                                                                                                              \
-    if (sh.threads == T && sh.slots == SL)                                                                                                \
-    {                                                                                                                                     \
-      int rc_ = KMD_OK;                                                                                                                   \
-      for (int wide_ = 1; wide_ >= 0 && rc_ == KMD_OK; --wide_)                                                                            \
-      {                                                                                                                                   \
-        if (J.n_tiles && (J.g_shift == 6) != (wide_ == 1)) continue;          /* way known on the host: launch that one only */           \
-        if (!J.n_tiles && wide_ == 0 && wide_for_sure) continue;                                                                          \
-        const size_t lds_ = two ? sizeof(tile_lds<SL, T / 64, true>) : sizeof(tile_lds<SL, T / 64, false>);                              \
-        if (wide_)                                                                                                                        \
-          rc_ = fused ? (two ? launch(k_tile_sums<T, SL, true, true, true>, T, lds_, tiles_at_most)                                      \
-                             : launch(k_tile_sums<T, SL, true, false, true>, T, lds_, tiles_at_most))                                    \
-                      : (two ? launch(k_tile_sums<T, SL, false, true, true>, T, lds_, tiles_at_most)                                     \
-                             : launch(k_tile_sums<T, SL, false, false, true>, T, lds_, tiles_at_most));                                  \
-        else                                                                                                                              \
-          rc_ = fused ? (two ? launch(k_tile_sums<T, SL, true, true, false>, T, lds_, tiles_at_most)                                     \
-                             : launch(k_tile_sums<T, SL, true, false, false>, T, lds_, tiles_at_most))                                   \
-                      : (two ? launch(k_tile_sums<T, SL, false, true, false>, T, lds_, tiles_at_most)                                    \
-                             : launch(k_tile_sums<T, SL, false, false, false>, T, lds_, tiles_at_most));                                 \
-      }                                                                                                                                   \
-      return rc_;                                                                                                                         \
-    }
-    KMD_TILE_CASE(512, 2048)
-    KMD_TILE_CASE(1024, 2048)
-    KMD_TILE_CASE(1024, 4096)
-    KMD_TILE_CASE(256, 2048)
-#undef KMD_TILE_CASE
+    // one instantiation per (shape, fused, two limbs, whole-wave runs, 32-bit sums)
+    auto pick = [&](auto shape_tag) -> int
+    {
+      constexpr int T = decltype(shape_tag)::threads;
+      constexpr uint32_t SL = decltype(shape_tag)::slots;
+      int rc_ = KMD_OK;
+      for (int wide_ = 1; wide_ >= 0 && rc_ == KMD_OK; --wide_)
+      {
+        if (J.n_tiles && (J.g_shift == 6) != (wide_ == 1)) continue;          // way known on the host: launch that one only
+        if (!J.n_tiles && wide_ == 0 && wide_for_sure) continue;
+        const unsigned sel = (fused ? 8u : 0u) | (two ? 4u : 0u) | (wide_ ? 2u : 0u) | (sum32 ? 1u : 0u);
+        switch (sel)
+        {
+#define KMD_TILE_SEL(F, W2, WD, S32) \
+          case ((F) ? 8u : 0u) | ((W2) ? 4u : 0u) | ((WD) ? 2u : 0u) | ((S32) ? 1u : 0u): \
+            rc_ = launch(k_tile_sums<T, SL, F, W2, WD, S32>, T, sizeof(tile_lds<SL, T / 64, W2, S32>), tiles_at_most); break;
+          KMD_TILE_SEL(false, false, false, false) KMD_TILE_SEL(false, false, false, true)
+          KMD_TILE_SEL(false, false, true, false)  KMD_TILE_SEL(false, false, true, true)
+          KMD_TILE_SEL(false, true, false, false)  KMD_TILE_SEL(false, true, false, true)
+          KMD_TILE_SEL(false, true, true, false)   KMD_TILE_SEL(false, true, true, true)
+          KMD_TILE_SEL(true, false, false, false)  KMD_TILE_SEL(true, false, false, true)
+          KMD_TILE_SEL(true, false, true, false)   KMD_TILE_SEL(true, false, true, true)
+          KMD_TILE_SEL(true, true, false, false)   KMD_TILE_SEL(true, true, false, true)
+          KMD_TILE_SEL(true, true, true, false)    KMD_TILE_SEL(true, true, true, true)
+#undef KMD_TILE_SEL
+        }
+      }
+      return rc_;
+    };
+    if (sh.threads == 512 && sh.slots == 2048) return pick(shape_tag<512, 2048>());
+    if (sh.threads == 1024 && sh.slots == 4096) return pick(shape_tag<1024, 4096>());
     kmd::set_error("kmd: KMD_TILE_SHAPE not built");
     return KMD_E_INVALID;
   };
@@ -1136,7 +1181,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     uint64_t rows = 0;
     for (uint32_t i = 0; i < n_over; ++i)
     {
-      const uint64_t cnt = h_over[n_over + i] & ~kAbortBit;
+      const uint64_t cnt = h_over[n_over + i] & ~(kAbortBit | kBigBit);
+      if (h_over[n_over + i] & kBigBit) sum32 = false;          // a count >= 2^22: the tiles listed from here on are redone with 64-bit sums
       uint64_t m = 2 * ((cnt + per_slice - 1) / per_slice);
       if (m < 2) m = 2;
       if (m > (1u << 20)) m = 1u << 20;

@@ -83,6 +83,26 @@ def test_merge_filter_equals_merge_then_diff(K, oracle, S, nc, presence):
     assert len(ref["row"]) > 20 or S <= 2
 
 
+def test_merge_filter_counts_too_large_for_32_bit_sums(K, oracle):
+    """The table keeps a k-mer's two sums in 32 bits; a tile that meets a count of 2^22 or more (1024 samples of
+    smaller counts cannot overflow) says so and is redone with 64-bit sums.  Here: a few k-mers whose counts add up
+    past 2^32 within the controls, the rest ordinary."""
+    rng = np.random.default_rng(4242)
+    S, nc = 12, 6
+    universe = np.unique(rng.integers(0, 1 << 62, 60_000, dtype=np.uint64))
+    streams = make_streams(rng, universe, S, 0.6)
+    big = set(universe[rng.choice(len(universe), 40, replace=False)].tolist())
+    for s in range(S):
+        km, cnt = streams[s]
+        hit = np.isin(km, np.fromiter(big, dtype=np.uint64))
+        cnt = cnt.copy()
+        cnt[hit] = np.uint32(3_000_000_000) if s < nc else np.uint32(5_000_000)
+        streams[s] = (km, cnt)
+    want, ref = run_fused(K, oracle, streams, nc, 0.01)
+    sums_c = want[:, :nc].sum(axis=1, dtype=np.uint64)
+    assert (sums_c > 2 ** 32).sum() >= 30                    # the case is really there
+
+
 def test_merge_sums_rows_are_compact_and_exact(K, oracle):
     """kmd_merge_sums: exactly one entry per distinct k-mer, no holes; KMD_E_OVERFLOW reports the rows needed."""
     rng = np.random.default_rng(99)
