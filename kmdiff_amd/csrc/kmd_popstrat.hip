@@ -237,8 +237,12 @@ __device__ __forceinline__ void irls_fit(const irls_args& A, const double* s_d, 
 }
 
 // pop_strat_corrector::apply(KmerSign&) (popstrat.hpp:249-333) for one survivor per lane
+#ifndef KMD_PS_WAVES
+#define KMD_PS_WAVES 1               // waves per SIMD the register allocator is held to (dev: A/B)
+#endif
 template <int F, bool LDSD>
-__global__ void __launch_bounds__(64) k_popstrat_apply(irls_args A, size_t n_surv, double null_likelihood,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KMD_PS_WAVES)))
+k_popstrat_apply(irls_args A, size_t n_surv, double null_likelihood,
                                                        double lg_half, double epsilon, double* __restrict__ out_p)
 {
   extern __shared__ double s_d[];

@@ -436,6 +436,9 @@ k_tile_sums(const tile_job J)
   auto load_segments = [&](uint32_t tile, uint32_t buf)
   {
     if (tile >= tile_end) return;
+#if KMD_TILE_ABLATE & 32   // dev: every workgroup streams the same 32 tiles again and again (cache-resident: the inserts alone; results wrong)
+    tile &= 31u;
+#endif
     uint32_t* beg = s_seg + (size_t)buf * 2 * S;
     uint32_t mine = 0;
     for (uint32_t s = tid; s < S; s += kThreads)
@@ -536,6 +539,10 @@ k_tile_sums(const tile_job J)
         {
           const uint64_t k = rk[d];
           const bool v = lane < rrem[d];
+#if KMD_TILE_ABLATE & 16   // dev: the loads alone (results wrong)
+          if (v && (k + rcnt[d]) == 0x123456789ull) M.hasmax = 1;
+          return;
+#endif
           const bool is_marker = k == kEmptyKey;
           if (v & is_marker)
           {
@@ -569,8 +576,12 @@ k_tile_sums(const tile_job J)
             uint32_t pos = 4;                                                         // where in the sequence to go on, if at all
             if (e0 | (e1 & !m0) | (e2 & !p2m) | (e3 & !p3m))                          // the first of them is an empty one: claim it
             {
+#if KMD_TILE_ABLATE & 1   // dev: a plain store instead of the compare-and-swap (results wrong)
+              M.key[slot] = k;
+#else
               const unsigned long long old = atomicCAS(&M.key[slot], (unsigned long long)kEmptyKey, (unsigned long long)k);
               if ((old != kEmptyKey) & (old != k)) { placed = false; pos = 0; }       // another k-mer took it: once more, slot by slot
+#endif
             }
             if (!placed)
             {
@@ -593,7 +604,12 @@ k_tile_sums(const tile_job J)
               if constexpr (kSum32)
               {
                 if (rcnt[d] >= kBigCount) M.big[buf] = 1;                             // (never, in practice: the tile is redone with 64-bit sums)
+#if KMD_TILE_ABLATE & 2   // dev: a plain store instead of the atomic add (results wrong)
+                M.s32[2u * slot + (rctl[d] ? 0u : 1u)] = rcnt[d];
+#elif KMD_TILE_ABLATE & 64   // dev: no sums at all
+#else
                 atomicAdd(&M.s32[2u * slot + (rctl[d] ? 0u : 1u)], rcnt[d]);          // (scalar choice of the half)
+#endif
               }
               else
               {
