@@ -75,6 +75,20 @@ def main():
     f = os.path.join(SRC, "pmc_tile.txt")
     if os.path.exists(f):
         out += ["", "# SQ counters per launch of k_tile_sums (tools/pmc_tile.sh)"] + [l.rstrip() for l in open(f) if "per launch" in l]
+    f = os.path.join(SRC, "pmc_tile2.txt")
+    if os.path.exists(f):
+        vals = {}
+        for l in open(f):
+            if "per launch" in l:
+                name, v = l.split()[0], float(l.split()[1])
+                vals[name] = v
+        out += ["", "# utilisation of the wide instantiation, whole GPU per launch (tools/pmc_tile2.sh)"] + ["%s %.4g" % kv for kv in sorted(vals.items())]
+        cu = vals.get("SQ_BUSY_CU_CYCLES")
+        if cu:
+            out.append("")
+            out.append("per busy CU cycle: LDS active %.0f %% (bank conflicts %.0f %% of that), scalar instructions %.0f %%, vector instructions x 4 cycles / 4 SIMDs %.0f %%"
+                       % (100 * vals.get("SQ_LDS_IDX_ACTIVE", 0) / cu, 100 * vals.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, vals.get("SQ_LDS_IDX_ACTIVE", 1)),
+                          100 * vals.get("SQ_INSTS_SALU", 0) / cu, 100 * vals.get("SQ_INSTS_VALU", 0) / cu))
     open(os.path.join(DST, "r02_pmc_tile.txt"), "w").write("\n".join(out) + "\n")
     print("  r02_pmc_tile.txt")
     b = os.path.join(DST, "bench_r02.json")
