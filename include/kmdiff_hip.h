@@ -89,7 +89,8 @@ int kmd_stream_create(void** stream);
 int kmd_stream_destroy(void* stream);
 int kmd_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes, void* stream);
 /* The library parks its internal scratch buffers (sort keys, flags, tallies) instead of
- * returning them to the driver after every call; this frees the parked ones. */
+ * returning them to the driver after every call; this frees the parked ones (and the per-stream
+ * near-threshold lists of the filter).  Call it with nothing in flight. */
 int kmd_release_cache(void);
 /* elapsed milliseconds of `fn`-independent timing helpers: HIP events on `stream` */
 int kmd_event_create(void** ev);

@@ -193,7 +193,12 @@ int kmd_stream_create(void** stream)
 }
 int kmd_stream_destroy(void* stream)
 {
-  if (stream) KMD_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  if (stream)
+  {
+    KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    kmd::near_list_forget(static_cast<hipStream_t>(stream));     // (a later stream may get the same handle)
+    KMD_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  }
   return KMD_OK;
 }
 int kmd_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes, void* stream)
@@ -215,7 +220,7 @@ int kmd_memset(void* d_dst, int value, size_t bytes, void* stream)
   KMD_HIP(hipMemsetAsync(d_dst, value, bytes, static_cast<hipStream_t>(stream)));
   return KMD_OK;
 }
-int kmd_release_cache(void) { kmd::scratch_release_all(); return KMD_OK; }
+int kmd_release_cache(void) { kmd::scratch_release_all(); kmd::near_lists_release(); return KMD_OK; }
 int kmd_stream_sync(void* stream) { KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return KMD_OK; }
 
 int kmd_event_create(void** ev)

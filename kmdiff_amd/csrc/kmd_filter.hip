@@ -1686,6 +1686,22 @@ std::map<std::pair<int, hipStream_t>, unsigned long long*> g_near_lists;
 constexpr size_t kNearListsMax = 256;                   // streams served with a kept list; beyond: allocated per launch
 }
 
+// kmd_stream_destroy / kmd_release_cache: the caller has nothing in flight on the stream(s)
+void kmd::near_list_forget(hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lock(g_near_mu);
+  for (auto it = g_near_lists.begin(); it != g_near_lists.end();)
+    if (it->first.second == stream) { (void)hipFree(it->second); it = g_near_lists.erase(it); }
+    else ++it;
+}
+
+void kmd::near_lists_release()
+{
+  std::lock_guard<std::mutex> lock(g_near_mu);
+  for (auto& kv : g_near_lists) (void)hipFree(kv.second);
+  g_near_lists.clear();
+}
+
 int kmd::near_list_begin(filter_params& P, hipStream_t stream)
 {
   P.near = nullptr;

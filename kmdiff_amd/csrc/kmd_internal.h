@@ -71,6 +71,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 hipError_t scratch_alloc(void** p, size_t bytes);
 void scratch_free(void* p);
 void scratch_release_all();
+// the near-threshold lists kept per stream (kmd_filter.hip): one stream's (it is being destroyed), all of them
+void near_list_forget(hipStream_t stream);
+void near_lists_release();
 
 // smallest LR at which igamc(1/2, LR) <= threshold, minus a safety margin; rows with a
 // likelihood ratio below it cannot pass `p <= threshold` (kmd_filter.hip).

@@ -82,3 +82,37 @@ def test_no_near_threshold_rows_in_an_ordinary_partition(K, oracle):
     K.diff_observer(model, acc, 0.05 / 100000).process(mat)
     c = acc.read_counters()
     assert int(c[K._native.CNT_SIG]) > 100 and int(c[K._native.CNT_NEAR_THRESHOLD]) == 0
+
+
+def test_near_list_survives_streams_and_cache_release(K, oracle):
+    """The list of near-threshold rows is kept per stream and handed back empty by the kernel that resolves it:
+    launches on streams that are created and destroyed in between, and after kmd_release_cache, decide the row
+    on the threshold the same way every time."""
+    n, nc, nk = 20_000, 5, 5
+    host, _, _ = oracle.synth_rows(SEED, 4, 0, n, nc, nk, 4)
+    tcs, tks = totals_of(host, nc)
+    ref = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), oracle.lf_table(10000), 1e-3)
+    ps = ref["pvalue"]
+    thr = float(np.sort(ps[ps > 1e-300])[len(ps) // 2])                  # ON a row's p-value
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, 10000)
+    mat = K.CountMatrix.from_host(np.ascontiguousarray(host.T), K.LAYOUT_SOA)
+    lib = K._native.lib()
+
+    def run(stream):
+        acc = K.SurvivorAccumulator(n)
+        K.diff_observer(model, acc, thr).process(mat, stream=stream)
+        if stream is not None:
+            assert lib.kmd_stream_sync(stream) == 0
+        ns = acc.finish()
+        c = acc.read_counters()
+        return ns, sorted(acc.get()["row"].tolist()), int(c[K._native.CNT_NEAR_THRESHOLD])
+
+    first = run(None)
+    assert first[2] >= 1
+    for _ in range(3):
+        st = C.c_void_p()
+        assert lib.kmd_stream_create(C.byref(st)) == 0
+        assert run(st) == first and run(st) == first              # twice on the same stream: the list came back empty
+        assert lib.kmd_stream_destroy(st) == 0
+    assert lib.kmd_release_cache() == 0
+    assert run(None) == first
