@@ -21,7 +21,8 @@ The JSON line also carries
                  workload, tail function evaluated for every row as the reference does;
   pipeline     : (N = 1) the kmtricks-side input of the same path: one partition's per-sample k-mer
                  streams resident in HBM -> survivors (kmd_merge_filter: k-way merge fused with the test),
-                 12 algorithmic bytes per record, HIP events around back-to-back calls;
+                 12 algorithmic bytes per record, HIP events around back-to-back calls; `overlapped` = the same
+                 with six partitions in flight on streams (and host threads) of their own, per partition;
   h2d_inclusive: (N = 1) the headline step with the host-to-device copy of the partition (from page-locked
                  memory) inside the timed loop -- never `value`.
 """
@@ -145,7 +146,43 @@ def pipeline_leg(K, lib, rows=4_000_000, iters=6):
     c = acc.read_counters()
     assert int(c[0]) == iters * n_rows == iters * rows, (int(c[0]), n_rows, rows)
     gbs = 12.0 * ss.total / (ms * 1e-3) / 1e9
-    return {"what": "one partition's per-sample k-mer streams resident in HBM -> survivors (kmd_merge_filter: k-way merge "
+    # partitions in flight: a job has hundreds of partitions; with six of them on streams (and host threads) of
+    # their own, the boundary searches, the candidate evaluation and the read-back of one run beside the merge
+    # kernel of another
+    import threading
+    in_flight, per = 6, max(4, iters)
+    workers = []
+    for _ in range(in_flight):
+        st = C.c_void_p()
+        K._native.check(lib.kmd_stream_create(C.byref(st)), "kmd_stream_create")
+        acc_t = K.SurvivorAccumulator(max(1 << 16, rows // 100))
+        workers.append((st, acc_t, K.diff_observer(model, acc_t, THRESHOLD / CUTOFF, NC, NK)))
+
+    def work(w, k):
+        for _ in range(k):
+            K.merge_filter(ss, w[2], stream=w[0])
+    for w in workers:
+        work(w, 1)
+    K._native.check(lib.kmd_stream_sync(None))
+    threads = [threading.Thread(target=work, args=(w, per)) for w in workers]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for w in workers:
+        K._native.check(lib.kmd_stream_sync(w[0]))
+    ms_o = (time.perf_counter() - t0) / (in_flight * per) * 1e3
+    for w in workers:
+        cw = w[1].read_counters()
+        assert int(cw[0]) == (per + 1) * rows and int(cw[1]) == (per + 1) * (int(c[1]) // iters), (int(cw[0]), int(cw[1]))
+        lib.kmd_stream_destroy(w[0])
+    gbs_o = 12.0 * ss.total / (ms_o * 1e-3) / 1e9
+    overlapped = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "kmers_per_s": rows / (ms_o * 1e-3),
+                  "records_per_s": ss.total / (ms_o * 1e-3),
+                  "roofline": {"bound": "hbm", "achieved": gbs_o, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_o / HBM_PEAK_GBS}}
+    return {"overlapped": overlapped,
+            "what": "one partition's per-sample k-mer streams resident in HBM -> survivors (kmd_merge_filter: k-way merge "
                     "fused with the Poisson test; tile plan + boundary search + merge kernel + candidate evaluation, host "
                     "round trip included)",
             "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),

@@ -437,16 +437,17 @@ def merge_sums(streams, nb_controls, row_capacity=None):
     return out
 
 
-def merge_filter(streams, observer):
+def merge_filter(streams, observer, stream=None):
     """km::KmerMerger::merge(diff_observer) for one partition (merge.hpp:265-289, 68-103): streams in,
     survivors into the observer's accumulator; returns the number of distinct k-mers.  Survivor `row` =
-    low limb of the k-mer (SurvivorAccumulator.sort_by_kmer() gives the reference's order)."""
+    low limb of the k-mer (SurvivorAccumulator.sort_by_kmer() gives the reference's order).  `stream`: a
+    handle from kmd_stream_create (partitions on different streams, from different host threads, overlap)."""
     ss = streams if isinstance(streams, StreamSet) else StreamSet(streams)
     n_rows = C.c_uint64(0)
     s = observer.acc.struct()
     dk, dh, dc = ss.ptrs()
     check(lib().kmd_merge_filter(observer.model.handle, ss.n_samples, dk, dh, dc, ss.offs.ctypes.data, observer.threshold,
-                                 C.byref(s), observer.acc.counters.ptr, C.byref(n_rows), None), "kmd_merge_filter")
+                                 C.byref(s), observer.acc.counters.ptr, C.byref(n_rows), stream), "kmd_merge_filter")
     observer.acc._size = None
     return int(n_rows.value)
 

@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--keys", default="random")
 ap.add_argument("--sparse", type=float, default=1.0, help="keep each record with this probability (rows of few records)")
 ap.add_argument("--fused-only", action="store_true", help="only kmd_merge_filter (no matrix path beside it, no cross-check)")
+ap.add_argument("--overlap", type=int, default=0, help="also: this many host threads, each with a stream of its own, running the fused call on the same partition at once")
 ap.add_argument("--triples", action="store_true", help="also time kmd_merge_sums + kmd_poisson_filter_sums")
 a = ap.parse_args()
 S = a.nc + a.nk
@@ -84,6 +85,34 @@ sig_fused = int(cf[1])
 assert rows_f == int(cf[0]) and (a.fused_only or (rows_f == rows_matrix and sig_fused == sig_matrix)), (rows_f, rows_matrix, int(cf[0]), sig_fused, sig_matrix)
 print("pipeline keys=%s S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of 12 B/record  sig=%d"
       % (a.keys, S, n, rows_f, best_f * 1e3, rows_f / best_f, n / best_f, 12e-9 * n / best_f, sig_fused))
+if a.overlap > 1:
+    # partitions in flight on several streams: the boundary searches and the candidate evaluation of one call
+    # run beside the merge kernel of another
+    import threading
+    T, per = a.overlap, max(4, a.iters)
+    workers = []
+    for t in range(T):
+        st = C.c_void_p()
+        K._native.check(lib.kmd_stream_create(C.byref(st)), "stream")
+        acc_t = K.SurvivorAccumulator(1 << 20)
+        workers.append((st, acc_t, K.diff_observer(model, acc_t, 5e-7)))
+    def work(w, k):
+        for _ in range(k):
+            K.merge_filter(ss, w[2], stream=w[0])
+    for w in workers: work(w, 1)                                  # warm-up (lists, scratch)
+    lib.kmd_stream_sync(None)
+    th = [threading.Thread(target=work, args=(w, per)) for w in workers]
+    t0 = time.perf_counter()
+    for x in th: x.start()
+    for x in th: x.join()
+    for w in workers: lib.kmd_stream_sync(w[0])
+    dt = (time.perf_counter() - t0) / (T * per)
+    for w in workers:
+        cw = w[1].read_counters()
+        assert int(cw[1]) == sig_fused * (per + 1) and int(cw[0]) == rows_f * (per + 1), (int(cw[0]), int(cw[1]))
+        lib.kmd_stream_destroy(w[0])
+    print("pipeline keys=%s S=%d records=%d rows=%d  fused, %d partitions in flight (streams, host threads) %.3f ms per partition  %.3e rows/s  %.3e records/s  %.0f GB/s of 12 B/record"
+          % (a.keys, S, n, rows_f, T, dt * 1e3, rows_f / dt, n / dt, 12e-9 * n / dt))
 if a.triples:
     # rows as (k-mer, control sum, case sum), then the test on the sums
     sums = K.RowSums(a.rows)
