@@ -355,15 +355,21 @@ struct tile_lds
 };
 
 // One workgroup per tile on a persistent grid.  Per tile:
-//   [segment table of the NEXT tile | walk of the table = rows of this tile] barrier [inserts of the next
-//   tile] barrier ...: two barriers per tile.
+//   [inserts] barrier [segment table of the NEXT tile | walk of the table = rows of this tile: count the
+//   rows that leave] barrier [one workgroup-wide reservation in the output] barrier [write them, wipe the
+//   slots] barrier.
 // Tile order: each XCD (workgroup b runs on XCD b % 8) takes one contiguous eighth of the tiles and its
 // workgroups stride through it, so tiles that share cache lines at the ends of their runs meet in one L2.
 //
 // The table holds DISTINCT k-mers, and how many a tile has is not known beforehand (the plan sizes tiles
-// by an estimate of records per row): every wave adds the slots it claimed to a counter once per round,
-// and a probe sequence is bounded; past 3/4 full, or a probe sequence exhausted, the tile gives up -- its
-// slots are wiped, it is listed, the host cuts it.
+// by an estimate of records per row).  A probe sequence is bounded (kMaxProbe slots): a table that fills
+// up shows as a sequence that does not end, the tile gives up -- its slots are wiped, it is listed, the
+// host cuts it.  (The sub-group path, !kWide, also counts the slots its waves claim and gives up past
+// 3/4 full; the whole-wave path dropped the count: it cost more than the tiles it saved.)
+//
+// kSum32: a slot's control and case sums are the 32-bit halves of one word.  1024 samples of counts below
+// 2^22 cannot overflow them; a record with a larger count flags the tile, which is listed like one that
+// gave up and redone by the 64-bit instantiation.
 //
 // kTwo (32 < k <= 64): the table is keyed by the LOW limb.  Within a tile the high limbs (62 bits of a
 // k = 63 k-mer) almost always agree wherever the low limbs do -- they are the slowly varying part of a
