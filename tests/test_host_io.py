@@ -170,3 +170,20 @@ def test_kff_writer_round_trip(tmp_path, k):
     want = [KF.kmer_to_string2(v >> 64, v & (2 ** 64 - 1), k) if k > 32 else KF.kmer_to_string(v, k) for v in vals]
     assert kmers == want
     assert os.path.getsize(tmp_path / "out.kff") == 12 + (1 + 8 + (2 + 8) + (4 + 8) + (10 + 8)) + (1 + 8) + len(vals) * ((k + 3) // 4) + 49 + 3
+
+
+def test_case_sum_is_printed_like_fmt_braces():
+    """FASTA header `case={}` (aggregator.hpp:51-55): fmt prints a double with the shortest digits that round-trip,
+    in fixed notation -- no trailing .0 -- for 1e-4 <= |v| < 1e16 and in exponent notation (two exponent digits at
+    least) outside.  Literal expectations, independent of the implementation."""
+    exe = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kmdiff_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    cases = [("10", "10"), ("100", "100"), ("1200", "1200"), ("1000000", "1000000"), ("1e15", "1000000000000000"),
+             ("1e16", "1e+16"), ("3e22", "3e+22"), ("0.0001", "0.0001"), ("0.00001", "1e-05"), ("2.5e-5", "2.5e-05"),
+             ("1e-7", "1e-07"), ("0.1", "0.1"), ("0.3", "0.3"), ("1.5", "1.5"), ("123456789.125", "123456789.125"),
+             ("1234567", "1234567"), ("0.3333333333333333", "0.3333333333333333"), ("5e-324", "5e-324"),
+             ("1.7976931348623157e308", "1.7976931348623157e+308"), ("0", "0"), ("4294967296", "4294967296"),
+             ("9007199254740993", "9007199254740992"), ("-2.5", "-2.5")]
+    out = subprocess.run([exe, "fmt"] + [c[0] for c in cases], check=True, capture_output=True, text=True).stdout.split()
+    assert out == [c[1] for c in cases]
