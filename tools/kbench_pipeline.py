@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--keys", default="random")
 ap.add_argument("--sparse", type=float, default=1.0, help="keep each record with this probability (rows of few records)")
 ap.add_argument("--fused-only", action="store_true", help="only kmd_merge_filter (no matrix path beside it, no cross-check)")
+ap.add_argument("--limbs", type=int, default=1, help="2: two-limb k-mers (32 < k <= 64); fused path only")
 ap.add_argument("--overlap", type=int, default=0, help="also: this many host threads, each with a stream of its own, running the fused call on the same partition at once")
 ap.add_argument("--triples", action="store_true", help="also time kmd_merge_sums + kmd_poisson_filter_sums")
 a = ap.parse_args()
@@ -71,7 +72,17 @@ if not a.fused_only:
         best = min(best, time.perf_counter() - t0)
     sig_matrix, rows_matrix = int(acc.read_counters()[1]), out.n_rows
 # the same partition without the matrix or any rows in HBM: merge + test in one kernel (kmd_merge_filter)
-ss = K.StreamSet([(k_, c_) for k_, c_ in zip(ks, cs)])
+if a.limbs == 2:
+    assert a.fused_only, "--limbs 2 goes with --fused-only"
+    # a k = 63 k-mer: the high limb (31 bases) orders the rows, the low limb (32 bases) is 64 bits of its own
+    def low_limb(k_):
+        z = (k_ + np.uint64(0x9E3779B97F4A7C15)) * np.uint64(0xBF58476D1CE4E5B9)
+        return z ^ (z >> np.uint64(31))
+    ss = K.StreamSet([(low_limb(k_), c_, k_) for k_, c_ in zip(ks, cs)])
+    acc = K.SurvivorAccumulator(1 << 20, kmer_limbs=2)
+    obs = K.diff_observer(model, acc, 5e-7)
+else:
+    ss = K.StreamSet([(k_, c_) for k_, c_ in zip(ks, cs)])
 best_f, ev0, ev1 = 1e9, K.Event(), K.Event()
 for _ in range(a.iters + 1):
     acc.counters.zero()
@@ -83,8 +94,9 @@ for _ in range(a.iters + 1):
 cf = acc.read_counters()
 sig_fused = int(cf[1])
 assert rows_f == int(cf[0]) and (a.fused_only or (rows_f == rows_matrix and sig_fused == sig_matrix)), (rows_f, rows_matrix, int(cf[0]), sig_fused, sig_matrix)
-print("pipeline keys=%s S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of 12 B/record  sig=%d"
-      % (a.keys, S, n, rows_f, best_f * 1e3, rows_f / best_f, n / best_f, 12e-9 * n / best_f, sig_fused))
+bpr = 12 if a.limbs == 1 else 20
+print("pipeline keys=%s S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of %d B/record  sig=%d"
+      % (a.keys, S, n, rows_f, best_f * 1e3, rows_f / best_f, n / best_f, bpr * 1e-9 * n / best_f, bpr, sig_fused))
 if a.overlap > 1:
     # partitions in flight on several streams: the boundary searches and the candidate evaluation of one call
     # run beside the merge kernel of another
