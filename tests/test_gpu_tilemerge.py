@@ -233,3 +233,57 @@ def test_pca_sampling_from_the_streams_equals_sampling_the_matrix(K, oracle, two
     b.sample_streams(streams)
     assert a.count() == b.count() and a.count() > 200
     assert (a.gram() == b.gram()).all()
+
+
+def test_merge_filter_at_the_sample_limit(K, oracle):
+    """1024 samples is what the tile's segment tables hold (more: refused, not mangled); runs of a handful of
+    records each -- the sub-group path."""
+    rng = np.random.default_rng(1024)
+    S, nc = 1024, 500
+    universe = np.unique(rng.integers(0, 1 << 62, 9_000, dtype=np.uint64))
+    streams = make_streams(rng, universe, S, rng.uniform(0.02, 0.3, S), count_hi=40, empty=(7, 1000))
+    run_fused(K, oracle, streams, nc, 1e-3)
+    model = K.PoissonLikelihood(513, 512, np.ones(513, np.uint64), np.ones(512, np.uint64), 100)
+    acc = K.SurvivorAccumulator(16)
+    with pytest.raises(K.KmdError):
+        K.merge_filter(streams + [streams[0]], K.diff_observer(model, acc, 0.5))
+
+
+def test_merge_filter_partitions_in_flight(K, oracle):
+    """Three different partitions at once, each from a host thread and on a stream of its own (scratch per call,
+    near-threshold list per stream): the same survivors as one after the other."""
+    import ctypes as C
+    import threading
+    lib = K._native.lib()
+    S, nc = 16, 8
+    jobs = []
+    for j in range(3):
+        rng = np.random.default_rng(300 + j)
+        universe = np.unique(rng.integers(0, 1 << 62, 120_000 + 30_000 * j, dtype=np.uint64))
+        streams = make_streams(rng, universe, S, 0.55)
+        want, wlo = oracle.merge_partition(streams)
+        tcs, tks = totals_of(want, nc)
+        ref = oracle.diff_partition(want, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(10000), 0.01)
+        model = K.PoissonLikelihood(nc, S - nc, tcs, tks, 10000)
+        acc = K.SurvivorAccumulator(4 * want.shape[0])
+        st = C.c_void_p()
+        assert lib.kmd_stream_create(C.byref(st)) == 0
+        jobs.append({"ss": K.StreamSet(streams), "obs": K.diff_observer(model, acc, 0.01), "acc": acc, "st": st,
+                     "want_rows": want.shape[0], "want_kmers": wlo[ref["row"].astype(np.int64)].tolist(), "ref": ref, "rows": []})
+
+    def work(job, reps):
+        for _ in range(reps):
+            job["rows"].append(K.merge_filter(job["ss"], job["obs"], stream=job["st"]))
+    th = [threading.Thread(target=work, args=(job, 4)) for job in jobs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for job in jobs:
+        assert lib.kmd_stream_sync(job["st"]) == 0
+        assert job["rows"] == [job["want_rows"]] * 4
+        n = job["acc"].finish(by_kmer=True)
+        got = job["acc"].get()
+        assert n == 4 * len(job["want_kmers"])
+        assert got["kmer_lo"].tolist() == sorted(job["want_kmers"] * 4)
+        c = job["acc"].read_counters()
+        assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == tuple(4 * v for v in job["ref"]["counters"])
+        assert lib.kmd_stream_destroy(job["st"]) == 0
