@@ -111,17 +111,18 @@ if a.overlap > 1:
     def work(w, k):
         for _ in range(k):
             K.merge_filter(ss, w[2], stream=w[0])
-    for w in workers: work(w, 1)                                  # warm-up (lists, scratch)
-    lib.kmd_stream_sync(None)
-    th = [threading.Thread(target=work, args=(w, per)) for w in workers]
+    def run_all(k):
+        th = [threading.Thread(target=work, args=(w, k)) for w in workers]
+        for x in th: x.start()
+        for x in th: x.join()
+        for w in workers: lib.kmd_stream_sync(w[0])
+    run_all(2)                                                    # warm-up: lists, the scratch of T concurrent calls
     t0 = time.perf_counter()
-    for x in th: x.start()
-    for x in th: x.join()
-    for w in workers: lib.kmd_stream_sync(w[0])
+    run_all(per)
     dt = (time.perf_counter() - t0) / (T * per)
     for w in workers:
         cw = w[1].read_counters()
-        assert int(cw[1]) == sig_fused * (per + 1) and int(cw[0]) == rows_f * (per + 1), (int(cw[0]), int(cw[1]))
+        assert int(cw[1]) == sig_fused * (per + 2) and int(cw[0]) == rows_f * (per + 2), (int(cw[0]), int(cw[1]))
         lib.kmd_stream_destroy(w[0])
     print("pipeline keys=%s S=%d records=%d rows=%d  fused, %d partitions in flight (streams, host threads) %.3f ms per partition  %.3e rows/s  %.3e records/s  %.0f GB/s of 12 B/record"
           % (a.keys, S, n, rows_f, T, dt * 1e3, rows_f / dt, n / dt, 12e-9 * n / dt))
