@@ -116,3 +116,37 @@ def test_near_list_survives_streams_and_cache_release(K, oracle):
         assert lib.kmd_stream_destroy(st) == 0
     assert lib.kmd_release_cache() == 0
     assert run(None) == first
+
+
+def test_threshold_on_a_p_value_through_the_fused_merge(K, oracle):
+    """The same guard behind kmd_merge_filter (rows reach the exact evaluation as candidates of the merge; their list
+    entries name the candidate, the survivor's `row` is its k-mer): thresholds ON a row's p-value and one ulp either
+    side give the survivors the matrix path gives -- which test_threshold_placed_on_a_p_value holds to the oracle."""
+    n, nc, nk = 30_000, 6, 6
+    host, lo, _ = oracle.synth_rows(SEED, 5, 0, n, nc, nk, 4)
+    tcs, tks = totals_of(host, nc)
+    ref = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), oracle.lf_table(10000), 1e-3)
+    ps = np.sort(ref["pvalue"][ref["pvalue"] > 1e-300])
+    assert len(ps) > 100
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, 10000)
+    mat = K.CountMatrix.from_host(host, K.LAYOUT_ROWS, kmer_lo=lo)
+    ss = K.StreamSet([(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(nc + nk)])
+    seen_near = 0
+    for p in ps[:: max(1, len(ps) // 12)][:12]:
+        for thr in (float(p), float(np.nextafter(p, 0.0)), float(np.nextafter(p, 1.0))):
+            a = K.SurvivorAccumulator(n)
+            K.diff_observer(model, a, thr).process(mat)
+            na = a.finish()
+            ga, ca = a.get(), a.read_counters()
+            b = K.SurvivorAccumulator(n)
+            assert K.merge_filter(ss, K.diff_observer(model, b, thr)) == n
+            nb = b.finish(by_kmer=True)
+            gb, cb = b.get(), b.read_counters()
+            assert nb == na and [int(x) for x in cb[:4]] == [int(x) for x in ca[:4]]
+            assert int(cb[K._native.CNT_NEAR_THRESHOLD]) == int(ca[K._native.CNT_NEAR_THRESHOLD]) >= 1
+            order = np.argsort(ga["kmer_lo"], kind="stable")
+            assert gb["kmer_lo"].tolist() == ga["kmer_lo"][order].tolist()
+            assert gb["pvalue"].tolist() == ga["pvalue"][order].tolist()        # incl. the rounded p of the row on the threshold
+            assert gb["sign"].tolist() == ga["sign"][order].tolist()
+            seen_near += int(cb[K._native.CNT_NEAR_THRESHOLD])
+    assert seen_near >= 36
