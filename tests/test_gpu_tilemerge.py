@@ -83,22 +83,26 @@ def test_merge_filter_equals_merge_then_diff(K, oracle, S, nc, presence):
     assert len(ref["row"]) > 20 or S <= 2
 
 
-def test_merge_filter_counts_too_large_for_32_bit_sums(K, oracle):
+@pytest.mark.parametrize("two", [False, True])
+def test_merge_filter_counts_too_large_for_32_bit_sums(K, oracle, two):
     """The table keeps a k-mer's two sums in 32 bits; a tile that meets a count of 2^22 or more (1024 samples of
     smaller counts cannot overflow) says so and is redone with 64-bit sums.  Here: a few k-mers whose counts add up
-    past 2^32 within the controls, the rest ordinary."""
-    rng = np.random.default_rng(4242)
+    past 2^32 within the controls, the rest ordinary; one- and two-limb k-mers."""
+    rng = np.random.default_rng(4242 + two)
     S, nc = 12, 6
     universe = np.unique(rng.integers(0, 1 << 62, 60_000, dtype=np.uint64))
-    streams = make_streams(rng, universe, S, 0.6)
+    hi = np.sort(rng.integers(0, 1 << 40, len(universe), dtype=np.uint64)) if two else None
+    if two:
+        order = np.lexsort((universe, hi)); universe, hi = universe[order], hi[order]
+    streams = make_streams(rng, universe, S, 0.6, hi=hi)
     big = set(universe[rng.choice(len(universe), 40, replace=False)].tolist())
     for s in range(S):
-        km, cnt = streams[s]
+        km, cnt = streams[s][0], streams[s][1]
         hit = np.isin(km, np.fromiter(big, dtype=np.uint64))
         cnt = cnt.copy()
         cnt[hit] = np.uint32(3_000_000_000) if s < nc else np.uint32(5_000_000)
-        streams[s] = (km, cnt)
-    want, ref = run_fused(K, oracle, streams, nc, 0.01)
+        streams[s] = (km, cnt) + tuple(streams[s][2:])
+    want, ref = run_fused(K, oracle, streams, nc, 0.01, two=two)
     sums_c = want[:, :nc].sum(axis=1, dtype=np.uint64)
     assert (sums_c > 2 ** 32).sum() >= 30                    # the case is really there
 
