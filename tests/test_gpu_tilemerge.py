@@ -291,3 +291,27 @@ def test_merge_filter_partitions_in_flight(K, oracle):
         c = job["acc"].read_counters()
         assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == tuple(4 * v for v in job["ref"]["counters"])
         assert lib.kmd_stream_destroy(job["st"]) == 0
+
+
+@pytest.mark.parametrize("env", [{"KMD_TILE_CAND_CAP": "500"}, {"KMD_TILE_FILL": "60000", "KMD_TILE_LOAD_PCT": "50"},
+                                 {"KMD_TILE_G": "3"}, {"KMD_TILE_SUM64": "1"}, {"KMD_TILE_SHAPE": "1024x4096"}])
+def test_merge_filter_forced_paths(K, oracle, env):
+    """The ways round that ordinary inputs rarely take, forced through the library's development switches: a
+    candidate list that overflows (the evaluation enqueued behind the merge must hold still, the merge runs again
+    with the size it reported), tiles far too large for the table (every one gives up and is cut again), the
+    sub-group path on long runs, 64-bit sums from the start, the other table shape."""
+    import os
+    rng = np.random.default_rng(77)
+    S, nc = 10, 5
+    universe = np.unique(rng.integers(0, 1 << 62, 50_000, dtype=np.uint64))
+    streams = make_streams(rng, universe, S, 0.6)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        run_fused(K, oracle, streams, nc, 0.3)                      # ~ every third row survives: a long candidate list
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
