@@ -315,3 +315,38 @@ def test_merge_filter_forced_paths(K, oracle, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_fused_equals_matrix_path_at_bench_size(K):
+    """The bench's `pipeline` partition (20v20, 4 M rows, 104 M records): the fused merge + test and the merge into a
+    count matrix followed by the test on it give the same survivors -- k-mers, p-values, signs bit for bit (one code
+    evaluates both) -- and the same counters; every record is accounted for (sum of the rows' two sums = sum of the
+    counts handed in)."""
+    rows, nc, nk = 4_000_000, 20, 20
+    S = nc + nk
+    mat = K.synth_matrix(0x6B6D64696666, 0, rows, nc, nk, 4, K.LAYOUT_ROWS)
+    host, lo = mat.to_host(), mat.kmers_to_host()[0]
+    del mat
+    streams = [(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(S)]
+    tot = host.sum(axis=0, dtype=np.uint64)
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    thr = 1e-4
+    ss = K.StreamSet(streams)
+    a = K.SurvivorAccumulator(rows // 50)
+    assert K.merge_filter(ss, K.diff_observer(model, a, thr)) == rows
+    na = a.finish(by_kmer=True)
+    ga, ca = a.get(), a.read_counters()
+    out = K.merge_partition(streams, count_bytes=4, layout=K.LAYOUT_TILED)
+    assert out.n_rows == rows
+    b = K.SurvivorAccumulator(rows // 50)
+    K.diff_observer(model, b, thr).process(out)
+    nb = b.finish()
+    gb, cb = b.get(), b.read_counters()
+    assert na == nb > 1000 and [int(x) for x in ca[:4]] == [int(x) for x in cb[:4]] and int(ca[6]) == int(cb[6]) == 0
+    assert ga["kmer_lo"].tolist() == gb["kmer_lo"].tolist()          # (rows ascend with their k-mers)
+    assert ga["pvalue"].tolist() == gb["pvalue"].tolist() and ga["sign"].tolist() == gb["sign"].tolist()
+    assert ga["mean_case"].tolist() == gb["mean_case"].tolist() and ga["mean_control"].tolist() == gb["mean_control"].tolist()
+    sums = K.merge_sums(ss, nc, row_capacity=rows)
+    km, sc, sk, _ = sums.to_host()
+    assert sums.n_rows == rows and int(sc.sum(dtype=np.uint64)) == int(tot[:nc].sum()) and int(sk.sum(dtype=np.uint64)) == int(tot[nc:].sum())
+    assert np.array_equal(np.sort(km), lo)
