@@ -350,3 +350,40 @@ def test_fused_equals_matrix_path_at_bench_size(K):
     km, sc, sk, _ = sums.to_host()
     assert sums.n_rows == rows and int(sc.sum(dtype=np.uint64)) == int(tot[:nc].sum()) and int(sk.sum(dtype=np.uint64)) == int(tot[nc:].sum())
     assert np.array_equal(np.sort(km), lo)
+
+
+def test_merge_filter_random_small_cases(K, oracle):
+    """Forty seeded small partitions of every shape at once: 2..14 samples, 0..3000 k-mers spread over the whole range
+    or packed into a few thousand consecutive integers, presence per sample from almost none to all, empty samples,
+    counts of 3e9 here and there, thresholds from 1 to 1e-6."""
+    rng = np.random.default_rng(20261002)
+    for case in range(40):
+        S = int(rng.integers(2, 15))
+        nc = int(rng.integers(1, S))
+        n = int(rng.integers(0, 3000))
+        if rng.random() < 0.4:
+            base = int(rng.integers(0, 1 << 60))
+            universe = np.unique(np.uint64(base) + rng.integers(0, 4 * n + 8, n).astype(np.uint64))
+        else:
+            universe = np.unique(rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64))
+        if case % 7 == 0 and len(universe):
+            universe = np.unique(np.concatenate([universe, np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
+        pres = rng.uniform(0.02, 1.0, S)
+        empty = tuple(int(x) for x in rng.choice(S, size=int(rng.integers(0, max(1, S // 3))), replace=False)) if S > 2 else ()
+        # (count sums stay below ~3e4 or go past 2^31: the oracle follows the reference's O(sum) loop for every sum
+        # between the table's end and 2^31, seconds per row at 1e9)
+        streams = make_streams(rng, universe, S, pres, count_hi=int(rng.integers(2, 2000)), empty=empty)
+        if sum(len(t[0]) for t in streams) == 0:
+            continue
+        if case % 5 == 0:
+            for s in range(S):
+                km, cnt = streams[s]
+                if len(cnt):
+                    cnt = cnt.copy()
+                    cnt[rng.integers(0, len(cnt), 3)] = np.uint32(3_000_000_000)
+                    streams[s] = (km, cnt)
+        want, _ = oracle.merge_partition(streams)
+        tcs, tks = totals_of(want, nc)
+        if int(tcs.sum()) == 0 or int(tks.sum()) == 0:
+            continue                                                 # (the model needs counts on both sides)
+        run_fused(K, oracle, streams, nc, float(rng.choice([1.0, 0.2, 1e-2, 1e-6])), lf_n=int(rng.choice([10000, 200])))
