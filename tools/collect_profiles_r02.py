@@ -52,6 +52,8 @@ def main():
     copy("prof_bench/**/*kernel_stats.csv", "r02_bench_kernel_stats.csv")
     copy("prof_pipe/**/*kernel_stats.csv", "r02_pipeline_kernel_stats.csv")
     copy("prof_sparse/**/*kernel_stats.csv", "r02_sparse_kernel_stats.csv")
+    copy("prof_overlap/**/*kernel_stats.csv", "r02_overlap_kernel_stats.csv")
+    copy("overlap.txt", "r02_overlap.txt")
     copy("kbench.txt", "r02_kbench.txt")
     copy("cli_throughput.txt", "r02_cli_throughput.txt")
     copy("pmc_popstrat.txt", "r02_pmc_popstrat.txt")

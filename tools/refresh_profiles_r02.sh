@@ -16,6 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python3 tools/kbench_pipeline.py --fused-only --iters 2 > $O/pmc_$c.log 2>&1 < /dev/null
 done
+bash tools/prof_overlap.sh > /dev/null 2>&1
 bash tools/pmc_tile.sh > $O/pmc_tile.txt 2>&1
 bash tools/pmc_tile2.sh > $O/pmc_tile2.txt 2>&1
 bash tools/pmc_popstrat.sh --thr 0.05 > $O/pmc_popstrat.txt 2>&1
