@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__
 // k_tile_coarse works it out for itself from the probe's 512 counts (the first one writes it down for the
 // kernels behind): no launch of its own.
 __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t S,
-                                               uint32_t slots, float load, uint32_t fill_fixed, uint32_t g_fixed, double* s_part)
+                                               uint32_t slots, float load, uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
+                                               double* s_part)
 {
   double acc = 0;
   for (uint32_t p = threadIdx.x; p < kProbes; p += blockDim.x) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
@@ -184,6 +185,16 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   if (r < 1) r = 1;
   uint64_t nb = (n_l + r - 1) / r;
   if (nb < 1) nb = 1;
+  // a whole number of tiles per workgroup of the persistent grid (3963 tiles on 1024 workgroups: one in eight
+  // workgroups idles through the last quarter of the kernel): somewhat smaller tiles, at most the next multiple
+  if (grid_hint && !fill_fixed && nb > grid_hint && r > 1)
+  {
+    const uint64_t target = (nb + grid_hint - 1) / grid_hint * grid_hint;
+    r = (n_l + target - 1) / target;
+    if (r < 1) r = 1;
+    nb = (n_l + r - 1) / r;
+    fill = (double)r * (double)n / (double)n_l;
+  }
   // lanes per run: the power of two nearest the average run (one round of a sub-group takes most of it)
   const double run = fill / (double)S;
   uint32_t g = 3;
@@ -200,11 +211,11 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
 __global__ void __launch_bounds__(256) k_tile_coarse(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                      const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
                                                      const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
-                                                     uint32_t fill_fixed, uint32_t g_fixed,
+                                                     uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
                                                      tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse)
 {
   __shared__ double s_part[256];
-  const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, s_part);
+  const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, s_part);
   if (blockIdx.x == 0 && threadIdx.x == 0) *plan = pl;
   const uint32_t nb = pl.nb, r = pl.r;
   const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;               // coarse rows 0 .. n_chunks
@@ -1061,7 +1072,9 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   uint32_t fill_min = (uint32_t)std::max(64.0f, load * (float)sh.slots);
   if (const uint32_t f = env_u32("KMD_TILE_FILL", 0)) fill_min = std::min(fill_min, std::max(64u, f));
   const uint64_t r_min = std::max<uint64_t>(1, (uint64_t)((double)n_l * (double)fill_min / (double)n));
-  const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min);
+  const uint32_t grid_hint = env_u32("KMD_TILE_GRID_HINT", (uint32_t)n_cu * (sh.threads == 512 ? 4u : 2u));   // workgroups of the level-0 launch
+  // (+ grid_hint: the plan may round the number of tiles up to a multiple of it)
+  const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min) + grid_hint;
   const uint32_t chunks_max = (nb_max + kChunk - 1) / kChunk;
 
   scratch_set sc;
@@ -1083,7 +1096,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     const size_t cells_c = ((size_t)chunks_max + 1) * S;
     hipLaunchKernelGGL(k_tile_coarse, dim3((unsigned)((cells_c + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
-                       d_plan, static_cast<uint32_t*>(p_coarse));
+                       grid_hint, d_plan, static_cast<uint32_t*>(p_coarse));
     const size_t waves_f = (size_t)chunks_max * S;
     hipLaunchKernelGGL(k_tile_fine, dim3((unsigned)((waves_f + 3) / 4)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
                        d_plan, static_cast<const uint32_t*>(p_coarse), static_cast<uint32_t*>(p_table));
