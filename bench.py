@@ -212,6 +212,21 @@ def h2d_leg(K, lib, obs, mat, steps=3):
                     "serial, per step" % nbytes}
 
 
+def launch_ranks(n):
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process and
+    return its exit code (the caller has not touched the GPU runtime yet)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,11 +240,19 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the streams -> survivors and H2D-inclusive legs (N = 1 extras)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as a CHILD process, before this
+    # process has imported torch or touched HIP (an exec after a GPU call takes the box down; a child does not) --
+    # forward its output and leave with its return code.  Under torchrun (WORLD_SIZE set) this is skipped.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # dev switches (not used by the driver): KMD_BENCH_OVERSUBSCRIBE=1 folds the ranks onto the GPUs
@@ -243,7 +266,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    # how many ranks the collective library really connected: an all-reduce of 1 over the job's backend
+    n_ranks_seen = world
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        n_ranks_seen = int(one.item())
 
     import kmdiff_amd as K
     from kmdiff_amd import dist as D
@@ -292,9 +320,12 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_min = -D.max_over_ranks(-elapsed)
     elapsed = D.max_over_ranks(elapsed)
 
-    avg_kernel_ms = D.max_over_ranks(ev0.elapsed_ms(ev1) / args.steps)    # back-to-back launches
+    my_kernel_ms = ev0.elapsed_ms(ev1) / args.steps                       # back-to-back launches
+    kernel_ms_min = -D.max_over_ranks(-my_kernel_ms)
+    avg_kernel_ms = D.max_over_ranks(my_kernel_ms)
     near = int(acc.read_counters()[K._native.CNT_NEAR_THRESHOLD])    # rows decided with correctly rounded log / exp
     kept = D.allreduce_counters([int(keep.sum()), n_ctrl, n_case, near])
 
@@ -340,6 +371,9 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "backend": backend if world > 1 else None, "rccl_ranks": n_ranks_seen,
+            "per_rank": {"ms_per_step_min": elapsed_min * 1e3 / args.steps, "ms_per_step_max": elapsed * 1e3 / args.steps,
+                         "kernel_ms_min": kernel_ms_min, "kernel_ms_max": avg_kernel_ms},
             "config": {"workload": "configs[2]: 256-partition synthetic matrix, 20v20, k=31, u32 counts; "
                                    "step = one partition of %d rows resident in HBM (%s layout); partition p on "
                                    "rank p %% N" % (args.rows, args.layout),

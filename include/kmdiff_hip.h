@@ -151,7 +151,10 @@ enum { KMD_CNT_TOTAL = 0, KMD_CNT_SIG = 1, KMD_CNT_SIG_CONTROL = 2, KMD_CNT_SIG_
        KMD_CNT_DEFERRED = 5,     /* rows with a count sum >= log_factorial_size            */
        KMD_CNT_NEAR_THRESHOLD = 6, /* candidates with |p / threshold - 1| <= 1e-8: decided with correctly rounded
                                       log / exp, so that no libm's last bit can move them across (kmd_ddmath.h) */
-       KMD_CNT_RESERVED7 = 7, KMD_NCOUNTERS = 8 };
+       KMD_CNT_NEAR_UNRESOLVED = 7, /* near-threshold rows beyond the 4096 a launch can list: they were counted in
+                                       [6] but kept the device libm's decision -- a caller that wants the guard's
+                                       guarantee for them reruns the partition in smaller pieces (0 in practice) */
+       KMD_NCOUNTERS = 8 };
 
 typedef struct {
   const void*     d_counts;   /* count matrix tile                                         */
@@ -237,7 +240,8 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
  * counts and the sum of its case counts (model.hpp:144-145), so no matrix is built: the streams are
  * read once (12 bytes per record), rows exist only in LDS (kmd_tilemerge.hip).
  *   m          : the model; n_samples must be its controls + cases, samples [0, nc) are the controls
- *                (merge.hpp:70-72); at most 1024 samples
+ *                (merge.hpp:70-72); at most 1024 samples, fewer than 2^32-129 records in the partition and
+ *                fewer than 2^29 records of any one sample (positions and run extents are 32-bit on the device)
  *   d_kmers_hi : high limbs for 32 < k <= 64, else NULL
  *   out        : survivor sink as in kmd_poisson_filter.  A row has no index here: `row` holds the low
  *                limb of the k-mer; kmd_survivors_sort_by_kmer gives the reference's ascending order

@@ -16,7 +16,8 @@ SIGN_CONTROL, SIGN_CASE, SIGN_NO = 0, 1, 2
 CORR_NOTHING, CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM = 0, 1, 2, 3, 4
 LAYOUT_ROWS, LAYOUT_SOA, LAYOUT_TILED = 0, 1, 2
 NCOUNTERS = 8
-(CNT_TOTAL, CNT_SIG, CNT_SIG_CONTROL, CNT_SIG_CASE, CNT_CANDIDATES, CNT_DEFERRED, CNT_NEAR_THRESHOLD) = range(7)
+(CNT_TOTAL, CNT_SIG, CNT_SIG_CONTROL, CNT_SIG_CASE, CNT_CANDIDATES, CNT_DEFERRED, CNT_NEAR_THRESHOLD,
+ CNT_NEAR_UNRESOLVED) = range(8)
 
 
 class KmdError(RuntimeError):

@@ -93,7 +93,7 @@ __device__ __forceinline__ void finish_row(const filter_params& P, const double2
                                            const row_state& st, uint32_t& n_beyond)
 {
 #ifdef KMD_ABLATE_MATH   // dev only: memory-side ceiling of the load loop (results are wrong)
-  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
+  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_NEAR_UNRESOLVED] = st.row;
   return;
 #endif
   row_state e = st;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void defer_row(const filter_params& P, const double2*
                                           uint32_t& n_beyond, wave_queue& Q)
 {
 #ifdef KMD_ABLATE_MATH
-  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_RESERVED7] = st.row;
+  if (st.valid && (st.sum_c ^ st.sum_k) == 0x7fffffffffffull) P.counters[KMD_CNT_NEAR_UNRESOLVED] = st.row;
   return;
 #endif
   const bool maybe = row_may_pass(P, st, n_beyond);
@@ -1581,9 +1581,12 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
 template <int kRowMode>
 __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
 {
-  const unsigned long long listed = P.near[0] < kNearCap ? P.near[0] : kNearCap;
+  const unsigned long long flagged = P.near[0];
+  const unsigned long long listed = flagged < kNearCap ? flagged : kNearCap;
   if (listed == 0) return;
   const int lane = (int)threadIdx.x;
+  // rows flagged beyond the list's capacity keep the decision the filter made: said so, not hidden
+  if (lane == 0 && flagged > kNearCap) atomicAdd(&P.counters[KMD_CNT_NEAR_UNRESOLVED], flagged - kNearCap);
   unsigned long long struck = 0;
   for (unsigned long long e0 = 0; e0 < listed; e0 += 64)
   {
@@ -1639,7 +1642,8 @@ __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
   // compact the sink in place (this wave alone, behind the filter kernel on its stream): records marked
   // p = -1 leave, the others close ranks in order
   __threadfence();
-  const unsigned long long n = P.counters[KMD_CNT_SIG] < P.out.capacity ? P.counters[KMD_CNT_SIG] : P.out.capacity;
+  const unsigned long long n_sig = P.counters[KMD_CNT_SIG];
+  const unsigned long long n = n_sig < P.out.capacity ? n_sig : P.out.capacity;
   unsigned long long w = 0;
   for (unsigned long long r0 = 0; r0 < n; r0 += 64)
   {
@@ -1673,7 +1677,9 @@ __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
     w += (unsigned long long)__popcll(km);
     __threadfence();
   }
-  if (lane == 0) P.counters[KMD_CNT_SIG] = w;             // (= the old count - struck, when nothing was truncated)
+  // the count stays a count of survivors, also when the sink was too small for them: the host compares it with
+  // the capacity and runs the partition again with a larger sink (w alone would hide that)
+  if (lane == 0) P.counters[KMD_CNT_SIG] = n_sig <= P.out.capacity ? w : n_sig - struck;
 }
 
 // The list of a launch: one per (device, stream), made at the first filter launch on that stream and kept; it is

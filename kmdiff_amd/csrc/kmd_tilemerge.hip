@@ -81,6 +81,10 @@ constexpr uint32_t kProbes = 512;                // records sampled for the reco
 constexpr uint32_t kChunk = 64;                  // tile boundaries per coarse step of the start table
 constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
 constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a count too large for 32-bit sums
+// record positions and run extents are 32-bit: a run's byte extent (8 x its records) must fit the buffer descriptor's
+// 32-bit range and a lane's position may step up to two sub-groups past the last record before it is checked
+constexpr uint64_t kMaxRecords = 0xFFFFFFFFull - 128ull;
+constexpr uint64_t kMaxRun = 1ull << 29;
 constexpr uint32_t kBigCount = 1u << 22;         // 1024 samples of counts below this cannot overflow a 32-bit sum
 
 // what k_tile_plan decides, on the device
@@ -187,16 +191,25 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   if (nb < 1) nb = 1;
   // a whole number of tiles per workgroup of the persistent grid (3963 tiles on 1024 workgroups: one in eight
   // workgroups idles through the last quarter of the kernel): somewhat smaller tiles, at most the next multiple
+  // Lanes per run are chosen from the fill BEFORE that rounding: the host skips the launch of the sub-group
+  // instantiation when every plan it can predict takes whole waves (wide_for_sure in tile_merge: fill >= load x
+  // slots), and the rounding -- which may shrink a tile to a little over half -- must not take the plan to the
+  // instantiation that was not launched (the partition's rows would be lost without an error).
+  const double fill_planned = fill;
   if (grid_hint && !fill_fixed && nb > grid_hint && r > 1)
   {
     const uint64_t target = (nb + grid_hint - 1) / grid_hint * grid_hint;
-    r = (n_l + target - 1) / target;
-    if (r < 1) r = 1;
-    nb = (n_l + r - 1) / r;
-    fill = (double)r * (double)n / (double)n_l;
+    // (only where it costs at most a quarter of a tile: 1100 tiles on 1024 workgroups stay 1100, not 2048 half-filled ones)
+    if (target * 4 <= nb * 5)
+    {
+      r = (n_l + target - 1) / target;
+      if (r < 1) r = 1;
+      nb = (n_l + r - 1) / r;
+      fill = (double)r * (double)n / (double)n_l;
+    }
   }
   // lanes per run: the power of two nearest the average run (one round of a sub-group takes most of it)
-  const double run = fill / (double)S;
+  const double run = fill_planned / (double)S;
   uint32_t g = 3;
   while (g < 6 && (double)(1u << g) < run * 0.75) ++g;
   if (g_fixed) g = g_fixed;
@@ -1008,16 +1021,26 @@ template <typename K> int allow_lds(K kernel, size_t lds_bytes)
   return KMD_OK;
 }
 
+// The blocks go back to the process-wide cache when the set dies -- where another call (another partition in
+// flight on another host thread) may take them at once.  On the normal way out the caller has synchronised the
+// stream; on an error return kernels enqueued on it may still be running: the set then drains the stream first.
 struct scratch_set
 {
   std::vector<void*> blocks;
+  hipStream_t stream = nullptr;
+  bool drained = false;                                    // set by the owner once nothing enqueued reads the blocks
+  explicit scratch_set(hipStream_t st) : stream(st) {}
   hipError_t take(void** out, size_t bytes)
   {
     const hipError_t e = kmd::scratch_alloc(out, bytes ? bytes : 1);
     if (e == hipSuccess) blocks.push_back(*out);
     return e;
   }
-  ~scratch_set() { for (void* b : blocks) kmd::scratch_free(b); }
+  ~scratch_set()
+  {
+    if (!drained && !blocks.empty()) (void)hipStreamSynchronize(stream);
+    for (void* b : blocks) kmd::scratch_free(b);
+  }
 };
 
 struct tile_shape { int threads; uint32_t slots; };
@@ -1077,7 +1100,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min) + grid_hint;
   const uint32_t chunks_max = (nb_max + kChunk - 1) / kChunk;
 
-  scratch_set sc;
+  scratch_set sc(st);
   void *p_offs = nullptr, *p_table = nullptr, *p_coarse = nullptr, *p_over = nullptr, *p_small = nullptr;
   KMD_HIP(sc.take(&p_offs, ((size_t)S + 1) * 8));
   KMD_HIP(sc.take(&p_table, ((size_t)nb_max + 1) * (size_t)S * 4));
@@ -1248,6 +1271,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   std::memcpy(h_rows, h_small + 32, sizeof h_rows);               // (read back with the last level)
   if (n_entries) *n_entries = (uint64_t)h_rows[0];
   if (totals) { totals[0] = fused ? (uint64_t)h_rows[1] : (uint64_t)h_rows[0]; totals[1] = (uint64_t)h_rows[2]; }
+  sc.drained = true;                                            // (the last level's read-back waited for the stream)
   return KMD_OK;
 }
 
@@ -1263,8 +1287,12 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   KMD_REQUIRE(n_samples == m->nc + m->nk, "kmd_merge_filter: n_samples != controls + cases of the model");
   KMD_REQUIRE((uint32_t)n_samples <= kMaxStreams, "kmd_merge_filter: more than 1024 samples");
   const size_t n = (size_t)offsets[n_samples];
-  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_merge_filter: more than 2^32-1 records in one partition");
-  for (int s = 0; s < n_samples; ++s) KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_filter: offsets must be ascending");
+  KMD_REQUIRE(n < kMaxRecords, "kmd_merge_filter: more than 2^32-129 records in one partition");
+  for (int s = 0; s < n_samples; ++s)
+  {
+    KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_filter: offsets must be ascending");
+    KMD_REQUIRE(offsets[s + 1] - offsets[s] < kMaxRun, "kmd_merge_filter: more than 2^29-1 records of one sample in one partition");
+  }
   if (n_rows_out) *n_rows_out = 0;
   if (n == 0) return KMD_OK;
   KMD_REQUIRE(d_kmers && d_counts, "kmd_merge_filter: NULL device buffers");
@@ -1282,7 +1310,7 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   size_t cap = std::max<size_t>((size_t)1 << 18, n / 8);
   if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) cap = e;
   uint64_t entries = 0, totals[2] = { 0, 0 };
-  scratch_set sc;
+  scratch_set sc(st);
   void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr;
   for (int attempt = 0;; ++attempt)
   {
@@ -1304,7 +1332,7 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
     if (entries <= cap)
     {
       if (n_rows_out) *n_rows_out = totals[0];
-      if (clean) return KMD_OK;                               // the gated launch did the work; tile_merge has synchronised behind it
+      if (clean) { sc.drained = true; return KMD_OK; }        // the gated launch did the work; tile_merge has synchronised behind it
       break;
     }
     KMD_REQUIRE(attempt == 0, "kmd_merge_filter: candidate list overflowed twice");
@@ -1315,6 +1343,7 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
                                      static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), (size_t)entries, totals[0], totals[1], st);
   if (rc != KMD_OK) return rc;
   KMD_HIP(hipStreamSynchronize(st));                            // the scratch list goes back to the cache
+  sc.drained = true;
   return KMD_OK;
 }
 
@@ -1328,8 +1357,12 @@ extern "C" int kmd_merge_sums(int n_samples, int nb_controls, const uint64_t* d_
   KMD_REQUIRE(n_samples > 0 && nb_controls >= 0 && nb_controls <= n_samples && offsets && n_rows_out, "kmd_merge_sums: arguments");
   KMD_REQUIRE((uint32_t)n_samples <= kMaxStreams, "kmd_merge_sums: more than 1024 samples");
   const size_t n = (size_t)offsets[n_samples];
-  KMD_REQUIRE(n < 0xFFFFFFFFull, "kmd_merge_sums: more than 2^32-1 records in one partition");
-  for (int s = 0; s < n_samples; ++s) KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_sums: offsets must be ascending");
+  KMD_REQUIRE(n < kMaxRecords, "kmd_merge_sums: more than 2^32-129 records in one partition");
+  for (int s = 0; s < n_samples; ++s)
+  {
+    KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_merge_sums: offsets must be ascending");
+    KMD_REQUIRE(offsets[s + 1] - offsets[s] < kMaxRun, "kmd_merge_sums: more than 2^29-1 records of one sample in one partition");
+  }
   *n_rows_out = 0;
   if (n == 0) return KMD_OK;
   KMD_REQUIRE(d_kmers && d_counts && d_kmer_out && d_sum_control && d_sum_case, "kmd_merge_sums: NULL device buffers");

@@ -440,7 +440,7 @@ def merge_sums(streams, nb_controls, row_capacity=None):
 def merge_filter(streams, observer, stream=None):
     """km::KmerMerger::merge(diff_observer) for one partition (merge.hpp:265-289, 68-103): streams in,
     survivors into the observer's accumulator; returns the number of distinct k-mers.  Survivor `row` =
-    low limb of the k-mer (SurvivorAccumulator.sort_by_kmer() gives the reference's order).  `stream`: a
+    low limb of the k-mer (SurvivorAccumulator.finish(by_kmer=True) gives the reference's order).  `stream`: a
     handle from kmd_stream_create (partitions on different streams, from different host threads, overlap)."""
     ss = streams if isinstance(streams, StreamSet) else StreamSet(streams)
     n_rows = C.c_uint64(0)

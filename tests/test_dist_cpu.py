@@ -76,3 +76,25 @@ def test_two_ranks_gloo_exchange():
     assert g0 == g1 == [4000 + 3001, 21, 9, 12]
     assert cat0 == cat1 == [0.0, 1.0, 2.0] and offs0 == offs1 == [0, 3, 3]
     assert mx0 == mx1 == 1.5
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_ranks_as_children_without_a_launcher():
+    """`python bench.py --gpus 2` run bare (no torchrun, as the driver runs the N = 1 line) must start the two ranks
+    itself.  Without a GPU each rank stops at "needs an MI355X" -- after the rendezvous environment was set up by
+    the child launcher, which is what this checks -- and bench.py leaves with the launcher's non-zero code."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=280, cwd=root, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    # and a mismatch between the launcher's world size and --gpus is refused before anything touches the GPU
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
+                       cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE (2) != --gpus (4)" in r.stderr

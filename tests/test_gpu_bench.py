@@ -52,6 +52,36 @@ def test_bench_two_ranks_on_one_gpu(correction):
     assert 0 < c["kept_after_correction"] <= c["n_sig"]
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver runs the N = 1 line): bench.py starts
+    the two ranks itself, as a child process, before touching the GPU runtime; one JSON line comes back."""
+    env = dict(os.environ, KMD_BENCH_OVERSUBSCRIBE="1", KMD_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", str(ROWS), "--steps", "4",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["counters"]["total"] == ROWS * 4 * 2
+    pr = d["per_rank"]
+    assert 0 < pr["ms_per_step_min"] <= pr["ms_per_step_max"] == d["ms_per_step"]
+
+
+def test_bench_two_gpus_over_rccl():
+    """The same entry point on two real GPUs with RCCL as the wire (skipped on a one-GPU box)."""
+    import kmdiff_amd as K
+    if K.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "KMD_BENCH_OVERSUBSCRIBE", "KMD_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", str(ROWS), "--steps", "4",
+                        "--warmup", "1", "--correction", "benjamini"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "nccl"
+
+
 def test_collectives_through_rccl():
     """tests/nccl_probe.py: the dtypes and calls of kmdiff_amd/dist.py over backend "nccl" (= RCCL)."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",

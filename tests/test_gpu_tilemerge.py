@@ -253,6 +253,34 @@ def test_merge_filter_at_the_sample_limit(K, oracle):
         K.merge_filter(streams + [streams[0]], K.diff_observer(model, acc, 0.5))
 
 
+@pytest.mark.parametrize("S,n", [(16, 1_300_000), (20, 1_300_000), (23, 2_000_000), (20, 1_150_000)])
+def test_disjoint_kmers_between_one_and_two_grids_of_tiles(K, S, n):
+    """Every record a row of its own (disjoint k-mers, rho = 1), at the sizes where the plan asks for a little more
+    than one persistent grid's worth of tiles: the plan used to round the tile count up to the next multiple of the
+    grid (halving the tiles), pick sub-groups of lanes per run from the halved tiles -- and the host had not launched
+    that instantiation: zero rows, KMD_OK.  Rows must equal records, every count accounted for."""
+    rng = np.random.default_rng(S * 1000 + n % 997)
+    keys = np.unique(rng.integers(0, 1 << 62, n + n // 50, dtype=np.uint64))[:n]
+    owner = rng.integers(0, S, len(keys))
+    streams = []
+    for s in range(S):
+        km = keys[owner == s]
+        streams.append((km, rng.integers(1, 50, len(km)).astype(np.uint32)))
+    nc = S // 2
+    sums = K.merge_sums(streams, nc, row_capacity=len(keys))
+    km, sc, sk, _ = sums.to_host()
+    assert sums.n_rows == len(keys)
+    assert np.array_equal(np.sort(km), keys)
+    want_c = sum(int(streams[s][1].sum(dtype=np.uint64)) for s in range(nc))
+    want_k = sum(int(streams[s][1].sum(dtype=np.uint64)) for s in range(nc, S))
+    assert int(sc.sum(dtype=np.uint64)) == want_c and int(sk.sum(dtype=np.uint64)) == want_k
+    tot = np.array([int(t[1].sum(dtype=np.uint64)) for t in streams], dtype=np.uint64)
+    model = K.PoissonLikelihood(nc, S - nc, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(1 << 16)
+    assert K.merge_filter(K.StreamSet(streams), K.diff_observer(model, acc, 1e-9)) == len(keys)
+    assert int(acc.read_counters()[0]) == len(keys)
+
+
 def test_merge_filter_partitions_in_flight(K, oracle):
     """Three different partitions at once, each from a host thread and on a stream of its own (scratch per call,
     near-threshold list per stream): the same survivors as one after the other."""
