@@ -27,10 +27,11 @@ def pmc(name):
     return agg
 
 
-shutil.copy(os.path.join(G, "prof_r01", "bench_kernel_stats.csv"), os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
-for f in ("bench_r01.json", "bench_r01_soa.json", "bench_r01_rows.json", "bench_r01_bh.json"):
-    if os.path.exists(os.path.join(G, f)):
-        shutil.copy(os.path.join(G, f), os.path.join(P, f.replace("r01", tag)))
+if tag == "r01":          # (later rounds copy their bench files with their own collectors: tools/collect_profiles_rNN.py)
+    shutil.copy(os.path.join(G, "prof_r01", "bench_kernel_stats.csv"), os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
+    for f in ("bench_r01.json", "bench_r01_soa.json", "bench_r01_rows.json", "bench_r01_bh.json"):
+        if os.path.exists(os.path.join(G, f)):
+            shutil.copy(os.path.join(G, f), os.path.join(P, f.replace("r01", tag)))
 
 fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 lines = ["# %s: PMC passes (rocprofv3 --pmc, one counter set per pass; tools/traffic_probe.py)" % tag, ""]
