@@ -41,6 +41,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 using namespace kmd::eval;
@@ -53,6 +54,9 @@ using namespace kmd::eval;
 #endif
 #ifndef KMD_TILE_ABLATE
 #define KMD_TILE_ABLATE 0
+#endif
+#ifndef KMD_TILE_RPL
+#define KMD_TILE_RPL 1               // whole-wave path: records per lane and round (1: 64-record rounds, 2: 128: spills at 64 registers)
 #endif
 #ifndef KMD_TILE_RING
 #define KMD_TILE_RING 4              // rounds of loads in flight per wave (8, 12, 16 measured: no faster, more registers)
@@ -72,6 +76,7 @@ constexpr uint64_t kEmptyKey = ~0ull;
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u64x2 lds_u64x2;        // a bucket of two slots, read with one ds_read_b128
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRsrcFlags = 0x00020000;           // buffer descriptor, dword 3: raw 32-bit data, no swizzle (gfx9 family)
 constexpr int kAuxNt = 2;                        // buffer load: non-temporal
 // the lanes' predicate as a mask, straight from the compare (HIP's __ballot takes an int: a select and a second compare)
@@ -364,12 +369,18 @@ constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 template <uint32_t kSlots, int kWaves, bool kTwo, bool kSum32>
 struct tile_lds
 {
-  unsigned long long key[kSlots];
-  unsigned long long sc[kSum32 ? 1 : kSlots];
-  unsigned long long sk[kSum32 ? 1 : kSlots];
-  uint32_t s32[kSum32 ? 2 * kSlots : 2];                 // [2 i] control sum, [2 i + 1] case sum of slot i
-  unsigned long long key_hi[kTwo ? kSlots : 1];
-  unsigned long long hi_min[kTwo ? kSlots : 1];          // see k_tile_sums: every record's high limb must agree with its slot's
+  // kSlots of the main table, kSlots / 8 of the second table behind it (whole-wave path: where the ~1 % of the k-mers
+  // go that find their four home slots taken), and a spare slot behind every array (+ 2 / + 4) -- where the
+  // whole-wave path lets lanes that have nothing to add add it: its key is 0, never the empty marker, and nothing
+  // reads its sums
+  static constexpr uint32_t kAll = kSlots + kSlots / 8;
+  unsigned long long key[kAll + 2];
+  unsigned long long sc[kSum32 ? 2 : kAll + 2];
+  unsigned long long sk[kSum32 ? 2 : kAll + 2];
+  uint32_t c32[kSum32 ? kAll + 4 : 4];                   // kSum32: control sum of slot i (arrays of their own: a round adds to ONE
+  uint32_t k32[kSum32 ? kAll + 4 : 4];                   // of them -- the run is a control's or a case's -- so its lanes spread over all banks)
+  unsigned long long key_hi[kTwo ? kAll + 2 : 2];
+  unsigned long long hi_min[kTwo ? kAll + 2 : 2];        // see k_tile_sums: every record's high limb must agree with its slot's
   unsigned long long maxsum[2];
   unsigned long long max_hi[2];                          // kTwo: min / max high limb of the records whose low limb is all ones
   unsigned long long base;
@@ -409,7 +420,8 @@ k_tile_sums(const tile_job J)
   constexpr uint32_t kMask = kSlots - 1;
   constexpr int kShift = 32 - ilog2_c(kSlots);
   constexpr int kWaves = kThreads / 64;
-  constexpr int kWalk = kSlots / kThreads;               // table slots per thread in the walk
+  constexpr uint32_t kSec = kSlots / 8, kAll = kSlots + kSec;   // second table (whole-wave path), all slots
+  constexpr int kWalk = (int)((kAll + kThreads - 1) / kThreads);   // table slots per thread in the walk
   constexpr int kU = KMD_TILE_U;                         // records per lane and round
   constexpr int kDepth = KMD_TILE_DEPTH;                 // rounds in flight per wave
   constexpr uint32_t kFullAt = kSlots / 4 * 3;           // distinct k-mers at which a tile gives up
@@ -417,7 +429,7 @@ k_tile_sums(const tile_job J)
   static_assert((kSlots & kMask) == 0 && kSlots % kThreads == 0, "shape");
   static_assert(kWalk <= 32, "walk bits");
   using lds_t = tile_lds<kSlots, kWaves, kTwo, kSum32>;
-  extern __shared__ unsigned long long s_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_raw[];      // (16: a bucket of two keys is one ds_read_b128)
   lds_t& M = *reinterpret_cast<lds_t*>(s_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t S = J.S;
@@ -443,21 +455,22 @@ k_tile_sums(const tile_job J)
   // a slot's sums: two 64-bit words, or (kSum32) the halves of one
   auto wipe_sums = [&](uint32_t i)
   {
-    if constexpr (kSum32) *reinterpret_cast<unsigned long long*>(&M.s32[2 * i]) = 0ull;
+    if constexpr (kSum32) { M.c32[i] = 0; M.k32[i] = 0; }
     else { M.sc[i] = 0; M.sk[i] = 0; }
   };
   auto read_sums = [&](uint32_t i, unsigned long long& c, unsigned long long& k)
   {
-    if constexpr (kSum32) { const unsigned long long w = *reinterpret_cast<const unsigned long long*>(&M.s32[2 * i]); c = w & 0xFFFFFFFFull; k = w >> 32; }
+    if constexpr (kSum32) { c = M.c32[i]; k = M.k32[i]; }
     else { c = M.sc[i]; k = M.sk[i]; }
   };
-  for (uint32_t i = tid; i < kSlots; i += kThreads)
+  for (uint32_t i = tid; i < kAll; i += kThreads)
   {
     M.key[i] = kEmptyKey; wipe_sums(i);
     if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
   }
   if (tid == 0)
   {
+    M.key[kAll] = 0; M.key[kAll + 1] = 0;                  // the spare slot: never the empty marker
     M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0; M.big[0] = 0; M.big[1] = 0;
     M.hasmax = 0; M.bad = 0; M.maxsum[0] = 0; M.maxsum[1] = 0;
     M.max_hi[0] = ~0ull; M.max_hi[1] = 0;
@@ -510,164 +523,264 @@ k_tile_sums(const tile_job J)
       if (process)
       {
         constexpr int kRing = KMD_TILE_RING;
+        constexpr int kR = KMD_TILE_RPL;                                              // records per lane and round (lane l: records l, 64 + l, ...)
+        constexpr uint32_t kStep = 64u * kR;                                          // records per round
+        constexpr uint32_t kBatch = 63;                                               // runs of a wave whose description its lanes hold at a time
         const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
         const uint32_t* len = beg + S;
-        // A round's 64 records are read through buffer descriptors of the run: base = the run's first record,
-        // extent = the run, scalar offset = records done, a lane's offset = 8 x its number, always.  The
-        // hardware's range check (on gfx950 it covers the scalar offset too: measured, a per-round extent with
-        // the scalar offset on top returned zeros from the second round on) gives 0 to the lanes past the end
-        // of the run: no clamped index and no address arithmetic in vector registers, and nothing is read
-        // once the runs are exhausted (extent 0).  The descriptors are made once per run; a round costs the
-        // scalar unit a subtraction, two shifts, an addition and a compare.
-        uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);          // current run
-        uint32_t rl = 0, rc = 0, ctl_now = 0;                                         // its length (0: no run left), records done, control sample?
-        auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys), (short)0, 0, kRsrcFlags);
-        auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts), (short)0, 0, kRsrcFlags);
-        auto dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(kTwo ? J.keys_hi : J.keys), (short)0, 0, kRsrcFlags);
-        auto next_run = [&]()
+        // What the scalar unit does per round decides this kernel (PMC, round 2: 73 scalar instructions per round of
+        // 64 records, most of them lane-mask algebra and the iterator's register shuffling -- one scalar unit serves
+        // the CU's four SIMDs).  So:
+        //  * the wave's runs are described in its LANES (lane j: first record and length of the wave's j-th run with
+        //    records in this tile; read from the segment table once per tile, empty runs squeezed out): a round reads
+        //    its run with two v_readlane, builds the buffer descriptors from them and steps (run, offset) with
+        //    selects -- no branch, no LDS read, nothing carried round to round but two counters;
+        //  * a round's records are read through buffer descriptors of the run: base = the run's first record, extent
+        //    = the run, scalar offset = bytes done, a lane's offset = 8 x its number; the hardware's range check (on
+        //    gfx950 it covers the scalar offset) returns 0 past the end of the run and reads nothing once the runs
+        //    are exhausted (extent 0).  Which lanes hold a record is decided from the scalar count of records left,
+        //    never from what was loaded;
+        //  * a lane's state in the table is ONE number (insert_w).
+        uint32_t cmax = 0;                                                            // largest count this lane met (kSum32: one look per tile)
+        bool gave_up = false;
+        const uint32_t lane_k = lane * 8u, lane_c = lane * 4u;
+        for (uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); first < S && !gave_up; first += kBatch * (uint32_t)kWaves)
         {
-          rc = 0; rl = 0;
-          while (rs < S)
+          // lane j < 63: the wave's run `first + kWaves j`
+          const uint32_t my_s = first + (uint32_t)kWaves * lane;
+          const bool mine_ok = lane < kBatch && my_s < S;
+          uint32_t v_rb = mine_ok ? beg[my_s] : 0u;
+          uint32_t v_rl = mine_ok ? len[my_s] : 0u;                                   // (< 2^29: bit 31 marks a control sample's run)
+          v_rl |= (mine_ok && v_rl != 0u && my_s < J.nc) ? 0x80000000u : 0u;
           {
-            const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg[rs]);
-            rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)len[rs]);
-            if (rl) 
-            {
-              dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
-              dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts + rb), (short)0, (int)(rl * 4u), kRsrcFlags);
-              if constexpr (kTwo) dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys_hi + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
-              ctl_now = rs < J.nc ? 1u : 0u;
-              return;
-            }
-            rs += kWaves;
+            // runs with records first, in order (a forward permute: lane i sends to lane dst(i))
+            const unsigned long long have = ballot(v_rl != 0u);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t dst = v_rl != 0u ? (uint32_t)__popcll(have & below) : (uint32_t)__popcll(have) + (uint32_t)__popcll(~have & below);
+            v_rb = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst * 4u), (int)v_rb);
+            v_rl = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst * 4u), (int)v_rl);
           }
-          // no run left: extent 0, every further load returns 0 without touching memory
-          dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys), (short)0, 0, kRsrcFlags);
-          dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts), (short)0, 0, kRsrcFlags);
-          if constexpr (kTwo) dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys_hi), (short)0, 0, kRsrcFlags);
-        };
-        next_run();
-        uint64_t rk[kRing], rkh[kTwo ? kRing : 1];
-        uint32_t rcnt[kRing], rrem[kRing], rctl[kRing];                               // rrem / rctl: scalar
-        bool stop = false;
-        const uint32_t lane8 = lane * 8u, lane4 = lane * 4u;
-        auto fetch_w = [&](const int d)
-        {
-          const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(dk, (int)lane8, (int)(rc * 8u), kAuxNt);
-          rk[d] = ((uint64_t)kk.y << 32) | kk.x;
-          rcnt[d] = __builtin_amdgcn_raw_buffer_load_b32(dc, (int)lane4, (int)(rc * 4u), kAuxNt);
-          if constexpr (kTwo)
+          uint32_t j = 0, off = 0;                                                    // next round: run j of the batch, records done in it
+          uint64_t rk[kRing][kR], rkh[kTwo ? kRing : 1][kR];
+          uint32_t rcnt[kRing][kR], rrem[kRing], rctl[kRing];                         // rrem / rctl: scalar
+          auto fetch_w = [&](const int d)
           {
-            const u32x2 hh = __builtin_amdgcn_raw_buffer_load_b64(dh, (int)lane8, (int)(rc * 8u), kAuxNt);
-            rkh[d] = ((uint64_t)hh.y << 32) | hh.x;
-          }
-          rrem[d] = rl - rc;                                                          // (0 when no run is left: rl = rc = 0)
-          rctl[d] = ctl_now;
-          if (rc + 64u >= rl) { rs += kWaves; next_run(); } else rc += 64u;
-        };
-        auto insert_w = [&](const int d)
-        {
-          const uint64_t k = rk[d];
-          const bool v = lane < rrem[d];
-#if KMD_TILE_ABLATE & 16   // dev: the loads alone (results wrong)
-          if (v && (k + rcnt[d]) == 0x123456789ull) M.hasmax = 1;
-          return;
-#endif
-          const bool is_marker = k == kEmptyKey;
-          if (v & is_marker)
-          {
-            // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
-            atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)rcnt[d]);
-            if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d]); }
-            M.hasmax = 1;
-          }
-          // A k-mer's probe sequence: the two slots of its home bucket 0, the two of its home bucket 1, then one
-          // slot after the other from there.  The first step reads both buckets (two 16-byte LDS reads, four
-          // candidates): at 1/3 load ~0.3 % of the k-mers live beyond them, so the loop below runs in one
-          // round of seven (with two single-slot homes it ran in nine of ten: a wave pays for the longest
-          // sequence among its 64 records).  The first of the four that holds the k-mer OR is empty is the
-          // one: slots are never released within a tile, so a k-mer is never behind an empty slot.
-          // No count of claimed slots is kept: a table that fills up shows as a sequence that does not end.
-          if (v & !is_marker)
-          {
-            const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
-            const uint32_t b0 = ((x * 0x9E3779B1u) >> (kShift + 1)) << 1;
-            const uint32_t b1 = (((x ^ (x >> 15)) * 0x85EBCA6Bu) >> (kShift + 1)) << 1;
-            const u64x2 q0 = *(const lds_u64x2*)(&M.key[b0]), q1 = *(const lds_u64x2*)(&M.key[b1]);
-            // (bitwise operators on purpose: the short-circuit forms become a branch per term)
-            const bool e0 = q0.x == kEmptyKey, e1 = q0.y == kEmptyKey, e2 = q1.x == kEmptyKey, e3 = q1.y == kEmptyKey;
-            const bool m0 = e0 | (q0.x == k), m1 = e1 | (q0.y == k), m2 = e2 | (q1.x == k), m3 = e3 | (q1.y == k);
-            uint32_t slot = b1 + 1u;
-            slot = m2 ? b1 : slot;
-            slot = m1 ? b0 + 1u : slot;
-            slot = m0 ? b0 : slot;
-            bool placed = m0 | m1 | m2 | m3;
-            const bool p2m = m0 | m1, p3m = p2m | m2;
-            uint32_t pos = 4;                                                         // where in the sequence to go on, if at all
-            if (e0 | (e1 & !m0) | (e2 & !p2m) | (e3 & !p3m))                          // the first of them is an empty one: claim it
+            const uint32_t jj = j < kBatch ? j : kBatch;                              // (lane 63 never holds a run: length 0)
+            const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)v_rb, (int)jj);
+            const uint32_t rle = (uint32_t)__builtin_amdgcn_readlane((int)v_rl, (int)jj);
+            const uint32_t rl = rle & 0x7FFFFFFFu;
+            const auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
+            const auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts + rb), (short)0, (int)(rl * 4u), kRsrcFlags);
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
             {
-#if KMD_TILE_ABLATE & 1   // dev: a plain store instead of the compare-and-swap (results wrong)
-              M.key[slot] = k;
-#else
-              const unsigned long long old = atomicCAS(&M.key[slot], (unsigned long long)kEmptyKey, (unsigned long long)k);
-              if ((old != kEmptyKey) & (old != k)) { placed = false; pos = 0; }       // another k-mer took it: once more, slot by slot
-#endif
-            }
-            if (!placed)
-            {
-              // the rest of the sequence, one slot per step (position 0, 1: bucket 0; from 2 on: bucket 1 and behind it)
-              for (uint32_t step = 0;; ++step, ++pos)
+              const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(dk, (int)lane_k, (int)((off + 64u * (uint32_t)u) * 8u), kAuxNt);
+              rk[d][u] = ((uint64_t)kk.y << 32) | kk.x;
+              rcnt[d][u] = __builtin_amdgcn_raw_buffer_load_b32(dc, (int)lane_c, (int)((off + 64u * (uint32_t)u) * 4u), kAuxNt);
+              if constexpr (kTwo)
               {
-                if (step >= kMaxProbe) { M.abort[buf] = 1; break; }
-                const uint32_t nxt = pos < 2u ? b0 + pos : (b1 + pos - 2u) & kMask;
-                unsigned long long seen = __hip_atomic_load(&M.key[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (seen == kEmptyKey)
-                {
-                  seen = atomicCAS(&M.key[nxt], (unsigned long long)kEmptyKey, (unsigned long long)k);
-                  if (seen == kEmptyKey) seen = k;
-                }
-                if (seen == k) { slot = nxt; placed = true; break; }
+                const auto dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys_hi + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
+                const u32x2 hh = __builtin_amdgcn_raw_buffer_load_b64(dh, (int)lane_k, (int)((off + 64u * (uint32_t)u) * 8u), kAuxNt);
+                rkh[d][u] = ((uint64_t)hh.y << 32) | hh.x;
               }
             }
-            if (placed)
+            rrem[d] = rl - off;                                                       // (0 when the batch is exhausted: rl = 0, off = 0)
+            rctl[d] = rle >> 31;
+            const bool more = off + kStep < rl;
+            off = more ? off + kStep : 0u;
+            j = more ? j : j + 1u;
+          };
+          // One round into the table.  A k-mer's probe sequence: the two slots of its home bucket 0, the two of its
+          // home bucket 1, then a slot of the small second table behind the first (another hash) and on from there;
+          // slots are never released within a tile, so a k-mer is never behind an empty slot and the first slot of
+          // the sequence that holds it OR is empty is its place.  Three stages, cheapest first:
+          //   1. both buckets are read (two 16-byte LDS reads per record, four candidates).  A row has rho records
+          //      and only the first claims a slot: for most records one of the four IS the k-mer -- four compares,
+          //      four selects, done;
+          //   2. the lanes left (a few per round: first records of their rows) take the first empty candidate with a
+          //      compare-and-swap;
+          //   3. the rare lane that found its four candidates taken (~1 % of the k-mers at half load) goes on in the
+          //      second table, which those few k-mers barely fill: one more step, as a rule; a lane that lost its
+          //      claim to another k-mer walks the whole sequence again.  (Round 2 walked on slot by slot in the main
+          //      table: three to four steps, in every second round -- a quarter of the kernel.)
+          // A lane's state is ONE number, the byte offset of its slot in key[] (kNone: not placed yet).  kNone is the
+          // offset of a spare slot behind the tables: a lane that has nothing to add (no record, a tile that gave up)
+          // adds its count there -- no lane mask around the adds, no masks kept across the stages.
+          // kThere / kMarker: whether lanes without a record / the all-ones k-mer have to be looked for.  In the
+          // middle of a run every lane holds a record and none is the all-ones k-mer (a run ascends: only its last
+          // record can be).
+          constexpr uint32_t kNone = kAll * 8u;
+          char* const key_bytes = reinterpret_cast<char*>(M.key);
+          auto insert_w = [&](const int d, auto there_tag, auto marker_tag)
+          {
+            constexpr bool kThere = decltype(there_tag)::value, kMarker = decltype(marker_tag)::value;
+            uint32_t a0[kR], a1[kR], sl[kR], cnt[kR];
+            u64x2 q0[kR], q1[kR];
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
+            {
+              const uint64_t k = rk[d][u];
+#if KMD_TILE_ABLATE & 16   // dev: the loads alone (results wrong)
+              if ((k + rcnt[d][u]) == 0x123456789ull) M.hasmax = 1;
+              continue;
+#endif
+              const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
+              a0[u] = ((x * 0x9E3779B1u) >> (kShift - 3)) & ~15u;                     // bucket 0: byte offset in key[] (two slots = 16 bytes)
+              a1[u] = (((x ^ (x >> 15)) * 0x85EBCA6Bu) >> (kShift - 3)) & ~15u;
+              q0[u] = *(const lds_u64x2*)(key_bytes + a0[u]);
+              q1[u] = *(const lds_u64x2*)(key_bytes + a1[u]);
+            }
+#if KMD_TILE_ABLATE & 16
+            return;
+#endif
+            // whether a lane's record u is one to place (always, in the middle of a run)
+            auto real = [&](int u) -> bool
+            {
+              bool r = true;
+              if constexpr (kThere) r = r & (lane + 64u * (uint32_t)u < rrem[d]);
+              if constexpr (kMarker) r = r & (rk[d][u] != kEmptyKey);
+              return r;
+            };
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
+            {
+              const uint64_t k = rk[d][u];
+              cnt[u] = rcnt[d][u];
+              if constexpr (kMarker)
+              {
+                bool is_marker = k == kEmptyKey;
+                if constexpr (kThere) is_marker = is_marker & (lane + 64u * (uint32_t)u < rrem[d]);
+                if (is_marker)
+                {
+                  // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
+                  atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)cnt[u]);
+                  if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d][u]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d][u]); }
+                  M.hasmax = 1;
+                }
+              }
+              // no record, or that one: nothing to add, nothing to claim (stage 1 may well "find" an empty slot for
+              // the marker, or the k-mer 0 for a lane without a record: adding 0 there changes nothing)
+              if constexpr (kThere || kMarker) cnt[u] = real(u) ? cnt[u] : 0u;
+              // stage 1 (a k-mer sits in one slot at most: the order of the four is free)
+              uint32_t s1 = kNone;
+              s1 = (q1[u].y == k) ? a1[u] + 8u : s1;
+              s1 = (q1[u].x == k) ? a1[u] : s1;
+              s1 = (q0[u].y == k) ? a0[u] + 8u : s1;
+              s1 = (q0[u].x == k) ? a0[u] : s1;
+              sl[u] = s1;
+            }
+            // stage 2, one region for the round's kR records: a lane with an unplaced record claims the first empty one
+            // of its four candidates (its other record, if placed, swaps on the spare slot, which never is empty)
+            uint32_t pos0[kR];                                                        // where stage 3 starts, if it has to
+            bool some = false;
+#pragma unroll
+            for (int u = 0; u < kR; ++u) { some |= (sl[u] == kNone) & real(u); pos0[u] = 4u; }
+            if (some)
+            {
+#pragma unroll
+              for (int u = 0; u < kR; ++u)
+              {
+                const uint64_t k = rk[d][u];
+                uint32_t se = kNone;
+                se = (q1[u].y == kEmptyKey) ? a1[u] + 8u : se;
+                se = (q1[u].x == kEmptyKey) ? a1[u] : se;
+                se = (q0[u].y == kEmptyKey) ? a0[u] + 8u : se;
+                se = (q0[u].x == kEmptyKey) ? a0[u] : se;
+                se = (sl[u] == kNone) & real(u) ? se : kNone;                         // (placed already, or no record: nothing to claim)
+#if KMD_TILE_ABLATE & 1   // dev: a plain store instead of the compare-and-swap (results wrong)
+                *reinterpret_cast<unsigned long long*>(key_bytes + se) = k; sl[u] = sl[u] == kNone ? se : sl[u];
+#else
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(key_bytes + se), (unsigned long long)kEmptyKey, (unsigned long long)k);
+                uint32_t got = kNone;
+                got = (old == kEmptyKey) ? se : got;                                  // claimed
+                got = (old == k) ? se : got;                                          // another record of the k-mer was faster
+                pos0[u] = (se != kNone) & (got == kNone) ? 0u : 4u;                   // another k-mer took it meanwhile: the whole sequence again
+                sl[u] = se == kNone ? sl[u] : got;
+#endif
+              }
+            }
+            // stage 3: the sequence from position pos0 on, one slot per step (0, 1: bucket 0; 2, 3: bucket 1; then the second table)
+            bool left = false;
+#pragma unroll
+            for (int u = 0; u < kR; ++u) left |= (sl[u] == kNone) & real(u);
+#if KMD_TILE_ABLATE & 128   // dev: no stage 3 (results wrong)
+            left = false;
+#endif
+            if (ballot(left))
+            {
+#pragma unroll
+              for (int u = 0; u < kR; ++u)
+              {
+                const uint64_t k = rk[d][u];
+                if ((sl[u] == kNone) & real(u))
+                {
+                  const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
+                  const uint32_t h2 = ((x ^ (x >> 11)) * 0xC2B2AE35u) >> (32 - ilog2_c(kSec));
+                  for (uint32_t pos = pos0[u];; ++pos)
+                  {
+                    if (pos >= 4u + kMaxProbe) { M.abort[buf] = 1; break; }
+                    const uint32_t at = pos < 2u ? a0[u] + 8u * pos : pos < 4u ? a1[u] + 8u * (pos - 2u) : (kSlots + ((h2 + pos - 4u) & (kSec - 1u))) * 8u;
+                    unsigned long long* where = reinterpret_cast<unsigned long long*>(key_bytes + at);
+                    unsigned long long seen = __hip_atomic_load(where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (seen == kEmptyKey)
+                    {
+                      seen = atomicCAS(where, (unsigned long long)kEmptyKey, (unsigned long long)k);
+                      if (seen == kEmptyKey) seen = k;
+                    }
+                    if (seen == k) { sl[u] = at; break; }
+                  }
+                }
+              }
+            }
+            // the counts (a lane without a place adds to the spare slot)
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
             {
               if constexpr (kSum32)
               {
-                if (rcnt[d] >= kBigCount) M.big[buf] = 1;                             // (never, in practice: the tile is redone with 64-bit sums)
+                cmax = cnt[u] > cmax ? cnt[u] : cmax;                                 // looked at once per tile (below)
+                uint32_t* sums = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(rctl[d] ? M.c32 : M.k32) + (sl[u] >> 1));   // (scalar choice of the array)
 #if KMD_TILE_ABLATE & 2   // dev: a plain store instead of the atomic add (results wrong)
-                M.s32[2u * slot + (rctl[d] ? 0u : 1u)] = rcnt[d];
+                *sums = cnt[u];
 #elif KMD_TILE_ABLATE & 64   // dev: no sums at all
 #else
-                atomicAdd(&M.s32[2u * slot + (rctl[d] ? 0u : 1u)], rcnt[d]);          // (scalar choice of the half)
+                atomicAdd(sums, cnt[u]);
 #endif
               }
               else
               {
-                unsigned long long* sums = rctl[d] ? M.sc : M.sk;                     // (scalar choice)
-                atomicAdd(&sums[slot], (unsigned long long)rcnt[d]);
+                unsigned long long* sums = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(rctl[d] ? M.sc : M.sk) + sl[u]);
+                atomicAdd(sums, (unsigned long long)cnt[u]);
               }
               if constexpr (kTwo)
               {
-                atomicMax(&M.key_hi[slot], (unsigned long long)rkh[d]);
-                atomicMin(&M.hi_min[slot], (unsigned long long)rkh[d]);
+                // (a lane without a record folds its zero into the spare slot's pair)
+                const uint32_t at = real(u) ? sl[u] : kNone;
+                atomicMax(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(M.key_hi) + at), (unsigned long long)rkh[d][u]);
+                atomicMin(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(M.hi_min) + at), (unsigned long long)rkh[d][u]);
               }
             }
-          }
-        };
+          };
 #pragma unroll
-        for (int d = 0; d < kRing; ++d) fetch_w(d);
-        while (!stop)
-        {
-#pragma unroll
-          for (int d = 0; d < kRing; ++d)
+          for (int d = 0; d < kRing; ++d) fetch_w(d);
+          for (bool more = true; more;)
           {
-            if (stop) break;
-            if (rrem[d] == 0) { stop = true; break; }                                 // the runs are exhausted in order
-            insert_w(d);
-            fetch_w(d);
-            if ((d & (KMD_TILE_ABORT_EVERY - 1)) == KMD_TILE_ABORT_EVERY - 1 && M.abort[buf]) { stop = true; break; }   // (LDS read, same for the whole wave)
+#pragma unroll
+            for (int d = 0; d < kRing; ++d)
+            {
+              if (!more) break;
+              if (rrem[d] == 0) { more = false; break; }                              // the batch's runs are exhausted in order
+              // (two-limb k-mers: the table's key is the LOW limb, which does not ascend along a run)
+              // (a run's LAST round may hold the all-ones k-mer, also when it is a full one)
+              if (rrem[d] > kStep) { if constexpr (kTwo) insert_w(d, std::false_type(), std::true_type()); else insert_w(d, std::false_type(), std::false_type()); }
+              else insert_w(d, std::true_type(), std::true_type());
+              fetch_w(d);
+              if ((d & (KMD_TILE_ABORT_EVERY - 1)) == KMD_TILE_ABORT_EVERY - 1 && M.abort[buf]) { more = false; gave_up = true; break; }   // (LDS read, same for the whole wave)
+            }
           }
         }
+        // a count too large for 32-bit sums: the tile is redone with 64-bit ones (never, in practice)
+        if constexpr (kSum32) if (ballot(cmax >= kBigCount) && lane == 0) M.big[buf] = 1;
       }
     }
     // ---- inserts, general: sub-group q0 (G lanes) streams the runs q0, q0 + Q, ... of this tile
@@ -828,7 +941,7 @@ k_tile_sums(const tile_job J)
             if constexpr (kSum32)
             {
               if (A.c[u] >= kBigCount) M.big[buf] = 1;
-              atomicAdd(&M.s32[2u * slot[u] + (ctl ? 0u : 1u)], A.c[u]);
+              atomicAdd(&(ctl ? M.c32 : M.k32)[slot[u]], A.c[u]);
             }
             else atomicAdd(ctl ? &M.sc[slot[u]] : &M.sk[slot[u]], (unsigned long long)A.c[u]);
             if constexpr (kTwo)
@@ -885,7 +998,7 @@ k_tile_sums(const tile_job J)
         // two k-mers in one slot?  then this tile is cut again instead of emitted
         bool bad = false;
         if (!aborted)
-          for (uint32_t i = tid; i < kSlots; i += kThreads)
+          for (uint32_t i = tid; i < kAll; i += kThreads)
             bad |= M.key[i] != kEmptyKey && M.key_hi[i] != M.hi_min[i];
         if (tid == 0 && !aborted && M.hasmax && M.max_hi[0] != M.max_hi[1]) bad = true;
         if (ballot(bad) && lane == 0) M.bad = 1;
@@ -909,7 +1022,7 @@ k_tile_sums(const tile_job J)
         for (int j = 0; j < kWalk; ++j)
         {
           const uint32_t i = tid + (uint32_t)j * kThreads;
-          const bool live = M.key[i] != kEmptyKey;
+          const bool live = i < kAll && M.key[i] != kEmptyKey;           // (the last step covers the end of the second table)
           bool leaves = live;
 #if KMD_TILE_ABLATE & 4   // dev: no pre-filter evaluation, nothing leaves (results wrong)
           leaves = false;
@@ -965,7 +1078,7 @@ k_tile_sums(const tile_job J)
       for (int j = 0; j < kWalk; ++j)
       {
         const uint32_t i = tid + (uint32_t)j * kThreads;
-        const uint64_t key = M.key[i];
+        const uint64_t key = i < kAll ? M.key[i] : kEmptyKey;
         const bool live = key != kEmptyKey;
         const bool leaves = (out_bits >> j) & 1u;
         const unsigned long long m = ballot(leaves);
