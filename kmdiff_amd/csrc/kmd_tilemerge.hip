@@ -58,6 +58,9 @@ using namespace kmd::eval;
 #ifndef KMD_TILE_RPL
 #define KMD_TILE_RPL 1               // whole-wave path: records per lane and round (1: 64-record rounds, 2: 128: spills at 64 registers)
 #endif
+#ifndef KMD_TILE_ASM
+#define KMD_TILE_ASM 1               // whole-wave path: stages 1 and 2 of a round in the middle of a run as hand-written gfx950 code
+#endif
 #ifndef KMD_TILE_RING
 #define KMD_TILE_RING 4              // rounds of loads in flight per wave (8, 12, 16 measured: no faster, more registers)
 #endif
@@ -544,14 +547,29 @@ k_tile_sums(const tile_job J)
         uint32_t cmax = 0;                                                            // largest count this lane met (kSum32: one look per tile)
         bool gave_up = false;
         const uint32_t lane_k = lane * 8u, lane_c = lane * 4u;
-        for (uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); first < S && !gave_up; first += kBatch * (uint32_t)kWaves)
+        // The tile's records -- its S runs one behind the other -- are cut into kWaves equal shares, whatever the runs'
+        // lengths: wave w takes records [w n / kWaves, (w + 1) n / kWaves) of that sequence, i.e. a few whole runs and
+        // a piece of the run at either end.  (Whole runs dealt out in turn left the waves of a workgroup up to 15 %
+        // apart at the tile's barrier -- samples differ in depth -- and a sample ten times deeper than the rest would
+        // have cost its wave ten times the others' time.)
+        const uint32_t w_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+        const uint32_t share_lo = (uint32_t)(((uint64_t)n * w_u) / (uint32_t)kWaves), share_hi = (uint32_t)(((uint64_t)n * (w_u + 1u)) / (uint32_t)kWaves);
+        uint32_t seq0 = 0;                                                            // records of the tile before stream `first`
+        for (uint32_t first = 0; first < S && seq0 < share_hi && !gave_up; first += kBatch)
         {
-          // lane j < 63: the wave's run `first + kWaves j`
-          const uint32_t my_s = first + (uint32_t)kWaves * lane;
+          // lane j < 63: the piece of run `first + j` that lies in this wave's share
+          const uint32_t my_s = first + lane;
           const bool mine_ok = lane < kBatch && my_s < S;
-          uint32_t v_rb = mine_ok ? beg[my_s] : 0u;
-          uint32_t v_rl = mine_ok ? len[my_s] : 0u;                                   // (< 2^29: bit 31 marks a control sample's run)
-          v_rl |= (mine_ok && v_rl != 0u && my_s < J.nc) ? 0x80000000u : 0u;
+          const uint32_t my_len = mine_ok ? len[my_s] : 0u;
+          uint32_t incl = my_len;                                                     // records up to and including this run, from `first` on
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, (unsigned)o, 64); incl += lane >= (uint32_t)o ? t : 0u; }
+          const uint32_t run_lo = seq0 + incl - my_len, run_hi = seq0 + incl;
+          seq0 += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          if (seq0 <= share_lo) continue;                                             // (none of these runs reaches the share)
+          const uint32_t p_lo = run_lo > share_lo ? run_lo : share_lo, p_hi = run_hi < share_hi ? run_hi : share_hi;
+          uint32_t v_rl = p_hi > p_lo ? p_hi - p_lo : 0u;                             // (< 2^29: bit 31 marks a control sample's run)
+          uint32_t v_rb = mine_ok ? beg[my_s] + (p_lo - run_lo) : 0u;
+          v_rl |= (v_rl != 0u && my_s < J.nc) ? 0x80000000u : 0u;
           {
             // runs with records first, in order (a forward permute: lane i sends to lane dst(i))
             const unsigned long long have = ballot(v_rl != 0u);
@@ -561,34 +579,45 @@ k_tile_sums(const tile_job J)
             v_rl = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst * 4u), (int)v_rl);
           }
           uint32_t j = 0, off = 0;                                                    // next round: run j of the batch, records done in it
+          uint32_t rl = 0, ctl_now = 0;                                               // the run's length, whether it is a control sample's
+          u32x4 dk = { 0u, 0u, 0u, (uint32_t)kRsrcFlags }, dc = dk, dh = dk;          // the run's buffer descriptors
           uint64_t rk[kRing][kR], rkh[kTwo ? kRing : 1][kR];
           uint32_t rcnt[kRing][kR], rrem[kRing], rctl[kRing];                         // rrem / rctl: scalar
           auto fetch_w = [&](const int d)
           {
-            const uint32_t jj = j < kBatch ? j : kBatch;                              // (lane 63 never holds a run: length 0)
-            const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)v_rb, (int)jj);
-            const uint32_t rle = (uint32_t)__builtin_amdgcn_readlane((int)v_rl, (int)jj);
-            const uint32_t rl = rle & 0x7FFFFFFFu;
-            const auto dk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
-            const auto dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(J.counts + rb), (short)0, (int)(rl * 4u), kRsrcFlags);
+            // The loads are issued and waited for BY HAND (vm_wait below): hipcc's own wait counts let a round's loads
+            // stay in flight in the first pass of the ring only -- where the paths into a ring stage meet it settles for
+            // the smallest count any of them allows, vmcnt(1) / (0) for stage 0, (3) / (2) for stage 1 ... -- so every
+            // round sat out the latency of loads issued one or two rounds before, and four rounds in flight or sixteen
+            // made no difference (round 2's observation).  Written as inline assembly the compiler does not see them.
+            if (off == 0)
+            {
+              // a new run: its description out of the lanes, its descriptors (base = its first record, extent = the run)
+              const uint32_t jj = j < kBatch ? j : kBatch;                            // (lane 63 never holds a run: length 0)
+              const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)v_rb, (int)jj);
+              const uint32_t rle = (uint32_t)__builtin_amdgcn_readlane((int)v_rl, (int)jj);
+              rl = rle & 0x7FFFFFFFu;
+              ctl_now = rle >> 31;
+              const uint64_t ak = (uint64_t)(uintptr_t)(J.keys + rb), ac = (uint64_t)(uintptr_t)(J.counts + rb);
+              dk.x = (uint32_t)ak; dk.y = (uint32_t)(ak >> 32) & 0xFFFFu; dk.z = rl * 8u;
+              dc.x = (uint32_t)ac; dc.y = (uint32_t)(ac >> 32) & 0xFFFFu; dc.z = rl * 4u;
+              if constexpr (kTwo)
+              {
+                const uint64_t ah = (uint64_t)(uintptr_t)(J.keys_hi + rb);
+                dh.x = (uint32_t)ah; dh.y = (uint32_t)(ah >> 32) & 0xFFFFu; dh.z = rl * 8u;
+              }
+            }
 #pragma unroll
             for (int u = 0; u < kR; ++u)
             {
-              const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(dk, (int)lane_k, (int)((off + 64u * (uint32_t)u) * 8u), kAuxNt);
-              rk[d][u] = ((uint64_t)kk.y << 32) | kk.x;
-              rcnt[d][u] = __builtin_amdgcn_raw_buffer_load_b32(dc, (int)lane_c, (int)((off + 64u * (uint32_t)u) * 4u), kAuxNt);
-              if constexpr (kTwo)
-              {
-                const auto dh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(J.keys_hi + rb), (short)0, (int)(rl * 8u), kRsrcFlags);
-                const u32x2 hh = __builtin_amdgcn_raw_buffer_load_b64(dh, (int)lane_k, (int)((off + 64u * (uint32_t)u) * 8u), kAuxNt);
-                rkh[d][u] = ((uint64_t)hh.y << 32) | hh.x;
-              }
+              asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(rk[d][u]) : "v"(lane_k), "s"(dk), "s"((off + 64u * (uint32_t)u) * 8u));
+              asm volatile("buffer_load_dword %0, %1, %2, %3 offen nt" : "=v"(rcnt[d][u]) : "v"(lane_c), "s"(dc), "s"((off + 64u * (uint32_t)u) * 4u));
+              if constexpr (kTwo) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(rkh[d][u]) : "v"(lane_k), "s"(dh), "s"((off + 64u * (uint32_t)u) * 8u));
             }
             rrem[d] = rl - off;                                                       // (0 when the batch is exhausted: rl = 0, off = 0)
-            rctl[d] = rle >> 31;
-            const bool more = off + kStep < rl;
-            off = more ? off + kStep : 0u;
-            j = more ? j : j + 1u;
+            rctl[d] = ctl_now;
+            off += kStep;
+            if (off >= rl) { off = 0; ++j; }
           };
           // One round into the table.  A k-mer's probe sequence: the two slots of its home bucket 0, the two of its
           // home bucket 1, then a slot of the small second table behind the first (another hash) and on from there;
@@ -597,168 +626,350 @@ k_tile_sums(const tile_job J)
           //   1. both buckets are read (two 16-byte LDS reads per record, four candidates).  A row has rho records
           //      and only the first claims a slot: for most records one of the four IS the k-mer -- four compares,
           //      four selects, done;
-          //   2. the lanes left (a few per round: first records of their rows) take the first empty candidate with a
-          //      compare-and-swap;
-          //   3. the rare lane that found its four candidates taken (~1 % of the k-mers at half load) goes on in the
-          //      second table, which those few k-mers barely fill: one more step, as a rule; a lane that lost its
-          //      claim to another k-mer walks the whole sequence again.  (Round 2 walked on slot by slot in the main
-          //      table: three to four steps, in every second round -- a quarter of the kernel.)
+          //   2. the lanes left (a few per round: first records of their rows, and the records of the ~1 % of the k-mers
+          //      that found their four home slots taken) swap on the first empty candidate -- or, if none is empty, on
+          //      their slot of the second table, which those few k-mers barely fill: the swap claims the slot or finds
+          //      the k-mer there;
+          //   3. what is left -- a claim lost to another k-mer, two k-mers on one slot of the second table -- walks the
+          //      whole sequence slot by slot (once in a hundred rounds).  (Round 2 sent every record of a k-mer beyond
+          //      its home buckets down such a walk in the main table: three to four steps, in every second round -- a
+          //      quarter of the kernel's instructions.)
           // A lane's state is ONE number, the byte offset of its slot in key[] (kNone: not placed yet).  kNone is the
           // offset of a spare slot behind the tables: a lane that has nothing to add (no record, a tile that gave up)
           // adds its count there -- no lane mask around the adds, no masks kept across the stages.
           // kThere / kMarker: whether lanes without a record / the all-ones k-mer have to be looked for.  In the
           // middle of a run every lane holds a record and none is the all-ones k-mer (a run ascends: only its last
           // record can be).
-          constexpr uint32_t kNone = kAll * 8u;
-          char* const key_bytes = reinterpret_cast<char*>(M.key);
-          auto insert_w = [&](const int d, auto there_tag, auto marker_tag)
+          // (all slot numbers below are LDS byte addresses: of a key in M.key; >> 1 or as they are, plus a constant, of its sums)
+          typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+          typedef __attribute__((address_space(3))) uint32_t lds_u32;
+          const uint32_t key_lds = (uint32_t)(uintptr_t)(lds_u64*)M.key;             // (16-byte aligned: s_raw is)
+          const uint32_t kNone = key_lds + kAll * 8u;
+          constexpr uint32_t kHashMul = 0x9E3779B1u;
+          constexpr int kBucketBits = ilog2_c(kSlots) - 1;                          // two slots per bucket
+          auto key_at = [&](uint32_t at) -> unsigned long long* { return (unsigned long long*)(lds_u64*)(uintptr_t)at; };
+          // where a k-mer's probe sequence is at position `pos` (0, 1: bucket 0; 2, 3: bucket 1; then the second table)
+          auto seq_at = [&](uint64_t k, uint32_t pos) -> uint32_t
           {
-            constexpr bool kThere = decltype(there_tag)::value, kMarker = decltype(marker_tag)::value;
-            uint32_t a0[kR], a1[kR], sl[kR], cnt[kR];
-            u64x2 q0[kR], q1[kR];
-#pragma unroll
-            for (int u = 0; u < kR; ++u)
+            const uint32_t pr = ((uint32_t)k ^ (uint32_t)(k >> 29)) * kHashMul;       // ONE multiply: its top bits are bucket 0, the next
+            const uint32_t c0 = key_lds + ((pr >> (32 - kBucketBits)) << 4);          // ones bucket 1 (two slots = 16 bytes), bits 4 .. the
+            const uint32_t c1 = key_lds + (((pr >> (32 - 2 * kBucketBits)) & ((1u << kBucketBits) - 1u)) << 4);     // second table's slot
+            return pos < 2u ? c0 + 8u * pos : pos < 4u ? c1 + 8u * (pos - 2u) : key_lds + (kSlots + (((pr >> 4) + pos - 4u) & (kSec - 1u))) * 8u;
+          };
+          // stage 3 for one record: the whole sequence, one slot per step; kNone (and the tile gives up) if it does not end
+          auto walk_seq = [&](uint64_t k) -> uint32_t
+          {
+            for (uint32_t pos = 0; pos < 4u + kMaxProbe; ++pos)
             {
-              const uint64_t k = rk[d][u];
-#if KMD_TILE_ABLATE & 16   // dev: the loads alone (results wrong)
-              if ((k + rcnt[d][u]) == 0x123456789ull) M.hasmax = 1;
-              continue;
-#endif
-              const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
-              a0[u] = ((x * 0x9E3779B1u) >> (kShift - 3)) & ~15u;                     // bucket 0: byte offset in key[] (two slots = 16 bytes)
-              a1[u] = (((x ^ (x >> 15)) * 0x85EBCA6Bu) >> (kShift - 3)) & ~15u;
-              q0[u] = *(const lds_u64x2*)(key_bytes + a0[u]);
-              q1[u] = *(const lds_u64x2*)(key_bytes + a1[u]);
-            }
-#if KMD_TILE_ABLATE & 16
-            return;
-#endif
-            // whether a lane's record u is one to place (always, in the middle of a run)
-            auto real = [&](int u) -> bool
-            {
-              bool r = true;
-              if constexpr (kThere) r = r & (lane + 64u * (uint32_t)u < rrem[d]);
-              if constexpr (kMarker) r = r & (rk[d][u] != kEmptyKey);
-              return r;
-            };
-#pragma unroll
-            for (int u = 0; u < kR; ++u)
-            {
-              const uint64_t k = rk[d][u];
-              cnt[u] = rcnt[d][u];
-              if constexpr (kMarker)
+              const uint32_t at = seq_at(k, pos);
+              unsigned long long seen = __hip_atomic_load(key_at(at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (seen == kEmptyKey)
               {
-                bool is_marker = k == kEmptyKey;
-                if constexpr (kThere) is_marker = is_marker & (lane + 64u * (uint32_t)u < rrem[d]);
-                if (is_marker)
-                {
-                  // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
-                  atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)cnt[u]);
-                  if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d][u]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d][u]); }
-                  M.hasmax = 1;
-                }
+                seen = atomicCAS(key_at(at), (unsigned long long)kEmptyKey, (unsigned long long)k);
+                if (seen == kEmptyKey) seen = k;
               }
-              // no record, or that one: nothing to add, nothing to claim (stage 1 may well "find" an empty slot for
-              // the marker, or the k-mer 0 for a lane without a record: adding 0 there changes nothing)
-              if constexpr (kThere || kMarker) cnt[u] = real(u) ? cnt[u] : 0u;
-              // stage 1 (a k-mer sits in one slot at most: the order of the four is free)
-              uint32_t s1 = kNone;
-              s1 = (q1[u].y == k) ? a1[u] + 8u : s1;
-              s1 = (q1[u].x == k) ? a1[u] : s1;
-              s1 = (q0[u].y == k) ? a0[u] + 8u : s1;
-              s1 = (q0[u].x == k) ? a0[u] : s1;
-              sl[u] = s1;
+              if (seen == k) return at;
             }
-            // stage 2, one region for the round's kR records: a lane with an unplaced record claims the first empty one
-            // of its four candidates (its other record, if placed, swaps on the spare slot, which never is empty)
-            uint32_t pos0[kR];                                                        // where stage 3 starts, if it has to
-            bool some = false;
-#pragma unroll
-            for (int u = 0; u < kR; ++u) { some |= (sl[u] == kNone) & real(u); pos0[u] = 4u; }
-            if (some)
+            M.abort[buf] = 1;
+            return kNone;
+          };
+          // the count of a record into its slot's sum (a lane without a place adds to the spare slot)
+          auto add_count = [&](const int d, uint32_t slot, uint32_t c, uint64_t kh, bool is_real)
+          {
+            if constexpr (kSum32)
             {
-#pragma unroll
-              for (int u = 0; u < kR; ++u)
-              {
-                const uint64_t k = rk[d][u];
-                uint32_t se = kNone;
-                se = (q1[u].y == kEmptyKey) ? a1[u] + 8u : se;
-                se = (q1[u].x == kEmptyKey) ? a1[u] : se;
-                se = (q0[u].y == kEmptyKey) ? a0[u] + 8u : se;
-                se = (q0[u].x == kEmptyKey) ? a0[u] : se;
-                se = (sl[u] == kNone) & real(u) ? se : kNone;                         // (placed already, or no record: nothing to claim)
-#if KMD_TILE_ABLATE & 1   // dev: a plain store instead of the compare-and-swap (results wrong)
-                *reinterpret_cast<unsigned long long*>(key_bytes + se) = k; sl[u] = sl[u] == kNone ? se : sl[u];
-#else
-                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(key_bytes + se), (unsigned long long)kEmptyKey, (unsigned long long)k);
-                uint32_t got = kNone;
-                got = (old == kEmptyKey) ? se : got;                                  // claimed
-                got = (old == k) ? se : got;                                          // another record of the k-mer was faster
-                pos0[u] = (se != kNone) & (got == kNone) ? 0u : 4u;                   // another k-mer took it meanwhile: the whole sequence again
-                sl[u] = se == kNone ? sl[u] : got;
-#endif
-              }
-            }
-            // stage 3: the sequence from position pos0 on, one slot per step (0, 1: bucket 0; 2, 3: bucket 1; then the second table)
-            bool left = false;
-#pragma unroll
-            for (int u = 0; u < kR; ++u) left |= (sl[u] == kNone) & real(u);
-#if KMD_TILE_ABLATE & 128   // dev: no stage 3 (results wrong)
-            left = false;
-#endif
-            if (ballot(left))
-            {
-#pragma unroll
-              for (int u = 0; u < kR; ++u)
-              {
-                const uint64_t k = rk[d][u];
-                if ((sl[u] == kNone) & real(u))
-                {
-                  const uint32_t x = (uint32_t)k ^ (uint32_t)(k >> 29);
-                  const uint32_t h2 = ((x ^ (x >> 11)) * 0xC2B2AE35u) >> (32 - ilog2_c(kSec));
-                  for (uint32_t pos = pos0[u];; ++pos)
-                  {
-                    if (pos >= 4u + kMaxProbe) { M.abort[buf] = 1; break; }
-                    const uint32_t at = pos < 2u ? a0[u] + 8u * pos : pos < 4u ? a1[u] + 8u * (pos - 2u) : (kSlots + ((h2 + pos - 4u) & (kSec - 1u))) * 8u;
-                    unsigned long long* where = reinterpret_cast<unsigned long long*>(key_bytes + at);
-                    unsigned long long seen = __hip_atomic_load(where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (seen == kEmptyKey)
-                    {
-                      seen = atomicCAS(where, (unsigned long long)kEmptyKey, (unsigned long long)k);
-                      if (seen == kEmptyKey) seen = k;
-                    }
-                    if (seen == k) { sl[u] = at; break; }
-                  }
-                }
-              }
-            }
-            // the counts (a lane without a place adds to the spare slot)
-#pragma unroll
-            for (int u = 0; u < kR; ++u)
-            {
-              if constexpr (kSum32)
-              {
-                cmax = cnt[u] > cmax ? cnt[u] : cmax;                                 // looked at once per tile (below)
-                uint32_t* sums = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(rctl[d] ? M.c32 : M.k32) + (sl[u] >> 1));   // (scalar choice of the array)
+              cmax = c > cmax ? c : cmax;                                             // looked at once per tile (below)
+              // (scalar choice of the array; a key's address / 2 + a constant = its sum's)
+              const uint32_t sums_lds = (uint32_t)(uintptr_t)(lds_u32*)(rctl[d] ? M.c32 : M.k32) - (key_lds >> 1);
+              uint32_t* sums = (uint32_t*)(lds_u32*)(uintptr_t)(sums_lds + (slot >> 1));
 #if KMD_TILE_ABLATE & 2   // dev: a plain store instead of the atomic add (results wrong)
-                *sums = cnt[u];
+              *sums = c;
 #elif KMD_TILE_ABLATE & 64   // dev: no sums at all
 #else
-                atomicAdd(sums, cnt[u]);
+              atomicAdd(sums, c);
 #endif
-              }
-              else
+            }
+            else
+            {
+              const uint32_t sums_lds = (uint32_t)(uintptr_t)(lds_u64*)(rctl[d] ? M.sc : M.sk) - key_lds;
+              atomicAdd((unsigned long long*)(lds_u64*)(uintptr_t)(sums_lds + slot), (unsigned long long)c);
+            }
+            if constexpr (kTwo)
+            {
+              // (a lane without a record folds its zero into the spare slot's pair)
+              const uint32_t at = (is_real ? slot : kNone) - key_lds;
+              atomicMax(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(M.key_hi) + at), (unsigned long long)kh);
+              atomicMin(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(M.hi_min) + at), (unsigned long long)kh);
+            }
+          };
+          // ONE record per lane, all stages, as the compiler writes them: the rounds at the end of a run (kThere: some
+          // lanes hold no record; kMarker: the all-ones k-mer may be among them), two-limb k-mers, 64-bit sums
+          auto insert_rec = [&](const int d, const int u, auto there_tag, auto marker_tag)
+          {
+            constexpr bool kThere = decltype(there_tag)::value, kMarker = decltype(marker_tag)::value;
+            const uint64_t k = rk[d][u];
+            uint32_t cnt = rcnt[d][u];
+            bool real = true;
+            if constexpr (kThere) real = real & (lane + 64u * (uint32_t)u < rrem[d]);
+            if constexpr (kMarker)
+            {
+              if (real & (k == kEmptyKey))
               {
-                unsigned long long* sums = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(rctl[d] ? M.sc : M.sk) + sl[u]);
-                atomicAdd(sums, (unsigned long long)cnt[u]);
+                // an all-ones (low) limb is the table's empty marker: such a k-mer has its own pair of sums
+                atomicAdd(&M.maxsum[rctl[d] ? 0 : 1], (unsigned long long)cnt);
+                if constexpr (kTwo) { atomicMin(&M.max_hi[0], (unsigned long long)rkh[d][u]); atomicMax(&M.max_hi[1], (unsigned long long)rkh[d][u]); }
+                M.hasmax = 1;
               }
-              if constexpr (kTwo)
+              real = real & (k != kEmptyKey);
+            }
+            // no record, or that one: nothing to add, nothing to claim (stage 1 may well "find" an empty slot for the
+            // marker, or the k-mer 0 for a lane without a record: adding 0 there changes nothing)
+            if constexpr (kThere || kMarker) cnt = real ? cnt : 0u;
+            const uint32_t c0 = seq_at(k, 0), c1 = seq_at(k, 2);
+            const u64x2 q0 = *(const lds_u64x2*)(uintptr_t)c0, q1 = *(const lds_u64x2*)(uintptr_t)c1;
+            // stage 1 (a k-mer sits in one slot at most: the order of the four is free)
+            uint32_t sl = kNone;
+            sl = (q1.y == k) ? c1 + 8u : sl;
+            sl = (q1.x == k) ? c1 : sl;
+            sl = (q0.y == k) ? c0 + 8u : sl;
+            sl = (q0.x == k) ? c0 : sl;
+            // stage 2: the first empty one of the four, else the second table's slot
+            if ((sl == kNone) & real)
+            {
+              uint32_t e = seq_at(k, 4);
+              e = (q1.y == kEmptyKey) ? c1 + 8u : e;
+              e = (q1.x == kEmptyKey) ? c1 : e;
+              e = (q0.y == kEmptyKey) ? c0 + 8u : e;
+              e = (q0.x == kEmptyKey) ? c0 : e;
+#if KMD_TILE_ABLATE & 1   // dev: a plain store instead of the compare-and-swap (results wrong)
+              *key_at(e) = k; sl = e;
+#else
+              const unsigned long long old = atomicCAS(key_at(e), (unsigned long long)kEmptyKey, (unsigned long long)k);
+              // claimed, or another record of the k-mer was faster; else another k-mer took it meanwhile (stage 3)
+              sl = (old == kEmptyKey) | (old == k) ? e : kNone;
+#endif
+            }
+#if !(KMD_TILE_ABLATE & 128)   // dev: no stage 3 (results wrong)
+            if (ballot((sl == kNone) & real)) { if ((sl == kNone) & real) sl = walk_seq(k); }
+#endif
+            add_count(d, sl, cnt, kTwo ? rkh[d][u] : 0ull, real);
+          };
+          // One round into the table.  A k-mer's probe sequence: the two slots of its home bucket 0, the two of its
+          // home bucket 1, then a slot of the small second table behind the first and on from there; slots are never
+          // released within a tile, so a k-mer is never behind an empty slot and the first slot of the sequence that
+          // holds it OR is empty is its place.  Three stages, cheapest first:
+          //   1. both buckets are read (two 16-byte LDS reads per record, four candidates).  A row has rho records
+          //      and only the first claims a slot: for most records one of the four IS the k-mer -- four compares,
+          //      four selects, done;
+          //   2. the lanes left (a few per round: first records of their rows, and the records of the ~1 % of the k-mers
+          //      that found their four home slots taken) swap on the first empty candidate -- or, if none is empty, on
+          //      their slot of the second table, which those few k-mers barely fill: the swap claims the slot or finds
+          //      the k-mer there;
+          //   3. what is left -- a claim lost to another k-mer, two k-mers on one slot of the second table -- walks the
+          //      whole sequence slot by slot (once in a hundred rounds).  (Round 2 sent every record of a k-mer beyond
+          //      its home buckets down such a walk in the main table: three to four steps, in every second round -- a
+          //      quarter of the kernel's instructions.)
+          // A lane's state is ONE number, the LDS address of its slot's key (kNone: not placed yet).  kNone is the
+          // address of a spare slot behind the tables: a lane that has nothing to add (no record, a tile that gave up)
+          // adds its count there -- no lane mask around the adds, no masks kept across the stages.
+          // In the middle of a run every lane holds a record and none is the all-ones k-mer (a run ascends: only its
+          // last record can be): stages 1 and 2 of such a round are written by hand below -- the compiler's version of
+          // them spent a third of its instructions on lane-mask algebra and wait states -- for one or two records per lane.
+          auto insert_mid = [&](const int d)
+          {
+#if KMD_TILE_ABLATE & 16   // dev: the loads alone (results wrong)
+#pragma unroll
+            for (int u = 0; u < kR; ++u) if ((rk[d][u] + rcnt[d][u]) == 0x123456789ull) M.hasmax = 1;
+            return;
+#endif
+#if KMD_TILE_ASM && !KMD_TILE_ABLATE
+            if constexpr (!kTwo && kSum32 && kR == 2)
+            {
+              // two records per lane (A: v[40:47], B: v[48:55]): four bucket reads behind one wait, both swaps behind
+              // one wait -- half the LDS round trips a wave sits out per record, half the scalar work
+              const uint64_t kA = rk[d][0], kB = rk[d][1];
+              uint32_t a0, a1, b0, b1, t0, t1, u0, u1, sea, seb, sla, slb;
+              uint64_t m0, m1, m2, nA, nB, sv;
+              const uint64_t empty = kEmptyKey;
+              asm volatile(
+                  "v_alignbit_b32 %[a0], %[kAhi], %[kAlo], 29\n\t"
+                  "v_alignbit_b32 %[b0], %[kBhi], %[kBlo], 29\n\t"
+                  "v_xor_b32 %[a0], %[a0], %[kAlo]\n\t"
+                  "v_xor_b32 %[b0], %[b0], %[kBlo]\n\t"
+                  "v_mul_lo_u32 %[sea], %[a0], %[c1]\n\t"
+                  "v_mul_lo_u32 %[seb], %[b0], %[c1]\n\t"
+                  "v_mov_b32 %[sla], %[none]\n\t"
+                  "v_mov_b32 %[slb], %[none]\n\t"
+                  "v_lshrrev_b32 %[a0], %[sh0], %[sea]\n\t"
+                  "v_bfe_u32 %[a1], %[sea], %[sh1], %[nb]\n\t"
+                  "v_lshrrev_b32 %[b0], %[sh0], %[seb]\n\t"
+                  "v_bfe_u32 %[b1], %[seb], %[sh1], %[nb]\n\t"
+                  "v_lshl_add_u32 %[a0], %[a0], 4, %[kb]\n\t"
+                  "v_lshl_add_u32 %[a1], %[a1], 4, %[kb]\n\t"
+                  "v_lshl_add_u32 %[b0], %[b0], 4, %[kb]\n\t"
+                  "v_lshl_add_u32 %[b1], %[b1], 4, %[kb]\n\t"
+                  "ds_read_b128 v[40:43], %[a0]\n\t"
+                  "ds_read_b128 v[44:47], %[a1]\n\t"
+                  "ds_read_b128 v[48:51], %[b0]\n\t"
+                  "ds_read_b128 v[52:55], %[b1]\n\t"
+                  "v_bfe_u32 %[sea], %[sea], 4, %[nsec]\n\t"
+                  "v_bfe_u32 %[seb], %[seb], 4, %[nsec]\n\t"
+                  "v_add_u32 %[t0], 8, %[a0]\n\t"
+                  "v_add_u32 %[t1], 8, %[a1]\n\t"
+                  "v_add_u32 %[u0], 8, %[b0]\n\t"
+                  "v_add_u32 %[u1], 8, %[b1]\n\t"
+                  "v_lshl_add_u32 %[sea], %[sea], 3, %[sb]\n\t"
+                  "v_lshl_add_u32 %[seb], %[seb], 3, %[sb]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "v_cmp_eq_u64 %[m0], v[46:47], %[kA]\n\t"
+                  "v_cmp_eq_u64 %[m1], v[44:45], %[kA]\n\t"
+                  "v_cmp_eq_u64 %[m2], v[42:43], %[kA]\n\t"
+                  "v_cmp_eq_u64 vcc, v[40:41], %[kA]\n\t"
+                  "v_cndmask_b32 %[sla], %[sla], %[t1], %[m0]\n\t"
+                  "v_cndmask_b32 %[sla], %[sla], %[a1], %[m1]\n\t"
+                  "v_cndmask_b32 %[sla], %[sla], %[t0], %[m2]\n\t"
+                  "v_cndmask_b32 %[sla], %[sla], %[a0], vcc\n\t"
+                  "v_cmp_eq_u64 %[m0], v[54:55], %[kB]\n\t"
+                  "v_cmp_eq_u64 %[m1], v[52:53], %[kB]\n\t"
+                  "v_cmp_eq_u64 %[m2], v[50:51], %[kB]\n\t"
+                  "v_cmp_eq_u64 vcc, v[48:49], %[kB]\n\t"
+                  "v_cndmask_b32 %[slb], %[slb], %[u1], %[m0]\n\t"
+                  "v_cndmask_b32 %[slb], %[slb], %[b1], %[m1]\n\t"
+                  "v_cndmask_b32 %[slb], %[slb], %[u0], %[m2]\n\t"
+                  "v_cndmask_b32 %[slb], %[slb], %[b0], vcc\n\t"
+                  "v_cmp_eq_u32 %[nA], %[sla], %[none]\n\t"
+                  "v_cmp_eq_u32 %[nB], %[slb], %[none]\n\t"
+                  "s_or_b64 vcc, %[nA], %[nB]\n\t"
+                  "s_and_saveexec_b64 %[sv], vcc\n\t"
+                  "s_cbranch_execz 1f\n\t"
+                  "v_cmp_eq_u64 %[m0], -1, v[46:47]\n\t"
+                  "v_cmp_eq_u64 %[m1], -1, v[44:45]\n\t"
+                  "v_cmp_eq_u64 %[m2], -1, v[42:43]\n\t"
+                  "v_cmp_eq_u64 vcc, -1, v[40:41]\n\t"
+                  "v_cndmask_b32 %[sea], %[sea], %[t1], %[m0]\n\t"
+                  "v_cndmask_b32 %[sea], %[sea], %[a1], %[m1]\n\t"
+                  "v_cndmask_b32 %[sea], %[sea], %[t0], %[m2]\n\t"
+                  "v_cndmask_b32 %[sea], %[sea], %[a0], vcc\n\t"
+                  "v_cmp_eq_u64 %[m0], -1, v[54:55]\n\t"
+                  "v_cmp_eq_u64 %[m1], -1, v[52:53]\n\t"
+                  "v_cmp_eq_u64 %[m2], -1, v[50:51]\n\t"
+                  "v_cmp_eq_u64 vcc, -1, v[48:49]\n\t"
+                  "v_cndmask_b32 %[seb], %[seb], %[u1], %[m0]\n\t"
+                  "v_cndmask_b32 %[seb], %[seb], %[b1], %[m1]\n\t"
+                  "v_cndmask_b32 %[seb], %[seb], %[u0], %[m2]\n\t"
+                  "v_cndmask_b32 %[seb], %[seb], %[b0], vcc\n\t"
+                  "v_cndmask_b32 %[sea], %[none], %[sea], %[nA]\n\t"            // (a record placed already swaps on the spare slot)
+                  "v_cndmask_b32 %[seb], %[none], %[seb], %[nB]\n\t"
+                  "ds_cmpst_rtn_b64 v[40:41], %[sea], %[empty], %[kA]\n\t"      // (the buckets are done with: their registers take what the swaps return)
+                  "ds_cmpst_rtn_b64 v[48:49], %[seb], %[empty], %[kB]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "v_cmp_eq_u64 %[m0], -1, v[40:41]\n\t"
+                  "v_cmp_eq_u64 %[m1], v[40:41], %[kA]\n\t"
+                  "v_cmp_eq_u64 %[m2], -1, v[48:49]\n\t"
+                  "v_cmp_eq_u64 vcc, v[48:49], %[kB]\n\t"
+                  "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+                  "s_or_b64 vcc, vcc, %[m2]\n\t"
+                  "v_cndmask_b32 %[t0], %[none], %[sea], %[m0]\n\t"
+                  "v_cndmask_b32 %[u0], %[none], %[seb], vcc\n\t"
+                  "v_cndmask_b32 %[sla], %[sla], %[t0], %[nA]\n\t"
+                  "v_cndmask_b32 %[slb], %[slb], %[u0], %[nB]\n\t"
+                  "1:\n\t"
+                  "s_or_b64 exec, exec, %[sv]"
+                  : [sla] "=&v"(sla), [slb] "=&v"(slb), [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                    [u0] "=&v"(u0), [u1] "=&v"(u1), [sea] "=&v"(sea), [seb] "=&v"(seb),
+                    [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [nA] "=&s"(nA), [nB] "=&s"(nB), [sv] "=&s"(sv)
+                  : [kA] "v"(kA), [kAlo] "v"((uint32_t)kA), [kAhi] "v"((uint32_t)(kA >> 32)), [kB] "v"(kB), [kBlo] "v"((uint32_t)kB), [kBhi] "v"((uint32_t)(kB >> 32)),
+                    [none] "v"(kNone), [empty] "v"(empty), [kb] "s"(key_lds), [sb] "s"(key_lds + kSlots * 8u), [c1] "s"(kHashMul),
+                    [sh0] "n"(32 - kBucketBits), [sh1] "n"(32 - 2 * kBucketBits), [nb] "n"(kBucketBits), [nsec] "n"(ilog2_c(kSec))
+                  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+              if (ballot((sla == kNone) | (slb == kNone)))
               {
-                // (a lane without a record folds its zero into the spare slot's pair)
-                const uint32_t at = real(u) ? sl[u] : kNone;
-                atomicMax(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(M.key_hi) + at), (unsigned long long)rkh[d][u]);
-                atomicMin(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(M.hi_min) + at), (unsigned long long)rkh[d][u]);
+                if (sla == kNone) sla = walk_seq(kA);
+                if (slb == kNone) slb = walk_seq(kB);
               }
+              add_count(d, sla, rcnt[d][0], 0ull, true);
+              add_count(d, slb, rcnt[d][1], 0ull, true);
+              return;
+            }
+            else if constexpr (!kTwo && kSum32 && kR == 1)
+            {
+              // 8 vector instructions of hashing, two 16-byte LDS reads, four compares + four selects (stage 1); for
+              // the lanes left four compares + four selects, the swap, three more (stage 2) -- no wait states (a
+              // compare's mask is used three instructions later at the earliest), three scalar instructions in all.
+              // v[40:47] hold the two buckets.
+              const uint64_t k = rk[d][0];
+              uint32_t a0, a1, t0, t1, se, sl;
+              uint64_t m0, m1, m2, sv;
+              const uint64_t empty = kEmptyKey;
+              asm volatile(
+                  "v_alignbit_b32 %[a0], %[khi], %[klo], 29\n\t"
+                  "v_xor_b32 %[a0], %[a0], %[klo]\n\t"
+                  "v_mul_lo_u32 %[se], %[a0], %[c1]\n\t"                        // p
+                  "v_mov_b32 %[sl], %[none]\n\t"
+                  "v_lshrrev_b32 %[a0], %[sh0], %[se]\n\t"                      // bucket 0: the top bits of p
+                  "v_bfe_u32 %[a1], %[se], %[sh1], %[nb]\n\t"                   // bucket 1: the bits below them
+                  "v_lshl_add_u32 %[a0], %[a0], 4, %[kb]\n\t"
+                  "v_lshl_add_u32 %[a1], %[a1], 4, %[kb]\n\t"
+                  "ds_read_b128 v[40:43], %[a0]\n\t"
+                  "ds_read_b128 v[44:47], %[a1]\n\t"
+                  "v_bfe_u32 %[se], %[se], 4, %[nsec]\n\t"                      // the second table's slot
+                  "v_add_u32 %[t0], 8, %[a0]\n\t"
+                  "v_add_u32 %[t1], 8, %[a1]\n\t"
+                  "v_lshl_add_u32 %[se], %[se], 3, %[sb]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "v_cmp_eq_u64 %[m0], v[46:47], %[k]\n\t"
+                  "v_cmp_eq_u64 %[m1], v[44:45], %[k]\n\t"
+                  "v_cmp_eq_u64 %[m2], v[42:43], %[k]\n\t"
+                  "v_cmp_eq_u64 vcc, v[40:41], %[k]\n\t"
+                  "v_cndmask_b32 %[sl], %[sl], %[t1], %[m0]\n\t"
+                  "v_cndmask_b32 %[sl], %[sl], %[a1], %[m1]\n\t"
+                  "v_cndmask_b32 %[sl], %[sl], %[t0], %[m2]\n\t"
+                  "v_cndmask_b32 %[sl], %[sl], %[a0], vcc\n\t"
+                  "v_cmp_eq_u32 vcc, %[sl], %[none]\n\t"
+                  "s_and_saveexec_b64 %[sv], vcc\n\t"
+                  "s_cbranch_execz 1f\n\t"
+                  "v_cmp_eq_u64 %[m0], -1, v[46:47]\n\t"
+                  "v_cmp_eq_u64 %[m1], -1, v[44:45]\n\t"
+                  "v_cmp_eq_u64 %[m2], -1, v[42:43]\n\t"
+                  "v_cmp_eq_u64 vcc, -1, v[40:41]\n\t"
+                  "v_cndmask_b32 %[se], %[se], %[t1], %[m0]\n\t"
+                  "v_cndmask_b32 %[se], %[se], %[a1], %[m1]\n\t"
+                  "v_cndmask_b32 %[se], %[se], %[t0], %[m2]\n\t"
+                  "v_cndmask_b32 %[se], %[se], %[a0], vcc\n\t"
+                  "ds_cmpst_rtn_b64 v[40:41], %[se], %[empty], %[k]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "v_cmp_eq_u64 %[m0], -1, v[40:41]\n\t"
+                  "v_cmp_eq_u64 vcc, v[40:41], %[k]\n\t"
+                  "s_or_b64 vcc, vcc, %[m0]\n\t"
+                  "v_cndmask_b32 %[sl], %[none], %[se], vcc\n\t"
+                  "1:\n\t"
+                  "s_or_b64 exec, exec, %[sv]"
+                  : [sl] "=&v"(sl), [a0] "=&v"(a0), [a1] "=&v"(a1), [se] "=&v"(se), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                    [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [sv] "=&s"(sv)
+                  : [k] "v"(k), [klo] "v"((uint32_t)k), [khi] "v"((uint32_t)(k >> 32)), [none] "v"(kNone), [empty] "v"(empty),
+                    [kb] "s"(key_lds), [sb] "s"(key_lds + kSlots * 8u), [c1] "s"(kHashMul), [sh0] "n"(32 - kBucketBits), [sh1] "n"(32 - 2 * kBucketBits),
+                    [nb] "n"(kBucketBits), [nsec] "n"(ilog2_c(kSec))
+                  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+              if (ballot(sl == kNone)) { if (sl == kNone) sl = walk_seq(k); }
+              add_count(d, sl, rcnt[d][0], 0ull, true);
+              return;
+            }
+#endif
+            // (two-limb k-mers: the table's key is the LOW limb, which does not ascend along a run -- the marker is looked for)
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
+              if constexpr (kTwo) insert_rec(d, u, std::false_type(), std::true_type()); else insert_rec(d, u, std::false_type(), std::false_type());
+          };
+          // the oldest round in flight has arrived (the kRing - 1 younger ones may still be under way); the round's
+          // registers pass through the statement, so nothing that reads them can be moved above it
+          auto vm_wait = [&](const int d)
+          {
+            constexpr int kLoads = kR * (kTwo ? 3 : 2);                               // load instructions per round
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
+            {
+              if constexpr (kTwo) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(rk[d][u]), "+v"(rcnt[d][u]), "+v"(rkh[d][u]) : "n"(kLoads * (kRing - 1)));
+              else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rk[d][u]), "+v"(rcnt[d][u]) : "n"(kLoads * (kRing - 1)));
             }
           };
 #pragma unroll
@@ -770,14 +981,21 @@ k_tile_sums(const tile_job J)
             {
               if (!more) break;
               if (rrem[d] == 0) { more = false; break; }                              // the batch's runs are exhausted in order
-              // (two-limb k-mers: the table's key is the LOW limb, which does not ascend along a run)
+              vm_wait(d);
               // (a run's LAST round may hold the all-ones k-mer, also when it is a full one)
-              if (rrem[d] > kStep) { if constexpr (kTwo) insert_w(d, std::false_type(), std::true_type()); else insert_w(d, std::false_type(), std::false_type()); }
-              else insert_w(d, std::true_type(), std::true_type());
+              if (rrem[d] > kStep) insert_mid(d);
+              else
+              {
+#pragma unroll
+                for (int u = 0; u < kR; ++u) insert_rec(d, u, std::true_type(), std::true_type());
+              }
               fetch_w(d);
               if ((d & (KMD_TILE_ABORT_EVERY - 1)) == KMD_TILE_ABORT_EVERY - 1 && M.abort[buf]) { more = false; gave_up = true; break; }   // (LDS read, same for the whole wave)
             }
           }
+          // (the loads still in flight -- of nothing: the batch is exhausted, or of a tile that gave up -- must have
+          // landed before their registers serve anything else)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         // a count too large for 32-bit sums: the tile is redone with 64-bit ones (never, in practice)
         if constexpr (kSum32) if (ballot(cmax >= kBigCount) && lane == 0) M.big[buf] = 1;
