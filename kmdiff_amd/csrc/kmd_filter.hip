@@ -645,6 +645,8 @@ __global__ void __launch_bounds__(kCandBlock) k_filter_candidates(const filter_p
     st.row = i;
     st.valid = i < n_rows;
     st.sum_c = st.valid ? sum_c[i] : 0ull;
+    st.valid = st.valid && st.sum_c != ~0ull;             // (a hole of the list: the fused merge hands its list out in chunks, kmd_tilemerge.hip)
+    st.sum_c = st.valid ? st.sum_c : 0ull;
     st.sum_k = st.valid ? sum_k[i] : 0ull;
     const row_result R = evaluate_core(P, nullptr, st);
     const unsigned long long cm = __ballot(R.cand);

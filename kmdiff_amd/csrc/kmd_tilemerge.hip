@@ -61,6 +61,9 @@ using namespace kmd::eval;
 #ifndef KMD_TILE_ASM
 #define KMD_TILE_ASM 1               // whole-wave path: stages 1 and 2 of a round in the middle of a run as hand-written gfx950 code
 #endif
+#ifndef KMD_TILE_TIMING
+#define KMD_TILE_TIMING 0
+#endif
 #ifndef KMD_TILE_RING
 #define KMD_TILE_RING 4              // rounds of loads in flight per wave (8, 12, 16 measured: no faster, more registers)
 #endif
@@ -93,7 +96,9 @@ constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a 
 // 32-bit range and a lane's position may step up to two sub-groups past the last record before it is checked
 constexpr uint64_t kMaxRecords = 0xFFFFFFFFull - 128ull;
 constexpr uint64_t kMaxRun = 1ull << 29;
-constexpr uint32_t kBigCount = 1u << 22;         // 1024 samples of counts below this cannot overflow a 32-bit sum
+constexpr uint32_t kBigCount = 1u << 22;
+constexpr uint32_t kOutChunk = 256;              // candidates mode: entries of the list a workgroup takes at a time
+constexpr unsigned long long kHole = ~0ull;      // sum_c of an entry that holds no row (no sum of 32-bit counts reaches it)         // 1024 samples of counts below this cannot overflow a 32-bit sum
 
 // what k_tile_plan decides, on the device
 struct tile_plan
@@ -126,6 +131,11 @@ struct tile_job
   // candidates mode: what the chi-square pre-filter needs of the model (kmd_eval.h, row_may_pass)
   double dTc, dTk, dTcTk, pf_cut;
   uint32_t lf_n;
+  // candidates mode: the list is handed out in chunks of kOutChunk entries.  Workgroup b of a launch owns chunk
+  // first_base / kOutChunk + b from the start (no atomic); *n_entries starts at first_base + n_regions x kOutChunk,
+  // further chunks come from it.  Entries of a chunk that stay unused are marked as holes (sum_c = kHole).
+  unsigned long long first_base;
+  uint32_t n_regions;
   uint32_t* over_n;                              // tiles listed
   uint32_t* over;                                // [i] tile, [over_stride + i] its records (| kAbortBit)
   uint32_t over_stride;
@@ -233,11 +243,12 @@ __global__ void __launch_bounds__(256) k_tile_coarse(const uint64_t* __restrict_
                                                      const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
                                                      const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
                                                      uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
-                                                     tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse)
+                                                     tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse,
+                                                     unsigned long long* __restrict__ list_len, unsigned long long list_len0)
 {
   __shared__ double s_part[256];
   const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, s_part);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *plan = pl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *plan = pl; *list_len = list_len0; }     // (candidates mode: the workgroups' first chunks are spoken for)
   const uint32_t nb = pl.nb, r = pl.r;
   const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;               // coarse rows 0 .. n_chunks
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,6 +398,8 @@ struct tile_lds
   unsigned long long maxsum[2];
   unsigned long long max_hi[2];                          // kTwo: min / max high limb of the records whose low limb is all ones
   unsigned long long base;
+  unsigned long long out_base, late_base;          // candidates mode: the workgroup's current chunk of the list; where late entries go
+  uint32_t out_used, out_cap, late_cnt, out_pad;
   uint32_t n[2], fresh[2], abort[2], big[2];
   uint32_t hasmax, bad;
   uint32_t wcnt[kWaves];
@@ -474,6 +487,7 @@ k_tile_sums(const tile_job J)
   if (tid == 0)
   {
     M.key[kAll] = 0; M.key[kAll + 1] = 0;                  // the spare slot: never the empty marker
+    M.out_base = J.first_base + (unsigned long long)blockIdx.x * kOutChunk; M.out_used = 0; M.out_cap = kOutChunk; M.late_cnt = 0;
     M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0; M.big[0] = 0; M.big[1] = 0;
     M.hasmax = 0; M.bad = 0; M.maxsum[0] = 0; M.maxsum[1] = 0;
     M.max_hi[0] = ~0ull; M.max_hi[1] = 0;
@@ -510,6 +524,9 @@ k_tile_sums(const tile_job J)
   uint32_t it = 0;
   for (uint32_t tile = tile_first; tile < tile_end; tile += stride, ++it)
   {
+#if KMD_TILE_TIMING
+    const unsigned long long tp_tile = __builtin_readcyclecounter();
+#endif
     const uint32_t buf = it & 1u;
     const uint32_t n = M.n[buf];
     const bool wanted = J.todo == nullptr || J.todo[tile] != 0;
@@ -546,6 +563,10 @@ k_tile_sums(const tile_job J)
         //  * a lane's state in the table is ONE number (insert_w).
         uint32_t cmax = 0;                                                            // largest count this lane met (kSum32: one look per tile)
         bool gave_up = false;
+#if KMD_TILE_TIMING   // dev: cycles a wave sits out per LDS round trip (bucket reads, swap), printed by one wave
+        uint32_t tm_read = 0, tm_nread = 0, tm_cas = 0, tm_ncas = 0;
+        const unsigned long long tm_t0 = __builtin_readcyclecounter();
+#endif
         const uint32_t lane_k = lane * 8u, lane_c = lane * 4u;
         // The tile's records -- its S runs one behind the other -- are cut into kWaves equal shares, whatever the runs'
         // lengths: wave w takes records [w n / kWaves, (w + 1) n / kWaves) of that sequence, i.e. a few whole runs and
@@ -910,6 +931,10 @@ k_tile_sums(const tile_job J)
                   "v_bfe_u32 %[a1], %[se], %[sh1], %[nb]\n\t"                   // bucket 1: the bits below them
                   "v_lshl_add_u32 %[a0], %[a0], 4, %[kb]\n\t"
                   "v_lshl_add_u32 %[a1], %[a1], 4, %[kb]\n\t"
+#if KMD_TILE_TIMING
+                  "s_memtime s[90:91]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+#endif
                   "ds_read_b128 v[40:43], %[a0]\n\t"
                   "ds_read_b128 v[44:47], %[a1]\n\t"
                   "v_bfe_u32 %[se], %[se], 4, %[nsec]\n\t"                      // the second table's slot
@@ -917,6 +942,13 @@ k_tile_sums(const tile_job J)
                   "v_add_u32 %[t1], 8, %[a1]\n\t"
                   "v_lshl_add_u32 %[se], %[se], 3, %[sb]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
+#if KMD_TILE_TIMING
+                  "s_memtime s[92:93]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "s_sub_u32 s92, s92, s90\n\t"
+                  "s_add_u32 %[tr], %[tr], s92\n\t"
+                  "s_add_u32 %[nr], %[nr], 1\n\t"
+#endif
                   "v_cmp_eq_u64 %[m0], v[46:47], %[k]\n\t"
                   "v_cmp_eq_u64 %[m1], v[44:45], %[k]\n\t"
                   "v_cmp_eq_u64 %[m2], v[42:43], %[k]\n\t"
@@ -936,8 +968,19 @@ k_tile_sums(const tile_job J)
                   "v_cndmask_b32 %[se], %[se], %[a1], %[m1]\n\t"
                   "v_cndmask_b32 %[se], %[se], %[t0], %[m2]\n\t"
                   "v_cndmask_b32 %[se], %[se], %[a0], vcc\n\t"
+#if KMD_TILE_TIMING
+                  "s_memtime s[90:91]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+#endif
                   "ds_cmpst_rtn_b64 v[40:41], %[se], %[empty], %[k]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
+#if KMD_TILE_TIMING
+                  "s_memtime s[92:93]\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "s_sub_u32 s92, s92, s90\n\t"
+                  "s_add_u32 %[tc], %[tc], s92\n\t"
+                  "s_add_u32 %[nc_], %[nc_], 1\n\t"
+#endif
                   "v_cmp_eq_u64 %[m0], -1, v[40:41]\n\t"
                   "v_cmp_eq_u64 vcc, v[40:41], %[k]\n\t"
                   "s_or_b64 vcc, vcc, %[m0]\n\t"
@@ -946,10 +989,17 @@ k_tile_sums(const tile_job J)
                   "s_or_b64 exec, exec, %[sv]"
                   : [sl] "=&v"(sl), [a0] "=&v"(a0), [a1] "=&v"(a1), [se] "=&v"(se), [t0] "=&v"(t0), [t1] "=&v"(t1),
                     [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [sv] "=&s"(sv)
+#if KMD_TILE_TIMING
+                    , [tr] "+s"(tm_read), [nr] "+s"(tm_nread), [tc] "+s"(tm_cas), [nc_] "+s"(tm_ncas)
+#endif
                   : [k] "v"(k), [klo] "v"((uint32_t)k), [khi] "v"((uint32_t)(k >> 32)), [none] "v"(kNone), [empty] "v"(empty),
                     [kb] "s"(key_lds), [sb] "s"(key_lds + kSlots * 8u), [c1] "s"(kHashMul), [sh0] "n"(32 - kBucketBits), [sh1] "n"(32 - 2 * kBucketBits),
                     [nb] "n"(kBucketBits), [nsec] "n"(ilog2_c(kSec))
-                  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+                  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47"
+#if KMD_TILE_TIMING
+                    , "s90", "s91", "s92", "s93"
+#endif
+                  );
               if (ballot(sl == kNone)) { if (sl == kNone) sl = walk_seq(k); }
               add_count(d, sl, rcnt[d][0], 0ull, true);
               return;
@@ -982,12 +1032,27 @@ k_tile_sums(const tile_job J)
               if (!more) break;
               if (rrem[d] == 0) { more = false; break; }                              // the batch's runs are exhausted in order
               vm_wait(d);
-              // (a run's LAST round may hold the all-ones k-mer, also when it is a full one)
+              // A run's LAST round may hold the all-ones k-mer (also when it is a full one) and lanes without a record.
+              // Without that k-mer -- almost always -- it goes the fast way too, with its empty lanes switched off
+              // around it (one record per lane: the lanes that hold one are the first `rem`).
               if (rrem[d] > kStep) insert_mid(d);
               else
               {
+                bool fast = false;
+                if constexpr (kR == 1 && !kTwo && kSum32 && KMD_TILE_ASM && !KMD_TILE_ABLATE && !KMD_TILE_TIMING)
+                {
+                  const bool there = lane < rrem[d];
+                  if (!ballot(there & (rk[d][0] == kEmptyKey)))
+                  {
+                    fast = true;
+                    if (there) insert_mid(d);
+                  }
+                }
+                if (!fast)
+                {
 #pragma unroll
-                for (int u = 0; u < kR; ++u) insert_rec(d, u, std::true_type(), std::true_type());
+                  for (int u = 0; u < kR; ++u) insert_rec(d, u, std::true_type(), std::true_type());
+                }
               }
               fetch_w(d);
               if ((d & (KMD_TILE_ABORT_EVERY - 1)) == KMD_TILE_ABORT_EVERY - 1 && M.abort[buf]) { more = false; gave_up = true; break; }   // (LDS read, same for the whole wave)
@@ -997,6 +1062,12 @@ k_tile_sums(const tile_job J)
           // landed before their registers serve anything else)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#if KMD_TILE_TIMING
+        if (blockIdx.x == 77 && tid == 64 && tm_nread)
+          printf("[tile timing] tile %u: %u rounds, bucket reads %.0f cycles each, %u swaps %.0f cycles each, whole insert loop %llu cycles (%.0f per round)\n",
+                 tile, tm_nread, (double)tm_read / tm_nread, tm_ncas, tm_ncas ? (double)tm_cas / tm_ncas : 0.0,
+                 __builtin_readcyclecounter() - tm_t0, (double)(__builtin_readcyclecounter() - tm_t0) / tm_nread);
+#endif
         // a count too large for 32-bit sums: the tile is redone with 64-bit ones (never, in practice)
         if constexpr (kSum32) if (ballot(cmax >= kBigCount) && lane == 0) M.big[buf] = 1;
       }
@@ -1203,10 +1274,20 @@ k_tile_sums(const tile_job J)
         run_ring(fetch);
       }
     }
+#if KMD_TILE_TIMING
+    const unsigned long long tp_ins = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#if KMD_TILE_TIMING
+    const unsigned long long tp_bar1 = __builtin_readcyclecounter();
+#endif
 
     // ---- the next tile's segment table; the table walk: this tile's rows
     load_segments(tile + stride, buf ^ 1u);
+#if KMD_TILE_TIMING
+    const unsigned long long tp_seg = __builtin_readcyclecounter();
+    unsigned long long tp_walk1 = 0, tp_resv = 0;
+#endif
     if (process)
     {
       const bool big = kSum32 && M.big[buf] != 0;
@@ -1229,9 +1310,104 @@ k_tile_sums(const tile_job J)
         const uint32_t at = atomicAdd(J.over_n, 1u);
         J.over[at] = tile; J.over[J.over_stride + at] = (n < kBigBit ? n : kBigBit - 1u) | kAbortBit | (big ? kBigBit : 0u);
       }
-      // the walk: every thread owns kWalk slots.  Pass 1 counts the rows that leave (all of them, or --
-      // kFilter -- the ones the chi-square pre-filter lets through, ~1 %); the tile takes that many
-      // consecutive entries of the output with ONE global atomic; pass 2 writes them and wipes the slots.
+      if constexpr (kFilter)
+      {
+        // The walk, candidates mode: ONE pass.  Every thread owns kWalk slots; a live slot goes through the chi-square
+        // pre-filter, the ~1 % that pass leave for the list, every slot is wiped.  The list is handed out in chunks:
+        // a row's entry is the next one of the workgroup's chunk (an LDS counter) -- no global atomic, no barrier
+        // around it (round 2 reserved a tile's entries with one returning global atomic between two barriers: 5 500
+        // of a tile's 62 000 cycles went there, and the second pass over the table another 2 700).  A row that finds
+        // the chunk full waits in its slot for the next chunk (below; rare: a chunk is 256 entries, a tile sends ~10).
+        uint32_t late_bits = 0;
+        auto emit = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k) -> bool
+        {
+          const uint32_t pos = atomicAdd(&M.out_used, 1u);
+          if (pos >= M.out_cap) return false;
+          const unsigned long long e = M.out_base + pos;
+          if (e < J.row_capacity)
+          {
+            J.kmer_out[e] = key; J.sum_c_out[e] = sum_c; J.sum_k_out[e] = sum_k;
+            if constexpr (kTwo) J.kmer_hi_out[e] = key_hi;
+          }
+          return true;
+        };
+#pragma unroll
+        for (int j = 0; j < kWalk; ++j)
+        {
+          const uint32_t i = tid + (uint32_t)j * kThreads;
+          const uint64_t key = i < kAll ? M.key[i] : kEmptyKey;          // (the last step covers the end of the second table)
+          const bool live = key != kEmptyKey;
+          unsigned long long sum_c = 0, sum_k = 0;
+          if (live) read_sums(i, sum_c, sum_k);
+          bool leaves = false;
+#if !(KMD_TILE_ABLATE & 4)   // dev: no pre-filter evaluation, nothing leaves (results wrong)
+          if (!bad_tile)
+          {
+            row_state st; st.sum_c = sum_c; st.sum_k = sum_k; st.row = 0; st.valid = live;
+            leaves = row_may_pass(J, st, n_beyond);
+          }
+#endif
+          rows_local += live && !bad_tile ? 1u : 0u;
+          bool late = false;
+          if (leaves) late = !emit(key, kTwo ? M.key_hi[i] : 0ull, sum_c, sum_k);
+          late_bits |= late ? 1u << j : 0u;
+          if (live && !late)
+          {
+            M.key[i] = kEmptyKey; wipe_sums(i);
+            if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
+          }
+        }
+        bool special_late = false;
+        if (tid == 0 && M.hasmax && !bad_tile)             // the all-ones k-mer, if this tile had it
+        {
+          row_state st; st.sum_c = M.maxsum[0]; st.sum_k = M.maxsum[1]; st.row = 0; st.valid = true;
+          ++rows_local;
+          if (row_may_pass(J, st, n_beyond)) special_late = !emit(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
+        }
+        __syncthreads();
+        if (M.out_used > M.out_cap)
+        {
+          // the chunk ran out: the rows left over take the first entries of a new chunk (as many chunks as they need)
+          const uint32_t extra = M.out_used - M.out_cap;
+          __syncthreads();
+          if (tid == 0)
+          {
+            const uint32_t take = (extra + kOutChunk - 1u) / kOutChunk * kOutChunk;
+            M.late_base = atomicAdd(J.n_rows, (unsigned long long)take);
+            M.late_cnt = 0; M.out_used = extra; M.out_cap = take;
+          }
+          __syncthreads();
+          auto emit_late = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k)
+          {
+            const unsigned long long e = M.late_base + atomicAdd(&M.late_cnt, 1u);
+            if (e < J.row_capacity)
+            {
+              J.kmer_out[e] = key; J.sum_c_out[e] = sum_c; J.sum_k_out[e] = sum_k;
+              if constexpr (kTwo) J.kmer_hi_out[e] = key_hi;
+            }
+          };
+#pragma unroll
+          for (int j = 0; j < kWalk; ++j)
+            if ((late_bits >> j) & 1u)
+            {
+              const uint32_t i = tid + (uint32_t)j * kThreads;
+              unsigned long long sum_c, sum_k;
+              read_sums(i, sum_c, sum_k);
+              emit_late(M.key[i], kTwo ? M.key_hi[i] : 0ull, sum_c, sum_k);
+              M.key[i] = kEmptyKey; wipe_sums(i);
+              if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
+            }
+          if (special_late) emit_late(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
+          __syncthreads();
+          if (tid == 0) M.out_base = M.late_base;
+        }
+        if (tid == 0 && M.hasmax) { M.hasmax = 0; M.maxsum[0] = 0; M.maxsum[1] = 0; M.max_hi[0] = ~0ull; M.max_hi[1] = 0; }
+      }
+      else
+      {
+      // the walk, rows mode (kmd_merge_sums: every row leaves, the output is compact): every thread owns kWalk
+      // slots.  Pass 1 counts the rows; the tile takes that many consecutive entries of the output with ONE
+      // global atomic; pass 2 writes them and wipes the slots.
       uint32_t out_bits = 0, mine = 0;
       bool special_out = false;
       if (!bad_tile)
@@ -1269,6 +1445,9 @@ k_tile_sums(const tile_job J)
           mine += special_out ? 1u : 0u;
         }
       }
+#if KMD_TILE_TIMING
+      tp_walk1 = __builtin_readcyclecounter();
+#endif
 #if !(KMD_TILE_ABLATE & 8)   // dev: no reservation (and its two barriers)
       for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
       if (lane == 0) M.wcnt[wave] = mine;
@@ -1280,6 +1459,9 @@ k_tile_sums(const tile_job J)
         M.base = total ? atomicAdd(J.n_rows, (unsigned long long)total) : 0ull;
       }
       __syncthreads();
+#endif
+#if KMD_TILE_TIMING
+      tp_resv = __builtin_readcyclecounter();
 #endif
       unsigned long long out_at = M.base;
       for (uint32_t w = 0; w < wave; ++w) out_at += M.wcnt[w];
@@ -1319,12 +1501,29 @@ k_tile_sums(const tile_job J)
         out_at += (unsigned long long)__popcll(m);
       }
       if (tid == 0 && M.hasmax) { M.hasmax = 0; M.maxsum[0] = 0; M.maxsum[1] = 0; M.max_hi[0] = ~0ull; M.max_hi[1] = 0; }
+      }
     }
+#if KMD_TILE_TIMING
+    const unsigned long long tp_walk2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#if KMD_TILE_TIMING
+    if (blockIdx.x == 77 && tid == 64)
+      printf("[tile phases] tile %u: tile start -> inserts done %llu, barrier %llu, next segments %llu, walk pass 1 %llu, reservation %llu, walk pass 2 %llu, last barrier %llu\n",
+             tile, tp_ins - tp_tile, tp_bar1 - tp_ins, tp_seg - tp_bar1, tp_walk1 - tp_seg, tp_resv - tp_walk1, tp_walk2 - tp_resv, __builtin_readcyclecounter() - tp_walk2);
+#endif
   }
 
   if constexpr (kFilter)
   {
+    // what is left of this workgroup's chunk, and the first chunks of workgroups this launch does not have (the
+    // list was laid out for n_regions of them): holes
+    __syncthreads();
+    for (unsigned long long e = M.out_base + (M.out_used < M.out_cap ? M.out_used : M.out_cap) + tid; e < M.out_base + M.out_cap; e += kThreads)
+      if (e < J.row_capacity) J.sum_c_out[e] = kHole;
+    for (uint32_t r = blockIdx.x + gridDim.x; r < J.n_regions; r += gridDim.x)
+      for (unsigned long long e = J.first_base + (unsigned long long)r * kOutChunk + tid; e < J.first_base + (unsigned long long)(r + 1u) * kOutChunk; e += kThreads)
+        if (e < J.row_capacity) J.sum_c_out[e] = kHole;
     // this workgroup's rows and rows beyond the log-factorial table (merge.hpp:76; kmd_filter.hip counts
     // the same two for rows of a matrix)
     for (int o = 32; o > 0; o >>= 1) { rows_local += __shfl_down(rows_local, o, 64); n_beyond += __shfl_down(n_beyond, o, 64); }
@@ -1430,6 +1629,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   // (+ grid_hint: the plan may round the number of tiles up to a multiple of it)
   const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min) + grid_hint;
   const uint32_t chunks_max = (nb_max + kChunk - 1) / kChunk;
+  // candidates mode: the most workgroups a launch of the merge kernel can have -- each owns a first chunk of the list
+  const uint32_t regions_max = (uint32_t)n_cu * std::max<uint32_t>(env_u32("KMD_TILE_BLOCKS_PER_CU", 0), 2048u / (uint32_t)sh.threads);
 
   scratch_set sc(st);
   void *p_offs = nullptr, *p_table = nullptr, *p_coarse = nullptr, *p_over = nullptr, *p_small = nullptr;
@@ -1450,7 +1651,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     const size_t cells_c = ((size_t)chunks_max + 1) * S;
     hipLaunchKernelGGL(k_tile_coarse, dim3((unsigned)((cells_c + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
-                       grid_hint, d_plan, static_cast<uint32_t*>(p_coarse));
+                       grid_hint, d_plan, static_cast<uint32_t*>(p_coarse), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0));
     const size_t waves_f = (size_t)chunks_max * S;
     hipLaunchKernelGGL(k_tile_fine, dim3((unsigned)((waves_f + 3) / 4)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
                        d_plan, static_cast<const uint32_t*>(p_coarse), static_cast<uint32_t*>(p_table));
@@ -1467,6 +1668,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   J.row_capacity = row_capacity;
   J.n_rows = d_rows;
   J.row_total = d_rows + 1;
+  J.first_base = 0; J.n_regions = regions_max;
   if (pf) { J.dTc = pf->dTc; J.dTk = pf->dTk; J.dTcTk = pf->dTcTk; J.pf_cut = pf->pf_cut; J.lf_n = pf->lf_n; }
 
   auto launch = [&](auto kernel, int threads, size_t lds_fixed, uint32_t tiles_at_most) -> int
@@ -1480,6 +1682,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     if (const uint32_t e = env_u32("KMD_TILE_BLOCKS_PER_CU", 0)) per_cu = (int)e;
     size_t grid = (size_t)n_cu * (size_t)per_cu;
     if (grid > tiles_at_most) grid = tiles_at_most;
+    if (grid > regions_max) grid = regions_max;
     if (dbg) std::fprintf(stderr, "[tile_merge] <= %u tiles, grid %zu x %d (%d per CU), lds %zu\n", tiles_at_most, grid, threads, per_cu, lds);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, J);
     KMD_HIP(hipGetLastError());
@@ -1540,6 +1743,15 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   {
     KMD_HIP(sc.take(&p_over, 2 * (size_t)list_cap * 4));
     if (level > 0) KMD_HIP(hipMemsetAsync(d_over_n, 0, 4, st));
+    if (level > 0 && fused)
+    {
+      // the first chunks of this launch's workgroups lie behind what the list holds so far
+      unsigned long long so_far = 0;
+      std::memcpy(&so_far, h_small + 32, 8);
+      J.first_base = so_far;
+      const unsigned long long len0 = so_far + (unsigned long long)regions_max * kOutChunk;
+      KMD_HIP(hipMemcpyAsync(d_rows, &len0, 8, hipMemcpyHostToDevice, st));
+    }
     J.start = table; J.todo = todo; J.n_tiles = n_tiles;
     J.over_n = d_over_n; J.over = static_cast<uint32_t*>(p_over); J.over_stride = list_cap;
     int rc = run(list_cap);
@@ -1638,7 +1850,7 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   // pre-filter is off) in a scratch list; should the list prove too small, the merge runs again with
   // the size it reported -- nothing of the first run has reached the caller's counters or sink.
   const bool two = d_kmers_hi != nullptr;
-  size_t cap = std::max<size_t>((size_t)1 << 18, n / 8);
+  size_t cap = std::max<size_t>((size_t)1 << 19, n / 8);               // (the workgroups' first chunks alone are up to 2^18 entries)
   if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) cap = e;
   uint64_t entries = 0, totals[2] = { 0, 0 };
   scratch_set sc(st);
