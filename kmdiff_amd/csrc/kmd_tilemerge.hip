@@ -97,6 +97,7 @@ constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a 
 constexpr uint64_t kMaxRecords = 0xFFFFFFFFull - 128ull;
 constexpr uint64_t kMaxRun = 1ull << 29;
 constexpr uint32_t kBigCount = 1u << 22;
+constexpr uint32_t kStage = 32;                  // candidates mode: rows of a tile parked in LDS on their way to the list
 constexpr uint32_t kOutChunk = 256;              // candidates mode: entries of the list a workgroup takes at a time
 constexpr unsigned long long kHole = ~0ull;      // sum_c of an entry that holds no row (no sum of 32-bit counts reaches it)         // 1024 samples of counts below this cannot overflow a 32-bit sum
 
@@ -399,7 +400,8 @@ struct tile_lds
   unsigned long long max_hi[2];                          // kTwo: min / max high limb of the records whose low limb is all ones
   unsigned long long base;
   unsigned long long out_base, late_base;          // candidates mode: the workgroup's current chunk of the list; where late entries go
-  uint32_t out_used, out_cap, late_cnt, out_pad;
+  uint32_t out_used, out_cap, late_cnt, stage_n;
+  unsigned long long stage_key[kStage], stage_c[kStage], stage_k[kStage], stage_hi[kTwo ? kStage : 1];   // rows parked for the list (k_tile_sums, the walk)
   uint32_t n[2], fresh[2], abort[2], big[2];
   uint32_t hasmax, bad;
   uint32_t wcnt[kWaves];
@@ -487,7 +489,7 @@ k_tile_sums(const tile_job J)
   if (tid == 0)
   {
     M.key[kAll] = 0; M.key[kAll + 1] = 0;                  // the spare slot: never the empty marker
-    M.out_base = J.first_base + (unsigned long long)blockIdx.x * kOutChunk; M.out_used = 0; M.out_cap = kOutChunk; M.late_cnt = 0;
+    M.out_base = J.first_base + (unsigned long long)blockIdx.x * kOutChunk; M.out_used = 0; M.out_cap = kOutChunk; M.late_cnt = 0; M.stage_n = 0;
     M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0; M.big[0] = 0; M.big[1] = 0;
     M.hasmax = 0; M.bad = 0; M.maxsum[0] = 0; M.maxsum[1] = 0;
     M.max_hi[0] = ~0ull; M.max_hi[1] = 0;
@@ -511,6 +513,43 @@ k_tile_sums(const tile_job J)
   };
   load_segments(tile_first, 0);
   __syncthreads();
+  // a workgroup barrier that waits for this wave's LDS operations only (__syncthreads also waits for its global
+  // stores to be acknowledged -- microseconds, with the whole workgroup standing by)
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // candidates mode: the rows a tile's walk parked in LDS go to the list (wave 0; the next entries of the workgroup's
+  // chunk, or -- should they not fit -- of a fresh chunk, what was left of the old one becoming holes)
+  auto flush_stage = [&]()
+  {
+    if constexpr (kFilter)
+    {
+      if (wave != 0) return;
+      const uint32_t n_st = M.stage_n < kStage ? M.stage_n : kStage;
+      if (n_st == 0) return;
+      unsigned long long base = M.out_base;
+      uint32_t used = M.out_used < M.out_cap ? M.out_used : M.out_cap;
+      const uint32_t cap = M.out_cap;
+      if (used + n_st > cap)
+      {
+        for (unsigned long long e = base + used + lane; e < base + cap; e += 64)
+          if (e < J.row_capacity) J.sum_c_out[e] = kHole;
+        unsigned long long fresh = 0;
+        if (lane == 0) fresh = atomicAdd(J.n_rows, (unsigned long long)kOutChunk);
+        base = __shfl(fresh, 0, 64);
+        used = 0;
+        if (lane == 0) { M.out_base = base; M.out_cap = kOutChunk; }
+      }
+      if (lane < n_st)
+      {
+        const unsigned long long e = base + used + lane;
+        if (e < J.row_capacity)
+        {
+          J.kmer_out[e] = M.stage_key[lane]; J.sum_c_out[e] = M.stage_c[lane]; J.sum_k_out[e] = M.stage_k[lane];
+          if constexpr (kTwo) J.kmer_hi_out[e] = M.stage_hi[lane];
+        }
+      }
+      if (lane == 0) { M.out_used = used + n_st; M.stage_n = 0; }
+    }
+  };
 
   const uint32_t G = 1u << g_shift, sub = tid & (G - 1u), q0 = tid >> g_shift, Q = (uint32_t)kThreads >> g_shift;
   uint32_t n_beyond = 0, rows_local = 0;
@@ -573,6 +612,8 @@ k_tile_sums(const tile_job J)
         // a piece of the run at either end.  (Whole runs dealt out in turn left the waves of a workgroup up to 15 %
         // apart at the tile's barrier -- samples differ in depth -- and a sample ten times deeper than the rest would
         // have cost its wave ten times the others' time.)
+        // (the loads below are counted by hand: nothing else -- a row on its way to the list -- may be in flight)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t w_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
         const uint32_t share_lo = (uint32_t)(((uint64_t)n * w_u) / (uint32_t)kWaves), share_hi = (uint32_t)(((uint64_t)n * (w_u + 1u)) / (uint32_t)kWaves);
         uint32_t seq0 = 0;                                                            // records of the tile before stream `first`
@@ -1277,7 +1318,9 @@ k_tile_sums(const tile_job J)
 #if KMD_TILE_TIMING
     const unsigned long long tp_ins = __builtin_readcyclecounter();
 #endif
-    __syncthreads();
+    // (candidates mode: the rows the previous tile parked go to the list now -- their stores land while this tile's
+    // table is walked -- and the barriers wait for LDS only)
+    if constexpr (kFilter) { flush_stage(); lds_barrier(); } else __syncthreads();
 #if KMD_TILE_TIMING
     const unsigned long long tp_bar1 = __builtin_readcyclecounter();
 #endif
@@ -1312,15 +1355,25 @@ k_tile_sums(const tile_job J)
       }
       if constexpr (kFilter)
       {
-        // The walk, candidates mode: ONE pass.  Every thread owns kWalk slots; a live slot goes through the chi-square
-        // pre-filter, the ~1 % that pass leave for the list, every slot is wiped.  The list is handed out in chunks:
-        // a row's entry is the next one of the workgroup's chunk (an LDS counter) -- no global atomic, no barrier
-        // around it (round 2 reserved a tile's entries with one returning global atomic between two barriers: 5 500
-        // of a tile's 62 000 cycles went there, and the second pass over the table another 2 700).  A row that finds
-        // the chunk full waits in its slot for the next chunk (below; rare: a chunk is 256 entries, a tile sends ~10).
+        // The walk, candidates mode: ONE pass.  Every thread owns kWalk slots -- their keys and sums are read first,
+        // all of them, then looked at: a live slot goes through the chi-square pre-filter, the ~1 % that pass leave
+        // for the list, every slot is wiped.  The rows that leave are parked in LDS (kStage of them; the list's
+        // chunks take what does not fit, at once) and written to the list by wave 0 when the NEXT tile's inserts are
+        // done: nothing waits for the stores -- the barriers of the tile loop wait for LDS only -- and they have a
+        // whole walk to land before the loads of the following tile are counted again.  (Round 2 reserved a tile's
+        // entries with one returning global atomic between two barriers and wrote them in a second pass over the
+        // table: 5 500 + 2 700 of a tile's 62 000 cycles; writing them in the one pass, behind a barrier that waited
+        // for the stores as __syncthreads does, still cost 3 500.)
         uint32_t late_bits = 0;
         auto emit = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k) -> bool
         {
+          const uint32_t at = atomicAdd(&M.stage_n, 1u);
+          if (at < kStage)
+          {
+            M.stage_key[at] = key; M.stage_c[at] = sum_c; M.stage_k[at] = sum_k;
+            if constexpr (kTwo) M.stage_hi[at] = key_hi;
+            return true;
+          }
           const uint32_t pos = atomicAdd(&M.out_used, 1u);
           if (pos >= M.out_cap) return false;
           const unsigned long long e = M.out_base + pos;
@@ -1331,25 +1384,37 @@ k_tile_sums(const tile_job J)
           }
           return true;
         };
+        uint64_t w_key[kWalk];
+        unsigned long long w_c[kWalk], w_k[kWalk];
 #pragma unroll
         for (int j = 0; j < kWalk; ++j)
         {
           const uint32_t i = tid + (uint32_t)j * kThreads;
-          const uint64_t key = i < kAll ? M.key[i] : kEmptyKey;          // (the last step covers the end of the second table)
-          const bool live = key != kEmptyKey;
-          unsigned long long sum_c = 0, sum_k = 0;
-          if (live) read_sums(i, sum_c, sum_k);
+          w_key[j] = i < kAll ? M.key[i] : kEmptyKey;                   // (the last step covers the end of the second table)
+        }
+#pragma unroll
+        for (int j = 0; j < kWalk; ++j)
+        {
+          const uint32_t i = tid + (uint32_t)j * kThreads;
+          w_c[j] = 0; w_k[j] = 0;
+          if (i < kAll) read_sums(i, w_c[j], w_k[j]);                    // (an empty slot's sums are 0)
+        }
+#pragma unroll
+        for (int j = 0; j < kWalk; ++j)
+        {
+          const uint32_t i = tid + (uint32_t)j * kThreads;
+          const bool live = w_key[j] != kEmptyKey;
           bool leaves = false;
 #if !(KMD_TILE_ABLATE & 4)   // dev: no pre-filter evaluation, nothing leaves (results wrong)
           if (!bad_tile)
           {
-            row_state st; st.sum_c = sum_c; st.sum_k = sum_k; st.row = 0; st.valid = live;
+            row_state st; st.sum_c = w_c[j]; st.sum_k = w_k[j]; st.row = 0; st.valid = live;
             leaves = row_may_pass(J, st, n_beyond);
           }
 #endif
           rows_local += live && !bad_tile ? 1u : 0u;
           bool late = false;
-          if (leaves) late = !emit(key, kTwo ? M.key_hi[i] : 0ull, sum_c, sum_k);
+          if (leaves) late = !emit(w_key[j], kTwo ? M.key_hi[i] : 0ull, w_c[j], w_k[j]);
           late_bits |= late ? 1u << j : 0u;
           if (live && !late)
           {
@@ -1364,12 +1429,18 @@ k_tile_sums(const tile_job J)
           ++rows_local;
           if (row_may_pass(J, st, n_beyond)) special_late = !emit(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
         }
-        __syncthreads();
+#if KMD_TILE_TIMING
+        tp_walk1 = __builtin_readcyclecounter();
+#endif
+        lds_barrier();
+#if KMD_TILE_TIMING
+        tp_resv = __builtin_readcyclecounter();
+#endif
         if (M.out_used > M.out_cap)
         {
           // the chunk ran out: the rows left over take the first entries of a new chunk (as many chunks as they need)
           const uint32_t extra = M.out_used - M.out_cap;
-          __syncthreads();
+          lds_barrier();
           if (tid == 0)
           {
             const uint32_t take = (extra + kOutChunk - 1u) / kOutChunk * kOutChunk;
@@ -1391,14 +1462,12 @@ k_tile_sums(const tile_job J)
             if ((late_bits >> j) & 1u)
             {
               const uint32_t i = tid + (uint32_t)j * kThreads;
-              unsigned long long sum_c, sum_k;
-              read_sums(i, sum_c, sum_k);
-              emit_late(M.key[i], kTwo ? M.key_hi[i] : 0ull, sum_c, sum_k);
+              emit_late(w_key[j], kTwo ? M.key_hi[i] : 0ull, w_c[j], w_k[j]);
               M.key[i] = kEmptyKey; wipe_sums(i);
               if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
             }
           if (special_late) emit_late(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
-          __syncthreads();
+          lds_barrier();
           if (tid == 0) M.out_base = M.late_base;
         }
         if (tid == 0 && M.hasmax) { M.hasmax = 0; M.maxsum[0] = 0; M.maxsum[1] = 0; M.max_hi[0] = ~0ull; M.max_hi[1] = 0; }
@@ -1506,18 +1575,20 @@ k_tile_sums(const tile_job J)
 #if KMD_TILE_TIMING
     const unsigned long long tp_walk2 = __builtin_readcyclecounter();
 #endif
-    __syncthreads();
+    if constexpr (kFilter) lds_barrier(); else __syncthreads();
 #if KMD_TILE_TIMING
     if (blockIdx.x == 77 && tid == 64)
-      printf("[tile phases] tile %u: tile start -> inserts done %llu, barrier %llu, next segments %llu, walk pass 1 %llu, reservation %llu, walk pass 2 %llu, last barrier %llu\n",
-             tile, tp_ins - tp_tile, tp_bar1 - tp_ins, tp_seg - tp_bar1, tp_walk1 - tp_seg, tp_resv - tp_walk1, tp_walk2 - tp_resv, __builtin_readcyclecounter() - tp_walk2);
+      printf("[tile phases] tile %u: inserts -> barrier %llu, next segments %llu, walk %llu (rows mode: pass 1 %llu, reservation %llu), last barrier %llu\n",
+             tile, tp_bar1 - tp_ins, tp_seg - tp_bar1, tp_walk2 - tp_seg, tp_walk1 ? tp_walk1 - tp_seg : 0ull, tp_resv ? tp_resv - tp_walk1 : 0ull,
+             __builtin_readcyclecounter() - tp_walk2);
 #endif
   }
 
   if constexpr (kFilter)
   {
-    // what is left of this workgroup's chunk, and the first chunks of workgroups this launch does not have (the
-    // list was laid out for n_regions of them): holes
+    // the last tile's parked rows; then what is left of this workgroup's chunk, and the first chunks of workgroups
+    // this launch does not have (the list was laid out for n_regions of them): holes
+    flush_stage();
     __syncthreads();
     for (unsigned long long e = M.out_base + (M.out_used < M.out_cap ? M.out_used : M.out_cap) + tid; e < M.out_base + M.out_cap; e += kThreads)
       if (e < J.row_capacity) J.sum_c_out[e] = kHole;
