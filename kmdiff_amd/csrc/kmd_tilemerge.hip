@@ -84,12 +84,10 @@ typedef __attribute__((address_space(3))) u64x2 lds_u64x2;        // a bucket of
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRsrcFlags = 0x00020000;           // buffer descriptor, dword 3: raw 32-bit data, no swizzle (gfx9 family)
-constexpr int kAuxNt = 2;                        // buffer load: non-temporal
 // the lanes' predicate as a mask, straight from the compare (HIP's __ballot takes an int: a select and a second compare)
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile live in LDS (16 KB at 1024 streams)
 constexpr uint32_t kProbes = 512;                // records sampled for the records-per-row estimate (+-5 % at worst; 2048 cost 39 us, 4x this)
-constexpr uint32_t kChunk = 64;                  // tile boundaries per coarse step of the start table
 constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
 constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a count too large for 32-bit sums
 // record positions and run extents are 32-bit: a run's byte extent (8 x its records) must fit the buffer descriptor's
@@ -169,10 +167,94 @@ __device__ __forceinline__ size_t lower_bound_key(const uint64_t* __restrict__ k
   return lo;
 }
 
+// The boundary searches were bound by their dependent round trips to HBM: 21 steps of bisection over a 2.6 M-record
+// stream, each a miss on a line (and often a page) of its own -- 23 + 15 + 30 us of a 0.5 ms call in round 2's
+// k_tile_probe / k_tile_coarse / k_tile_fine.  Now:
+//   * a sampled INDEX of every stream (its every 4096th key and its last one; ~200 KB for a 20v20 partition:
+//     L2-resident) is searched first: ~10 steps that hit the cache, and the answer is confined to 4096 records;
+//   * inside that window the key's place is guessed by INTERPOLATION between the two index keys that bound it (a
+//     partition's k-mers are spread roughly evenly: they are hashed into partitions by their minimizers), the guess
+//     is bracketed by galloping away from it (16, 64, 256 ... records: a couple of steps, on the guess's own cache
+//     lines) and the bracket bisected.  Whatever the keys look like -- dense clusters, gaps -- the search stays within
+//     the window: at most ~30 steps, ~8 for evenly spread keys, two or three of them misses.
+constexpr uint32_t kIndexShift = 12;             // every 4096th key of a stream is in its index
+
+// samples of a stream of n records: positions 0, 4096, ... and n - 1
+__host__ __device__ inline uint32_t index_samples(uint64_t n) { return n ? (uint32_t)((n - 1) >> kIndexShift) + 2u : 0u; }
+__device__ __forceinline__ size_t index_pos(size_t begin, uint64_t n, uint32_t i) { const uint64_t p = (uint64_t)i << kIndexShift; return begin + (size_t)(p < n - 1 ? p : n - 1); }
+
+// one thread per sample: idx[ioff[s] + i] = key at the i-th sample position of stream s (ioff on the host: prefix of index_samples)
+__global__ void __launch_bounds__(256) k_tile_index(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi, const uint64_t* __restrict__ offs,
+                                                    const uint32_t* __restrict__ ioff, uint32_t S, uint64_t* __restrict__ idx, uint64_t* __restrict__ idx_hi)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ioff[S]) return;
+  uint32_t lo = 0, hi = S;                                     // stream of sample t: the last s with ioff[s] <= t
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ioff[mid] <= t) lo = mid; else hi = mid; }
+  const size_t at = index_pos(offs[lo], offs[lo + 1] - offs[lo], t - ioff[lo]);
+  idx[t] = keys[at];
+  if (keys_hi) idx_hi[t] = keys_hi[at];
+}
+
+struct stream_index { const uint64_t* idx; const uint64_t* idx_hi; const uint32_t* ioff; };
+
+// first position in stream s (records [begin, end)) whose key is >= (b, bh)
+__device__ __forceinline__ size_t lower_bound_indexed(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi, const stream_index X,
+                                                      uint32_t s, size_t begin, size_t end, uint64_t b, uint64_t bh)
+{
+  if (begin >= end) return begin;
+  const bool two = keys_hi != nullptr;
+  const uint64_t n = end - begin;
+  const uint64_t* ix = X.idx + X.ioff[s];
+  const uint64_t* ixh = two ? X.idx_hi + X.ioff[s] : nullptr;
+  const uint32_t m = X.ioff[s + 1] - X.ioff[s];
+  auto iless = [&](uint32_t i) -> bool { return two ? (ixh[i] < bh || (ixh[i] == bh && ix[i] < b)) : ix[i] < b; };
+  // first sample whose key is >= the key
+  uint32_t ilo = 0, ihi = m;
+  while (ilo < ihi) { const uint32_t mid = (ilo + ihi) >> 1; if (iless(mid)) ilo = mid + 1; else ihi = mid; }
+  if (ilo == 0) return begin;                                  // key <= the stream's first
+  if (ilo == m) return end;                                    // key > its last
+  // keys[lo] < key <= keys[hi1]
+  size_t lo = index_pos(begin, n, ilo - 1), hi1 = index_pos(begin, n, ilo);
+  auto val = [&](size_t i) -> uint64_t { return two ? keys_hi[i] : keys[i]; };     // (interpolated on; ties fall to the halving steps)
+  auto less = [&](size_t i) -> bool { return two ? (keys_hi[i] < bh || (keys_hi[i] == bh && keys[i] < b)) : keys[i] < b; };
+  const uint64_t target = two ? bh : b;
+  uint64_t vlo = two ? ixh[ilo - 1] : ix[ilo - 1], vhi = two ? ixh[ilo] : ix[ilo];
+  for (int pass = 0; hi1 - lo > 1; ++pass)
+  {
+    const size_t width = hi1 - lo;
+    if (width <= 8 || pass >= 2 || vhi <= vlo || target <= vlo)
+    {
+      const size_t mid = lo + (width >> 1);
+      if (less(mid)) lo = mid; else hi1 = mid;
+      continue;
+    }
+    size_t g = lo + (size_t)((double)(target - vlo) / (double)(vhi - vlo) * (double)width);
+    if (g <= lo) g = lo + 1;
+    if (g >= hi1) g = hi1 - 1;
+    if (less(g))
+    {
+      lo = g;
+      size_t step = 16;
+      while (lo + step < hi1 && less(lo + step)) { lo += step; step <<= 2; }
+      if (lo + step < hi1) hi1 = lo + step;
+    }
+    else
+    {
+      hi1 = g;
+      size_t step = 16;
+      while (hi1 > lo + step && !less(hi1 - step)) { hi1 -= step; step <<= 2; }
+      if (hi1 > lo + step) lo = hi1 - step;
+    }
+    vlo = val(lo); vhi = val(hi1);
+  }
+  return hi1;
+}
+
 // mult[p] = number of streams that hold the k-mer of probe record p (records drawn uniformly from all
 // n, so mean(1 / mult) estimates rows / records without bias); one thread per (probe, stream)
 __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
-                                                    const uint64_t* __restrict__ offs, uint32_t S, uint64_t n,
+                                                    const uint64_t* __restrict__ offs, const stream_index X, uint32_t S, uint64_t n,
                                                     uint32_t* __restrict__ mult)
 {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,7 +263,7 @@ __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__
   const size_t i = (size_t)__umul64hi(mix64(p), n);
   const uint64_t k = keys[i], kh = keys_hi ? keys_hi[i] : 0ull;
   const size_t begin = offs[s], end = offs[s + 1];
-  const size_t at = lower_bound_key(keys, keys_hi, begin, end, k, kh);
+  const size_t at = lower_bound_indexed(keys, keys_hi, X, s, begin, end, k, kh);
   if (at < end && keys[at] == k && (!keys_hi || keys_hi[at] == kh)) atomicAdd(&mult[p], 1u);
 }
 
@@ -238,66 +320,34 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   return pl;
 }
 
-// where stream s enters tile j: boundary j = key j * r of the longest stream L (b_0 = -inf, b_nb = +inf).
-// Two steps: every kChunk-th boundary by a search over the whole stream (coarse[c][s]) ...
-__global__ void __launch_bounds__(256) k_tile_coarse(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
-                                                     const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
+// where stream s enters tile j: boundary j = key j * r of the longest stream L (b_0 = -inf, b_nb = +inf); one thread
+// per (boundary, stream), each a search of its stream (lower_bound_indexed).  Every workgroup works the plan out for
+// itself from the probe's counts (the first one writes it down for the kernels behind): no launch of its own.
+__global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                     const uint64_t* __restrict__ offs, const stream_index X, uint32_t S, uint32_t L,
                                                      const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
                                                      uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
-                                                     tile_plan* __restrict__ plan, uint32_t* __restrict__ coarse,
+                                                     tile_plan* __restrict__ plan, uint32_t* __restrict__ start,
                                                      unsigned long long* __restrict__ list_len, unsigned long long list_len0)
 {
   __shared__ double s_part[256];
   const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, s_part);
   if (blockIdx.x == 0 && threadIdx.x == 0) { *plan = pl; *list_len = list_len0; }     // (candidates mode: the workgroups' first chunks are spoken for)
   const uint32_t nb = pl.nb, r = pl.r;
-  const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;               // coarse rows 0 .. n_chunks
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ((size_t)n_chunks + 1) * S) return;
-  const size_t c = i / S;
-  const uint32_t s = (uint32_t)(i - c * S);
-  const size_t begin = offs[s], end = offs[s + 1], j = c * kChunk;
+  if (i >= ((size_t)nb + 1) * S) return;
+  const size_t j = i / S;
+  const uint32_t s = (uint32_t)(i - j * S);
+  const size_t begin = offs[s], end = offs[s + 1];
   size_t pos;
   if (j == 0) pos = begin;
   else if (j >= nb) pos = end;
   else
   {
     const size_t at = offs[L] + j * r;
-    pos = s == L ? at : lower_bound_key(keys, keys_hi, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
+    pos = s == L ? at : lower_bound_indexed(keys, keys_hi, X, s, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
   }
-  coarse[i] = (uint32_t)pos;
-}
-
-// ... the ones in between inside the window two coarse entries enclose: one wave per (chunk, stream),
-// its 64 lanes search the same few KB
-__global__ void __launch_bounds__(256) k_tile_fine(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
-                                                   const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
-                                                   const tile_plan* __restrict__ plan, const uint32_t* __restrict__ coarse,
-                                                   uint32_t* __restrict__ start)
-{
-  const uint32_t nb = plan->nb, r = plan->r;
-  const uint32_t n_chunks = (nb + kChunk - 1) / kChunk;
-  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // wave = (chunk, stream), stream fastest
-  const uint32_t lane = threadIdx.x & 63;
-  if (w >= (size_t)n_chunks * S) return;
-  const size_t c = w / S;
-  const uint32_t s = (uint32_t)(w - c * S);
-  const size_t j = c * kChunk + lane;
-  if (j <= nb)
-  {
-    size_t pos;
-    if (j == 0) pos = offs[s];
-    else if (j == nb) pos = offs[s + 1];
-    else
-    {
-      const size_t at = offs[L] + j * r;
-      if (s == L) pos = at;
-      else pos = lower_bound_key(keys, keys_hi, coarse[c * S + s], coarse[(c + 1) * S + s], keys[at], keys_hi ? keys_hi[at] : 0ull);
-    }
-    start[j * S + s] = (uint32_t)pos;
-  }
-  // row nb closes the last tile; when nb is a multiple of kChunk no lane above reaches it
-  if (c + 1 == n_chunks && lane == 0 && nb % kChunk == 0) start[(size_t)nb * S + s] = (uint32_t)offs[s + 1];
+  start[i] = (uint32_t)pos;
 }
 
 // A listed tile becomes m equal slices of the key range its records really span: rows first ..
@@ -808,7 +858,7 @@ k_tile_sums(const tile_job J)
 #else
               const unsigned long long old = atomicCAS(key_at(e), (unsigned long long)kEmptyKey, (unsigned long long)k);
               // claimed, or another record of the k-mer was faster; else another k-mer took it meanwhile (stage 3)
-              sl = (old == kEmptyKey) | (old == k) ? e : kNone;
+              sl = ((old == kEmptyKey) | (old == k)) ? e : kNone;
 #endif
             }
 #if !(KMD_TILE_ABLATE & 128)   // dev: no stage 3 (results wrong)
@@ -1699,33 +1749,42 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   const uint32_t grid_hint = env_u32("KMD_TILE_GRID_HINT", (uint32_t)n_cu * (sh.threads == 512 ? 4u : 2u));   // workgroups of the level-0 launch
   // (+ grid_hint: the plan may round the number of tiles up to a multiple of it)
   const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min) + grid_hint;
-  const uint32_t chunks_max = (nb_max + kChunk - 1) / kChunk;
   // candidates mode: the most workgroups a launch of the merge kernel can have -- each owns a first chunk of the list
   const uint32_t regions_max = (uint32_t)n_cu * std::max<uint32_t>(env_u32("KMD_TILE_BLOCKS_PER_CU", 0), 2048u / (uint32_t)sh.threads);
 
   scratch_set sc(st);
-  void *p_offs = nullptr, *p_table = nullptr, *p_coarse = nullptr, *p_over = nullptr, *p_small = nullptr;
-  KMD_HIP(sc.take(&p_offs, ((size_t)S + 1) * 8));
+  void *p_offs = nullptr, *p_table = nullptr, *p_over = nullptr, *p_small = nullptr;
+  KMD_HIP(sc.take(&p_offs, ((size_t)S + 1 + ((size_t)S + 2) / 2) * 8));
   KMD_HIP(sc.take(&p_table, ((size_t)nb_max + 1) * (size_t)S * 4));
-  KMD_HIP(sc.take(&p_coarse, ((size_t)chunks_max + 1) * (size_t)S * 4));
   KMD_HIP(sc.take(&p_small, 64 + (size_t)kProbes * 4));              // [plan | entries, rows, rows beyond the table | probe multiplicities]
   tile_plan* d_plan = static_cast<tile_plan*>(p_small);
   unsigned long long* d_rows = reinterpret_cast<unsigned long long*>(static_cast<char*>(p_small) + 32);
   uint32_t* d_over_n = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 56);
   uint32_t* d_mult = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 64);
-  KMD_HIP(hipMemcpyAsync(p_offs, offsets, ((size_t)S + 1) * 8, hipMemcpyHostToDevice, st));
+  // [offsets (S + 1) x u64 | index offsets (S + 1) x u32]: one upload
+  std::vector<uint64_t> h_up((size_t)S + 1 + ((size_t)S + 2) / 2);
+  std::memcpy(h_up.data(), offsets, ((size_t)S + 1) * 8);
+  uint32_t* h_ioff = reinterpret_cast<uint32_t*>(h_up.data() + S + 1);
+  h_ioff[0] = 0;
+  for (int s = 0; s < S; ++s) h_ioff[s + 1] = h_ioff[s] + index_samples(offsets[s + 1] - offsets[s]);
+  const uint32_t n_index = h_ioff[S];
+  void *p_idx = nullptr, *p_idx_hi = nullptr;
+  KMD_HIP(sc.take(&p_idx, (size_t)n_index * 8));
+  if (two) KMD_HIP(sc.take(&p_idx_hi, (size_t)n_index * 8));
+  KMD_HIP(hipMemcpyAsync(p_offs, h_up.data(), h_up.size() * 8, hipMemcpyHostToDevice, st));
   KMD_HIP(hipMemsetAsync(p_small, 0, 64 + (size_t)kProbes * 4, st));
   const uint64_t* d_offs = static_cast<const uint64_t*>(p_offs);
+  const uint32_t* d_ioff = reinterpret_cast<const uint32_t*>(d_offs + S + 1);
+  const stream_index X { static_cast<const uint64_t*>(p_idx), static_cast<const uint64_t*>(p_idx_hi), d_ioff };
   {
-    hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S,
+    hipLaunchKernelGGL(k_tile_index, dim3((n_index + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, d_ioff, (uint32_t)S,
+                       static_cast<uint64_t*>(p_idx), static_cast<uint64_t*>(p_idx_hi));
+    hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
                        (uint64_t)n, d_mult);
-    const size_t cells_c = ((size_t)chunks_max + 1) * S;
-    hipLaunchKernelGGL(k_tile_coarse, dim3((unsigned)((cells_c + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
+    const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
+    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
-                       grid_hint, d_plan, static_cast<uint32_t*>(p_coarse), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0));
-    const size_t waves_f = (size_t)chunks_max * S;
-    hipLaunchKernelGGL(k_tile_fine, dim3((unsigned)((waves_f + 3) / 4)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
-                       d_plan, static_cast<const uint32_t*>(p_coarse), static_cast<uint32_t*>(p_table));
+                       grid_hint, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0));
     KMD_HIP(hipGetLastError());
   }
 
@@ -1753,7 +1812,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     if (const uint32_t e = env_u32("KMD_TILE_BLOCKS_PER_CU", 0)) per_cu = (int)e;
     size_t grid = (size_t)n_cu * (size_t)per_cu;
     if (grid > tiles_at_most) grid = tiles_at_most;
-    if (grid > regions_max) grid = regions_max;
+    if (grid > J.n_regions) grid = J.n_regions;
     if (dbg) std::fprintf(stderr, "[tile_merge] <= %u tiles, grid %zu x %d (%d per CU), lds %zu\n", tiles_at_most, grid, threads, per_cu, lds);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, J);
     KMD_HIP(hipGetLastError());
@@ -1809,6 +1868,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   tile_plan h_plan;
   std::memset(&h_plan, 0, sizeof h_plan);
   alignas(8) char h_small[64];
+  unsigned long long h_len0 = 0;                                  // (source of an asynchronous copy: lives as long as the function)
   std::vector<uint32_t> h_over;
   for (int level = 0;; ++level)
   {
@@ -1820,8 +1880,9 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
       unsigned long long so_far = 0;
       std::memcpy(&so_far, h_small + 32, 8);
       J.first_base = so_far;
-      const unsigned long long len0 = so_far + (unsigned long long)regions_max * kOutChunk;
-      KMD_HIP(hipMemcpyAsync(d_rows, &len0, 8, hipMemcpyHostToDevice, st));
+      J.n_regions = std::min<uint32_t>(regions_max, n_tiles);                 // (the launch has at most a workgroup per tile)
+      h_len0 = so_far + (unsigned long long)J.n_regions * kOutChunk;
+      KMD_HIP(hipMemcpyAsync(d_rows, &h_len0, 8, hipMemcpyHostToDevice, st));
     }
     J.start = table; J.todo = todo; J.n_tiles = n_tiles;
     J.over_n = d_over_n; J.over = static_cast<uint32_t*>(p_over); J.over_stride = list_cap;
@@ -1921,7 +1982,7 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   // pre-filter is off) in a scratch list; should the list prove too small, the merge runs again with
   // the size it reported -- nothing of the first run has reached the caller's counters or sink.
   const bool two = d_kmers_hi != nullptr;
-  size_t cap = std::max<size_t>((size_t)1 << 19, n / 8);               // (the workgroups' first chunks alone are up to 2^18 entries)
+  size_t cap = std::max<size_t>((size_t)1 << 20, n / 8);               // (the workgroups' first chunks alone are up to 2^18 entries)
   if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) cap = e;
   uint64_t entries = 0, totals[2] = { 0, 0 };
   scratch_set sc(st);
@@ -1949,8 +2010,10 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
       if (clean) { sc.drained = true; return KMD_OK; }        // the gated launch did the work; tile_merge has synchronised behind it
       break;
     }
-    KMD_REQUIRE(attempt == 0, "kmd_merge_filter: candidate list overflowed twice");
-    cap = (size_t)entries;
+    // (which tiles give up and are cut again can depend on the order their k-mers arrived in: a second run may need a
+    // chunk or two more than the first reported)
+    KMD_REQUIRE(attempt < 4, "kmd_merge_filter: candidate list kept overflowing");
+    cap = (size_t)entries + (size_t)entries / 4 + 4 * kOutChunk;
   }
   // the long way (tiles were cut again after the first pass): the list is complete only now
   rc = kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(p_k), static_cast<const uint64_t*>(p_h),
