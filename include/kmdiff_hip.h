@@ -59,13 +59,7 @@ enum { KMD_LAYOUT_ROWS = 0, KMD_LAYOUT_SOA = 1, KMD_LAYOUT_TILED = 2 };
 const char* kmd_status_string(int status);
 const char* kmd_last_error(void);
 int kmd_abi_version(void);
-/* test hooks: the correctly rounded log / exp (and Cephes igamc(1/2, x) over them) that decide rows whose
- * p-value lies within 1e-8 of the threshold (KMD_CNT_NEAR_THRESHOLD), evaluated on the host */
-double kmd_test_log_rounded(double x);
-double kmd_test_exp_rounded(double x);
-double kmd_test_igamc_half_rounded(double x);
-struct kmd_model;
-double kmd_test_row_pvalue_rounded(const struct kmd_model* m, uint64_t sum_control, uint64_t sum_case);
+/* (the test hooks kmd_test_* are declared in kmdiff_hip_test.h: not part of the interface a host binds) */
 
 /* ---- device plumbing (so that a C/C++ host needs nothing but this library) ----------- */
 int kmd_device_count(int* n);
@@ -252,6 +246,23 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
 int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_t* d_kmers, const uint64_t* d_kmers_hi,
                      const uint32_t* d_counts, const uint64_t* offsets, double threshold,
                      const kmd_survivors* out, uint64_t* d_counters, uint64_t* n_rows_out, void* stream);
+
+/* A batch of partitions through kmd_merge_filter, up to six of them in flight on streams of the library's own: a job
+ * (one ThreadPool task per partition, merge.hpp:259-307) has hundreds, and a quarter of a single call is not the merge
+ * kernel -- index, probe and boundary searches, candidate evaluation, launches, the read-back.  Enqueued without a
+ * host round trip, those run beside the merge kernel of another partition; the host waits once per partition.
+ *   d_kmers / d_kmers_hi / d_counts / offsets / d_counters : arrays of n_partitions pointers, each as in
+ *                 kmd_merge_filter (d_kmers_hi NULL, or NULL entries, for k <= 32; a partition of 0 records is skipped)
+ *   out         : NULL or n_partitions sinks (entries may name the same sink and counters: calls accumulate)
+ *   n_rows_out  : NULL or n_partitions host values, distinct k-mers per partition
+ *   stream      : what it holds so far is waited for; the call returns when every partition is done
+ * Same results as n_partitions single calls (survivor order within a sink aside).  A partition that needs the
+ * slow way (tiles cut again, a candidate list that overflowed) is run again synchronously: nothing of its first
+ * run has reached the counters or the sink.  Returns the first error met; the other partitions are still done. */
+int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int n_samples, const uint64_t* const* d_kmers,
+                           const uint64_t* const* d_kmers_hi, const uint32_t* const* d_counts,
+                           const uint64_t* const* offsets, double threshold, const kmd_survivors* out,
+                           uint64_t* const* d_counters, uint64_t* n_rows_out, void* stream);
 
 /* The same merge for a consumer that wants the rows themselves: every distinct k-mer leaves as
  * (k-mer, sum of its control counts, sum of its case counts), 24 (two limbs: 32) bytes instead of

@@ -39,14 +39,18 @@ class Tile(C.Structure):
 # name -> (restype, argtypes); the list mirrors include/kmdiff_hip.h and is what
 # tests/test_abi.py checks against the header and the built library.
 _vp, _sz, _u64, _i, _d = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_double
-SIGNATURES = {
-    "kmd_status_string": (C.c_char_p, [_i]),
-    "kmd_last_error": (C.c_char_p, []),
-    "kmd_abi_version": (_i, []),
+# include/kmdiff_hip_test.h: test hooks, not part of the interface a host binds
+TEST_SIGNATURES = {
     "kmd_test_log_rounded": (_d, [_d]),
     "kmd_test_exp_rounded": (_d, [_d]),
     "kmd_test_igamc_half_rounded": (_d, [_d]),
     "kmd_test_row_pvalue_rounded": (_d, [_vp, _u64, _u64]),
+}
+
+SIGNATURES = {
+    "kmd_status_string": (C.c_char_p, [_i]),
+    "kmd_last_error": (C.c_char_p, []),
+    "kmd_abi_version": (_i, []),
     "kmd_device_count": (_i, [C.POINTER(_i)]),
     "kmd_set_device": (_i, [_i]),
     "kmd_device_name": (_i, [C.c_char_p, _sz]),
@@ -84,6 +88,7 @@ SIGNATURES = {
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_filter": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, C.POINTER(Survivors), _vp, C.POINTER(_u64), _vp]),
+    "kmd_merge_filter_batch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, C.POINTER(Survivors), _vp, C.POINTER(_u64), _vp]),
     "kmd_survivors_gather_counts_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "kmd_survivors_sort_by_kmer": (_i, [C.POINTER(Survivors), _sz, _vp]),
     "kmd_poisson_filter_sums": (_i, [_vp, _vp, _vp, _vp, _sz, _d, C.POINTER(Survivors), _vp, _vp]),
@@ -129,7 +134,7 @@ def lib():
             L = C.CDLL(LIB_PATH)
         except OSError as e:
             raise KmdError("cannot load %s: %s" % (LIB_PATH, e))
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -2,6 +2,7 @@
 // event helpers, the model object, the synthetic-matrix generator and the small support
 // kernels (column sums, copy probe).
 #include "kmd_internal.h"
+#include "../../include/kmdiff_hip_test.h"
 #include "kmd_math.h"
 #include "kmd_synth_tables.h"
 

@@ -40,6 +40,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -1724,10 +1725,21 @@ inline uint32_t env_u32(const char* name, uint32_t dflt)
 // table] and of the count of unfinished tiles, and must gate itself on them (k_filter_candidates does).
 // *clean = the first pass finished every tile (the gated work was live if the list did not overflow either).
 using level0_hook = std::function<int(const uint64_t* d_live, const uint32_t* d_over_n)>;
+// `async` (kmd_merge_filter_batch): the first pass and what the hook puts behind it are enqueued, the 64 bytes that
+// say how it went are copied to async->h_small (page-locked), and the function returns WITHOUT waiting: the caller
+// synchronises the stream later and reads them (tiles that gave up, a list that overflowed: it runs the partition
+// again the synchronous way).  The scratch blocks and the upload staging then belong to *async.
+struct merge_async
+{
+  scratch_set sc;
+  std::vector<uint64_t> h_up;
+  char* h_small = nullptr;                         // 64 page-locked bytes
+  explicit merge_async(hipStream_t st) : sc(st) {}
+};
 int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi, const uint32_t* d_counts,
                const uint64_t* offsets, const filter_params* pf, uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out,
                uint64_t* d_sum_c, uint64_t* d_sum_k, size_t row_capacity, uint64_t* n_entries, uint64_t totals[2], hipStream_t st,
-               const level0_hook& behind_level0 = level0_hook(), bool* clean = nullptr)
+               const level0_hook& behind_level0 = level0_hook(), bool* clean = nullptr, struct merge_async* async = nullptr)
 {
   const bool fused = pf != nullptr;
   const size_t n = (size_t)offsets[S];
@@ -1752,7 +1764,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   // candidates mode: the most workgroups a launch of the merge kernel can have -- each owns a first chunk of the list
   const uint32_t regions_max = (uint32_t)n_cu * std::max<uint32_t>(env_u32("KMD_TILE_BLOCKS_PER_CU", 0), 2048u / (uint32_t)sh.threads);
 
-  scratch_set sc(st);
+  scratch_set sc_own(st);
+  scratch_set& sc = async ? async->sc : sc_own;
   void *p_offs = nullptr, *p_table = nullptr, *p_over = nullptr, *p_small = nullptr;
   KMD_HIP(sc.take(&p_offs, ((size_t)S + 1 + ((size_t)S + 2) / 2) * 8));
   KMD_HIP(sc.take(&p_table, ((size_t)nb_max + 1) * (size_t)S * 4));
@@ -1762,7 +1775,9 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   uint32_t* d_over_n = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 56);
   uint32_t* d_mult = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 64);
   // [offsets (S + 1) x u64 | index offsets (S + 1) x u32]: one upload
-  std::vector<uint64_t> h_up((size_t)S + 1 + ((size_t)S + 2) / 2);
+  std::vector<uint64_t> h_up_own;
+  std::vector<uint64_t>& h_up = async ? async->h_up : h_up_own;
+  h_up.assign((size_t)S + 1 + ((size_t)S + 2) / 2, 0);
   std::memcpy(h_up.data(), offsets, ((size_t)S + 1) * 8);
   uint32_t* h_ioff = reinterpret_cast<uint32_t*>(h_up.data() + S + 1);
   h_ioff[0] = 0;
@@ -1894,6 +1909,11 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
       if (rc != KMD_OK) return rc;
     }
     // one read-back per level: [plan | entries, rows, rows beyond the table | tiles listed]
+    if (async)
+    {
+      KMD_HIP(hipMemcpyAsync(async->h_small, p_small, 64, hipMemcpyDeviceToHost, st));
+      return KMD_OK;                                              // (the caller waits, reads, and owns the scratch)
+    }
     KMD_HIP(hipMemcpyAsync(h_small, p_small, 64, hipMemcpyDeviceToHost, st));
     KMD_HIP(hipStreamSynchronize(st));
     std::memcpy(&h_plan, h_small, sizeof h_plan);
@@ -2022,6 +2042,148 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   KMD_HIP(hipStreamSynchronize(st));                            // the scratch list goes back to the cache
   sc.drained = true;
   return KMD_OK;
+}
+
+// ---- a batch of partitions ----------------------------------------------------------------------
+// A job has hundreds of partitions and a quarter of a kmd_merge_filter call is not the merge kernel (index, probe,
+// boundary searches, candidate evaluation, launches, the read-back and its wake-up).  Here the calls of up to
+// kBatchStreams partitions are in flight on streams of the library's own -- everything a partition needs is enqueued
+// without a host round trip (tile_merge, async), so the small kernels of one run beside the merge kernel of another
+// -- and the host waits once per partition, in turn, when its stream slot is needed again.  A partition whose first
+// pass did not finish every tile, or whose candidate list overflowed (both rare), is run again the synchronous way:
+// nothing of its first run has reached the caller's counters or sink.
+namespace {
+constexpr int kBatchStreams = 6;
+struct batch_streams
+{
+  hipStream_t st[kBatchStreams] = {};
+  char* h_small = nullptr;                         // kBatchStreams x 64 page-locked bytes
+  hipEvent_t ev = nullptr;
+};
+std::mutex g_batch_mu;
+std::map<int, batch_streams> g_batch;              // per device
+
+int batch_get(batch_streams** out)
+{
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_batch_mu);
+  batch_streams& B = g_batch[dev];
+  if (!B.h_small)
+  {
+    for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipStreamCreateWithFlags(&B.st[i], hipStreamNonBlocking));
+    void* p = nullptr;
+    KMD_HIP(hipHostMalloc(&p, (size_t)kBatchStreams * 64, hipHostMallocDefault));
+    B.h_small = static_cast<char*>(p);
+    KMD_HIP(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+  }
+  *out = &B;
+  return KMD_OK;
+}
+} // namespace
+
+extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int n_samples, const uint64_t* const* d_kmers,
+                                      const uint64_t* const* d_kmers_hi, const uint32_t* const* d_counts,
+                                      const uint64_t* const* offsets, double threshold, const kmd_survivors* out,
+                                      uint64_t* const* d_counters, uint64_t* n_rows_out, void* stream)
+{
+  KMD_REQUIRE(m && n_partitions >= 0 && d_kmers && d_counts && offsets && d_counters, "kmd_merge_filter_batch: NULL arguments");
+  KMD_REQUIRE(n_samples == m->nc + m->nk, "kmd_merge_filter_batch: n_samples != controls + cases of the model");
+  KMD_REQUIRE((uint32_t)n_samples <= kMaxStreams, "kmd_merge_filter_batch: more than 1024 samples");
+  if (n_partitions == 0) return KMD_OK;
+  batch_streams* B = nullptr;
+  int rc = batch_get(&B);
+  if (rc != KMD_OK) return rc;
+  // one batch at a time per device (the streams and the read-back slots are the library's); what the caller's stream
+  // holds so far comes first
+  static std::mutex run_mu;
+  std::lock_guard<std::mutex> run_lock(run_mu);
+  hipStream_t user = static_cast<hipStream_t>(stream);
+  KMD_HIP(hipEventRecord(B->ev, user));
+  for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipStreamWaitEvent(B->st[i], B->ev, 0));
+
+  struct in_flight { int part = -1; std::unique_ptr<merge_async> A; size_t cap = 0; void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr; };
+  in_flight F[kBatchStreams];
+  int first_error = KMD_OK;
+  // the synchronous way, for the partitions the fast way could not finish
+  auto redo = [&](int p) -> int
+  {
+    return kmd_merge_filter(m, n_samples, d_kmers[p], d_kmers_hi ? d_kmers_hi[p] : nullptr, d_counts[p], offsets[p], threshold,
+                            out ? &out[p] : nullptr, d_counters[p], n_rows_out ? &n_rows_out[p] : nullptr, B->st[0]);
+  };
+  auto finish = [&](int slot) -> int
+  {
+    in_flight& f = F[slot];
+    if (f.part < 0) return KMD_OK;
+    const int p = f.part;
+    f.part = -1;
+    KMD_HIP(hipStreamSynchronize(B->st[slot]));
+    f.A->sc.drained = true;
+    const char* h = B->h_small + (size_t)slot * 64;
+    unsigned long long rows3[3];
+    std::memcpy(rows3, h + 32, sizeof rows3);
+    const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h + 56);
+    const bool ok = n_over == 0 && rows3[0] <= f.cap;
+    f.A.reset();                                                  // the scratch goes back to the cache
+    if (ok) { if (n_rows_out) n_rows_out[p] = rows3[1]; return KMD_OK; }
+    return redo(p);
+  };
+  for (int p = 0; p < n_partitions; ++p)
+  {
+    const int slot = p % kBatchStreams;
+    rc = finish(slot);
+    if (rc != KMD_OK && first_error == KMD_OK) first_error = rc;
+    if (n_rows_out) n_rows_out[p] = 0;
+    KMD_REQUIRE(offsets[p] && d_counters[p], "kmd_merge_filter_batch: NULL offsets or counters of a partition");
+    const uint64_t* offs = offsets[p];
+    const size_t n = (size_t)offs[n_samples];
+    if (n == 0) continue;
+    bool sane = n < kMaxRecords && d_kmers[p] && d_counts[p];
+    for (int s = 0; s < n_samples && sane; ++s) sane = offs[s] <= offs[s + 1] && offs[s + 1] - offs[s] < kMaxRun;
+    if (!sane)
+    {
+      rc = redo(p);                                               // (says what is wrong with it)
+      if (rc != KMD_OK && first_error == KMD_OK) first_error = rc;
+      continue;
+    }
+    hipStream_t st = B->st[slot];
+    in_flight& f = F[slot];
+    f.A.reset(new merge_async(st));
+    f.A->h_small = B->h_small + (size_t)slot * 64;
+    kmd_tile t { d_counts[p], 4, KMD_LAYOUT_SOA, n, nullptr, nullptr, n, 0 };
+    filter_params P;
+    rc = kmd::fill_filter_params(P, m, &t, threshold);
+    if (rc != KMD_OK) { f.A.reset(); if (first_error == KMD_OK) first_error = rc; continue; }
+    P.counters = reinterpret_cast<unsigned long long*>(d_counters[p]);
+    if (out) P.out = out[p];
+    const bool two = d_kmers_hi && d_kmers_hi[p];
+    f.cap = std::max<size_t>((size_t)1 << 20, n / 8);
+    if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) f.cap = e;
+    hipError_t he = f.A->sc.take(&f.p_k, f.cap * 8);
+    if (he == hipSuccess) he = f.A->sc.take(&f.p_c, f.cap * 8);
+    if (he == hipSuccess) he = f.A->sc.take(&f.p_s, f.cap * 8);
+    if (he == hipSuccess && two) he = f.A->sc.take(&f.p_h, f.cap * 8);
+    if (he != hipSuccess) { (void)hipGetLastError(); f.A.reset(); rc = redo(p); if (rc != KMD_OK && first_error == KMD_OK) first_error = rc; continue; }
+    const size_t cap_now = f.cap;
+    auto speculate = [&](const uint64_t* d_live, const uint32_t* d_over_n) -> int
+    {
+      return kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(f.p_k), static_cast<const uint64_t*>(f.p_h),
+                                           static_cast<const uint64_t*>(f.p_c), static_cast<const uint64_t*>(f.p_s), 0, 0, 0, st,
+                                           d_live, d_over_n, cap_now);
+    };
+    uint64_t entries = 0, totals[2] = { 0, 0 };
+    rc = tile_merge(n_samples, m->nc, d_kmers[p], two ? d_kmers_hi[p] : nullptr, d_counts[p], offs, &P, static_cast<uint64_t*>(f.p_k),
+                    static_cast<uint64_t*>(f.p_h), static_cast<uint64_t*>(f.p_c), static_cast<uint64_t*>(f.p_s), f.cap, &entries, totals, st,
+                    speculate, nullptr, f.A.get());
+    if (rc != KMD_OK) { (void)hipStreamSynchronize(st); f.A.reset(); if (first_error == KMD_OK) first_error = rc; continue; }
+    f.part = p;
+  }
+  for (int slot = 0; slot < kBatchStreams; ++slot)
+  {
+    rc = finish(slot);
+    if (rc != KMD_OK && first_error == KMD_OK) first_error = rc;
+  }
+  return first_error;
 }
 
 // The same merge for a consumer that wants the rows themselves: every distinct k-mer leaves as

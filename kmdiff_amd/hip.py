@@ -452,6 +452,33 @@ def merge_filter(streams, observer, stream=None):
     return int(n_rows.value)
 
 
+def merge_filter_batch(stream_sets, observers, stream=None):
+    """km::KmerMerger::merge(diff_observer) for a batch of partitions (global_merge's loop over the partitions,
+    merge.hpp:259-307): kmd_merge_filter_batch keeps up to six of them in flight on streams of the library's own.
+    `stream_sets`: one StreamSet per partition; `observers`: one diff_observer per partition (several may share an
+    accumulator: survivors and counters add up).  Returns the partitions' numbers of distinct k-mers."""
+    P = len(stream_sets)
+    assert len(observers) == P
+    if P == 0:
+        return []
+    model = observers[0].model
+    S = stream_sets[0].n_samples
+    assert all(o.model is model and o.threshold == observers[0].threshold for o in observers) and all(ss.n_samples == S for ss in stream_sets)
+    vp = C.c_void_p * P
+    ptrs = [ss.ptrs() for ss in stream_sets]
+    any_hi = any(pt[1] is not None for pt in ptrs)
+    dk = vp(*[pt[0] for pt in ptrs]); dh = vp(*[pt[1] for pt in ptrs]); dc = vp(*[pt[2] for pt in ptrs])
+    offs = vp(*[ss.offs.ctypes.data for ss in stream_sets])
+    ctr = vp(*[o.acc.counters.ptr for o in observers])
+    sinks = (N.Survivors * P)(*[o.acc.struct() for o in observers])
+    n_rows = (C.c_uint64 * P)()
+    check(lib().kmd_merge_filter_batch(model.handle, P, S, dk, dh if any_hi else None, dc, offs, observers[0].threshold, sinks, ctr,
+                                       n_rows, stream), "kmd_merge_filter_batch")
+    for o in observers:
+        o.acc._size = None
+    return [int(v) for v in n_rows]
+
+
 def gather_counts_streams(sums, rows_buf, n, row_kmers=None, row_kmers_hi=None):
     """KmerSign::m_counts_ratio for n survivors of the fused paths: host array [n][S] of doubles, every
     count looked up in the per-sample streams.  `sums`: a RowSums (rows_buf = the survivors' `row` on the

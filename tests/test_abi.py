@@ -11,8 +11,8 @@ from kmdiff_amd import _native as N
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "kmdiff_hip.h")).read()
+def header_functions(header="kmdiff_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b(kmd_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
@@ -20,11 +20,14 @@ def header_functions():
 
 def test_header_declares_what_python_binds():
     assert header_functions() == sorted(N.SIGNATURES)
+    # the test hooks have a header of their own: none of them in the interface a host binds
+    assert header_functions("kmdiff_hip_test.h") == sorted(N.TEST_SIGNATURES)
+    assert not [f for f in header_functions() if f.startswith("kmd_test_")]
 
 
 def test_library_exports_every_declared_symbol():
     L = C.CDLL(N.LIB_PATH)
-    for name in header_functions():
+    for name in header_functions() + header_functions("kmdiff_hip_test.h"):
         assert hasattr(L, name), name
 
 

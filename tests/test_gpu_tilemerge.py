@@ -321,6 +321,63 @@ def test_merge_filter_partitions_in_flight(K, oracle):
         assert lib.kmd_stream_destroy(job["st"]) == 0
 
 
+def test_merge_filter_batch_equals_single_calls(K, oracle):
+    """kmd_merge_filter_batch: nine partitions of different sizes and kinds (an empty one, one whose tiles must be cut
+    again, two-limb k-mers apart) through the batch entry point -- the same survivors, bit for bit, and the same
+    counters and row counts as nine single calls; partitions that share a sink add up."""
+    rng = np.random.default_rng(515)
+    S, nc = 12, 5
+    sets, want = [], []
+    for j in range(9):
+        if j == 3:
+            streams = [(np.zeros(0, np.uint64), np.zeros(0, np.uint32)) for _ in range(S)]
+        elif j == 5:                                             # dense clusters: tiles are cut again (the slow way inside the batch)
+            starts = np.sort(rng.integers(0, 1 << 61, 40, dtype=np.uint64))
+            universe = np.unique((starts[:, None] + np.arange(3000, dtype=np.uint64)[None, :]).ravel())
+            streams = make_streams(rng, universe, S, rng.uniform(0.3, 0.9, S))
+        else:
+            universe = np.unique(rng.integers(0, 1 << 62, 20_000 + 15_000 * j, dtype=np.uint64))
+            streams = make_streams(rng, universe, S, rng.uniform(0.2, 0.8, S))
+        sets.append(K.StreamSet(streams))
+        want.append(streams)
+    tot = np.zeros(S, dtype=np.uint64)
+    for streams in want:
+        tot += np.array([int(t[1].sum(dtype=np.uint64)) for t in streams], dtype=np.uint64)
+    model = K.PoissonLikelihood(nc, S - nc, tot[:nc], tot[nc:], 10000)
+    thr = 1e-6
+    single = []
+    for ss in sets:
+        acc = K.SurvivorAccumulator(1 << 18)
+        rows = K.merge_filter(ss, K.diff_observer(model, acc, thr)) if ss.total else 0
+        n = acc.finish(by_kmer=True)
+        single.append((rows, n, acc.get(), [int(x) for x in acc.read_counters()[:4]]))
+    accs = [K.SurvivorAccumulator(1 << 18) for _ in sets]
+    rows_b = K.merge_filter_batch(sets, [K.diff_observer(model, a, thr) for a in accs])
+    assert sum(s[1] for s in single) > 200
+    for j, a in enumerate(accs):
+        n = a.finish(by_kmer=True)
+        got = a.get()
+        assert rows_b[j] == single[j][0] and n == single[j][1], j
+        assert [int(x) for x in a.read_counters()[:4]] == single[j][3], j
+        for key in ("kmer_lo", "pvalue", "sign", "mean_control", "mean_case"):
+            assert got[key].tolist() == single[j][2][key].tolist(), (j, key)
+    # one sink for all of them
+    shared = K.SurvivorAccumulator(1 << 21)
+    obs = K.diff_observer(model, shared, thr)
+    rows_s = K.merge_filter_batch(sets, [obs] * len(sets))
+    n = shared.finish(by_kmer=True)
+    assert rows_s == rows_b and n == sum(s[1] for s in single)
+    assert [int(x) for x in shared.read_counters()[:4]] == [sum(s[3][i] for s in single) for i in range(4)]
+    assert sorted(shared.get()["kmer_lo"].tolist()) == sorted(k for s in single for k in s[2]["kmer_lo"].tolist())
+    # bad input in one partition: the batch says so, the others are done all the same
+    bad = K.StreamSet([(np.array([5, 3], dtype=np.uint64), np.array([1, 1], dtype=np.uint32))] + [(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * (S - 1))
+    bad.offs = bad.offs.copy(); bad.offs[1] = 3; bad.offs[2:] = 2                      # offsets not ascending
+    acc2 = [K.SurvivorAccumulator(1 << 18) for _ in range(3)]
+    with pytest.raises(K.KmdError):
+        K.merge_filter_batch([sets[0], bad, sets[1]], [K.diff_observer(model, a, thr) for a in acc2])
+    assert acc2[0].finish(by_kmer=True) == single[0][1] and acc2[2].finish(by_kmer=True) == single[1][1]
+
+
 @pytest.mark.parametrize("env", [{"KMD_TILE_CAND_CAP": "500"}, {"KMD_TILE_FILL": "60000", "KMD_TILE_LOAD_PCT": "50"},
                                  {"KMD_TILE_G": "3"}, {"KMD_TILE_SUM64": "1"}, {"KMD_TILE_SHAPE": "1024x4096"}])
 def test_merge_filter_forced_paths(K, oracle, env):
