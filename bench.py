@@ -22,7 +22,8 @@ The JSON line also carries
   pipeline     : (N = 1) the kmtricks-side input of the same path: one partition's per-sample k-mer
                  streams resident in HBM -> survivors (kmd_merge_filter: k-way merge fused with the test),
                  12 algorithmic bytes per record, HIP events around back-to-back calls; `overlapped` = the same
-                 with six partitions in flight on streams (and host threads) of their own, per partition;
+                 with six partitions in flight on streams (and host threads) of their own, per partition; `batched` =
+                 twelve partitions through kmd_merge_filter_batch (one host thread, six in flight inside the library);
   h2d_inclusive: (N = 1) the headline step with the host-to-device copy of the partition (from page-locked
                  memory) inside the timed loop -- never `value`.
 """
@@ -181,7 +182,31 @@ def pipeline_leg(K, lib, rows=4_000_000, iters=6):
     overlapped = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "kmers_per_s": rows / (ms_o * 1e-3),
                   "records_per_s": ss.total / (ms_o * 1e-3),
                   "roofline": {"bound": "hbm", "achieved": gbs_o, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_o / HBM_PEAK_GBS}}
-    return {"overlapped": overlapped,
+    # the same through ONE host thread: kmd_merge_filter_batch keeps six partitions in flight on streams of the
+    # library's own and waits once per partition (12 partitions = 12 copies of the streams in HBM)
+    n_batch = 12
+    sets = [ss] + [K.StreamSet(streams) for _ in range(n_batch - 1)]
+    accs = [K.SurvivorAccumulator(max(1 << 16, rows // 100)) for _ in range(n_batch)]
+    obs_b = [K.diff_observer(model, a_, THRESHOLD / CUTOFF, NC, NK) for a_ in accs]
+    K.merge_filter_batch(sets, obs_b)                      # untimed: scratch of six concurrent partitions, streams
+    for a_ in accs:
+        a_.counters.zero()
+    K._native.check(lib.kmd_stream_sync(None))
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rows_b = K.merge_filter_batch(sets, obs_b)
+    ms_b = (time.perf_counter() - t0) / (reps * n_batch) * 1e3
+    assert rows_b == [rows] * n_batch
+    for a_ in accs:
+        cb = a_.read_counters()
+        assert int(cb[0]) == reps * rows and int(cb[1]) == reps * (int(c[1]) // iters), (int(cb[0]), int(cb[1]))
+    gbs_b = 12.0 * ss.total / (ms_b * 1e-3) / 1e9
+    batched = {"partitions": n_batch, "in_flight": 6, "ms_per_partition": ms_b, "kmers_per_s": rows / (ms_b * 1e-3),
+               "records_per_s": ss.total / (ms_b * 1e-3), "what": "kmd_merge_filter_batch, one host thread",
+               "roofline": {"bound": "hbm", "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_b / HBM_PEAK_GBS}}
+    del sets, accs, obs_b
+    return {"overlapped": overlapped, "batched": batched,
             "what": "one partition's per-sample k-mer streams resident in HBM -> survivors (kmd_merge_filter: k-way merge "
                     "fused with the Poisson test; tile plan + boundary search + merge kernel + candidate evaluation, host "
                     "round trip included)",

@@ -335,10 +335,12 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict_
   const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, s_part);
   if (blockIdx.x == 0 && threadIdx.x == 0) { *plan = pl; *list_len = list_len0; }     // (candidates mode: the workgroups' first chunks are spoken for)
   const uint32_t nb = pl.nb, r = pl.r;
+  // (consecutive threads: consecutive boundaries of ONE stream -- their answers lie a tile's run apart, on the same
+  // pages: the searches are bound by the address translations they miss)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ((size_t)nb + 1) * S) return;
-  const size_t j = i / S;
-  const uint32_t s = (uint32_t)(i - j * S);
+  const uint32_t s = (uint32_t)(i / ((size_t)nb + 1));
+  const size_t j = i - (size_t)s * ((size_t)nb + 1);
   const size_t begin = offs[s], end = offs[s + 1];
   size_t pos;
   if (j == 0) pos = begin;
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict_
     const size_t at = offs[L] + j * r;
     pos = s == L ? at : lower_bound_indexed(keys, keys_hi, X, s, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
   }
-  start[i] = (uint32_t)pos;
+  start[j * S + s] = (uint32_t)pos;
 }
 
 // A listed tile becomes m equal slices of the key range its records really span: rows first ..
