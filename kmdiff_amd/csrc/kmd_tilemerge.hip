@@ -337,20 +337,23 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict_
   const uint32_t nb = pl.nb, r = pl.r;
   // (consecutive threads: consecutive boundaries of ONE stream -- their answers lie a tile's run apart, on the same
   // pages: the searches are bound by the address translations they miss)
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ((size_t)nb + 1) * S) return;
-  const uint32_t s = (uint32_t)(i / ((size_t)nb + 1));
-  const size_t j = i - (size_t)s * ((size_t)nb + 1);
-  const size_t begin = offs[s], end = offs[s + 1];
-  size_t pos;
-  if (j == 0) pos = begin;
-  else if (j >= nb) pos = end;
-  else
+  // (a grid of a fixed modest size strides over the cells: how many there are is known here, not on the host, whose
+  // upper bound -- every record a row of its own -- is two orders of magnitude too many with 200 samples)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((size_t)nb + 1) * S; i += (size_t)gridDim.x * blockDim.x)
   {
-    const size_t at = offs[L] + j * r;
-    pos = s == L ? at : lower_bound_indexed(keys, keys_hi, X, s, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
+    const uint32_t s = (uint32_t)(i / ((size_t)nb + 1));
+    const size_t j = i - (size_t)s * ((size_t)nb + 1);
+    const size_t begin = offs[s], end = offs[s + 1];
+    size_t pos;
+    if (j == 0) pos = begin;
+    else if (j >= nb) pos = end;
+    else
+    {
+      const size_t at = offs[L] + j * r;
+      pos = s == L ? at : lower_bound_indexed(keys, keys_hi, X, s, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
+    }
+    start[j * S + s] = (uint32_t)pos;
   }
-  start[j * S + s] = (uint32_t)pos;
 }
 
 // A listed tile becomes m equal slices of the key range its records really span: rows first ..
@@ -437,11 +440,11 @@ constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 template <uint32_t kSlots, int kWaves, bool kTwo, bool kSum32>
 struct tile_lds
 {
-  // kSlots of the main table, kSlots / 8 of the second table behind it (whole-wave path: where the ~1 % of the k-mers
+  // kSlots of the main table, kSlots / 16 of the second table behind it (whole-wave path: where the ~1 % of the k-mers
   // go that find their four home slots taken), and a spare slot behind every array (+ 2 / + 4) -- where the
   // whole-wave path lets lanes that have nothing to add add it: its key is 0, never the empty marker, and nothing
   // reads its sums
-  static constexpr uint32_t kAll = kSlots + kSlots / 8;
+  static constexpr uint32_t kAll = kSlots + kSlots / 16;
   unsigned long long key[kAll + 2];
   unsigned long long sc[kSum32 ? 2 : kAll + 2];
   unsigned long long sk[kSum32 ? 2 : kAll + 2];
@@ -491,7 +494,7 @@ k_tile_sums(const tile_job J)
   constexpr uint32_t kMask = kSlots - 1;
   constexpr int kShift = 32 - ilog2_c(kSlots);
   constexpr int kWaves = kThreads / 64;
-  constexpr uint32_t kSec = kSlots / 8, kAll = kSlots + kSec;   // second table (whole-wave path), all slots
+  constexpr uint32_t kSec = kSlots / 16, kAll = kSlots + kSec;   // second table (whole-wave path), all slots
   constexpr int kWalk = (int)((kAll + kThreads - 1) / kThreads);   // table slots per thread in the walk
   constexpr int kU = KMD_TILE_U;                         // records per lane and round
   constexpr int kDepth = KMD_TILE_DEPTH;                 // rounds in flight per wave
@@ -1799,7 +1802,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
                        (uint64_t)n, d_mult);
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
-    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
+    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
                        grid_hint, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0));
     KMD_HIP(hipGetLastError());
