@@ -234,6 +234,21 @@ def test_cli_partitions_sharded_over_gpus(synth_run, tmp_path):
         assert open(tmp_path / "b" / name, "rb").read() == ref and open(tmp_path / "c" / name, "rb").read() == ref, name
 
 
+def test_cli_partitions_on_two_real_gpus(synth_run, tmp_path):
+    """The same on a box that HAS two GPUs (skipped on the one-GPU test box): the workers are not folded, partition p
+    really runs on GPU p mod 2; byte-identical outputs."""
+    import kmdiff_amd as K
+    if K.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    run_dir, nc, nk, k, mats, kms = synth_run
+    common = ["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "-c", "benjamini", "--keep-tmp", "--pop-correction", "--kmer-pca", 0.05]
+    a, _ = run_cli(common + ["--devices", 1], tmp_path / "a")
+    b, err = run_cli(common + ["--devices", 2], tmp_path / "b")
+    assert a == b and a["n_sig"] > 10 and "folded" not in err
+    for name in ("control_kmers.fasta", "case_kmers.fasta", "popstrat/pcs.evec", "partitions/p0_uncorrected", "partitions/p1_popstrat_uncorrected"):
+        assert open(tmp_path / "b" / name, "rb").read() == open(tmp_path / "a" / name, "rb").read(), name
+
+
 def test_cli_cmodel_plugin_row_loop(synth_run, tmp_path):
     """--cmodel / --config (cli.cpp:246-262, model_manager.hpp:33-94): a user's IModel plugin is
     loaded with dlopen and called row by row on the host, like the reference; here the plugin is this
