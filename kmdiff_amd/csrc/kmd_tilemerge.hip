@@ -136,6 +136,7 @@ struct tile_job
   // further chunks come from it.  Entries of a chunk that stay unused are marked as holes (sum_c = kHole).
   unsigned long long first_base;
   uint32_t n_regions;
+  uint32_t* ran;                                 // set by the instantiation that takes the plan's way (a launch that did not is known by it)
   uint32_t* over_n;                              // tiles listed
   uint32_t* over;                                // [i] tile, [over_stride + i] its records (| kAbortBit)
   uint32_t over_stride;
@@ -513,6 +514,7 @@ k_tile_sums(const tile_job J)
   // streaming a tile (kWide: whole waves per run, g_shift 6; else sub-groups of lanes) the plan did
   // not choose returns at once
   if ((g_shift == 6) != kWide) return;
+  if (blockIdx.x == 0 && tid == 0) *J.ran = 1u;
   // segment tables of the current and the next tile, behind the fixed part: [2][begin[S] | length[S]]
   uint32_t* const s_seg = reinterpret_cast<uint32_t*>(s_raw + (sizeof(lds_t) + 7) / 8);
 
@@ -1737,10 +1739,14 @@ using level0_hook = std::function<int(const uint64_t* d_live, const uint32_t* d_
 struct merge_async
 {
   scratch_set sc;
-  std::vector<uint64_t> h_up;
-  char* h_small = nullptr;                         // 64 page-locked bytes
+  char* h_small = nullptr;                         // 64 page-locked bytes: the read-back
+  uint64_t* h_up = nullptr;                        // page-locked staging of the upload (offsets, index offsets), kUpWords words
+  int way = -1;                                    // -1: launch both instantiations (the plan picks one on the device); 1 / 0: only
+                                                   // the whole-wave / sub-group one -- a guess (the batch's earlier partitions): the
+                                                   // read-back says whether it was taken (bytes 60..63)
   explicit merge_async(hipStream_t st) : sc(st) {}
 };
+constexpr size_t kUpWords = (size_t)kMaxStreams + 1 + ((size_t)kMaxStreams + 2) / 2;
 int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi, const uint32_t* d_counts,
                const uint64_t* offsets, const filter_params* pf, uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out,
                uint64_t* d_sum_c, uint64_t* d_sum_k, size_t row_capacity, uint64_t* n_entries, uint64_t totals[2], hipStream_t st,
@@ -1778,20 +1784,22 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   tile_plan* d_plan = static_cast<tile_plan*>(p_small);
   unsigned long long* d_rows = reinterpret_cast<unsigned long long*>(static_cast<char*>(p_small) + 32);
   uint32_t* d_over_n = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 56);
+  uint32_t* d_ran = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 60);
   uint32_t* d_mult = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 64);
   // [offsets (S + 1) x u64 | index offsets (S + 1) x u32]: one upload
   std::vector<uint64_t> h_up_own;
-  std::vector<uint64_t>& h_up = async ? async->h_up : h_up_own;
-  h_up.assign((size_t)S + 1 + ((size_t)S + 2) / 2, 0);
-  std::memcpy(h_up.data(), offsets, ((size_t)S + 1) * 8);
-  uint32_t* h_ioff = reinterpret_cast<uint32_t*>(h_up.data() + S + 1);
+  const size_t up_words = (size_t)S + 1 + ((size_t)S + 2) / 2;
+  if (!async) h_up_own.assign(up_words, 0);
+  uint64_t* const h_up = async ? async->h_up : h_up_own.data();
+  std::memcpy(h_up, offsets, ((size_t)S + 1) * 8);
+  uint32_t* h_ioff = reinterpret_cast<uint32_t*>(h_up + S + 1);
   h_ioff[0] = 0;
   for (int s = 0; s < S; ++s) h_ioff[s + 1] = h_ioff[s] + index_samples(offsets[s + 1] - offsets[s]);
   const uint32_t n_index = h_ioff[S];
   void *p_idx = nullptr, *p_idx_hi = nullptr;
   KMD_HIP(sc.take(&p_idx, (size_t)n_index * 8));
   if (two) KMD_HIP(sc.take(&p_idx_hi, (size_t)n_index * 8));
-  KMD_HIP(hipMemcpyAsync(p_offs, h_up.data(), h_up.size() * 8, hipMemcpyHostToDevice, st));
+  KMD_HIP(hipMemcpyAsync(p_offs, h_up, up_words * 8, hipMemcpyHostToDevice, st));
   KMD_HIP(hipMemsetAsync(p_small, 0, 64 + (size_t)kProbes * 4, st));
   const uint64_t* d_offs = static_cast<const uint64_t*>(p_offs);
   const uint32_t* d_ioff = reinterpret_cast<const uint32_t*>(d_offs + S + 1);
@@ -1819,6 +1827,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   J.n_rows = d_rows;
   J.row_total = d_rows + 1;
   J.first_base = 0; J.n_regions = regions_max;
+  J.ran = d_ran;
   if (pf) { J.dTc = pf->dTc; J.dTk = pf->dTk; J.dTcTk = pf->dTcTk; J.pf_cut = pf->pf_cut; J.lf_n = pf->lf_n; }
 
   auto launch = [&](auto kernel, int threads, size_t lds_fixed, uint32_t tiles_at_most) -> int
@@ -1855,6 +1864,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
       {
         if (J.n_tiles && (J.g_shift == 6) != (wide_ == 1)) continue;          // way known on the host: launch that one only
         if (!J.n_tiles && wide_ == 0 && wide_for_sure) continue;
+        if (!J.n_tiles && async && async->way >= 0 && async->way != wide_) continue;          // (a guess: see merge_async)
         const unsigned sel = (fused ? 8u : 0u) | (two ? 4u : 0u) | (wide_ ? 2u : 0u) | (sum32 ? 1u : 0u);
         switch (sel)
         {
@@ -2059,10 +2069,11 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
 // nothing of its first run has reached the caller's counters or sink.
 namespace {
 constexpr int kBatchStreams = 6;
+constexpr size_t kBatchSlotBytes = 64 + kUpWords * 8;      // page-locked, per stream: [read-back | upload staging]
 struct batch_streams
 {
   hipStream_t st[kBatchStreams] = {};
-  char* h_small = nullptr;                         // kBatchStreams x 64 page-locked bytes
+  char* h_small = nullptr;                         // kBatchStreams x kBatchSlotBytes page-locked bytes
   hipEvent_t ev = nullptr;
 };
 std::mutex g_batch_mu;
@@ -2078,7 +2089,7 @@ int batch_get(batch_streams** out)
   {
     for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipStreamCreateWithFlags(&B.st[i], hipStreamNonBlocking));
     void* p = nullptr;
-    KMD_HIP(hipHostMalloc(&p, (size_t)kBatchStreams * 64, hipHostMallocDefault));
+    KMD_HIP(hipHostMalloc(&p, (size_t)kBatchStreams * kBatchSlotBytes, hipHostMallocDefault));
     B.h_small = static_cast<char*>(p);
     KMD_HIP(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
   }
@@ -2110,6 +2121,12 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
   struct in_flight { int part = -1; std::unique_ptr<merge_async> A; size_t cap = 0; void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr; };
   in_flight F[kBatchStreams];
   int first_error = KMD_OK;
+  // Which instantiation of the merge kernel a partition's plan takes -- whole waves per run, or sub-groups of lanes --
+  // is decided on the device, so a single call launches both and one leaves at once.  Among kernels of other
+  // partitions that empty launch still has to wait for its turn on the CUs (60 us in the kernel trace of a batch)
+  // with the rest of its stream behind it: once a partition of the batch has come back, the others launch only the
+  // way its plan took -- the read-back says whether that was right, and the synchronous way stands behind it.
+  int known_way = -1;
   // the synchronous way, for the partitions the fast way could not finish
   auto redo = [&](int p) -> int
   {
@@ -2124,11 +2141,14 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     f.part = -1;
     KMD_HIP(hipStreamSynchronize(B->st[slot]));
     f.A->sc.drained = true;
-    const char* h = B->h_small + (size_t)slot * 64;
+    const char* h = B->h_small + (size_t)slot * kBatchSlotBytes;
     unsigned long long rows3[3];
     std::memcpy(rows3, h + 32, sizeof rows3);
-    const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h + 56);
-    const bool ok = n_over == 0 && rows3[0] <= f.cap;
+    const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h + 56), ran = *reinterpret_cast<const uint32_t*>(h + 60);
+    tile_plan pl;
+    std::memcpy(&pl, h, sizeof pl);
+    if (ran) known_way = pl.g_shift == 6 ? 1 : 0;                // the way the plan of a partition of this job took
+    const bool ok = ran != 0 && n_over == 0 && rows3[0] <= f.cap;
     f.A.reset();                                                  // the scratch goes back to the cache
     if (ok) { if (n_rows_out) n_rows_out[p] = rows3[1]; return KMD_OK; }
     return redo(p);
@@ -2154,7 +2174,9 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     hipStream_t st = B->st[slot];
     in_flight& f = F[slot];
     f.A.reset(new merge_async(st));
-    f.A->h_small = B->h_small + (size_t)slot * 64;
+    f.A->h_small = B->h_small + (size_t)slot * kBatchSlotBytes;
+    f.A->h_up = reinterpret_cast<uint64_t*>(f.A->h_small + 64);
+    f.A->way = known_way;
     kmd_tile t { d_counts[p], 4, KMD_LAYOUT_SOA, n, nullptr, nullptr, n, 0 };
     filter_params P;
     rc = kmd::fill_filter_params(P, m, &t, threshold);
