@@ -120,6 +120,7 @@ struct tile_job
   const uint8_t* todo;                           // NULL: every tile; else only tiles with todo[r] != 0
   const tile_plan* plan;                         // n_tiles / g_shift when n_tiles == 0 (level 0: decided on the device)
   uint32_t S, nc, n_tiles, g_shift, xcd_order;
+  uint32_t force_wide;                           // level 0: whole waves per run whatever the plan's lanes per run (few samples: runs of >= 16 records)
   // rows as (k-mer, control sum, case sum) triples instead of the test (kmd_merge_sums)
   uint64_t* kmer_out;
   uint64_t* kmer_hi_out;
@@ -187,9 +188,11 @@ __device__ __forceinline__ size_t index_pos(size_t begin, uint64_t n, uint32_t i
 
 // one thread per sample: idx[ioff[s] + i] = key at the i-th sample position of stream s (ioff on the host: prefix of index_samples)
 __global__ void __launch_bounds__(256) k_tile_index(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi, const uint64_t* __restrict__ offs,
-                                                    const uint32_t* __restrict__ ioff, uint32_t S, uint64_t* __restrict__ idx, uint64_t* __restrict__ idx_hi)
+                                                    const uint32_t* __restrict__ ioff, uint32_t S, uint64_t* __restrict__ idx, uint64_t* __restrict__ idx_hi,
+                                                    uint32_t* __restrict__ zero, uint32_t zero_words)
 {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < zero_words) zero[t] = 0u;                            // (the call's small block of counters: no memset of its own)
   if (t >= ioff[S]) return;
   uint32_t lo = 0, hi = S;                                     // stream of sample t: the last s with ioff[s] <= t
   while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ioff[mid] <= t) lo = mid; else hi = mid; }
@@ -509,7 +512,7 @@ k_tile_sums(const tile_job J)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t S = J.S;
   const uint32_t n_tiles = J.n_tiles ? J.n_tiles : J.plan->nb;
-  const uint32_t g_shift = J.n_tiles ? J.g_shift : J.plan->g_shift;
+  const uint32_t g_shift = J.n_tiles ? J.g_shift : J.force_wide ? 6u : J.plan->g_shift;
   // two instantiations, both launched at level 0 where the plan is on the device: the one whose way of
   // streaming a tile (kWide: whole waves per run, g_shift 6; else sub-groups of lanes) the plan did
   // not choose returns at once
@@ -1800,13 +1803,13 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   KMD_HIP(sc.take(&p_idx, (size_t)n_index * 8));
   if (two) KMD_HIP(sc.take(&p_idx_hi, (size_t)n_index * 8));
   KMD_HIP(hipMemcpyAsync(p_offs, h_up, up_words * 8, hipMemcpyHostToDevice, st));
-  KMD_HIP(hipMemsetAsync(p_small, 0, 64 + (size_t)kProbes * 4, st));
   const uint64_t* d_offs = static_cast<const uint64_t*>(p_offs);
   const uint32_t* d_ioff = reinterpret_cast<const uint32_t*>(d_offs + S + 1);
   const stream_index X { static_cast<const uint64_t*>(p_idx), static_cast<const uint64_t*>(p_idx_hi), d_ioff };
   {
-    hipLaunchKernelGGL(k_tile_index, dim3((n_index + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, d_ioff, (uint32_t)S,
-                       static_cast<uint64_t*>(p_idx), static_cast<uint64_t*>(p_idx_hi));
+    constexpr uint32_t kZeroWords = 16 + kProbes;                     // p_small: 64 bytes + the probe's counts
+    hipLaunchKernelGGL(k_tile_index, dim3((std::max(n_index, kZeroWords) + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, d_ioff, (uint32_t)S,
+                       static_cast<uint64_t*>(p_idx), static_cast<uint64_t*>(p_idx_hi), static_cast<uint32_t*>(p_small), kZeroWords);
     hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
                        (uint64_t)n, d_mult);
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
@@ -1828,6 +1831,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   J.row_total = d_rows + 1;
   J.first_base = 0; J.n_regions = regions_max;
   J.ran = d_ran;
+  J.force_wide = 0;
   if (pf) { J.dTc = pf->dTc; J.dTk = pf->dTk; J.dTcTk = pf->dTcTk; J.pf_cut = pf->pf_cut; J.lf_n = pf->lf_n; }
 
   auto launch = [&](auto kernel, int threads, size_t lds_fixed, uint32_t tiles_at_most) -> int
@@ -1849,8 +1853,11 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   };
   // level 0: which way of streaming a tile the plan takes is decided on the device -- except that with few
   // samples every plan takes whole waves per run (a tile holds >= load x slots records, a run >= that / S)
+  // (up to 64 samples a run holds >= 16 records: the whole-wave path, which takes runs of any length, is the faster
+  // one there whatever the plan would say -- and the launch of an instantiation that only leaves again is saved)
   const bool wide_for_sure = !env_u32("KMD_TILE_FILL", 0) && !env_u32("KMD_TILE_G", 0) &&
-                             (double)std::max(64.0f, load * (float)sh.slots) / (double)S * 0.75 > 32.0;
+                             (double)std::max(64.0f, load * (float)sh.slots) / (double)S >= 16.0;
+  J.force_wide = wide_for_sure ? 1u : 0u;
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
   auto run = [&](uint32_t tiles_at_most) -> int
   {
@@ -1864,7 +1871,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
       {
         if (J.n_tiles && (J.g_shift == 6) != (wide_ == 1)) continue;          // way known on the host: launch that one only
         if (!J.n_tiles && wide_ == 0 && wide_for_sure) continue;
-        if (!J.n_tiles && async && async->way >= 0 && async->way != wide_) continue;          // (a guess: see merge_async)
+        if (!J.n_tiles && !wide_for_sure && async && async->way >= 0 && async->way != wide_) continue;          // (a guess: see merge_async)
         const unsigned sel = (fused ? 8u : 0u) | (two ? 4u : 0u) | (wide_ ? 2u : 0u) | (sum32 ? 1u : 0u);
         switch (sel)
         {
