@@ -461,88 +461,12 @@ __global__ void __launch_bounds__(kBlock, KMD_MINWAVES) k_filter_soa(const filte
 }
 
 // ---- row-major layout: counts[row][sample] -------------------------------------------------
-// What km::MatrixReader / KmerMerger hand the observer (merge.hpp:68,194-203).  A workgroup
-// copies a tile of kRowsBlock rows x one column chunk into LDS with coalesced loads (16 bytes
-// per lane when the pitch allows), re-pitched to an odd dword stride so that the per-lane
-// row walk is bank-conflict free; each lane then sums its own row out of LDS.
+// What km::MatrixReader / KmerMerger hand the observer (merge.hpp:68,194-203): k_filter_rows_wave / _wide (rows whose
+// pitch and base are 16-byte aligned), k_filter_rows_flat (any other pitch up to 8 KB) and k_filter_rows_direct (the
+// rest: every lane walks its own row) below.  (Rounds 1-2 also kept a workgroup-tile kernel with barriers and dword
+// loads, k_filter_rows<CT, VEC>, for what the flat kernel does not take -- 1.1-1.4 TB/s; those cases, a base pointer
+// that is not 16-byte aligned or an unaligned pitch over 8 KB, now go to the direct kernel.)
 constexpr int kRowsBlock = 256;
-
-template <typename CT, int VEC>
-__global__ void __launch_bounds__(kRowsBlock) k_filter_rows(const filter_params P, const uint32_t pitch_dw,
-                                                            const uint32_t chunk_dw)
-{
-  extern __shared__ double2 s_all[];
-  double2* s_lf = s_all;
-  uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_all + P.lds_n);
-  stage_table(P, s_lf);
-  uint32_t n_beyond = 0;       // rows of this lane with a count sum beyond the table
-
-  const uint32_t S = (uint32_t)(P.nc + P.nk);
-  constexpr uint32_t per = 4 / sizeof(CT);                      // counts per dword
-  constexpr uint32_t emask = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
-  const uint32_t row_dw = (S + per - 1) / per;                  // dwords spanned by one row
-  const size_t ld_dw = P.ld / per;                              // row pitch in dwords (exact)
-  const uint32_t* __restrict__ base = static_cast<const uint32_t*>(P.counts);
-  const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
-
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
-
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
-  {
-    const size_t row0 = tile * kRowsBlock;
-    const uint32_t rows_here = (uint32_t)((P.n_rows - row0) < (size_t)kRowsBlock ? (P.n_rows - row0) : kRowsBlock);
-    uint64_t sc = 0, sk = 0;
-    for (uint32_t c0 = 0; c0 < row_dw; c0 += chunk_dw)
-    {
-      const uint32_t cw = (row_dw - c0) < chunk_dw ? (row_dw - c0) : chunk_dw;
-      __syncthreads();                                          // previous chunk consumed
-      if constexpr (VEC == 4)
-      {
-        const uint32_t cw4 = cw >> 2;                           // cw % 4 == 0 by construction
-        const uint32_t n = rows_here * cw4;
-        for (uint32_t i = threadIdx.x; i < n; i += kRowsBlock)
-        {
-          const uint32_t r = i / cw4, c = (i - r * cw4) << 2;
-          const uint4 v = *reinterpret_cast<const uint4*>(base + (row0 + r) * ld_dw + c0 + c);
-          uint32_t* d = s_tile + r * pitch_dw + c;
-          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-      }
-      else
-      {
-        const uint32_t n = rows_here * cw;
-        for (uint32_t i = threadIdx.x; i < n; i += kRowsBlock)
-        {
-          const uint32_t r = i / cw, c = i - r * cw;
-          s_tile[r * pitch_dw + c] = base[(row0 + r) * ld_dw + c0 + c];
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x < rows_here)
-      {
-        const uint32_t* __restrict__ mine = s_tile + threadIdx.x * pitch_dw;
-        uint32_t el = c0 * per;
-        for (uint32_t d = 0; d < cw; ++d)
-        {
-          const uint32_t w = mine[d];
-#pragma unroll
-          for (uint32_t e = 0; e < per; ++e, ++el)
-          {
-            const uint32_t v = (per == 1) ? w : ((w >> (8 * sizeof(CT) * e)) & emask);
-            if (el < (uint32_t)P.nc) sc += v; else if (el < S) sk += v;
-          }
-        }
-      }
-    }
-    row_state st;
-    st.row = row0 + threadIdx.x;
-    st.valid = threadIdx.x < rows_here;
-    st.sum_c = sc; st.sum_k = sk;
-    finish_row(P, s_lf, st, n_beyond);
-  }
-  flush_beyond(P, n_beyond);
-}
 
 // ---- rows given by their two sums (the fused merge, kmd_merge_sums) ---------------------------
 // One lane per row: 16 bytes in, straight into the pre-filter and the deferred-evaluation queue.
@@ -1328,11 +1252,9 @@ int allow_big_lds(K kernel, size_t lds_bytes)
 template <typename CT>
 int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
 {
-  constexpr uint32_t per = 4 / sizeof(CT);
   const uint32_t S = (uint32_t)(P.nc + P.nk);
   const size_t half = m->lds_per_block_max / 2 - 256;
   const size_t n_tiles = (P.n_rows + kRowsBlock - 1) / kRowsBlock;
-  const bool dword_rows = (P.ld % per == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 3u) == 0);
   // pitch not a multiple of 16 bytes (21v21 four-byte counts: 168 B): the flat wave-private kernel,
   // with the most rows per span (64, 32, ... 2) that fit its tile (4 KB; 8 or 16 KB for very wide rows)
   // and keep spans 16-byte aligned
@@ -1367,25 +1289,10 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
     if (const uint32_t R = rows_per_span(8192)) return launch(k_filter_rows_flat<CT, 8, 768>, 8, 768, R);
     if (const uint32_t R = rows_per_span(16384)) return launch(k_filter_rows_flat<CT, 16, 512>, 16, 512, R);
   }
-  if (!dword_rows)
-  {
-    size_t want = (size_t)P.lf_n * sizeof(double2);
-    if (want > half) want = half / sizeof(double2) * sizeof(double2);
-    P.lds_n = (uint32_t)(want / sizeof(double2));
-    size_t grid = (size_t)m->n_cu * 4;
-    if (grid > n_tiles) grid = n_tiles;
-    int rc = allow_big_lds(k_filter_rows_direct<CT>, want);
-    if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_rows_direct<CT>), dim3((unsigned)grid), dim3(kRowsBlock), want, stream, P);
-    KMD_HIP(hipGetLastError());
-    return KMD_OK;
-  }
-  const uint32_t row_dw = (S + per - 1) / per;
-  const size_t ld_dw = P.ld / per;
   // 16-byte aligned rows: the wave-private kernel (a row's last vector may reach into the
   // padding up to the pitch, never past it)
   const bool vec_rows = ((P.ld * sizeof(CT)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);
-  if (vec_rows && std::getenv("KMD_ROWS_KERNEL_OLD") == nullptr)
+  if (vec_rows)
   {
     const uint32_t row_vecs = (uint32_t)(((size_t)S * sizeof(CT) + 15) / 16);
     auto launch = [&](auto kernel, int cv_max, int block, bool defer) -> int
@@ -1447,30 +1354,17 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
       return KMD_OK;
     }
   }
-  const bool vec4 = (row_dw % 4 == 0) && (ld_dw % 4 == 0) &&
-                    ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0);
-  // column chunk: whole rows when they fit in ~48 KiB of LDS, else 44-dword chunks
-  uint32_t chunk_dw = row_dw <= 47 ? row_dw : 44;
-  const uint32_t pitch = chunk_dw | 1u;                 // odd dword pitch: conflict-free walk
-  const size_t tile_bytes = (size_t)kRowsBlock * pitch * 4;
-  size_t want = (size_t)P.lf_n * sizeof(double2);
-  const size_t avail = half - tile_bytes;
-  if (want > avail) want = avail / sizeof(double2) * sizeof(double2);
-  P.lds_n = (uint32_t)(want / sizeof(double2));
-  const size_t lds = want + tile_bytes;
-  size_t grid = (size_t)m->n_cu * 2;
-  if (grid > n_tiles) grid = n_tiles;
-  if (vec4)
+  // everything else -- a base pointer that is not 16-byte aligned, a pitch that is not a whole number of dwords or an
+  // unaligned one beyond the flat kernel's tiles: each lane walks its own row
   {
-    int rc = allow_big_lds(k_filter_rows<CT, 4>, lds);
+    size_t want = (size_t)P.lf_n * sizeof(double2);
+    if (want > half) want = half / sizeof(double2) * sizeof(double2);
+    P.lds_n = (uint32_t)(want / sizeof(double2));
+    size_t grid = (size_t)m->n_cu * 4;
+    if (grid > n_tiles) grid = n_tiles;
+    int rc = allow_big_lds(k_filter_rows_direct<CT>, want);
     if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_rows<CT, 4>), dim3((unsigned)grid), dim3(kRowsBlock), lds, stream, P, pitch, chunk_dw);
-  }
-  else
-  {
-    int rc = allow_big_lds(k_filter_rows<CT, 1>, lds);
-    if (rc != KMD_OK) return rc;
-    hipLaunchKernelGGL((k_filter_rows<CT, 1>), dim3((unsigned)grid), dim3(kRowsBlock), lds, stream, P, pitch, chunk_dw);
+    hipLaunchKernelGGL((k_filter_rows_direct<CT>), dim3((unsigned)grid), dim3(kRowsBlock), want, stream, P);
   }
   KMD_HIP(hipGetLastError());
   return KMD_OK;
