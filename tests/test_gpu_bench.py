@@ -34,6 +34,12 @@ def test_bench_single_gpu_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert d["rccl_ranks"] == 1 and d["per_rank"]["ms_per_step_max"] == d["ms_per_step"]
+    pl = d["pipeline"]
+    for leg in (pl, pl["overlapped"], pl["batched"]):
+        rf = leg["roofline"]
+        assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert pl["batched"]["partitions"] == 12 and pl["batched"]["ms_per_partition"] <= pl["ms"] * 1.05
 
 
 @pytest.mark.parametrize("correction", ["bonferroni", "benjamini", "holm"])
