@@ -7,29 +7,33 @@
 // counts and the sum of its case counts (include/kmdiff/model.hpp:144-145).
 //
 // Shape of the work (HBM-bound: 12 bytes per record are read once, nothing else is large):
+//   * k_tile_index: every stream's every 4096th key -- the index all boundary searches start from (lower_bound_indexed);
 //   * k_tile_probe: how many records make a row here?  512 records drawn uniformly, the number m of
 //     streams holding each one's k-mer; mean(1/m) = distinct k-mers / records (unbiased).  The plan --
 //     records per tile such that a tile's distinct k-mers fill half of the hash table, the splitter
 //     stride, lanes per run -- stays on the device: no host round trip before the main kernel;
-//   * the key range of the partition is cut into TILES by splitters taken from the data (every r-th key
-//     of the longest stream); where each stream enters each tile: every 64th boundary by a search over
-//     the stream, the 63 in between inside the short window those enclose (k_tile_coarse/_fine);
+//   * k_tile_bounds: the key range of the partition is cut into TILES by splitters taken from the data (every
+//     r-th key of the longest stream); where each stream enters each tile: one indexed search per (tile, stream);
 //   * k_tile_sums: one WORKGROUP per tile on a persistent grid.  A tile is S contiguous runs of records,
-//     one per stream.  A wave takes whole runs, 64 records a round (one per lane) through a buffer
-//     descriptor of the run, 8 rounds in flight (kWide; for runs shorter than a wave: sub-groups of G
-//     lanes per run).  Every record goes into a workgroup-wide LDS hash set keyed by the k-mer -- two
-//     home buckets of two slots, both read in the first step, a compare-and-swap only to claim an empty
-//     slot -- and adds its count to that k-mer's control or case sum (64-bit LDS add);
+//     one per stream; its records are split evenly among the waves, a wave streams its share 64 records a
+//     round (one per lane) through a buffer descriptor of the run, 4 rounds in flight, the loads issued and
+//     waited for by hand (kWide; for runs of a handful of records: sub-groups of G lanes per run, the older
+//     code).  Every record goes into a workgroup-wide LDS hash set keyed by the k-mer -- two home buckets of
+//     two slots, both read in the first step; a compare-and-swap only to claim an empty slot; a small second
+//     table for the k-mers that find all four taken -- and adds its count to that k-mer's control or case sum;
 //   * after one barrier the table IS the tile's rows: every thread walks a few slots, a live slot goes
 //     through the chi-square pre-filter; the ~1 % that pass leave as (k-mer, control sum, case sum) for
-//     a list in HBM (one global atomic per tile).  k_filter_candidates (kmd_filter.hip; kmd_eval.h, the
-//     code K1 runs) evaluates the list exactly -- likelihood ratio, tail function, compaction into the
-//     survivor sink.  It is enqueued right behind this kernel, gated on the device (below);
+//     a list in HBM that is handed out in chunks (no global atomic per tile; holes are marked).
+//     k_filter_candidates (kmd_filter.hip; kmd_eval.h, the code K1 runs) evaluates the list exactly --
+//     likelihood ratio, tail function, compaction into the survivor sink.  It is enqueued right behind this
+//     kernel, gated on the device (below);
 //   * a tile whose k-mers do not fit the table (fewer records per row there than the plan assumed, or
 //     keys clustered where the longest stream has none) notices by a probe sequence that does not end,
 //     gives up and is listed; the host cuts the listed tiles into equal slices of the key range their
 //     records really span and runs the kernel again on those -- repeated until nothing is listed (every
-//     level divides a tile's key span).
+//     level divides a tile's key span);
+//   * kmd_merge_filter_batch: several partitions in flight on streams of the library's own, everything of a
+//     partition enqueued without a host round trip (tile_merge, async).
 // Two-limb k-mers (32 < k <= 64): the same kernel keyed by the low limb, see k_tile_sums.
 #include "kmd_internal.h"
 #include "kmd_math.h"
@@ -439,8 +443,8 @@ __global__ void __launch_bounds__(256) k_tile_refine(const uint64_t* __restrict_
 constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 
 // LDS of one workgroup, carved from the dynamic allocation (the segment tables follow it)
-// kSum32: a slot's two sums are 32-bit halves of one word (16 bytes per slot with the key: four workgroups per CU
-// instead of three, half the bytes per atomic add); kmd_tilemerge keeps 64-bit sums for the tiles that need them.
+// kSum32: a slot's two sums are 32-bit (16 bytes per slot with the key: four workgroups per CU instead of three,
+// half the bytes per atomic add); kmd_tilemerge keeps 64-bit sums for the tiles that need them.
 template <uint32_t kSlots, int kWaves, bool kTwo, bool kSum32>
 struct tile_lds
 {
@@ -467,10 +471,12 @@ struct tile_lds
   uint32_t wcnt[kWaves];
 };
 
-// One workgroup per tile on a persistent grid.  Per tile:
-//   [inserts] barrier [segment table of the NEXT tile | walk of the table = rows of this tile: count the
-//   rows that leave] barrier [one workgroup-wide reservation in the output] barrier [write them, wipe the
-//   slots] barrier.
+// One workgroup per tile on a persistent grid.  Per tile, candidates mode (kFilter):
+//   [inserts; wave 0: the rows the previous tile parked -> the list] barrier [segment table of the NEXT tile |
+//   walk of the table = rows of this tile: the rows that leave are parked in LDS, every slot is wiped] barrier
+// -- both barriers wait for LDS only -- and rows mode (kmd_merge_sums: every row leaves, compact output):
+//   [inserts] barrier [segment table | walk: count the rows] barrier [one workgroup-wide reservation in the output]
+//   barrier [write them, wipe the slots] barrier.
 // Tile order: each XCD (workgroup b runs on XCD b % 8) takes one contiguous eighth of the tiles and its
 // workgroups stride through it, so tiles that share cache lines at the ends of their runs meet in one L2.
 //
@@ -480,7 +486,7 @@ struct tile_lds
 // host cuts it.  (The sub-group path, !kWide, also counts the slots its waves claim and gives up past
 // 3/4 full; the whole-wave path dropped the count: it cost more than the tiles it saved.)
 //
-// kSum32: a slot's control and case sums are the 32-bit halves of one word.  1024 samples of counts below
+// kSum32: a slot's control and case sums are 32-bit (arrays of their own).  1024 samples of counts below
 // 2^22 cannot overflow them; a record with a larger count flags the tile, which is listed like one that
 // gave up and redone by the 64-bit instantiation.
 //
@@ -742,27 +748,6 @@ k_tile_sums(const tile_job J)
             off += kStep;
             if (off >= rl) { off = 0; ++j; }
           };
-          // One round into the table.  A k-mer's probe sequence: the two slots of its home bucket 0, the two of its
-          // home bucket 1, then a slot of the small second table behind the first (another hash) and on from there;
-          // slots are never released within a tile, so a k-mer is never behind an empty slot and the first slot of
-          // the sequence that holds it OR is empty is its place.  Three stages, cheapest first:
-          //   1. both buckets are read (two 16-byte LDS reads per record, four candidates).  A row has rho records
-          //      and only the first claims a slot: for most records one of the four IS the k-mer -- four compares,
-          //      four selects, done;
-          //   2. the lanes left (a few per round: first records of their rows, and the records of the ~1 % of the k-mers
-          //      that found their four home slots taken) swap on the first empty candidate -- or, if none is empty, on
-          //      their slot of the second table, which those few k-mers barely fill: the swap claims the slot or finds
-          //      the k-mer there;
-          //   3. what is left -- a claim lost to another k-mer, two k-mers on one slot of the second table -- walks the
-          //      whole sequence slot by slot (once in a hundred rounds).  (Round 2 sent every record of a k-mer beyond
-          //      its home buckets down such a walk in the main table: three to four steps, in every second round -- a
-          //      quarter of the kernel's instructions.)
-          // A lane's state is ONE number, the byte offset of its slot in key[] (kNone: not placed yet).  kNone is the
-          // offset of a spare slot behind the tables: a lane that has nothing to add (no record, a tile that gave up)
-          // adds its count there -- no lane mask around the adds, no masks kept across the stages.
-          // kThere / kMarker: whether lanes without a record / the all-ones k-mer have to be looked for.  In the
-          // middle of a run every lane holds a record and none is the all-ones k-mer (a run ascends: only its last
-          // record can be).
           // (all slot numbers below are LDS byte addresses: of a key in M.key; >> 1 or as they are, plus a constant, of its sums)
           typedef __attribute__((address_space(3))) unsigned long long lds_u64;
           typedef __attribute__((address_space(3))) uint32_t lds_u32;
