@@ -226,8 +226,10 @@ int fill_filter_params(eval::filter_params& P, const kmd_model* m, const kmd_til
 // when the device has no memory pools.  begin: before the filter kernel (fills P.near); end: right after it.
 int near_list_begin(eval::filter_params& P, hipStream_t stream);
 int near_list_end(const eval::filter_params& P, int row_mode, hipStream_t stream);
+// (d_work: filter_candidates_work_bytes(cap, m) bytes of device scratch, cap >= the list's entries)
+size_t filter_candidates_work_bytes(size_t cap, const kmd_model* m);
 int launch_filter_candidates(const eval::filter_params& P, const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_kmer_hi,
                              const uint64_t* d_sum_c, const uint64_t* d_sum_k, size_t n, uint64_t rows_total, uint64_t rows_beyond,
-                             hipStream_t stream, const uint64_t* d_gate = nullptr, const uint32_t* d_gate_over = nullptr,
-                             size_t gate_cap = 0);
+                             void* d_work, size_t cap, hipStream_t stream, const uint64_t* d_gate = nullptr,
+                             const uint32_t* d_gate_over = nullptr, size_t gate_cap = 0);
 }

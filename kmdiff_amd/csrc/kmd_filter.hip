@@ -502,126 +502,185 @@ __global__ void __launch_bounds__(kBlock) k_filter_sums(const filter_params P, c
 }
 
 // ---- candidate rows of the fused merge (kmd_tilemerge.hip): a device-resident list of rows that passed the
-// pre-filter.  Unlike the rows K1 sees, a good part of these are survivors -- on data where k-mers are rare
-// and sample-specific, millions per partition -- and one atomic per counter and 64-row step on the same
-// four addresses then IS the kernel's time (measured: 4.6 ms for 36 M rows).  So a wave parks its survivors
-// in an LDS staging area of its own and sends ~200 of them off at a time: one atomic on the sink's cursor,
-// consecutive records written by consecutive lanes; the other counters stay in registers until the wave
-// is done.
-constexpr int kCandBlock = 256;
-constexpr uint32_t kCandStage = 256;                     // staged survivors per wave (flushed at >= 192: room for 64 more)
-
-// `gate` (may be NULL): the launch was enqueued BEHIND the merge that fills the list, before the host knew how
+// pre-filter.  Unlike the rows K1 sees, a good part of these are survivors -- on data where k-mers are rare and
+// sample-specific, millions per partition -- and the sink's cursor is ONE address: a returning atomic on it costs
+// ~22 ns, one after the other, from wherever on the chip it comes (measured: a wave that parked ~200 survivors in
+// LDS per atomic still spent 0.44 ms on 1.7 M survivors -- 17 000 atomics and nothing else; its arithmetic, a
+// continued fraction in double precision per row, would fit in 0.15).  So there is no atomic per anything here:
+//   k_cand_eval  evaluates the list -- wave g of W takes entries [64 (r W + g), +64), r = 0, 1, ... -- and leaves
+//                p_bits[i] per entry (all ones: nothing to emit; else the p-value, its sign bit set if the row is
+//                within 1e-8 of the threshold, kmd_eval.h) and four counts per wave;
+//   k_cand_scan  (one workgroup) turns the waves' survivor counts into sink offsets -- ONE fetch-add on the sink's
+//                cursor per partition -- and adds the totals to the counters;
+//   k_cand_emit  walks the list the same way and writes the survivors' records: wave g's land at its offset, in
+//                list order.
+// `gate` (may be NULL): the launches were enqueued BEHIND the merge that fills the list, before the host knew how
 // the merge went -- gate[0..2] = entries, distinct k-mers, rows beyond the table as the merge left them on the
-// device, *gate_over = tiles it could not finish.  If any tile is unfinished or the list overflowed, the kernel
-// does nothing at all (the host then goes the long way and launches it again without a gate).
-__global__ void __launch_bounds__(kCandBlock) k_filter_candidates(const filter_params P, const unsigned long long* __restrict__ sum_c,
-                                                                  const unsigned long long* __restrict__ sum_k,
-                                                                  unsigned long long rows_total, unsigned long long rows_beyond,
-                                                                  const unsigned long long* __restrict__ gate,
-                                                                  const uint32_t* __restrict__ gate_over, unsigned long long gate_cap)
+// device, *gate_over = tiles it could not finish.  If any tile is unfinished or the list overflowed, the kernels
+// do nothing at all (the host then goes the long way and launches them again without a gate).
+constexpr int kCandBlock = 256;
+constexpr unsigned long long kCandNone = ~0ull;
+struct cand_counts { uint32_t surv, cand, near, ctrl; };
+
+__device__ __forceinline__ bool cand_gate(const unsigned long long* __restrict__ gate, const uint32_t* __restrict__ gate_over,
+                                          unsigned long long gate_cap, size_t& n_rows)
+{
+  if (!gate) return true;
+  if (*gate_over != 0 || gate[0] > gate_cap) return false;
+  n_rows = (size_t)gate[0];
+  return true;
+}
+
+__global__ void __launch_bounds__(kCandBlock) k_cand_eval(const filter_params P, const unsigned long long* __restrict__ sum_c,
+                                                          const unsigned long long* __restrict__ sum_k,
+                                                          const unsigned long long* __restrict__ gate, const uint32_t* __restrict__ gate_over,
+                                                          unsigned long long gate_cap, unsigned long long* __restrict__ p_bits,
+                                                          cand_counts* __restrict__ wave_counts)
 {
   size_t n_rows = P.n_rows;
-  if (gate)
-  {
-    if (*gate_over != 0 || gate[0] > gate_cap) return;
-    n_rows = (size_t)gate[0]; rows_total = gate[1]; rows_beyond = gate[2];
-  }
-  __shared__ unsigned long long s_row[kCandBlock / 64][kCandStage];
-  __shared__ double s_p[kCandBlock / 64][kCandStage], s_mc[kCandBlock / 64][kCandStage], s_mk[kCandBlock / 64][kCandStage];
-  __shared__ int s_sign[kCandBlock / 64][kCandStage];
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    if (rows_total) atomicAdd(&P.counters[KMD_CNT_TOTAL], rows_total);                    // merge.hpp:76
-    if (rows_beyond) atomicAdd(&P.counters[KMD_CNT_DEFERRED], rows_beyond);
-  }
-  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t staged = 0, n_cand = 0, n_near = 0, n_ctrl = 0, n_case = 0;                    // wave-uniform
-  auto flush = [&]()
-  {
-    if (staged == 0) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&P.counters[KMD_CNT_SIG], (unsigned long long)staged);   // merge.hpp:101
-    base = __shfl(base, 0, 64);
-    for (uint32_t t = lane; t < staged; t += 64)
-    {
-      const unsigned long long slot = base + t;
-      if (slot < P.out.capacity)
-      {
-        const unsigned long long row = s_row[w][t];
-        if (P.out.d_row) P.out.d_row[slot] = P.kmer_lo[row];
-        if (P.out.d_kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[row];
-        if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[row];
-        if (P.out.d_pvalue) P.out.d_pvalue[slot] = s_p[w][t];
-        if (P.out.d_sign) P.out.d_sign[slot] = s_sign[w][t];
-        if (P.out.d_mean_control) P.out.d_mean_control[slot] = s_mc[w][t];
-        if (P.out.d_mean_case) P.out.d_mean_case[slot] = s_mk[w][t];
-      }
-    }
-    staged = 0;
-    queue_fence();
-  };
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t n_round = (n_rows + stride - 1) / stride * stride;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
+  if (!cand_gate(gate, gate_over, gate_cap, n_rows)) return;
+  const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * (kCandBlock / 64) + (threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * kCandBlock;
+  uint32_t n_surv = 0, n_cand = 0, n_near = 0, n_ctrl = 0;                                // wave-uniform
+  // (the next step's sums are on their way while this step's rows are evaluated)
+  size_t i = (size_t)g * 64 + lane;
+  unsigned long long nx_c = i < n_rows ? sum_c[i] : kCandNone, nx_k = i < n_rows ? sum_k[i] : 0ull;
+  for (size_t i0 = (size_t)g * 64; i0 < n_rows; i0 += stride, i += stride)
   {
     row_state st;
     st.row = i;
-    st.valid = i < n_rows;
-    st.sum_c = st.valid ? sum_c[i] : 0ull;
-    st.valid = st.valid && st.sum_c != ~0ull;             // (a hole of the list: the fused merge hands its list out in chunks, kmd_tilemerge.hip)
-    st.sum_c = st.valid ? st.sum_c : 0ull;
-    st.sum_k = st.valid ? sum_k[i] : 0ull;
+    st.valid = nx_c != kCandNone;                         // (a hole of the list: the fused merge hands its list out in chunks, kmd_tilemerge.hip; or beyond its end)
+    st.sum_c = st.valid ? nx_c : 0ull;
+    st.sum_k = st.valid ? nx_k : 0ull;
+    {
+      const size_t j = i + stride;
+      nx_c = j < n_rows ? sum_c[j] : kCandNone; nx_k = j < n_rows ? sum_k[j] : 0ull;
+    }
     const row_result R = evaluate_core(P, nullptr, st);
+    unsigned long long bits = kCandNone;
+    if (R.cand && (R.surv || R.near)) bits = (unsigned long long)__double_as_longlong(R.p) | (R.near ? 1ull << 63 : 0ull);
+    if (i < n_rows) p_bits[i] = bits;
     const unsigned long long cm = __ballot(R.cand);
     if (!cm) continue;
-    const unsigned long long sm = __ballot(R.surv);
     n_cand += (uint32_t)__popcll(cm);
-    const unsigned long long nm = __ballot(R.near);
-    if (nm)
-    {
-      // a row on the threshold (never, in practice): its sink slot must be known now -- what is staged goes
-      // out first, then this step's survivors, then the list entry
-      n_near += (uint32_t)__popcll(nm);
-      flush();
-      unsigned long long base = 0;
-      if (lane == 0 && sm) base = atomicAdd(&P.counters[KMD_CNT_SIG], (unsigned long long)__popcll(sm));
-      base = __shfl(base, 0, 64);
-      const unsigned long long slot = base + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
-      if (R.surv && slot < P.out.capacity)
-      {
-        if (P.out.d_row) P.out.d_row[slot] = P.kmer_lo[i];
-        if (P.out.d_kmer_lo) P.out.d_kmer_lo[slot] = P.kmer_lo[i];
-        if (P.out.d_kmer_hi && P.kmer_hi) P.out.d_kmer_hi[slot] = P.kmer_hi[i];
-        if (P.out.d_pvalue) P.out.d_pvalue[slot] = R.p;
-        if (P.out.d_sign) P.out.d_sign[slot] = R.sign;
-        if (P.out.d_mean_control) P.out.d_mean_control[slot] = R.mean_control;
-        if (P.out.d_mean_case) P.out.d_mean_case[slot] = (double)st.sum_k;
-      }
-      if (R.near) note_near_row(P, st, R.surv ? (long long)slot : -1ll);
-      const uint32_t nctl2 = (uint32_t)__popcll(__ballot(R.surv && R.sign == KMD_SIGN_CONTROL));
-      n_ctrl += nctl2; n_case += (uint32_t)__popcll(sm) - nctl2;
-      continue;
-    }
-    if (!sm) continue;
-    const uint32_t nctl = (uint32_t)__popcll(__ballot(R.surv && R.sign == KMD_SIGN_CONTROL));
-    n_ctrl += nctl; n_case += (uint32_t)__popcll(sm) - nctl;                             // merge.hpp:95-98
-    if (R.surv)
-    {
-      const uint32_t at = staged + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-      s_row[w][at] = i; s_p[w][at] = R.p; s_sign[w][at] = R.sign; s_mc[w][at] = R.mean_control; s_mk[w][at] = (double)st.sum_k;
-    }
-    staged += (uint32_t)__popcll(sm);
-    queue_fence();
-    if (staged >= kCandStage - 64) flush();
+    n_near += (uint32_t)__popcll(__ballot(R.near));
+    n_surv += (uint32_t)__popcll(__ballot(R.surv));                                        // merge.hpp:78
+    n_ctrl += (uint32_t)__popcll(__ballot(R.surv && R.sign == KMD_SIGN_CONTROL));          // merge.hpp:95-98
   }
-  flush();
+  if (lane == 0) { cand_counts c; c.surv = n_surv; c.cand = n_cand; c.near = n_near; c.ctrl = n_ctrl; wave_counts[g] = c; }
+}
+
+// one workgroup: wave_off[g] = the sink slot of wave g's first survivor
+__global__ void __launch_bounds__(1024) k_cand_scan(const filter_params P, unsigned long long rows_total, unsigned long long rows_beyond,
+                                                    const unsigned long long* __restrict__ gate, const uint32_t* __restrict__ gate_over,
+                                                    unsigned long long gate_cap, const cand_counts* __restrict__ wave_counts, uint32_t n_waves,
+                                                    unsigned long long* __restrict__ wave_off)
+{
+  size_t n_rows = P.n_rows;
+  if (!cand_gate(gate, gate_over, gate_cap, n_rows)) return;
+  if (gate) { rows_total = gate[1]; rows_beyond = gate[2]; }
+  __shared__ unsigned long long s_wave[16];              // the scan's waves: survivors (then their exclusive prefix)
+  __shared__ unsigned long long s_tot[3];
+  __shared__ unsigned long long s_base;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t per = (n_waves + 1023u) / 1024u, first = threadIdx.x * per;
+  unsigned long long surv = 0, cand = 0, near = 0, ctrl = 0;
+  for (uint32_t g = first; g < first + per && g < n_waves; ++g)
+  {
+    const cand_counts c = wave_counts[g];
+    surv += c.surv; cand += c.cand; near += c.near; ctrl += c.ctrl;
+  }
+  if (threadIdx.x < 3) s_tot[threadIdx.x] = 0;
+  unsigned long long incl = surv;                        // inclusive scan within the wave
+  for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+  for (int o = 32; o > 0; o >>= 1) { cand += __shfl_down(cand, o, 64); near += __shfl_down(near, o, 64); ctrl += __shfl_down(ctrl, o, 64); }
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
   if (lane == 0)
   {
-    if (n_cand) atomicAdd(&P.counters[KMD_CNT_CANDIDATES], (unsigned long long)n_cand);
-    if (n_near) atomicAdd(&P.counters[KMD_CNT_NEAR_THRESHOLD], (unsigned long long)n_near);
-    if (n_ctrl) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], (unsigned long long)n_ctrl);
-    if (n_case) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], (unsigned long long)n_case);
+    if (cand) atomicAdd(&s_tot[0], cand);
+    if (near) atomicAdd(&s_tot[1], near);
+    if (ctrl) atomicAdd(&s_tot[2], ctrl);
+  }
+  if (threadIdx.x == 0)
+  {
+    unsigned long long total = 0;
+    for (int k = 0; k < 16; ++k) { const unsigned long long v = s_wave[k]; s_wave[k] = total; total += v; }
+    s_base = total ? atomicAdd(&P.counters[KMD_CNT_SIG], total) : 0ull;                   // merge.hpp:101
+    if (rows_total) atomicAdd(&P.counters[KMD_CNT_TOTAL], rows_total);                    // merge.hpp:76
+    if (rows_beyond) atomicAdd(&P.counters[KMD_CNT_DEFERRED], rows_beyond);
+  }
+  __syncthreads();
+  unsigned long long at = s_base + s_wave[w] + incl - surv;
+  for (uint32_t g = first; g < first + per && g < n_waves; ++g) { wave_off[g] = at; at += wave_counts[g].surv; }
+  if (threadIdx.x == 1023)
+  {
+    const unsigned long long total = s_wave[15] + incl;  // the last thread's inclusive sum closes the scan
+    if (s_tot[0]) atomicAdd(&P.counters[KMD_CNT_CANDIDATES], s_tot[0]);
+    if (s_tot[1]) atomicAdd(&P.counters[KMD_CNT_NEAR_THRESHOLD], s_tot[1]);
+    if (s_tot[2]) atomicAdd(&P.counters[KMD_CNT_SIG_CONTROL], s_tot[2]);
+    if (total - s_tot[2]) atomicAdd(&P.counters[KMD_CNT_SIG_CASE], total - s_tot[2]);     // merge.hpp:95-98
+  }
+}
+
+__global__ void __launch_bounds__(kCandBlock) k_cand_emit(const filter_params P, const unsigned long long* __restrict__ sum_c,
+                                                          const unsigned long long* __restrict__ sum_k,
+                                                          const unsigned long long* __restrict__ gate, const uint32_t* __restrict__ gate_over,
+                                                          unsigned long long gate_cap, const unsigned long long* __restrict__ p_bits,
+                                                          const unsigned long long* __restrict__ wave_off)
+{
+  size_t n_rows = P.n_rows;
+  if (!cand_gate(gate, gate_over, gate_cap, n_rows)) return;
+  // (the sink's arrays and the list do not overlap -- said here, with __restrict__, because the compiler cannot know)
+  const uint64_t* __restrict__ const in_lo = P.kmer_lo;
+  const uint64_t* __restrict__ const in_hi = P.kmer_hi;
+  uint64_t* __restrict__ const o_row = P.out.d_row;
+  uint64_t* __restrict__ const o_lo = P.out.d_kmer_lo;
+  uint64_t* __restrict__ const o_hi = P.kmer_hi ? P.out.d_kmer_hi : nullptr;
+  double* __restrict__ const o_p = P.out.d_pvalue;
+  int32_t* __restrict__ const o_sign = P.out.d_sign;
+  double* __restrict__ const o_mc = P.out.d_mean_control;
+  double* __restrict__ const o_mk = P.out.d_mean_case;
+  const unsigned long long o_cap = P.out.capacity;
+  const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * (kCandBlock / 64) + (threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * kCandBlock;
+  unsigned long long at = wave_off[g];                                                    // wave-uniform
+  size_t i = (size_t)g * 64 + lane;
+  unsigned long long nx = i < n_rows ? p_bits[i] : kCandNone;
+  for (size_t i0 = (size_t)g * 64; i0 < n_rows; i0 += stride, i += stride)
+  {
+    const unsigned long long bits = nx;
+    { const size_t j = i + stride; nx = j < n_rows ? p_bits[j] : kCandNone; }
+    const bool has = bits != kCandNone;
+    if (!__ballot(has)) continue;
+    const bool near = has && (bits >> 63) != 0;
+    const double p = __longlong_as_double((long long)(bits & ~(1ull << 63)));
+    const bool surv = has && p <= P.threshold;                                            // merge.hpp:78
+    const unsigned long long sm = __ballot(surv);
+    const unsigned long long slot = at + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
+    at += (unsigned long long)__popcll(sm);
+    if (has)
+    {
+      const unsigned long long sc = sum_c[i], sk = sum_k[i];
+      if (surv && slot < o_cap)
+      {
+        const uint64_t klo = in_lo[i], khi = o_hi ? in_hi[i] : 0ull;
+        double mean_control; int sign;
+        kmd::sign_of(sc, sk, P.dTc, P.dTk, mean_control, sign);
+        if (o_row) o_row[slot] = klo;
+        if (o_lo) o_lo[slot] = klo;
+        if (o_hi) o_hi[slot] = khi;
+        if (o_p) o_p[slot] = p;
+        if (o_sign) o_sign[slot] = sign;
+        if (o_mc) o_mc[slot] = mean_control;
+        if (o_mk) o_mk[slot] = (double)sk;
+      }
+      if (near)
+      {
+        row_state st; st.row = i; st.valid = true; st.sum_c = sc; st.sum_k = sk;
+        note_near_row(P, st, surv ? (long long)slot : -1ll);
+      }
+    }
   }
 }
 
@@ -1651,22 +1710,38 @@ int kmd::near_list_end(const filter_params& P, int row_mode, hipStream_t stream)
   return KMD_OK;
 }
 
+// device scratch the three kernels need for a list of up to `cap` entries: [p_bits: cap x 8][per wave: offset 8 + counts 16]
+static uint32_t cand_waves(const kmd_model* m) { return (uint32_t)m->n_cu * 4u * (kCandBlock / 64); }
+size_t kmd::filter_candidates_work_bytes(size_t cap, const kmd_model* m)
+{
+  return cap * 8 + (size_t)cand_waves(m) * (8 + sizeof(cand_counts));
+}
+
 int kmd::launch_filter_candidates(const filter_params& P_in, const kmd_model* m, const uint64_t* d_kmer, const uint64_t* d_kmer_hi,
                                   const uint64_t* d_sum_c, const uint64_t* d_sum_k, size_t n, uint64_t rows_total, uint64_t rows_beyond,
-                                  hipStream_t stream, const uint64_t* d_gate, const uint32_t* d_gate_over, size_t gate_cap)
+                                  void* d_work, size_t cap, hipStream_t stream, const uint64_t* d_gate, const uint32_t* d_gate_over, size_t gate_cap)
 {
   filter_params P = P_in;
   P.kmer_lo = d_kmer; P.kmer_hi = d_kmer_hi; P.row_base = 0; P.n_rows = n;
   P.lds_n = 0;                                            // the table is read for candidates only: from L2
-  // gated: the number of entries is on the device, the grid is the full one (idle workgroups leave at once)
-  size_t grid = d_gate ? (size_t)m->n_cu * 8 : std::min<size_t>((size_t)m->n_cu * 8, (n + kCandBlock - 1) / kCandBlock);
+  if ((d_gate ? gate_cap : n) > cap) { kmd::set_error("launch_filter_candidates: scratch smaller than the list"); return KMD_E_INVALID; }
+  // gated: the number of entries is on the device, the grid is the full one (idle waves leave at once)
+  const uint32_t waves_max = cand_waves(m);
+  size_t grid = d_gate ? (size_t)waves_max / (kCandBlock / 64) : std::min<size_t>((size_t)waves_max / (kCandBlock / 64), (n + kCandBlock - 1) / kCandBlock);
   if (grid < 1) grid = 1;
+  const uint32_t n_waves = (uint32_t)grid * (kCandBlock / 64);
+  unsigned long long* p_bits = static_cast<unsigned long long*>(d_work);
+  unsigned long long* wave_off = p_bits + cap;
+  cand_counts* wave_counts = reinterpret_cast<cand_counts*>(wave_off + waves_max);
+  const unsigned long long* sc = reinterpret_cast<const unsigned long long*>(d_sum_c);
+  const unsigned long long* sk = reinterpret_cast<const unsigned long long*>(d_sum_k);
+  const unsigned long long* gate = reinterpret_cast<const unsigned long long*>(d_gate);
   int rc = near_list_begin(P, stream);
   if (rc != KMD_OK) return rc;
-  hipLaunchKernelGGL(k_filter_candidates, dim3((unsigned)grid), dim3(kCandBlock), 0, stream, P,
-                     reinterpret_cast<const unsigned long long*>(d_sum_c), reinterpret_cast<const unsigned long long*>(d_sum_k),
-                     (unsigned long long)rows_total, (unsigned long long)rows_beyond,
-                     reinterpret_cast<const unsigned long long*>(d_gate), d_gate_over, (unsigned long long)gate_cap);
+  hipLaunchKernelGGL(k_cand_eval, dim3((unsigned)grid), dim3(kCandBlock), 0, stream, P, sc, sk, gate, d_gate_over, (unsigned long long)gate_cap, p_bits, wave_counts);
+  hipLaunchKernelGGL(k_cand_scan, dim3(1), dim3(1024), 0, stream, P, (unsigned long long)rows_total, (unsigned long long)rows_beyond, gate, d_gate_over,
+                     (unsigned long long)gate_cap, wave_counts, n_waves, wave_off);
+  hipLaunchKernelGGL(k_cand_emit, dim3((unsigned)grid), dim3(kCandBlock), 0, stream, P, sc, sk, gate, d_gate_over, (unsigned long long)gate_cap, p_bits, wave_off);
   KMD_HIP(hipGetLastError());
   return near_list_end(P, 1, stream);
 }

@@ -24,7 +24,7 @@
 //   * after one barrier the table IS the tile's rows: every thread walks a few slots, a live slot goes
 //     through the chi-square pre-filter; the ~1 % that pass leave as (k-mer, control sum, case sum) for
 //     a list in HBM that is handed out in chunks (no global atomic per tile; holes are marked).
-//     k_filter_candidates (kmd_filter.hip; kmd_eval.h, the code K1 runs) evaluates the list exactly --
+//     k_cand_eval / _scan / _emit (kmd_filter.hip; kmd_eval.h, the code K1 runs) evaluate the list exactly --
 //     likelihood ratio, tail function, compaction into the survivor sink.  It is enqueued right behind this
 //     kernel, gated on the device (below);
 //   * a tile whose k-mers do not fit the table (fewer records per row there than the plan assumed, or
@@ -134,8 +134,12 @@ struct tile_job
   unsigned long long* n_rows;                    // entries written: rows (kmd_merge_sums) or candidate rows (kmd_merge_filter)
   unsigned long long* row_total;                 // candidates mode: [0] distinct k-mers, [1] rows beyond the log-factorial table
   // candidates mode: what the chi-square pre-filter needs of the model (kmd_eval.h, row_may_pass)
-  double dTc, dTk, dTcTk, pf_cut;
+  double dTc, dTk, dTcTk, pf_cut, pf_rhs;        // (pf_rhs = pf_cut x dTcTk)
   uint32_t lf_n;
+  // ... and its second stage (row_may_pass_kl): control / case shares of the total, the candidate cut, the count
+  // sums it is applied below (0: off)
+  float kl_qc, kl_qk, kl_cut;
+  uint32_t kl_max;
   // candidates mode: the list is handed out in chunks of kOutChunk entries.  Workgroup b of a launch owns chunk
   // first_base / kOutChunk + b from the start (no atomic); *n_entries starts at first_base + n_regions x kOutChunk,
   // further chunks come from it.  Entries of a chunk that stay unused are marked as holes (sum_c = kHole).
@@ -146,6 +150,30 @@ struct tile_job
   uint32_t* over;                                // [i] tile, [over_stride + i] its records (| kAbortBit)
   uint32_t over_stride;
 };
+
+// The pre-filter's second stage, for the rows its chi-square bound lets through.  That bound (kmd_eval.h,
+// row_may_pass: LR <= (sc Tk - sk Tc)^2 / (n Tc Tk), passed from HALF the candidate cut) is tight where a row's
+// split is near the totals' and loose where it is one-sided: a k-mer seen in cases only passes from n = 7 counts
+// where the cut (12.6 at p = 5e-7) takes 18.  On data where k-mers are rare and sample-specific -- 3 records per
+// row, 36 M rows -- that is most of the list: 6.25 M entries for 1.67 M candidates, each costing the list's
+// evaluation two logarithms in double precision.  Here the likelihood ratio itself,
+//     LR = sc ln(sc / (n qc)) + sk ln(sk / (n qk)),  qc = Tc / T, qk = Tk / T
+// (the lf[k] and -lambda terms of model.hpp:152-156 cancel), in SINGLE precision with the hardware's reciprocal and
+// base-2 logarithm (1 ulp each): for count sums below 2^16 its error is below 5e-7 (sc + sk) + 2e-7 (|t_c| + |t_k|)
+// <= 0.07, ten times that is allowed for, and a row is dropped only if it stays below the candidate cut with it --
+// rows that pass are evaluated exactly as before (k_cand_eval, kmd_filter.hip), rows dropped were no candidates: every
+// exposed number is unchanged.  Sums at or beyond the log-factorial table (or 2^16) pass on the first stage alone.
+__device__ __forceinline__ bool row_may_pass_kl(const tile_job& J, unsigned long long sum_c, unsigned long long sum_k)
+{
+  if (sum_c >= J.kl_max || sum_k >= J.kl_max) return true;          // (also: stage off, kl_max = 0)
+  const float sc = (float)(uint32_t)sum_c, sk = (float)(uint32_t)sum_k, n = sc + sk;
+  const float lc = __builtin_amdgcn_logf(sc * __builtin_amdgcn_rcpf(n * J.kl_qc));
+  const float lk = __builtin_amdgcn_logf(sk * __builtin_amdgcn_rcpf(n * J.kl_qk));
+  const float tc = sum_c ? sc * lc : 0.0f, tk = sum_k ? sk * lk : 0.0f;        // (base 2)
+  const float lr = 0.69314718f * (tc + tk);
+  const float slack = 5e-6f * n + 2e-6f * (__builtin_fabsf(tc) + __builtin_fabsf(tk)) + 1e-3f;
+  return !(lr + slack < J.kl_cut);
+}
 
 __host__ __device__ inline uint64_t mix64(uint64_t x)
 {
@@ -1430,8 +1458,64 @@ k_tile_sums(const tile_job J)
           }
           return true;
         };
+        constexpr bool kFastWalk = kSum32 && !kTwo;
         uint64_t w_key[kWalk];
-        unsigned long long w_c[kWalk], w_k[kWalk];
+        unsigned long long w_c[kFastWalk ? 1 : kWalk], w_k[kFastWalk ? 1 : kWalk];       // (the fast walk's sums: c32 / k32)
+        [[maybe_unused]] uint32_t c32[kWalk], k32[kWalk];
+        auto sum_c_of = [&](int j) -> unsigned long long { if constexpr (kFastWalk) return c32[j]; else return w_c[j]; };
+        auto sum_k_of = [&](int j) -> unsigned long long { if constexpr (kFastWalk) return k32[j]; else return w_k[j]; };
+        if constexpr (kFastWalk)
+        {
+          // (one-limb k-mers, 32-bit sums -- the instantiation that matters: straight-line code.  All reads, all wipes
+          // -- of every slot, empty or not: a wipe under a lane mask costs what it costs without --, the chi-square
+          // bound of all slots without a branch, and only if a slot of the wave passes it, the second stage and the
+          // emission.  As the compiler wrote the general version below for this case, the walk was 390 vector + 230
+          // scalar instructions per wave, a fifth of them lane-mask algebra and re-reads of spilled scalars: on rows of
+          // 3 records, as long as the inserts.)
+#pragma unroll
+          for (int j = 0; j < kWalk; ++j)
+          {
+            const uint32_t i = tid + (uint32_t)j * kThreads;
+            const bool in = j + 1 < kWalk || i < kAll;                    // (the last step covers the end of the second table)
+            w_key[j] = in ? M.key[i] : kEmptyKey; c32[j] = in ? M.c32[i] : 0u; k32[j] = in ? M.k32[i] : 0u;
+          }
+#pragma unroll
+          for (int j = 0; j < kWalk; ++j)
+          {
+            const uint32_t i = tid + (uint32_t)j * kThreads;
+            if (j + 1 < kWalk || i < kAll) { M.key[i] = kEmptyKey; M.c32[i] = 0u; M.k32[i] = 0u; }
+          }
+          uint32_t pass = 0;
+          const uint32_t good = bad_tile ? 0u : 1u;
+#pragma unroll
+          for (int j = 0; j < kWalk; ++j)
+          {
+            // (bit operations, not && and ||: those became a branch each)
+            const uint32_t live = (w_key[j] != kEmptyKey ? 1u : 0u) & good;
+            rows_local += live;
+            n_beyond += live & ((c32[j] >= J.lf_n ? 1u : 0u) | (k32[j] >= J.lf_n ? 1u : 0u));
+            // (row_may_pass, kmd_eval.h, on sums that are exact in one conversion; pf_rhs = pf_cut Tc Tk from the host)
+            const double dsc = (double)c32[j], dsk = (double)k32[j];
+            const double a = dsc * J.dTk - dsk * J.dTc;
+            pass |= (live & (a * a < (dsc + dsk) * J.pf_rhs ? 0u : 1u)) << j;
+          }
+#if KMD_TILE_ABLATE & 4   // dev: no pre-filter evaluation, nothing leaves (results wrong)
+          pass = 0;
+#endif
+          // (the rows that leave -- one lane in forty has one, next to none has two: one copy of the second stage and
+          // of the emission, run for each lane's lowest pending slot until no lane has any)
+          while (ballot(pass != 0))
+          {
+            const int j = pass ? __builtin_ctz(pass) : 0;
+            uint64_t key = w_key[0]; uint32_t c = c32[0], k = k32[0];
+#pragma unroll
+            for (int t = 1; t < kWalk; ++t) if (j == t) { key = w_key[t]; c = c32[t]; k = k32[t]; }
+            if (pass && row_may_pass_kl(J, c, k) && !emit(key, 0ull, c, k)) late_bits |= 1u << j;
+            pass &= pass - 1u;
+          }
+        }
+        else
+        {
 #pragma unroll
         for (int j = 0; j < kWalk; ++j)
         {
@@ -1456,6 +1540,7 @@ k_tile_sums(const tile_job J)
           {
             row_state st; st.sum_c = w_c[j]; st.sum_k = w_k[j]; st.row = 0; st.valid = live;
             leaves = row_may_pass(J, st, n_beyond);
+            if (leaves) leaves = row_may_pass_kl(J, w_c[j], w_k[j]);
           }
 #endif
           rows_local += live && !bad_tile ? 1u : 0u;
@@ -1468,12 +1553,13 @@ k_tile_sums(const tile_job J)
             if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
           }
         }
+        }
         bool special_late = false;
         if (tid == 0 && M.hasmax && !bad_tile)             // the all-ones k-mer, if this tile had it
         {
           row_state st; st.sum_c = M.maxsum[0]; st.sum_k = M.maxsum[1]; st.row = 0; st.valid = true;
           ++rows_local;
-          if (row_may_pass(J, st, n_beyond)) special_late = !emit(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
+          if (row_may_pass(J, st, n_beyond) && row_may_pass_kl(J, st.sum_c, st.sum_k)) special_late = !emit(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
         }
 #if KMD_TILE_TIMING
         tp_walk1 = __builtin_readcyclecounter();
@@ -1508,7 +1594,7 @@ k_tile_sums(const tile_job J)
             if ((late_bits >> j) & 1u)
             {
               const uint32_t i = tid + (uint32_t)j * kThreads;
-              emit_late(w_key[j], kTwo ? M.key_hi[i] : 0ull, w_c[j], w_k[j]);
+              emit_late(w_key[j], kTwo ? M.key_hi[i] : 0ull, sum_c_of(j), sum_k_of(j));
               M.key[i] = kEmptyKey; wipe_sums(i);
               if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
             }
@@ -1717,7 +1803,7 @@ inline uint32_t env_u32(const char* name, uint32_t dflt)
 // Synchronous: the tiles that gave up are known only when the kernel has run.
 // `behind_level0` (may be empty): work the caller wants enqueued right behind the first pass, BEFORE the host
 // learns how that pass went -- it is given the device addresses of [entries, distinct k-mers, rows beyond the
-// table] and of the count of unfinished tiles, and must gate itself on them (k_filter_candidates does).
+// table] and of the count of unfinished tiles, and must gate itself on them (k_cand_eval / _scan / _emit do).
 // *clean = the first pass finished every tile (the gated work was live if the list did not overflow either).
 using level0_hook = std::function<int(const uint64_t* d_live, const uint32_t* d_over_n)>;
 // `async` (kmd_merge_filter_batch): the first pass and what the hook puts behind it are enqueued, the 64 bytes that
@@ -1817,7 +1903,17 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   J.first_base = 0; J.n_regions = regions_max;
   J.ran = d_ran;
   J.force_wide = 0;
-  if (pf) { J.dTc = pf->dTc; J.dTk = pf->dTk; J.dTcTk = pf->dTcTk; J.pf_cut = pf->pf_cut; J.lf_n = pf->lf_n; }
+  J.kl_max = 0; J.kl_qc = J.kl_qk = J.kl_cut = 0.0f;
+  if (pf)
+  {
+    J.dTc = pf->dTc; J.dTk = pf->dTk; J.dTcTk = pf->dTcTk; J.pf_cut = pf->pf_cut; J.pf_rhs = pf->pf_cut * pf->dTcTk; J.lf_n = pf->lf_n;
+    if (pf->pf_cut > -INFINITY && !std::getenv("KMD_PREFILTER_KL_OFF"))
+    {
+      J.kl_qc = (float)(pf->dTc / pf->dT); J.kl_qk = (float)(pf->dTk / pf->dT);
+      J.kl_cut = std::nextafterf((float)pf->lr_cut, -INFINITY);                 // (never above the cut)
+      J.kl_max = std::min<uint32_t>(pf->lf_n, 1u << 16);
+    }
+  }
 
   auto launch = [&](auto kernel, int threads, size_t lds_fixed, uint32_t tiles_at_most) -> int
   {
@@ -2013,11 +2109,12 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) cap = e;
   uint64_t entries = 0, totals[2] = { 0, 0 };
   scratch_set sc(st);
-  void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr;
+  void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr, *p_w = nullptr;
   for (int attempt = 0;; ++attempt)
   {
     KMD_HIP(sc.take(&p_k, cap * 8)); KMD_HIP(sc.take(&p_c, cap * 8)); KMD_HIP(sc.take(&p_s, cap * 8));
     if (two) KMD_HIP(sc.take(&p_h, cap * 8));
+    KMD_HIP(sc.take(&p_w, kmd::filter_candidates_work_bytes(cap, m)));          // (the exact evaluation's: p-values per entry, offsets per wave)
     // The exact evaluation of the list is enqueued right behind the first pass of the merge, gated on the device
     // by "every tile finished and the list did not overflow" (almost always): one host round trip per call.
     bool clean = false;
@@ -2025,12 +2122,13 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
     auto speculate = [&](const uint64_t* d_live, const uint32_t* d_over_n) -> int
     {
       return kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(p_k), static_cast<const uint64_t*>(p_h),
-                                           static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), 0, 0, 0, st,
+                                           static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), 0, 0, 0, p_w, cap_now, st,
                                            d_live, d_over_n, cap_now);
     };
     rc = tile_merge(n_samples, m->nc, d_kmers, d_kmers_hi, d_counts, offsets, &P, static_cast<uint64_t*>(p_k), static_cast<uint64_t*>(p_h),
                     static_cast<uint64_t*>(p_c), static_cast<uint64_t*>(p_s), cap, &entries, totals, st, speculate, &clean);
     if (rc != KMD_OK) return rc;
+    if (std::getenv("KMD_DEBUG")) std::fprintf(stderr, "[kmd_merge_filter] list: %llu entries of %zu (holes included), %llu rows\n", (unsigned long long)entries, cap, (unsigned long long)totals[0]);
     if (entries <= cap)
     {
       if (n_rows_out) *n_rows_out = totals[0];
@@ -2044,7 +2142,7 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   }
   // the long way (tiles were cut again after the first pass): the list is complete only now
   rc = kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(p_k), static_cast<const uint64_t*>(p_h),
-                                     static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), (size_t)entries, totals[0], totals[1], st);
+                                     static_cast<const uint64_t*>(p_c), static_cast<const uint64_t*>(p_s), (size_t)entries, totals[0], totals[1], p_w, cap, st);
   if (rc != KMD_OK) return rc;
   KMD_HIP(hipStreamSynchronize(st));                            // the scratch list goes back to the cache
   sc.drained = true;
@@ -2110,7 +2208,7 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
   KMD_HIP(hipEventRecord(B->ev, user));
   for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipStreamWaitEvent(B->st[i], B->ev, 0));
 
-  struct in_flight { int part = -1; std::unique_ptr<merge_async> A; size_t cap = 0; void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr; };
+  struct in_flight { int part = -1; std::unique_ptr<merge_async> A; size_t cap = 0; void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr, *p_w = nullptr; };
   in_flight F[kBatchStreams];
   int first_error = KMD_OK;
   // Which instantiation of the merge kernel a partition's plan takes -- whole waves per run, or sub-groups of lanes --
@@ -2182,12 +2280,13 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     if (he == hipSuccess) he = f.A->sc.take(&f.p_c, f.cap * 8);
     if (he == hipSuccess) he = f.A->sc.take(&f.p_s, f.cap * 8);
     if (he == hipSuccess && two) he = f.A->sc.take(&f.p_h, f.cap * 8);
+    if (he == hipSuccess) he = f.A->sc.take(&f.p_w, kmd::filter_candidates_work_bytes(f.cap, m));
     if (he != hipSuccess) { (void)hipGetLastError(); f.A.reset(); rc = redo(p); if (rc != KMD_OK && first_error == KMD_OK) first_error = rc; continue; }
     const size_t cap_now = f.cap;
     auto speculate = [&](const uint64_t* d_live, const uint32_t* d_over_n) -> int
     {
       return kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(f.p_k), static_cast<const uint64_t*>(f.p_h),
-                                           static_cast<const uint64_t*>(f.p_c), static_cast<const uint64_t*>(f.p_s), 0, 0, 0, st,
+                                           static_cast<const uint64_t*>(f.p_c), static_cast<const uint64_t*>(f.p_s), 0, 0, 0, f.p_w, cap_now, st,
                                            d_live, d_over_n, cap_now);
     };
     uint64_t entries = 0, totals[2] = { 0, 0 };

@@ -83,6 +83,26 @@ def test_merge_filter_equals_merge_then_diff(K, oracle, S, nc, presence):
     assert len(ref["row"]) > 20 or S <= 2
 
 
+@pytest.mark.parametrize("thr", [1e-2, 1e-4, 5e-7, 1e-12])
+@pytest.mark.parametrize("scale", [1, 3])
+def test_merge_filter_every_pair_of_small_sums(K, oracle, thr, scale):
+    """Every (control sum, case sum) in [0, 100)^2 is a row: the candidate cut of each threshold runs through the middle of
+    them, one-sided rows and balanced ones -- where the pre-filter's two stages (the chi-square bound in double precision,
+    the likelihood ratio in single precision, kmd_tilemerge.hip row_may_pass_kl) must let every candidate through."""
+    a, b = np.meshgrid(np.arange(100, dtype=np.uint32), np.arange(100, dtype=np.uint32), indexing="ij")
+    a, b = a.ravel()[1:], (b.ravel()[1:] * np.uint32(scale)).astype(np.uint32)
+    keys = np.sort(np.random.default_rng(99).choice(1 << 40, len(a), replace=False).astype(np.uint64))
+    streams = [(keys[a > 0], a[a > 0]), (keys[b > 0], b[b > 0])]
+    want, ref = run_fused(K, oracle, streams, 1, thr)
+    assert 50 < len(ref["row"]) < len(a) - 50
+    import os
+    os.environ["KMD_PREFILTER_KL_OFF"] = "1"                   # the same without the second stage: the same survivors
+    try:
+        run_fused(K, oracle, streams, 1, thr)
+    finally:
+        del os.environ["KMD_PREFILTER_KL_OFF"]
+
+
 @pytest.mark.parametrize("two", [False, True])
 def test_merge_filter_counts_too_large_for_32_bit_sums(K, oracle, two):
     """The table keeps a k-mer's two sums in 32 bits; a tile that meets a count of 2^22 or more (1024 samples of

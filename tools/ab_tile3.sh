@@ -22,7 +22,7 @@ for f in glob.glob('gpurun_out/ab_%s/**/*kernel_stats.csv' % tag, recursive=True
 out = []
 for r in rows:
     n = r['Name']
-    for key in ('k_tile_sums', 'k_tile_probe', 'k_tile_bounds', 'k_filter_candidates', 'k_resolve_near', 'k_tile_index', 'k_tile_refine'):
+    for key in ('k_tile_sums', 'k_tile_probe', 'k_tile_bounds', 'k_cand_eval', 'k_cand_scan', 'k_cand_emit', 'k_resolve_near', 'k_tile_index', 'k_tile_refine'):
         if key in n:
             short = key + ('<' + n.split('<')[1].split('>')[0] + '>' if key == 'k_tile_sums' else '')
             out.append('%s %sx %.1fus' % (short, r['Calls'], float(r['AverageNs']) / 1e3))

@@ -95,8 +95,8 @@ cf = acc.read_counters()
 sig_fused = int(cf[1])
 assert rows_f == int(cf[0]) and (a.fused_only or (rows_f == rows_matrix and sig_fused == sig_matrix)), (rows_f, rows_matrix, int(cf[0]), sig_fused, sig_matrix)
 bpr = 12 if a.limbs == 1 else 20
-print("pipeline keys=%s S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of %d B/record  sig=%d"
-      % (a.keys, S, n, rows_f, best_f * 1e3, rows_f / best_f, n / best_f, bpr * 1e-9 * n / best_f, bpr, sig_fused))
+print("pipeline keys=%s S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of %d B/record  sig=%d  candidates=%d"
+      % (a.keys, S, n, rows_f, best_f * 1e3, rows_f / best_f, n / best_f, bpr * 1e-9 * n / best_f, bpr, sig_fused, int(cf[4])))
 if a.overlap > 1:
     # partitions in flight on several streams: the boundary searches and the candidate evaluation of one call
     # run beside the merge kernel of another

@@ -1,11 +1,13 @@
 #!/bin/bash
 # dev tool (GPU box): SQ counters of the wide merge kernel for library variants, one block per variant.
-# usage: bash tools/pmc_ab.sh [-a "<kbench_pipeline args>"] build_sweep/a.so ...
+# usage: bash tools/pmc_ab.sh [-a "<kbench_pipeline args>"] [-k <kernel name substring>] build_sweep/a.so ...
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
 extra=""
 if [ "$1" = "-a" ]; then extra=$2; shift 2; fi
+kern=""
+if [ "$1" = "-k" ]; then kern=$2; shift 2; fi
 for lib in "$@"; do
   tag=$(basename $lib .so)
   i=0
@@ -16,16 +18,18 @@ for lib in "$@"; do
     rm -rf gpurun_out/pab_${tag}_$i
     KMD_LIB=$repo/$lib timeout 200 rocprofv3 --pmc $set -d gpurun_out/pab_${tag}_$i -o pmc --output-format csv -- python3 tools/kbench_pipeline.py --fused-only --iters 1 $extra > gpurun_out/pab_$tag.log 2>&1 < /dev/null
   done
-  python3 - "$tag" <<'PY'
+  python3 - "$tag" "$kern" <<'PY'
 import csv, glob, sys, collections
-tag = sys.argv[1]
+tag, kern = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob('gpurun_out/pab_%s_*/**/*counter_collection.csv' % tag, recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_tile_sums' not in r['Kernel_Name'] or 'true, false, true' not in r['Kernel_Name']: continue
+        if kern:
+            if kern not in r['Kernel_Name']: continue
+        elif 'k_tile_sums' not in r['Kernel_Name'] or 'true, false, true' not in r['Kernel_Name']: continue
         acc[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 v = {c: acc[c] / n[c] for c in acc}
-print('== %s' % tag)
+print('== %s %s' % (tag, kern))
 print('  ' + '  '.join('%s %.4g' % (c, x) for c, x in sorted(v.items())))
 cu = v.get('SQ_BUSY_CU_CYCLES', 0)
 if cu:
