@@ -202,6 +202,38 @@ __device__ __forceinline__ size_t lower_bound_key(const uint64_t* __restrict__ k
   return lo;
 }
 
+// first index in [lo, hi) whose key is >= (b, bh), hi if none, looked for AROUND a guess g: doubling steps away from it
+// until the answer is bracketed, then a bisection of that bracket -- a handful of loads on one or two lines when the
+// guess is good (k_tile_bounds interpolates it between two boundaries it knows), 2 log2(hi - lo) when it is not
+__device__ __forceinline__ size_t lower_bound_near(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
+                                                   size_t lo, size_t hi, size_t g, uint64_t b, uint64_t bh)
+{
+  if (lo >= hi) return lo;
+  auto less = [&](size_t i) -> bool { return keys_hi ? (keys_hi[i] < bh || (keys_hi[i] == bh && keys[i] < b)) : keys[i] < b; };
+  if (g < lo) g = lo;
+  if (g >= hi) g = hi - 1;
+  size_t a, e;                                                 // the answer is in [a, e]
+  if (less(g))
+  {
+    a = g + 1; e = hi;
+    for (size_t step = 1; a + step - 1 < hi; step <<= 1)
+    {
+      if (less(a + step - 1)) a += step; else { e = a + step - 1; break; }
+    }
+    if (a > e) a = e;
+  }
+  else
+  {
+    a = lo; e = g;
+    for (size_t step = 1; e >= lo + step; step <<= 1)
+    {
+      if (!less(e - step)) e -= step; else { a = e - step + 1; break; }
+    }
+  }
+  while (a < e) { const size_t mid = a + ((e - a) >> 1); if (less(mid)) a = mid + 1; else e = mid; }
+  return a;
+}
+
 // The boundary searches were bound by their dependent round trips to HBM: 21 steps of bisection over a 2.6 M-record
 // stream, each a miss on a line (and often a page) of its own -- 23 + 15 + 30 us of a 0.5 ms call in round 2's
 // k_tile_probe / k_tile_coarse / k_tile_fine.  Now:
@@ -289,11 +321,35 @@ __device__ __forceinline__ size_t lower_bound_indexed(const uint64_t* __restrict
 }
 
 // mult[p] = number of streams that hold the k-mer of probe record p (records drawn uniformly from all
-// n, so mean(1 / mult) estimates rows / records without bias); one thread per (probe, stream)
+// n, so mean(1 / mult) estimates rows / records without bias); one thread per (probe, stream).
+// In the same launch, behind the probe's workgroups: the COARSE boundaries -- where every stream meets every R0-th
+// key of the longest stream L (C of them; coarse[c * S + s], c = 0: the stream's begin, c = C: its end).  They do not
+// depend on the plan, which the probe is there to make, so the two chains of memory latencies run side by side; a
+// tile boundary is then looked for between the two coarse ones around it (k_tile_bounds): a short search, on lines
+// its neighbours touch too.
 __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                     const uint64_t* __restrict__ offs, const stream_index X, uint32_t S, uint64_t n,
-                                                    uint32_t* __restrict__ mult)
+                                                    uint32_t* __restrict__ mult, uint32_t L, uint32_t R0, uint32_t C, uint32_t* __restrict__ coarse)
 {
+  const uint32_t probe_blocks = (kProbes * S + 255u) / 256u;
+  if (blockIdx.x >= probe_blocks)
+  {
+    const size_t t = (size_t)(blockIdx.x - probe_blocks) * 256 + threadIdx.x;
+    if (t >= ((size_t)C + 1) * S) return;
+    // (consecutive threads: consecutive boundaries of ONE stream -- their answers lie on the same pages)
+    const uint32_t s = (uint32_t)(t / ((size_t)C + 1)), c = (uint32_t)(t - (size_t)s * ((size_t)C + 1));
+    const size_t begin = offs[s], end = offs[s + 1];
+    size_t pos;
+    if (c == 0) pos = begin;
+    else if (c >= C) pos = end;
+    else
+    {
+      const size_t at = offs[L] + (size_t)c * R0;
+      pos = s == L ? at : lower_bound_indexed(keys, keys_hi, X, s, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
+    }
+    coarse[(size_t)c * S + s] = (uint32_t)pos;
+    return;
+  }
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= kProbes * S) return;
   const uint32_t p = t / S, s = t - p * S;
@@ -365,7 +421,8 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict_
                                                      const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
                                                      uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
                                                      tile_plan* __restrict__ plan, uint32_t* __restrict__ start,
-                                                     unsigned long long* __restrict__ list_len, unsigned long long list_len0)
+                                                     unsigned long long* __restrict__ list_len, unsigned long long list_len0,
+                                                     uint32_t R0, uint32_t C, const uint32_t* __restrict__ coarse)
 {
   __shared__ double s_part[256];
   const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, s_part);
@@ -386,7 +443,22 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict_
     else
     {
       const size_t at = offs[L] + j * r;
-      pos = s == L ? at : lower_bound_indexed(keys, keys_hi, X, s, begin, end, keys[at], keys_hi ? keys_hi[at] : 0ull);
+      if (s == L) pos = at;
+      else
+      {
+        // (between the coarse boundaries around it: key c R0 <= this key <= key (c + 1) R0 of L, and so are their positions here)
+        // (... and about as far along between them as the key is between theirs, if k-mers are spread evenly there:
+        // the guess the search starts from -- a bisection of the bracket touched six lines nobody else wanted)
+        uint32_t c = (uint32_t)((j * r) / R0);
+        if (c >= C) c = C - 1u;
+        const size_t lo = coarse[(size_t)c * S + s], hi = coarse[(size_t)(c + 1u) * S + s];
+        const size_t at_c = offs[L] + (size_t)c * R0, at_n = offs[L] + (c + 1u < C ? (size_t)(c + 1u) * R0 : (size_t)n_l - 1);
+        const bool on_hi = keys_hi && keys_hi[at_c] != keys_hi[at_n];
+        const uint64_t kc = on_hi ? keys_hi[at_c] : keys[at_c], kn = on_hi ? keys_hi[at_n] : keys[at_n], kj = on_hi ? keys_hi[at] : keys[at];
+        size_t g = lo;
+        if (kn > kc && kj >= kc) g = lo + (size_t)((double)(kj - kc) / (double)(kn - kc) * (double)(hi - lo));
+        pos = lower_bound_near(keys, keys_hi, lo, hi, g, keys[at], keys_hi ? keys_hi[at] : 0ull);
+      }
     }
     start[j * S + s] = (uint32_t)pos;
   }
@@ -1438,6 +1510,8 @@ k_tile_sums(const tile_job J)
         // entries with one returning global atomic between two barriers and wrote them in a second pass over the
         // table: 5 500 + 2 700 of a tile's 62 000 cycles; writing them in the one pass, behind a barrier that waited
         // for the stores as __syncthreads does, still cost 3 500.)
+        // (Measured and dropped: the workgroup's last wave fetching the next tile's segments instead of walking --
+        // the other seven cover its slots in the same five steps --: 20v20 281 -> 291 us, 3 records per row 758 -> 785.)
         uint32_t late_bits = 0;
         auto emit = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k) -> bool
         {
@@ -1855,6 +1929,14 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   KMD_HIP(sc.take(&p_offs, ((size_t)S + 1 + ((size_t)S + 2) / 2) * 8));
   KMD_HIP(sc.take(&p_table, ((size_t)nb_max + 1) * (size_t)S * 4));
   KMD_HIP(sc.take(&p_small, 64 + (size_t)kProbes * 4));              // [plan | entries, rows, rows beyond the table | probe multiplicities]
+  // coarse boundaries: every R0-th key of the longest stream, at most 4096 of them (fewer with many samples: <= 2^18
+  // searches, 2^16 beyond 64 samples -- as many as hide behind the probe's)
+  // (measured, 20v20 / 36 M rows of 3 records / 100v100: probe + boundaries 49 / 238 / 160 us before, 46 / 167 / 143 now)
+  const uint32_t c_max = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("KMD_TILE_COARSE", 4096u), (1u << env_u32("KMD_TILE_COARSE_CELLS", S <= 64 ? 18 : 16)) / (uint32_t)S));
+  const uint32_t R0 = (uint32_t)std::max<uint64_t>(1, (n_l + c_max - 1) / c_max);
+  const uint32_t C = (uint32_t)std::max<uint64_t>(1, (n_l + R0 - 1) / R0);
+  void* p_coarse = nullptr;
+  KMD_HIP(sc.take(&p_coarse, ((size_t)C + 1) * (size_t)S * 4));
   tile_plan* d_plan = static_cast<tile_plan*>(p_small);
   unsigned long long* d_rows = reinterpret_cast<unsigned long long*>(static_cast<char*>(p_small) + 32);
   uint32_t* d_over_n = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 56);
@@ -1881,12 +1963,14 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     constexpr uint32_t kZeroWords = 16 + kProbes;                     // p_small: 64 bytes + the probe's counts
     hipLaunchKernelGGL(k_tile_index, dim3((std::max(n_index, kZeroWords) + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, d_ioff, (uint32_t)S,
                        static_cast<uint64_t*>(p_idx), static_cast<uint64_t*>(p_idx_hi), static_cast<uint32_t*>(p_small), kZeroWords);
-    hipLaunchKernelGGL(k_tile_probe, dim3((kProbes * (unsigned)S + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
-                       (uint64_t)n, d_mult);
+    const size_t coarse_cells = ((size_t)C + 1) * S;
+    hipLaunchKernelGGL(k_tile_probe, dim3((unsigned)((kProbes * (size_t)S + 255) / 256 + (coarse_cells + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
+                       (uint64_t)n, d_mult, L, R0, C, static_cast<uint32_t*>(p_coarse));
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
     hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
-                       grid_hint, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0));
+                       grid_hint, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0),
+                       R0, C, static_cast<const uint32_t*>(p_coarse));
     KMD_HIP(hipGetLastError());
   }
 
