@@ -516,8 +516,8 @@ __global__ void __launch_bounds__(kBlock) k_filter_sums(const filter_params P, c
 //                list order.
 // `gate` (may be NULL): the launches were enqueued BEHIND the merge that fills the list, before the host knew how
 // the merge went -- gate[0..2] = entries, distinct k-mers, rows beyond the table as the merge left them on the
-// device, *gate_over = tiles it could not finish.  If any tile is unfinished or the list overflowed, the kernels
-// do nothing at all (the host then goes the long way and launches them again without a gate).
+// device, gate_over[0] = tiles it could not finish, gate_over[1] = 1 if the merge ran at all.  If any tile is
+// unfinished, the list overflowed or the merge did not run, the kernels do nothing at all (the host then goes the long way and launches them again without a gate).
 constexpr int kCandBlock = 256;
 constexpr unsigned long long kCandNone = ~0ull;
 struct cand_counts { uint32_t surv, cand, near, ctrl; };
@@ -526,7 +526,9 @@ __device__ __forceinline__ bool cand_gate(const unsigned long long* __restrict__
                                           unsigned long long gate_cap, size_t& n_rows)
 {
   if (!gate) return true;
-  if (*gate_over != 0 || gate[0] > gate_cap) return false;
+  // (gate_over[1]: set by the merge kernel that took the plan's way -- the host may have launched only the one it
+  // guessed, and a merge that never ran leaves a list of whatever the scratch held)
+  if (gate_over[0] != 0 || gate_over[1] == 0 || gate[0] > gate_cap) return false;
   n_rows = (size_t)gate[0];
   return true;
 }

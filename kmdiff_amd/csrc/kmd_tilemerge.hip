@@ -45,6 +45,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -92,6 +93,7 @@ constexpr int kRsrcFlags = 0x00020000;           // buffer descriptor, dword 3: 
 // the lanes' predicate as a mask, straight from the compare (HIP's __ballot takes an int: a select and a second compare)
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile live in LDS (16 KB at 1024 streams)
+constexpr uint32_t kSmallSlots = 2048, kBigSlots = 4096;   // the two table shapes built (512 / 1024 threads); make_plan picks one per partition
 constexpr uint32_t kProbes = 512;                // records sampled for the records-per-row estimate (+-5 % at worst; 2048 cost 39 us, 4x this)
 constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
 constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a count too large for 32-bit sums
@@ -112,7 +114,8 @@ struct tile_plan
   uint32_t g_shift;                              // lanes per run of records = 1 << g_shift
   uint32_t fill;                                 // records per tile aimed at
   float rho;                                     // records per row, estimated
-  uint32_t pad[3];
+  uint32_t slots;                                // the table the tiles are sized for: the instantiation of the merge kernel that takes them
+  uint32_t pad[2];
 };
 
 struct tile_job
@@ -364,8 +367,8 @@ __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__
 // k_tile_coarse works it out for itself from the probe's 512 counts (the first one writes it down for the
 // kernels behind): no launch of its own.
 __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t S,
-                                               uint32_t slots, float load, uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
-                                               double* s_part)
+                                               uint32_t slots_fixed, float load, uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint_small,
+                                               uint32_t grid_hint_big, double* s_part)
 {
   double acc = 0;
   for (uint32_t p = threadIdx.x; p < kProbes; p += blockDim.x) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
@@ -374,6 +377,15 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   __syncthreads();
   for (uint32_t o = blockDim.x >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
   const double rho = (double)kProbes / s_part[0];                    // records per row
+  // The table: 2048 slots for a workgroup of 512 threads, or 4096 for 1024 (kBigSlots) -- half the tiles, runs twice
+  // as long.  Where rows have few records a tile's run of a sample is short -- 36 M rows of 3 records from 40
+  // samples: 73 records, a full round of a wave and a round for the 9 left over -- and what a tile costs whatever it
+  // holds (barriers, its segment table, the walk's fixed part) is most of it: the larger shape wins from ~130
+  // records per run down (measured, whole call, small / large shape: runs of 665 records 0.42 / 0.46 ms, 400
+  // 0.46 / 0.50, 200 0.59 / 0.58, 133 0.72 / 0.67, 73 1.06 / 0.94; 8 or 200 samples with runs of 665: 0.52 / 0.55,
+  // 0.59 / 0.61).
+  const uint32_t slots = slots_fixed ? slots_fixed : (rho * (double)load * (double)kSmallSlots / (double)S < 160.0 ? kBigSlots : kSmallSlots);
+  const uint32_t grid_hint = slots == kBigSlots ? grid_hint_big : grid_hint_small;
   double fill = rho * (double)load * (double)slots;
   const double fill_max = 24.0 * (double)slots;                      // ~0.6 MB of records per tile at most
   if (fill > fill_max) fill = fill_max;
@@ -409,7 +421,7 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   if (g_fixed) g = g_fixed;
   tile_plan pl;
   pl.r = (uint32_t)r; pl.nb = (uint32_t)nb; pl.g_shift = g; pl.fill = (uint32_t)fill; pl.rho = (float)rho;
-  pl.pad[0] = pl.pad[1] = pl.pad[2] = 0;
+  pl.slots = slots; pl.pad[0] = pl.pad[1] = 0;
   return pl;
 }
 
@@ -419,13 +431,13 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
 __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
                                                      const uint64_t* __restrict__ offs, const stream_index X, uint32_t S, uint32_t L,
                                                      const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
-                                                     uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint,
+                                                     uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint, uint32_t grid_hint_big,
                                                      tile_plan* __restrict__ plan, uint32_t* __restrict__ start,
                                                      unsigned long long* __restrict__ list_len, unsigned long long list_len0,
                                                      uint32_t R0, uint32_t C, const uint32_t* __restrict__ coarse)
 {
   __shared__ double s_part[256];
-  const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, s_part);
+  const tile_plan pl = make_plan(mult, n, n_l, S, slots, load, fill_fixed, g_fixed, grid_hint, grid_hint_big, s_part);
   if (blockIdx.x == 0 && threadIdx.x == 0) { *plan = pl; *list_len = list_len0; }     // (candidates mode: the workgroups' first chunks are spoken for)
   const uint32_t nb = pl.nb, r = pl.r;
   // (consecutive threads: consecutive boundaries of ONE stream -- their answers lie a tile's run apart, on the same
@@ -623,6 +635,8 @@ k_tile_sums(const tile_job J)
   // streaming a tile (kWide: whole waves per run, g_shift 6; else sub-groups of lanes) the plan did
   // not choose returns at once
   if ((g_shift == 6) != kWide) return;
+  // ... and so does the one of the table shape the plan did not choose
+  if (!J.n_tiles && J.plan->slots != kSlots) return;
   if (blockIdx.x == 0 && tid == 0) *J.ran = 1u;
   // segment tables of the current and the next tile, behind the fixed part: [2][begin[S] | length[S]]
   uint32_t* const s_seg = reinterpret_cast<uint32_t*>(s_raw + (sizeof(lds_t) + 7) / 8);
@@ -1855,7 +1869,7 @@ template <int kT, uint32_t kS> struct shape_tag { static constexpr int threads =
 
 inline tile_shape pick_shape()
 {
-  tile_shape sh { 512, 2048 };
+  tile_shape sh { 0, 0 };                                 // (0: the plan picks, make_plan)
   if (const char* e = std::getenv("KMD_TILE_SHAPE"))     // dev: "threads x slots" (A/B)
   {
     int t = 0; unsigned s = 0;
@@ -1892,6 +1906,7 @@ struct merge_async
   int way = -1;                                    // -1: launch both instantiations (the plan picks one on the device); 1 / 0: only
                                                    // the whole-wave / sub-group one -- a guess (the batch's earlier partitions): the
                                                    // read-back says whether it was taken (bytes 60..63)
+  uint32_t shape = 0;                              // likewise the table shape (slots; 0: launch both)
   explicit merge_async(hipStream_t st) : sc(st) {}
 };
 constexpr size_t kUpWords = (size_t)kMaxStreams + 1 + ((size_t)kMaxStreams + 2) / 2;
@@ -1914,14 +1929,15 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   for (int s = 1; s < S; ++s) if (offsets[s + 1] - offsets[s] > offsets[L + 1] - offsets[L]) L = (uint32_t)s;
   const uint64_t n_l = offsets[L + 1] - offsets[L];
   // the most tiles the plan can ask for: every record its own row (rho = 1), or the dev override
-  uint32_t fill_min = (uint32_t)std::max(64.0f, load * (float)sh.slots);
+  const uint32_t slots_min = sh.slots ? sh.slots : kSmallSlots;
+  uint32_t fill_min = (uint32_t)std::max(64.0f, load * (float)slots_min);
   if (const uint32_t f = env_u32("KMD_TILE_FILL", 0)) fill_min = std::min(fill_min, std::max(64u, f));
   const uint64_t r_min = std::max<uint64_t>(1, (uint64_t)((double)n_l * (double)fill_min / (double)n));
-  const uint32_t grid_hint = env_u32("KMD_TILE_GRID_HINT", (uint32_t)n_cu * (sh.threads == 512 ? 4u : 2u));   // workgroups of the level-0 launch
+  const uint32_t grid_hint = env_u32("KMD_TILE_GRID_HINT", (uint32_t)n_cu * 4u), grid_hint_big = env_u32("KMD_TILE_GRID_HINT", (uint32_t)n_cu * 2u);   // workgroups of the level-0 launch (512 / 1024 threads)
   // (+ grid_hint: the plan may round the number of tiles up to a multiple of it)
-  const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min) + grid_hint;
+  const uint32_t nb_max = (uint32_t)std::max<uint64_t>(1, (n_l + r_min - 1) / r_min) + std::max(grid_hint, grid_hint_big);
   // candidates mode: the most workgroups a launch of the merge kernel can have -- each owns a first chunk of the list
-  const uint32_t regions_max = (uint32_t)n_cu * std::max<uint32_t>(env_u32("KMD_TILE_BLOCKS_PER_CU", 0), 2048u / (uint32_t)sh.threads);
+  const uint32_t regions_max = (uint32_t)n_cu * std::max<uint32_t>(env_u32("KMD_TILE_BLOCKS_PER_CU", 0), 2048u / (uint32_t)(sh.threads ? sh.threads : 512));
 
   scratch_set sc_own(st);
   scratch_set& sc = async ? async->sc : sc_own;
@@ -1940,7 +1956,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   tile_plan* d_plan = static_cast<tile_plan*>(p_small);
   unsigned long long* d_rows = reinterpret_cast<unsigned long long*>(static_cast<char*>(p_small) + 32);
   uint32_t* d_over_n = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 56);
-  uint32_t* d_ran = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 60);
+  uint32_t* d_ran = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 60);          // (= d_over_n + 1: the gate of the candidates' kernels reads both)
   uint32_t* d_mult = reinterpret_cast<uint32_t*>(static_cast<char*>(p_small) + 64);
   // [offsets (S + 1) x u64 | index offsets (S + 1) x u32]: one upload
   std::vector<uint64_t> h_up_own;
@@ -1969,7 +1985,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
     hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
-                       grid_hint, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0),
+                       grid_hint, grid_hint_big, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0),
                        R0, C, static_cast<const uint32_t*>(p_coarse));
     KMD_HIP(hipGetLastError());
   }
@@ -2020,9 +2036,17 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   // samples every plan takes whole waves per run (a tile holds >= load x slots records, a run >= that / S)
   // (up to 64 samples a run holds >= 16 records: the whole-wave path, which takes runs of any length, is the faster
   // one there whatever the plan would say -- and the launch of an instantiation that only leaves again is saved)
+  // (the smaller shape's tiles are the smaller ones: what holds for them holds for both)
   const bool wide_for_sure = !env_u32("KMD_TILE_FILL", 0) && !env_u32("KMD_TILE_G", 0) &&
-                             (double)std::max(64.0f, load * (float)sh.slots) / (double)S >= 16.0;
+                             (double)std::max(64.0f, load * (float)slots_min) / (double)S >= 16.0;
   J.force_wide = wide_for_sure ? 1u : 0u;
+  // Which TABLE SHAPE the plan takes is decided on the device too (make_plan).  A launch of the other one leaves at
+  // once, but not for free (its turn in the stream: ~5 us): level 0 launches the shape the last plan on this device
+  // took -- a job's partitions are alike -- and the read-back says whether that was right (bytes 60..63: did a merge
+  // kernel run); if not, level 0 is launched again with the shape the plan did take.  The batch keeps its own guess.
+  static std::atomic<uint32_t> g_last_shape[64];
+  uint32_t shape_level0 = sh.slots ? sh.slots : async ? async->shape : g_last_shape[dev & 63].load(std::memory_order_relaxed);   // 0: both
+  uint32_t shape_known = sh.slots;                               // levels > 0: the plan's, read back
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
   auto run = [&](uint32_t tiles_at_most) -> int
   {
@@ -2056,10 +2080,17 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
       }
       return rc_;
     };
-    if (sh.threads == 512 && sh.slots == 2048) return pick(shape_tag<512, 2048>());
-    if (sh.threads == 1024 && sh.slots == 4096) return pick(shape_tag<1024, 4096>());
-    kmd::set_error("kmd: KMD_TILE_SHAPE not built");
-    return KMD_E_INVALID;
+    const uint32_t which = J.n_tiles ? shape_known : shape_level0;     // 0: both (level 0 only)
+    if (which != 0 && which != kSmallSlots && which != kBigSlots) { kmd::set_error("kmd: KMD_TILE_SHAPE not built"); return KMD_E_INVALID; }
+    if (sh.threads && !((sh.threads == 512 && sh.slots == kSmallSlots) || (sh.threads == 1024 && sh.slots == kBigSlots)))
+    {
+      kmd::set_error("kmd: KMD_TILE_SHAPE not built");
+      return KMD_E_INVALID;
+    }
+    int rc_ = KMD_OK;
+    if (which == 0 || which == kSmallSlots) rc_ = pick(shape_tag<512, kSmallSlots>());
+    if (rc_ == KMD_OK && (which == 0 || which == kBigSlots)) rc_ = pick(shape_tag<1024, kBigSlots>());
+    return rc_;
   };
 
   // level 0: the planned table; further levels: the slices of the tiles that gave up
@@ -2105,6 +2136,22 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     KMD_HIP(hipStreamSynchronize(st));
     std::memcpy(&h_plan, h_small, sizeof h_plan);
     const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h_small + 56);
+    if (level == 0)
+    {
+      const uint32_t h_ran = *reinterpret_cast<const uint32_t*>(h_small + 60);
+      shape_known = h_plan.slots;
+      if (!sh.slots) g_last_shape[dev & 63].store(h_plan.slots, std::memory_order_relaxed);
+      if (!h_ran)
+      {
+        // the guessed shape was not the plan's: nothing ran (the candidates' kernels behind it included, which are
+        // gated on that) -- once more, with the plan's
+        KMD_REQUIRE(shape_level0 != 0 && shape_level0 != h_plan.slots, "kmd: the merge kernel did not run");
+        if (dbg) std::fprintf(stderr, "[tile_merge] level 0 again: the plan took the %u-slot table, the launch was the %u-slot one\n", h_plan.slots, shape_level0);
+        shape_level0 = h_plan.slots;
+        --level;
+        continue;
+      }
+    }
     if (dbg)
       std::fprintf(stderr, "[tile_merge] level %d: %u of %u tiles gave up (plan: %.2f records per row, %u records per tile, r %u, G %u)\n",
                    level, n_over, level ? n_tiles : h_plan.nb, h_plan.rho, h_plan.fill, h_plan.r, 1u << h_plan.g_shift);
@@ -2117,7 +2164,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     KMD_HIP(hipMemcpy(h_over.data(), static_cast<uint32_t*>(p_over), (size_t)n_over * 4, hipMemcpyDeviceToHost));
     KMD_HIP(hipMemcpy(h_over.data() + n_over, static_cast<uint32_t*>(p_over) + list_cap, (size_t)n_over * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> h_ref(3 * (size_t)n_over);              // tile, slices, first row
-    const uint64_t per_slice = std::max<uint64_t>(64, (uint64_t)(load * (float)sh.slots));
+    const uint64_t per_slice = std::max<uint64_t>(64, (uint64_t)(load * (float)shape_known));
     uint64_t rows = 0;
     for (uint32_t i = 0; i < n_over; ++i)
     {
@@ -2301,6 +2348,7 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
   // with the rest of its stream behind it: once a partition of the batch has come back, the others launch only the
   // way its plan took -- the read-back says whether that was right, and the synchronous way stands behind it.
   int known_way = -1;
+  uint32_t known_shape = 0;
   // the synchronous way, for the partitions the fast way could not finish
   auto redo = [&](int p) -> int
   {
@@ -2321,7 +2369,7 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h + 56), ran = *reinterpret_cast<const uint32_t*>(h + 60);
     tile_plan pl;
     std::memcpy(&pl, h, sizeof pl);
-    if (ran) known_way = pl.g_shift == 6 ? 1 : 0;                // the way the plan of a partition of this job took
+    if (ran) { known_way = pl.g_shift == 6 ? 1 : 0; known_shape = pl.slots; }   // the way and the table shape the plan of a partition of this job took
     const bool ok = ran != 0 && n_over == 0 && rows3[0] <= f.cap;
     f.A.reset();                                                  // the scratch goes back to the cache
     if (ok) { if (n_rows_out) n_rows_out[p] = rows3[1]; return KMD_OK; }
@@ -2351,6 +2399,7 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     f.A->h_small = B->h_small + (size_t)slot * kBatchSlotBytes;
     f.A->h_up = reinterpret_cast<uint64_t*>(f.A->h_small + 64);
     f.A->way = known_way;
+    f.A->shape = known_shape;
     kmd_tile t { d_counts[p], 4, KMD_LAYOUT_SOA, n, nullptr, nullptr, n, 0 };
     filter_params P;
     rc = kmd::fill_filter_params(P, m, &t, threshold);

@@ -398,6 +398,46 @@ def test_merge_filter_batch_equals_single_calls(K, oracle):
     assert acc2[0].finish(by_kmer=True) == single[0][1] and acc2[2].finish(by_kmer=True) == single[1][1]
 
 
+def test_merge_filter_batch_of_partitions_whose_plans_differ(K, oracle):
+    """A batch launches, for the partitions behind the first ones, only the instantiation of the merge kernel the plans so
+    far took (whole waves or sub-groups per run; the 2048- or the 4096-slot table): a guess.  Here it is wrong over and
+    over -- 80 samples, partitions of long runs, of short runs, of rows of two records, interleaved -- and nothing of a
+    partition whose merge did not run may reach the sink (the candidates' kernels are gated on it): the same survivors
+    and counters as single calls, which guess too (the shape of the last call on the device)."""
+    rng = np.random.default_rng(8181)
+    S, nc = 80, 40
+    kinds = [0.9, 0.9, 0.9, 0.9, 0.9, 0.9, 0.9, 0.03, 0.9, 0.03, 0.03, 0.9, 0.025, 0.9]
+    sets, host, tot = [], [], np.zeros(S, dtype=np.uint64)
+    for j, pres in enumerate(kinds):
+        universe = np.unique(rng.integers(0, 1 << 62, int(60_000 / (S * pres)) + 2000, dtype=np.uint64))
+        streams = make_streams(rng, universe, S, np.clip(pres * rng.uniform(0.7, 1.3, S), 0.005, 1.0))
+        sets.append(K.StreamSet(streams))
+        host.append(streams)
+        tot += np.array([int(t[1].sum(dtype=np.uint64)) for t in streams], dtype=np.uint64)
+    model = K.PoissonLikelihood(nc, S - nc, tot[:nc], tot[nc:], 10000)
+    thr = 1e-3
+    single = []
+    for ss in sets:
+        acc = K.SurvivorAccumulator(1 << 18)
+        rows = K.merge_filter(ss, K.diff_observer(model, acc, thr))
+        n = acc.finish(by_kmer=True)
+        single.append((rows, n, acc.get(), [int(x) for x in acc.read_counters()[:4]]))
+    assert sum(s[1] for s in single) > 100
+    for _ in range(2):
+        accs = [K.SurvivorAccumulator(1 << 18) for _ in sets]
+        rows_b = K.merge_filter_batch(sets, [K.diff_observer(model, a, thr) for a in accs])
+        for j, a in enumerate(accs):
+            n = a.finish(by_kmer=True)
+            got = a.get()
+            assert rows_b[j] == single[j][0] and n == single[j][1], j
+            assert [int(x) for x in a.read_counters()[:4]] == single[j][3], j
+            for key in ("kmer_lo", "pvalue", "sign", "mean_control", "mean_case"):
+                assert got[key].tolist() == single[j][2][key].tolist(), (j, key)
+    # single calls against the oracle, the table shape changing from call to call
+    for j in (0, 7, 1, 12):
+        run_fused(K, oracle, host[j], nc, thr)
+
+
 @pytest.mark.parametrize("env", [{"KMD_TILE_CAND_CAP": "500"}, {"KMD_TILE_FILL": "60000", "KMD_TILE_LOAD_PCT": "50"},
                                  {"KMD_TILE_G": "3"}, {"KMD_TILE_SUM64": "1"}, {"KMD_TILE_SHAPE": "1024x4096"}])
 def test_merge_filter_forced_paths(K, oracle, env):
