@@ -171,12 +171,14 @@ def pipeline_leg(K, lib, rows=4_000_000, iters=6):
         for w in workers:
             K._native.check(lib.kmd_stream_sync(w[0]))
     run_all(2)                                             # untimed: the scratch of six concurrent calls gets allocated here
-    t0 = time.perf_counter()
-    run_all(per)
-    ms_o = (time.perf_counter() - t0) / (in_flight * per) * 1e3
+    ms_o, n_timed = 1e9, 2                                 # the better of two timed rounds (six host threads: the one measurement here the host's scheduler has a say in)
+    for _ in range(n_timed):
+        t0 = time.perf_counter()
+        run_all(per)
+        ms_o = min(ms_o, (time.perf_counter() - t0) / (in_flight * per) * 1e3)
     for w in workers:
         cw = w[1].read_counters()
-        assert int(cw[0]) == (per + 2) * rows and int(cw[1]) == (per + 2) * (int(c[1]) // iters), (int(cw[0]), int(cw[1]))
+        assert int(cw[0]) == (n_timed * per + 2) * rows and int(cw[1]) == (n_timed * per + 2) * (int(c[1]) // iters), (int(cw[0]), int(cw[1]))
         lib.kmd_stream_destroy(w[0])
     gbs_o = 12.0 * ss.total / (ms_o * 1e-3) / 1e9
     overlapped = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "kmers_per_s": rows / (ms_o * 1e-3),

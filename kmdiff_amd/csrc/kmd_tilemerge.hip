@@ -1120,6 +1120,9 @@ k_tile_sums(const tile_job J)
               // compare's mask is used three instructions later at the earliest), three scalar instructions in all.
               // v[40:47] hold the two buckets.
               const uint64_t k = rk[d][0];
+              const uint32_t cnt = rcnt[d][0];
+              // (scalar choice of the array; a key's address / 2 + a constant = its sum's)
+              const uint32_t sums_lds = (uint32_t)(uintptr_t)(lds_u32*)(rctl[d] ? M.c32 : M.k32) - (key_lds >> 1);
               uint32_t a0, a1, t0, t1, se, sl;
               uint64_t m0, m1, m2, sv;
               const uint64_t empty = kEmptyKey;
@@ -1187,13 +1190,20 @@ k_tile_sums(const tile_job J)
                   "s_or_b64 vcc, vcc, %[m0]\n\t"
                   "v_cndmask_b32 %[sl], %[none], %[se], vcc\n\t"
                   "1:\n\t"
-                  "s_or_b64 exec, exec, %[sv]"
+                  "s_or_b64 exec, exec, %[sv]\n\t"
+                  // the count goes to the slot's sum (a lane without a slot yet: to the spare slot's, which nobody reads)
+                  // and the mask of those lanes leaves in m0 -- written here, as the compiler wrote the test and the
+                  // add behind the block they were ten and nine instructions, most of them scalar
+                  "v_cmp_eq_u32 %[m0], %[sl], %[none]\n\t"
+                  "v_lshrrev_b32 %[t0], 1, %[sl]\n\t"
+                  "v_add_u32 %[t0], %[sbase], %[t0]\n\t"
+                  "ds_add_u32 %[t0], %[cnt]"
                   : [sl] "=&v"(sl), [a0] "=&v"(a0), [a1] "=&v"(a1), [se] "=&v"(se), [t0] "=&v"(t0), [t1] "=&v"(t1),
                     [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [sv] "=&s"(sv)
 #if KMD_TILE_TIMING
                     , [tr] "+s"(tm_read), [nr] "+s"(tm_nread), [tc] "+s"(tm_cas), [nc_] "+s"(tm_ncas)
 #endif
-                  : [k] "v"(k), [klo] "v"((uint32_t)k), [khi] "v"((uint32_t)(k >> 32)), [none] "v"(kNone), [empty] "v"(empty),
+                  : [k] "v"(k), [klo] "v"((uint32_t)k), [khi] "v"((uint32_t)(k >> 32)), [none] "v"(kNone), [empty] "v"(empty), [cnt] "v"(cnt), [sbase] "s"(sums_lds),
                     [kb] "s"(key_lds), [sb] "s"(key_lds + kSlots * 8u), [c1] "s"(kHashMul), [sh0] "n"(32 - kBucketBits), [sh1] "n"(32 - 2 * kBucketBits),
                     [nb] "n"(kBucketBits), [nsec] "n"(ilog2_c(kSec))
                   : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47"
@@ -1201,8 +1211,8 @@ k_tile_sums(const tile_job J)
                     , "s90", "s91", "s92", "s93"
 #endif
                   );
-              if (ballot(sl == kNone)) { if (sl == kNone) sl = walk_seq(k); }
-              add_count(d, sl, rcnt[d][0], 0ull, true);
+              cmax = cnt > cmax ? cnt : cmax;                                        // looked at once per tile (below)
+              if (m0) { if (sl == kNone) add_count(d, walk_seq(k), cnt, 0ull, true); }   // (stage 3: a handful of rounds per tile)
               return;
             }
 #endif
@@ -1526,6 +1536,11 @@ k_tile_sums(const tile_job J)
         // for the stores as __syncthreads does, still cost 3 500.)
         // (Measured and dropped: the workgroup's last wave fetching the next tile's segments instead of walking --
         // the other seven cover its slots in the same five steps --: 20v20 281 -> 291 us, 3 records per row 758 -> 785.)
+        // (Measured, too: WHY the waves wait at the barrier below -- 4 000 of a 20v20 tile's 60 000 cycles, KMD_TILE_TIMING --:
+        // for wave 0, which fetches the next tile's segment table first (two loads' round trip).  Fetched at the tile's
+        // start instead, wave 0 taking that much less of the tile's records, the wait was gone -- 4 200 -> 600 cycles --
+        // and the kernel took what it took before (286 -> 287 us): with four workgroups to a CU, one's wait is the
+        // others' turn.  What bounds this kernel is what a CU gets done per cycle, not how long a workgroup stands.)
         uint32_t late_bits = 0;
         auto emit = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k) -> bool
         {
@@ -1651,10 +1666,18 @@ k_tile_sums(const tile_job J)
         }
 #if KMD_TILE_TIMING
         tp_walk1 = __builtin_readcyclecounter();
+        // (dev: when each wave reaches the walk's barrier -- the wait for its own LDS operations apart --, relative to wave 1)
+        if (lane == 0) M.wcnt[wave] = (uint32_t)tp_walk1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long tp_lgkm = __builtin_readcyclecounter();
 #endif
         lds_barrier();
 #if KMD_TILE_TIMING
         tp_resv = __builtin_readcyclecounter();
+        if (blockIdx.x == 77 && tid == 64)
+          printf("[walk barrier] tile %u: own LDS drained after %llu; waves reached it at %d %d %d %d %d %d %d %d relative to wave 1 (%llu after the walk began)\n", tile,
+                 tp_lgkm - tp_walk1, (int)(M.wcnt[0] - (uint32_t)tp_walk1), 0, (int)(M.wcnt[2] - (uint32_t)tp_walk1), (int)(M.wcnt[3] - (uint32_t)tp_walk1),
+                 (int)(M.wcnt[4] - (uint32_t)tp_walk1), (int)(M.wcnt[5] - (uint32_t)tp_walk1), (int)(M.wcnt[6] - (uint32_t)tp_walk1), (int)(M.wcnt[7] - (uint32_t)tp_walk1), tp_walk1 - tp_seg);
 #endif
         if (M.out_used > M.out_cap)
         {

@@ -50,8 +50,9 @@ def test_nothing_of_the_compilers_in_flight_between_the_hand_counted_loads(tile_
         assert not [l for l in span if "scratch_" in l], k
         # compiler-issued vector memory operations inside the span: none (its own loads would be counted by vmcnt too)
         assert not [l for l in span if re.search(r"\b(global|flat)_(load|store|atomic)", l)], k
-        loads_per_round = len(at) // 8            # 4 rounds in the prologue + 4 ring stages
-        assert loads_per_round in (2, 3), (k, len(at))
+        two_limbs = re.search(r"ELb[01]ELb1ELb1ELb[01]EEEv", k) is not None      # <threads, slots, filter, TWO LIMBS, whole waves, 32-bit sums>
+        loads_per_round = 3 if two_limbs else 2
+        assert len(at) == loads_per_round * 8, (k, len(at))      # 4 rounds in the prologue + 4 ring stages
         waits = [l for l in span if "s_waitcnt vmcnt" in l]
         want = "s_waitcnt vmcnt(%d)" % (loads_per_round * 3)
         assert waits and all(want in l for l in waits), (k, waits[:4], want)

@@ -27,7 +27,9 @@ bash tools/pmc_popstrat.sh --thr 0.05 > $O/pmc_popstrat.txt 2>&1
   run tools/kbench_pipeline.py --fused-only --nc 4 --nk 4 --rows 20000000
   run tools/kbench_pipeline.py --fused-only --nc 50 --nk 50 --rows 1600000
   run tools/kbench_pipeline.py --fused-only --nc 100 --nk 100 --rows 800000
+  run tools/kbench_pipeline.py --fused-only --sparse 0.6 --rows 6666666 --iters 3
   run tools/kbench_pipeline.py --fused-only --sparse 0.3 --rows 13333333 --iters 3
+  run tools/kbench_pipeline.py --fused-only --sparse 0.2 --rows 20000000 --iters 3
   run tools/kbench_pipeline.py --fused-only --sparse 0.1 --rows 40000000 --iters 3
   run tools/kbench_pipeline.py --fused-only --limbs 2
   run tools/kbench_pipeline.py --fused-only --limbs 2 --nc 50 --nk 50 --rows 1600000
