@@ -95,6 +95,9 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_
 constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile live in LDS (16 KB at 1024 streams)
 constexpr uint32_t kSmallSlots = 2048, kBigSlots = 4096;   // the two table shapes built (512 / 1024 threads); make_plan picks one per partition
 constexpr uint32_t kProbes = 512;                // records sampled for the records-per-row estimate (+-5 % at worst; 2048 cost 39 us, 4x this)
+// ... fewer with many samples -- a probe is a search in every stream, 100 000 of them at 200 samples (0.1 ms), and
+// the multiplicities it averages scatter less there: <= 32 768 searches, never under 128 probes
+__host__ __device__ inline uint32_t probes_for(uint32_t S) { const uint32_t p = 32768u / (S ? S : 1u); return p > kProbes ? kProbes : p < 128u ? 128u : p; }
 constexpr uint32_t kAbortBit = 0x80000000u;      // over list: the tile gave up on distinct k-mers, not on records
 constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a count too large for 32-bit sums
 // record positions and run extents are 32-bit: a run's byte extent (8 x its records) must fit the buffer descriptor's
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__
                                                     const uint64_t* __restrict__ offs, const stream_index X, uint32_t S, uint64_t n,
                                                     uint32_t* __restrict__ mult, uint32_t L, uint32_t R0, uint32_t C, uint32_t* __restrict__ coarse)
 {
-  const uint32_t probe_blocks = (kProbes * S + 255u) / 256u;
+  const uint32_t probe_blocks = (probes_for(S) * S + 255u) / 256u;
   if (blockIdx.x >= probe_blocks)
   {
     const size_t t = (size_t)(blockIdx.x - probe_blocks) * 256 + threadIdx.x;
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(256) k_tile_probe(const uint64_t* __restrict__
     return;
   }
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= kProbes * S) return;
+  if (t >= probes_for(S) * S) return;
   const uint32_t p = t / S, s = t - p * S;
   const size_t i = (size_t)__umul64hi(mix64(p), n);
   const uint64_t k = keys[i], kh = keys_hi ? keys_hi[i] : 0ull;
@@ -371,12 +374,12 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
                                                uint32_t grid_hint_big, double* s_part)
 {
   double acc = 0;
-  for (uint32_t p = threadIdx.x; p < kProbes; p += blockDim.x) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
+  for (uint32_t p = threadIdx.x; p < probes_for(S); p += blockDim.x) { const uint32_t m = mult[p]; acc += 1.0 / (double)(m ? m : 1u); }
   // (a fixed order of the sum: every workgroup must arrive at the same plan)
   s_part[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t o = blockDim.x >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
-  const double rho = (double)kProbes / s_part[0];                    // records per row
+  const double rho = (double)probes_for(S) / s_part[0];                    // records per row
   // The table: 2048 slots for a workgroup of 512 threads, or 4096 for 1024 (kBigSlots) -- half the tiles, runs twice
   // as long.  Where rows have few records a tile's run of a sample is short -- 36 M rows of 3 records from 40
   // samples: 73 records, a full round of a wave and a round for the 9 left over -- and what a tile costs whatever it
@@ -2003,7 +2006,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     hipLaunchKernelGGL(k_tile_index, dim3((std::max(n_index, kZeroWords) + 255) / 256), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, d_ioff, (uint32_t)S,
                        static_cast<uint64_t*>(p_idx), static_cast<uint64_t*>(p_idx_hi), static_cast<uint32_t*>(p_small), kZeroWords);
     const size_t coarse_cells = ((size_t)C + 1) * S;
-    hipLaunchKernelGGL(k_tile_probe, dim3((unsigned)((kProbes * (size_t)S + 255) / 256 + (coarse_cells + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
+    hipLaunchKernelGGL(k_tile_probe, dim3((unsigned)((probes_for((uint32_t)S) * (size_t)S + 255) / 256 + (coarse_cells + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
                        (uint64_t)n, d_mult, L, R0, C, static_cast<uint32_t*>(p_coarse));
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
     hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
