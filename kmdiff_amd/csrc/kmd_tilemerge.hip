@@ -11,9 +11,12 @@
 //   * k_tile_probe: how many records make a row here?  512 records drawn uniformly, the number m of
 //     streams holding each one's k-mer; mean(1/m) = distinct k-mers / records (unbiased).  The plan --
 //     records per tile such that a tile's distinct k-mers fill half of the hash table, the splitter
-//     stride, lanes per run -- stays on the device: no host round trip before the main kernel;
+//     stride, lanes per run, WHICH of the two table shapes (2048 slots / 512 threads, or 4096 / 1024 where runs are
+//     short) -- stays on the device: no host round trip before the main kernel.  The same launch finds the COARSE
+//     boundaries (where every stream meets every R0-th key of the longest one: they do not depend on the plan);
 //   * k_tile_bounds: the key range of the partition is cut into TILES by splitters taken from the data (every
-//     r-th key of the longest stream); where each stream enters each tile: one indexed search per (tile, stream);
+//     r-th key of the longest stream); where each stream enters each tile: a search between the two coarse
+//     boundaries around it, from an interpolated guess (lower_bound_near);
 //   * k_tile_sums: one WORKGROUP per tile on a persistent grid.  A tile is S contiguous runs of records,
 //     one per stream; its records are split evenly among the waves, a wave streams its share 64 records a
 //     round (one per lane) through a buffer descriptor of the run, 4 rounds in flight, the loads issued and
@@ -22,7 +25,8 @@
 //     two slots, both read in the first step; a compare-and-swap only to claim an empty slot; a small second
 //     table for the k-mers that find all four taken -- and adds its count to that k-mer's control or case sum;
 //   * after one barrier the table IS the tile's rows: every thread walks a few slots, a live slot goes
-//     through the chi-square pre-filter; the ~1 % that pass leave as (k-mer, control sum, case sum) for
+//     through the pre-filter (chi-square bound, then the likelihood ratio in single precision for the rows
+//     that pass it: row_may_pass_kl); the ~1 % that pass leave as (k-mer, control sum, case sum) for
 //     a list in HBM that is handed out in chunks (no global atomic per tile; holes are marked).
 //     k_cand_eval / _scan / _emit (kmd_filter.hip; kmd_eval.h, the code K1 runs) evaluate the list exactly --
 //     likelihood ratio, tail function, compaction into the survivor sink.  It is enqueued right behind this
@@ -189,25 +193,10 @@ __host__ __device__ inline uint64_t mix64(uint64_t x)
   return x ^ (x >> 31);
 }
 
-// first index in [lo, hi) whose key is >= (b, bh).  (Multi-way versions were measured -- 7 pivots per step, a third
-// of the dependent round trips: k_tile_probe 39 -> 61 us, k_tile_fine 38 -> 62 us; 3 pivots per step with a quarter
-// of the probes: k_tile_probe 23 -> 29 us, k_tile_coarse 12 -> 15 us.  These searches are bound by the number of
-// distinct lines and pages they touch in ~1 GB of keys, not by the length of the chain.)
-__device__ __forceinline__ size_t lower_bound_key(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
-                                                  size_t lo, size_t hi, uint64_t b, uint64_t bh)
-{
-  if (keys_hi)
-    while (lo < hi)
-    {
-      const size_t mid = lo + ((hi - lo) >> 1);
-      const uint64_t kh = keys_hi[mid];
-      if (kh < bh || (kh == bh && keys[mid] < b)) lo = mid + 1; else hi = mid;
-    }
-  else
-    while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < b) lo = mid + 1; else hi = mid; }
-  return lo;
-}
-
+// (Multi-way searches were measured, twice -- round 2: 7 pivots per step, a third of the dependent round trips:
+// k_tile_probe 39 -> 61 us, k_tile_fine 38 -> 62 us; 3 pivots per step: 23 -> 29 us, 12 -> 15 us; round 3, 8-ary over
+// the index and the 4096-record window: k_tile_bounds 28 -> 61 us, 224 -> 273 us on 36 M rows.  These searches are
+// bound by the number of distinct lines and pages they touch in ~1 GB of keys, not by the length of the chain.)
 // first index in [lo, hi) whose key is >= (b, bh), hi if none, looked for AROUND a guess g: doubling steps away from it
 // until the answer is bracketed, then a bisection of that bracket -- a handful of loads on one or two lines when the
 // guess is good (k_tile_bounds interpolates it between two boundaries it knows), 2 log2(hi - lo) when it is not
@@ -432,7 +421,7 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
 // per (boundary, stream), each a search of its stream (lower_bound_indexed).  Every workgroup works the plan out for
 // itself from the probe's counts (the first one writes it down for the kernels behind): no launch of its own.
 __global__ void __launch_bounds__(256) k_tile_bounds(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_hi,
-                                                     const uint64_t* __restrict__ offs, const stream_index X, uint32_t S, uint32_t L,
+                                                     const uint64_t* __restrict__ offs, uint32_t S, uint32_t L,
                                                      const uint32_t* __restrict__ mult, uint64_t n, uint64_t n_l, uint32_t slots, float load,
                                                      uint32_t fill_fixed, uint32_t g_fixed, uint32_t grid_hint, uint32_t grid_hint_big,
                                                      tile_plan* __restrict__ plan, uint32_t* __restrict__ start,
@@ -2009,7 +1998,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     hipLaunchKernelGGL(k_tile_probe, dim3((unsigned)((probes_for((uint32_t)S) * (size_t)S + 255) / 256 + (coarse_cells + 255) / 256)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S,
                        (uint64_t)n, d_mult, L, R0, C, static_cast<uint32_t*>(p_coarse));
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
-    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, X, (uint32_t)S, L,
+    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
                        d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
                        grid_hint, grid_hint_big, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0),
                        R0, C, static_cast<const uint32_t*>(p_coarse));
