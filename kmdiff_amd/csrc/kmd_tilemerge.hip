@@ -410,6 +410,11 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   const double run = fill_planned / (double)S;
   uint32_t g = 3;
   while (g < 6 && (double)(1u << g) < run * 0.75) ++g;
+  // (whole waves from runs of 14 records up: the whole-wave path -- hand-issued loads, the hand-written round -- beats
+  // the sub-group one, the older code, wherever it was tried against it: 200 samples, runs of 35 / 26 records: 1.56
+  // against 2.11 ms, 2.16 against 2.65; 600 samples, runs of 38 / 16: 1.19 against 1.72, 2.31 against 2.54;
+  // tools/sweep_way.sh)
+  if (run >= 14.0) g = 6;
   if (g_fixed) g = g_fixed;
   tile_plan pl;
   pl.r = (uint32_t)r; pl.nb = (uint32_t)nb; pl.g_shift = g; pl.fill = (uint32_t)fill; pl.rho = (float)rho;
