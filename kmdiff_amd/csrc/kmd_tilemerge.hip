@@ -2004,7 +2004,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
                        (uint64_t)n, d_mult, L, R0, C, static_cast<uint32_t*>(p_coarse));
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
     hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
-                       d_mult, (uint64_t)n, n_l, sh.slots, load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
+                       d_mult, (uint64_t)n, n_l, sh.slots ? sh.slots : (two && std::getenv("KMD_TILE_SUM64") ? kSmallSlots : 0u), load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
                        grid_hint, grid_hint_big, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0),
                        R0, C, static_cast<const uint32_t*>(p_coarse));
     KMD_HIP(hipGetLastError());
@@ -2068,6 +2068,10 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   uint32_t shape_level0 = sh.slots ? sh.slots : async ? async->shape : g_last_shape[dev & 63].load(std::memory_order_relaxed);   // 0: both
   uint32_t shape_known = sh.slots;                               // levels > 0: the plan's, read back
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
+  // (what the instantiations that can be launched take of the 160 KB of LDS, 1024 samples' segment tables included)
+  static_assert(sizeof(tile_lds<kBigSlots, 16, true, true>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, two limbs, 32-bit sums");
+  static_assert(sizeof(tile_lds<kBigSlots, 16, false, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, one limb, 64-bit sums");
+  static_assert(sizeof(tile_lds<kSmallSlots, 8, true, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "2048 slots, two limbs, 64-bit sums");
   auto run = [&](uint32_t tiles_at_most) -> int
   {
     // one instantiation per (shape, fused, two limbs, whole-wave runs, 32-bit sums)
@@ -2184,12 +2188,15 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     KMD_HIP(hipMemcpy(h_over.data(), static_cast<uint32_t*>(p_over), (size_t)n_over * 4, hipMemcpyDeviceToHost));
     KMD_HIP(hipMemcpy(h_over.data() + n_over, static_cast<uint32_t*>(p_over) + list_cap, (size_t)n_over * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> h_ref(3 * (size_t)n_over);              // tile, slices, first row
+    for (uint32_t i = 0; i < n_over; ++i)
+      if (h_over[n_over + i] & kBigBit) sum32 = false;            // a count >= 2^22: the tiles listed from here on are redone with 64-bit sums
+    // (two limbs AND 64-bit sums: the 4096-slot table does not fit the LDS -- the slices are cut for the smaller one)
+    if (two && !sum32) shape_known = kSmallSlots;
     const uint64_t per_slice = std::max<uint64_t>(64, (uint64_t)(load * (float)shape_known));
     uint64_t rows = 0;
     for (uint32_t i = 0; i < n_over; ++i)
     {
       const uint64_t cnt = h_over[n_over + i] & ~(kAbortBit | kBigBit);
-      if (h_over[n_over + i] & kBigBit) sum32 = false;          // a count >= 2^22: the tiles listed from here on are redone with 64-bit sums
       uint64_t m = 2 * ((cnt + per_slice - 1) / per_slice);
       if (m < 2) m = 2;
       if (m > (1u << 20)) m = 1u << 20;
