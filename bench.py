@@ -19,11 +19,13 @@ The JSON line also carries
   cpu_baseline : the reference's own arithmetic (oracle/_ref, kind "reference") or the C
                  restatement (kind "port") on the host cores, on a bounded sample of the same
                  workload, tail function evaluated for every row as the reference does;
-  pipeline     : (N = 1) the kmtricks-side input of the same path: one partition's per-sample k-mer
-                 streams resident in HBM -> survivors (kmd_merge_filter: k-way merge fused with the test),
-                 12 algorithmic bytes per record, HIP events around back-to-back calls; `overlapped` = the same
-                 with six partitions in flight on streams (and host threads) of their own, per partition; `batched` =
-                 twelve partitions through kmd_merge_filter_batch (one host thread, six in flight inside the library);
+  pipeline     : (N = 1) the kmtricks-side input of the same path: one WHOLE configs[2] partition's per-sample k-mer
+                 streams (39 062 500 rows, ~10^9 records, 12 GB; built on the device) resident in HBM -> survivors
+                 (kmd_merge_filter: k-way merge fused with the test), 12 algorithmic bytes per record, HIP events around
+                 back-to-back calls; `overlapped` = the same with six partitions in flight on streams (and host threads) of
+                 their own, per partition; `batched` = twelve partitions (four distinct ones in turn) through
+                 kmd_merge_filter_batch (one host thread, six in flight inside the library); `small` = the 4 M-row
+                 partition earlier rounds quoted (single calls only);
   h2d_inclusive: (N = 1) the headline step with the host-to-device copy of the partition (from page-locked
                  memory) inside the timed loop -- never `value`.
 """
@@ -120,21 +122,21 @@ def cpu_baseline(rows_per_part, tc, tk):
                       "with the tail function for every row; %d survivors" % (cores, n, c.n_sig)}
 
 
-def pipeline_leg(K, lib, rows=4_000_000, iters=6):
-    """Streams -> survivors on one partition: the per-sample (k-mer, count) streams kmtricks writes
-    (records of sample s = the rows with a non-zero count in column s), resident in HBM, through
-    kmd_merge_filter.  12 algorithmic bytes per record (8-byte k-mer + 4-byte count, each read once)."""
-    mat = K.synth_matrix(SEED, 0, rows, NC, NK, COUNT_BYTES, K.LAYOUT_ROWS)
-    host, lo = mat.to_host(), mat.kmers_to_host()[0]
-    streams = []
-    for s in range(NC + NK):
-        sel = host[:, s] > 0
-        streams.append((lo[sel], host[sel, s]))
-    tot = host.sum(axis=0, dtype=np.uint64)
-    del mat
-    ss = K.StreamSet(streams)
+def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=True):
+    """Streams -> survivors on one partition of `rows` rows: the per-sample (k-mer, count) streams kmtricks writes
+    (records of sample s = the rows with a non-zero count in column s), built on the device (kmd_synth_streams),
+    resident in HBM, through kmd_merge_filter.  12 algorithmic bytes per record (8-byte k-mer + 4-byte count, each
+    read once).  rows = 39 062 500 is a whole configs[2] partition -- what the reference merges per task
+    (merge.hpp:265-289)."""
+    sets, tot = [], None
+    for p in range(n_distinct):
+        ss_p, tot_p = K.synth_streams(SEED, p, rows, NC, NK)
+        sets.append(ss_p)
+        tot = tot_p if tot is None else tot + tot_p
+    ss = sets[0]
     model = K.PoissonLikelihood(NC, NK, tot[:NC], tot[NC:], LOG_FACTORIAL)
-    acc = K.SurvivorAccumulator(max(1 << 16, rows // 100))
+    cap = max(1 << 16, rows // 100)
+    acc = K.SurvivorAccumulator(cap)
     obs = K.diff_observer(model, acc, THRESHOLD / CUTOFF, NC, NK)
     n_rows = K.merge_filter(ss, obs)                       # warm-up (first-use costs)
     acc.counters.zero()
@@ -146,22 +148,34 @@ def pipeline_leg(K, lib, rows=4_000_000, iters=6):
     ms = e0.elapsed_ms(e1) / iters
     c = acc.read_counters()
     assert int(c[0]) == iters * n_rows == iters * rows, (int(c[0]), n_rows, rows)
+    n_sig0 = int(c[1]) // iters
     gbs = 12.0 * ss.total / (ms * 1e-3) / 1e9
+    roof = lambda g: {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS}
+    out = {"what": "one partition's per-sample k-mer streams resident in HBM -> survivors (kmd_merge_filter: k-way merge "
+                   "fused with the Poisson test; tile plan + boundary search + merge kernel + candidate evaluation, host "
+                   "round trip included)",
+           "config": {"workload": "%s: 20v20, k=31, %d rows, %d records of 12 bytes (8-byte k-mer + 4-byte count) in 40 per-sample "
+                                  "streams, built on the device (kmd_synth_streams)"
+                                  % ("one configs[2] partition (10^10 rows / 256)" if rows == ROWS_PER_PARTITION else "a reduced partition", rows, ss.total),
+                      "rows": rows, "records": ss.total, "samples": NC + NK},
+           "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),
+           "records_per_s": ss.total / (ms * 1e-3), "bytes_algorithmic": 12 * ss.total, "roofline": roof(gbs), "n_sig": n_sig0}
+    if not with_extras:
+        return out
     # partitions in flight: a job has hundreds of partitions; with six of them on streams (and host threads) of
     # their own, the boundary searches, the candidate evaluation and the read-back of one run beside the merge
     # kernel of another
-    import threading
     in_flight, per = 6, max(4, iters)
     workers = []
-    for _ in range(in_flight):
+    for w_i in range(in_flight):
         st = C.c_void_p()
         K._native.check(lib.kmd_stream_create(C.byref(st)), "kmd_stream_create")
-        acc_t = K.SurvivorAccumulator(max(1 << 16, rows // 100))
-        workers.append((st, acc_t, K.diff_observer(model, acc_t, THRESHOLD / CUTOFF, NC, NK)))
+        acc_t = K.SurvivorAccumulator(cap)
+        workers.append((st, acc_t, K.diff_observer(model, acc_t, THRESHOLD / CUTOFF, NC, NK), sets[w_i % n_distinct]))
 
     def work(w, k):
         for _ in range(k):
-            K.merge_filter(ss, w[2], stream=w[0])
+            K.merge_filter(w[3], w[2], stream=w[0])
     def run_all(k):
         threads = [threading.Thread(target=work, args=(w, k)) for w in workers]
         for t in threads:
@@ -178,44 +192,36 @@ def pipeline_leg(K, lib, rows=4_000_000, iters=6):
         ms_o = min(ms_o, (time.perf_counter() - t0) / (in_flight * per) * 1e3)
     for w in workers:
         cw = w[1].read_counters()
-        assert int(cw[0]) == (n_timed * per + 2) * rows and int(cw[1]) == (n_timed * per + 2) * (int(c[1]) // iters), (int(cw[0]), int(cw[1]))
+        assert int(cw[0]) == (n_timed * per + 2) * rows, int(cw[0])
         lib.kmd_stream_destroy(w[0])
-    gbs_o = 12.0 * ss.total / (ms_o * 1e-3) / 1e9
-    overlapped = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "kmers_per_s": rows / (ms_o * 1e-3),
-                  "records_per_s": ss.total / (ms_o * 1e-3),
-                  "roofline": {"bound": "hbm", "achieved": gbs_o, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_o / HBM_PEAK_GBS}}
+    rec_avg = sum(x.total for x in sets) / float(n_distinct)
+    gbs_o = 12.0 * rec_avg / (ms_o * 1e-3) / 1e9
+    out["overlapped"] = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "kmers_per_s": rows / (ms_o * 1e-3),
+                         "records_per_s": rec_avg / (ms_o * 1e-3), "roofline": roof(gbs_o)}
     # the same through ONE host thread: kmd_merge_filter_batch keeps six partitions in flight on streams of the
-    # library's own and waits once per partition (12 partitions = 12 copies of the streams in HBM)
-    n_batch = 12
-    sets = [ss] + [K.StreamSet(streams) for _ in range(n_batch - 1)]
-    accs = [K.SurvivorAccumulator(max(1 << 16, rows // 100)) for _ in range(n_batch)]
+    # library's own and waits once per partition (n_distinct different partitions in HBM, taken in turn)
+    b_sets = [sets[i % n_distinct] for i in range(n_batch)]
+    accs = [K.SurvivorAccumulator(cap) for _ in range(n_batch)]
     obs_b = [K.diff_observer(model, a_, THRESHOLD / CUTOFF, NC, NK) for a_ in accs]
-    K.merge_filter_batch(sets, obs_b)                      # untimed: scratch of six concurrent partitions, streams
+    K.merge_filter_batch(b_sets, obs_b)                    # untimed: scratch of six concurrent partitions, streams
     for a_ in accs:
         a_.counters.zero()
     K._native.check(lib.kmd_stream_sync(None))
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
-        rows_b = K.merge_filter_batch(sets, obs_b)
+        rows_b = K.merge_filter_batch(b_sets, obs_b)
     ms_b = (time.perf_counter() - t0) / (reps * n_batch) * 1e3
     assert rows_b == [rows] * n_batch
     for a_ in accs:
         cb = a_.read_counters()
-        assert int(cb[0]) == reps * rows and int(cb[1]) == reps * (int(c[1]) // iters), (int(cb[0]), int(cb[1]))
-    gbs_b = 12.0 * ss.total / (ms_b * 1e-3) / 1e9
-    batched = {"partitions": n_batch, "in_flight": 6, "ms_per_partition": ms_b, "kmers_per_s": rows / (ms_b * 1e-3),
-               "records_per_s": ss.total / (ms_b * 1e-3), "what": "kmd_merge_filter_batch, one host thread",
-               "roofline": {"bound": "hbm", "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_b / HBM_PEAK_GBS}}
-    del sets, accs, obs_b
-    return {"overlapped": overlapped, "batched": batched,
-            "what": "one partition's per-sample k-mer streams resident in HBM -> survivors (kmd_merge_filter: k-way merge "
-                    "fused with the Poisson test; tile plan + boundary search + merge kernel + candidate evaluation, host "
-                    "round trip included)",
-            "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),
-            "records_per_s": ss.total / (ms * 1e-3), "bytes_algorithmic": 12 * ss.total,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-            "n_sig": int(c[1]) // iters}
+        assert int(cb[0]) == reps * rows, int(cb[0])
+    assert int(accs[0].read_counters()[1]) == reps * n_sig0
+    gbs_b = 12.0 * rec_avg / (ms_b * 1e-3) / 1e9
+    out["batched"] = {"partitions": n_batch, "distinct_partitions": n_distinct, "in_flight": 6, "ms_per_partition": ms_b,
+                      "kmers_per_s": rows / (ms_b * 1e-3), "records_per_s": rec_avg / (ms_b * 1e-3),
+                      "what": "kmd_merge_filter_batch, one host thread", "roofline": roof(gbs_b)}
+    return out
 
 
 def h2d_leg(K, lib, obs, mat, steps=3):
@@ -263,6 +269,8 @@ def main():
     ap.add_argument("--resident", type=int, default=8, help="distinct partitions kept in HBM per rank")
     ap.add_argument("--correction", default="bonferroni")
     ap.add_argument("--layout", default="tiled", choices=["tiled", "soa", "rows"])
+    ap.add_argument("--pipeline-rows", type=int, default=ROWS_PER_PARTITION, help="rows of the partition of the streams -> survivors leg")
+    ap.add_argument("--pipeline-partitions", type=int, default=4, help="distinct partitions' streams kept in HBM for that leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the streams -> survivors and H2D-inclusive legs (N = 1 extras)")
     args = ap.parse_args()
@@ -421,7 +429,12 @@ def main():
                 out["h2d_inclusive"] = h2d_leg(K, lib, obs, mats[0])
             except Exception as e:                          # (a box without room for the page-locked copy)
                 out["h2d_inclusive"] = {"error": str(e)}
-            out["pipeline"] = pipeline_leg(K, lib)
+            # the resident matrices of the headline leg make room for the streams of whole partitions (4 x 12 GB)
+            del mats[1:]
+            K._native.check(lib.kmd_release_cache())
+            out["pipeline"] = pipeline_leg(K, lib, args.pipeline_rows, iters=6, n_distinct=args.pipeline_partitions)
+            if args.pipeline_rows > 4_000_000:
+                out["pipeline"]["small"] = pipeline_leg(K, lib, 4_000_000, iters=6, n_distinct=1, with_extras=False)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.rows, int(totals[:NC].sum()), int(totals[NC:].sum()))
         print(json.dumps(out), flush=True)

@@ -208,6 +208,42 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
                           const double* d_pvalue, const int32_t* d_sign, size_t n, uint8_t* d_keep,
                           uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream);
 
+/* ---- stage 3 across GPUs: the one exchange step of a sharded run ---------------------
+ * The reference sums its partitions' counters with std::accumulate (include/kmdiff/merge.hpp:316, 402-413) and pops ALL
+ * survivors from one priority queue in ascending p, BH / Holm stopping at the first rejection (include/kmdiff/
+ * aggregator.hpp:286-310, 325-339).  With partition p on rank p % N the survivors live on N devices; the global walk
+ * is reproduced without moving them (kmd_shard.hip): all-reduce of the counters; for BH / Holm an all-gather of the
+ * ranks' 4096-bin p-value histograms, the first bin the walk cannot accept wholesale, an all-gather of the p-values
+ * from that bin on only, and the exact walk over those on every rank.
+ *
+ * The wire: two collectives over DEVICE buffers, called by every rank in the same order; each returns when the result
+ * is in the caller's buffer (they synchronise `stream` themselves).  Two transports come with the library --
+ * kmd_transport_local_create (N host threads of one process: `kmdiff-hip diff --devices N`) and, in
+ * libkmdiff_hip_rccl.so, kmd_transport_rccl_create (one process per GPU: ncclAllReduce / ncclAllGather over xGMI); a
+ * host with a wire of its own fills the struct itself (kmdiff_amd/dist.py does, with torch.distributed). */
+typedef struct kmd_transport {
+  void* ctx;
+  int rank, world;
+  /* d_buf[i] = sum over ranks of d_buf[i], i < n, in place */
+  int (*allreduce_u64)(void* ctx, uint64_t* d_buf, size_t n, void* stream);
+  /* d_recv[r * bytes .. (r + 1) * bytes) = rank r's d_send; `bytes` is the same on every rank */
+  int (*allgather)(void* ctx, const void* d_send, void* d_recv, size_t bytes, void* stream);
+} kmd_transport;
+
+/* kmd_correct for the survivors of THIS rank in a run of t->world ranks (t == NULL: one rank):
+ *   counters_local  : host, this rank's uint64_t[KMD_NCOUNTERS] (diff_observer's counters summed over its partitions)
+ *   counters_global : host output (may be NULL), their sum over the ranks; [KMD_CNT_TOTAL] is the N of the correctors
+ *   d_keep / n_kept / n_control / n_case : as kmd_correct, for this rank's n survivors
+ * Every rank of the run must call it (the collectives inside are matched calls).  The decisions are those of
+ * kmd_correct over the concatenation of all ranks' survivors.  Synchronous. */
+int kmd_correct_sharded(const kmd_transport* t, int correction, double threshold, const uint64_t* counters_local,
+                        uint64_t* counters_global, const double* d_pvalue, const int32_t* d_sign, size_t n,
+                        uint8_t* d_keep, uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream);
+/* The in-process transport: out[0 .. world) are the ranks' handles (shared state behind them); rank r's collectives
+ * are called by a host thread of its own that has made rank r's device current (several ranks may share a device). */
+int kmd_transport_local_create(int world, kmd_transport* out);
+int kmd_transport_local_destroy(int world, kmd_transport* t);
+
 /* ---- stage 0: k-way merge of one partition -------------------------------------------------
  * Replaces km::KmerMerger<KSIZE,CMAX>(paths, ab_mins = 1.., k, r_min = 1, save_if = 0).merge(obs)
  * as kmdiff drives it (include/kmdiff/merge.hpp:265-289; kmtricks is an un-vendored
@@ -361,6 +397,17 @@ int kmd_pca_eigen(int n_samples, const double* xtx_host, int n_out, double* evec
 int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc,
                    int nk, int count_bytes, int layout, size_t ld, void* d_counts,
                    uint64_t* d_kmer_lo, uint64_t* d_kmer_hi, void* stream);
+/* The same synthetic partition as kmtricks would hand it to the merge: per-sample (k-mer, count) streams -- the
+ * records of sample s are the rows with a non-zero count in column s, in row order (ascending k-mer) --
+ * concatenated in sample order, as kmd_merge_filter takes them.  Built on the device, chunk by chunk (no matrix of the
+ * whole partition, no host copy: a configs[2] partition is 39 062 500 rows, ~10^9 records, 12 GB).  Two calls:
+ *   d_kmers == NULL : offsets[0 .. nc+nk] (host) are computed; d_totals[s] += column sums (may be NULL);
+ *   d_kmers != NULL : offsets is what the first call returned; d_kmers / d_counts (offsets[nc+nk] records) and
+ *                     d_kmers_hi (two-limb k-mers: the high limbs; else NULL) are filled.
+ * Synchronous. */
+int kmd_synth_streams(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc, int nk,
+                      uint64_t* offsets, uint64_t* d_kmers, uint64_t* d_kmers_hi, uint32_t* d_counts,
+                      uint64_t* d_totals, void* stream);
 /* d_totals[s] += sum over rows of counts[.][s]  (uint64_t[nc+nk], caller zeroes);
  * the role of get_total_kmer (src/kmtricks_utils.cpp:78-139) for synthetic data. */
 int kmd_column_sums(const void* d_counts, int count_bytes, int layout, size_t ld,

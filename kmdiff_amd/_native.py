@@ -36,6 +36,16 @@ class Tile(C.Structure):
                 ("n_rows", C.c_size_t), ("row_base", C.c_uint64)]
 
 
+# kmd_transport (include/kmdiff_hip.h): the wire of kmd_correct_sharded -- two collectives over device buffers
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int),
+                ("allreduce_u64", ALLREDUCE_FN), ("allgather", ALLGATHER_FN)]
+
+
 # name -> (restype, argtypes); the list mirrors include/kmdiff_hip.h and is what
 # tests/test_abi.py checks against the header and the built library.
 _vp, _sz, _u64, _i, _d = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_double
@@ -85,6 +95,10 @@ SIGNATURES = {
     "kmd_correct_critical_bin": (_i, [_i, _d, _u64, _vp, C.POINTER(C.c_uint32), C.POINTER(_u64), _vp]),
     "kmd_correct_from_rank": (_i, [_i, _d, _u64, _u64, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
                                    C.POINTER(_u64), _vp]),
+    "kmd_correct_sharded": (_i, [C.POINTER(Transport), _i, _d, _vp, _vp, _vp, _vp, _sz, _vp, C.POINTER(_u64), C.POINTER(_u64),
+                                 C.POINTER(_u64), _vp]),
+    "kmd_transport_local_create": (_i, [_i, C.POINTER(Transport)]),
+    "kmd_transport_local_destroy": (_i, [_i, C.POINTER(Transport)]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_filter": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, C.POINTER(Survivors), _vp, C.POINTER(_u64), _vp]),
@@ -105,6 +119,7 @@ SIGNATURES = {
     "kmd_pca_gram": (_i, [_vp, _vp, _vp]),
     "kmd_pca_eigen": (_i, [_i, _vp, _i, _vp, _vp]),
     "kmd_synth_fill": (_i, [_u64, C.c_uint32, _u64, _sz, _i, _i, _i, _i, _sz, _vp, _vp, _vp, _vp]),
+    "kmd_synth_streams": (_i, [_u64, C.c_uint32, _u64, _sz, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmd_column_sums": (_i, [_vp, _i, _i, _sz, _sz, _i, _vp, _vp]),
     "kmd_copy_probe": (_i, [_vp, _vp, _sz, _vp]),
     "kmd_read_probe": (_i, [_vp, _sz, _i, _vp, _vp]),
@@ -148,3 +163,34 @@ def check(status, what=""):
         msg = L.kmd_last_error().decode() or L.kmd_status_string(status).decode()
         raise KmdError("%s: %s (status %d)" % (what or "kmd", msg, status))
     return status
+
+
+# ---- libkmdiff_hip_rccl.so (include/kmdiff_hip_rccl.h): the RCCL transport, a library of its own
+RCCL_LIB_PATH = os.path.join(_HERE, "lib", "libkmdiff_hip_rccl.so")
+RCCL_SIGNATURES = {
+    "kmd_rccl_last_error": (C.c_char_p, []),
+    "kmd_rccl_unique_id": (_i, [_vp]),
+    "kmd_transport_rccl_init": (_i, [C.POINTER(Transport), _i, _i, _vp]),
+    "kmd_transport_rccl_wrap": (_i, [C.POINTER(Transport), _vp]),
+    "kmd_transport_rccl_destroy": (_i, [C.POINTER(Transport)]),
+}
+_rccl = None
+
+
+def rccl_lib():
+    """Load libkmdiff_hip_rccl.so (once; it pulls in librccl)."""
+    global _rccl
+    if _rccl is None:
+        lib()                                               # (the HIP runtime first, as lib() arranges it)
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise KmdError("libkmdiff_hip_rccl.so is not built (%s)" % RCCL_LIB_PATH)
+        try:
+            L = C.CDLL(RCCL_LIB_PATH)
+        except OSError as e:
+            raise KmdError("cannot load %s: %s" % (RCCL_LIB_PATH, e))
+        for name, (res, args) in RCCL_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _rccl = L
+    return _rccl

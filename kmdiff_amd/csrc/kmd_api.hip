@@ -6,6 +6,7 @@
 #include "kmd_math.h"
 #include "kmd_synth_tables.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,21 @@ struct scratch_cache
   size_t parked_bytes = 0;
 };
 scratch_cache& cache() { static scratch_cache c; return c; }
-constexpr size_t kMaxParked = 8ull << 30;                   // beyond this, free for real
+// Parked beyond this, blocks are freed for real: an eighth of the device's memory (36 GB of an MI355X's 288), at least
+// 8 GB.  (Six whole configs[2] partitions in flight hold ~2 GB of scratch each: with a fixed 8 GB every free past the
+// fourth partition was a hipFree -- a device-wide synchronisation -- and every allocation a hipMalloc: 44 ms per
+// partition instead of 2.5.)
+size_t max_parked()
+{
+  static const size_t limit = []
+  {
+    if (const char* e = std::getenv("KMD_SCRATCH_PARK_MB")) return (size_t)std::strtoull(e, nullptr, 10) << 20;     // dev: a small cache (evictions all the time)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+    return std::max<size_t>((size_t)8 << 30, total_b / 8);
+  }();
+  return limit;
+}
 }
 
 hipError_t kmd::scratch_alloc(void** p, size_t bytes)
@@ -84,7 +99,27 @@ void kmd::scratch_free(void* p)
   if (it == c.live.end()) { lock.unlock(); (void)hipFree(p); return; }
   const auto key = it->second;
   c.live.erase(it);
-  if (c.parked_bytes + key.second > kMaxParked) { lock.unlock(); (void)hipFree(p); return; }
+  const size_t limit = max_parked();
+  if (key.second > limit) { lock.unlock(); (void)hipFree(p); return; }
+  if (c.parked_bytes + key.second > limit)
+  {
+    // make room: the parked blocks go (largest classes first: they are what filled the cache), this one stays -- it is
+    // the size the caller works with NOW (a cache stuck full of an earlier job's large blocks turned every later
+    // small allocation into a hipMalloc / hipFree pair)
+    std::vector<void*> out;
+    for (auto it = c.parked.end(); it != c.parked.begin() && c.parked_bytes + key.second > limit;)
+    {
+      --it;
+      out.push_back(it->second);
+      c.parked_bytes -= it->first.second;
+      it = c.parked.erase(it);
+    }
+    c.parked.insert({ key, p });
+    c.parked_bytes += key.second;
+    lock.unlock();
+    for (void* q : out) (void)hipFree(q);
+    return;
+  }
   c.parked.insert({ key, p });
   c.parked_bytes += key.second;
 }
@@ -484,6 +519,77 @@ __global__ void __launch_bounds__(256) k_column_sums(const CT* __restrict__ coun
     atomicAdd(&totals[s], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+// ---- the same synthetic partition as per-sample streams (what kmtricks hands the merge) ---------------
+// Records of sample s = the rows with a non-zero count in column s, (k-mer, count), in row order (= ascending
+// k-mer).  Built chunk by chunk from k_synth's matrix (SoA scratch of `chunk` rows): per (sample, block of 1024
+// rows) the non-zero counts are counted, scanned per sample, and scattered behind the sample's cursor.
+constexpr int kStreamBlockRows = 1024;       // 256 threads x 4 rows
+
+__global__ void __launch_bounds__(256) k_streams_count(const uint32_t* __restrict__ counts, size_t ld, size_t n_rows,
+                                                       uint32_t n_blocks, uint32_t* __restrict__ cnt)
+{
+  __shared__ uint32_t s_part[4];
+  const uint32_t b = blockIdx.x, s = blockIdx.y;
+  const size_t r0 = (size_t)b * kStreamBlockRows + (size_t)threadIdx.x * 4;
+  uint32_t mine = 0;
+  for (int u = 0; u < 4; ++u) mine += (r0 + u < n_rows && counts[(size_t)s * ld + r0 + u] != 0) ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[(size_t)s * n_blocks + b] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// one workgroup per sample: cnt[s][b] -> where block b's records of sample s begin (cursor[s] + exclusive
+// prefix); cursor[s] += the chunk's records of sample s
+__global__ void __launch_bounds__(256) k_streams_scan(uint32_t n_blocks, const uint32_t* __restrict__ cnt,
+                                                      unsigned long long* __restrict__ blk_off, unsigned long long* __restrict__ cursor)
+{
+  __shared__ unsigned long long s_sum[256];
+  const uint32_t s = blockIdx.x, t = threadIdx.x;
+  const uint32_t per = (n_blocks + 255u) / 256u;
+  const uint32_t lo = t * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+  unsigned long long acc = 0;
+  for (uint32_t b = lo; b < hi; ++b) acc += cnt[(size_t)s * n_blocks + b];
+  s_sum[t] = acc;
+  __syncthreads();
+  if (t == 0)
+  {
+    unsigned long long run = cursor[s];
+    for (int i = 0; i < 256; ++i) { const unsigned long long v = s_sum[i]; s_sum[i] = run; run += v; }
+    cursor[s] = run;
+  }
+  __syncthreads();
+  unsigned long long run = s_sum[t];
+  for (uint32_t b = lo; b < hi; ++b) { blk_off[(size_t)s * n_blocks + b] = run; run += cnt[(size_t)s * n_blocks + b]; }
+}
+
+__global__ void __launch_bounds__(256) k_streams_scatter(const uint32_t* __restrict__ counts, size_t ld, size_t n_rows, uint32_t n_blocks,
+                                                         const uint64_t* __restrict__ kmer_lo, const uint64_t* __restrict__ kmer_hi,
+                                                         const unsigned long long* __restrict__ blk_off, uint64_t* __restrict__ out_k,
+                                                         uint64_t* __restrict__ out_kh, uint32_t* __restrict__ out_c)
+{
+  __shared__ uint32_t s_wave[4];
+  const uint32_t b = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const size_t r0 = (size_t)b * kStreamBlockRows + (size_t)threadIdx.x * 4;
+  uint32_t c[4], mine = 0;
+  for (int u = 0; u < 4; ++u) { c[u] = r0 + u < n_rows ? counts[(size_t)s * ld + r0 + u] : 0u; mine += c[u] != 0 ? 1u : 0u; }
+  uint32_t incl = mine;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, (unsigned)o, 64); incl += lane >= (uint32_t)o ? v : 0u; }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t before = incl - mine;
+  for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+  unsigned long long at = blk_off[(size_t)s * n_blocks + b] + before;
+  for (int u = 0; u < 4; ++u)
+    if (c[u] != 0)
+    {
+      out_k[at] = kmer_lo[r0 + u];
+      if (out_kh) out_kh[at] = kmer_hi[r0 + u];
+      out_c[at] = c[u];
+      ++at;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -570,6 +676,77 @@ int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_ro
     default: hipLaunchKernelGGL((k_synth<uint32_t>), dim3((unsigned)grid), dim3(256), 0, st, seed, partition, row0, n_rows, nc, nk, layout, ld, static_cast<uint32_t*>(d_counts), d_kmer_lo, d_kmer_hi, T); break;
   }
   KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+int kmd_synth_streams(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc, int nk,
+                      uint64_t* offsets, uint64_t* d_kmers, uint64_t* d_kmers_hi, uint32_t* d_counts,
+                      uint64_t* d_totals, void* stream)
+{
+  KMD_REQUIRE(offsets, "kmd_synth_streams: NULL offsets");
+  KMD_REQUIRE(nc > 0 && nk > 0 && nc + nk <= 1024, "kmd_synth_streams: nc, nk");
+  KMD_REQUIRE(partition < 256, "kmd_synth_streams: partition >= 256");
+  KMD_REQUIRE((d_kmers == nullptr) == (d_counts == nullptr), "kmd_synth_streams: d_kmers and d_counts go together");
+  KMD_REQUIRE(d_kmers || !d_kmers_hi, "kmd_synth_streams: d_kmers_hi without d_kmers");
+  const int S = nc + nk;
+  const bool fill = d_kmers != nullptr;
+  if (!fill) for (int s = 0; s <= S; ++s) offsets[s] = 0;
+  if (n_rows == 0) return KMD_OK;
+  synth_tables T;
+  int rc = ensure_tables(T);
+  if (rc != KMD_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // rows per chunk: ~512 MB of SoA scratch, whole blocks
+  size_t chunk = ((size_t)512 << 20) / (4 * (size_t)S) / kStreamBlockRows * kStreamBlockRows;
+  chunk = std::max<size_t>(kStreamBlockRows, std::min<size_t>(chunk, (size_t)1 << 22));
+  if (const char* e = std::getenv("KMD_SYNTH_CHUNK"))                 // dev: rows per chunk (tests: many chunks on a small partition)
+    chunk = std::max<size_t>(kStreamBlockRows, (size_t)std::strtoull(e, nullptr, 10) / kStreamBlockRows * kStreamBlockRows);
+  chunk = std::min(chunk, (n_rows + kStreamBlockRows - 1) / kStreamBlockRows * kStreamBlockRows);
+  const uint32_t nb_max = (uint32_t)(chunk / kStreamBlockRows);
+  struct bufs
+  {
+    void* p[6] = {};
+    ~bufs() { for (void* q : p) if (q) (void)hipFree(q); }
+  } B;
+  KMD_HIP(hipMalloc(&B.p[0], chunk * (size_t)S * 4));                 // counts[s][row]
+  KMD_HIP(hipMalloc(&B.p[1], chunk * 8));                             // k-mers of the chunk's rows
+  KMD_HIP(hipMalloc(&B.p[2], chunk * 8));                             // (high limbs)
+  KMD_HIP(hipMalloc(&B.p[3], (size_t)S * nb_max * 4));                // records per (sample, block)
+  KMD_HIP(hipMalloc(&B.p[4], (size_t)S * nb_max * 8));                // where they go
+  KMD_HIP(hipMalloc(&B.p[5], (size_t)S * 8));                         // cursor per sample
+  uint32_t* d_mat = static_cast<uint32_t*>(B.p[0]);
+  uint64_t *d_lo = static_cast<uint64_t*>(B.p[1]), *d_hi = static_cast<uint64_t*>(B.p[2]);
+  uint32_t* d_cnt = static_cast<uint32_t*>(B.p[3]);
+  unsigned long long *d_off = static_cast<unsigned long long*>(B.p[4]), *d_cur = static_cast<unsigned long long*>(B.p[5]);
+  if (fill) KMD_HIP(hipMemcpyAsync(d_cur, offsets, (size_t)S * 8, hipMemcpyHostToDevice, st));
+  else KMD_HIP(hipMemsetAsync(d_cur, 0, (size_t)S * 8, st));
+  for (size_t r = 0; r < n_rows; r += chunk)
+  {
+    const size_t m = std::min(chunk, n_rows - r);
+    const uint32_t nb = (uint32_t)((m + kStreamBlockRows - 1) / kStreamBlockRows);
+    size_t grid = (m + 255) / 256;
+    if (grid > 65535 * 4) grid = 65535 * 4;
+    // (two limbs: the high limb carries the row, the low one is a hash -- as kmd_synth_fill writes them)
+    hipLaunchKernelGGL((k_synth<uint32_t>), dim3((unsigned)grid), dim3(256), 0, st, seed, partition, row0 + r, m, nc, nk, (int)KMD_LAYOUT_SOA, chunk,
+                       d_mat, fill ? d_lo : nullptr, fill && d_kmers_hi ? d_hi : nullptr, T);
+    if (!fill && d_totals)
+      hipLaunchKernelGGL((k_column_sums<uint32_t>), dim3((unsigned)std::min<size_t>((m + 255) / 256, 1024), (unsigned)S), dim3(256), 0, st, d_mat,
+                         (int)KMD_LAYOUT_SOA, chunk, m, S, reinterpret_cast<unsigned long long*>(d_totals));
+    hipLaunchKernelGGL(k_streams_count, dim3(nb, (unsigned)S), dim3(256), 0, st, d_mat, chunk, m, nb, d_cnt);
+    hipLaunchKernelGGL(k_streams_scan, dim3((unsigned)S), dim3(256), 0, st, nb, d_cnt, d_off, d_cur);
+    if (fill)
+      hipLaunchKernelGGL(k_streams_scatter, dim3(nb, (unsigned)S), dim3(256), 0, st, d_mat, chunk, m, nb, d_lo, d_kmers_hi ? d_hi : nullptr, d_off,
+                         d_kmers, d_kmers_hi, d_counts);
+    KMD_HIP(hipGetLastError());
+  }
+  if (!fill)
+  {
+    std::vector<uint64_t> per((size_t)S);
+    KMD_HIP(hipMemcpyAsync(per.data(), d_cur, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    KMD_HIP(hipStreamSynchronize(st));
+    for (int s = 0; s < S; ++s) offsets[s + 1] = offsets[s] + per[(size_t)s];
+  }
+  else KMD_HIP(hipStreamSynchronize(st));
   return KMD_OK;
 }
 

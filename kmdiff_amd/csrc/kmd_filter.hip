@@ -1536,7 +1536,7 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
 // that is missing is appended; survivors that stay get the rounded p-value.  The list is empty in practice
 // (0 rows in 10^10 synthetic ones): the kernel then reads one word and leaves.
 template <int kRowMode>
-__global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
+__global__ void __launch_bounds__(64) k_resolve_near(const filter_params P, const int test_flip)
 {
   const unsigned long long flagged = P.near[0];
   const unsigned long long listed = flagged < kNearCap ? flagged : kNearCap;
@@ -1563,6 +1563,9 @@ __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P)
       kmd::sign_of(sum_c, sum_k, P.dTc, P.dTk, mean_control, sign);
     }
     const bool was = have && slot >= 0;
+    // dev (KMD_TEST_NEAR_FLIP, tests only): every listed row's decision is the opposite of the filter's, so that every
+    // one of them is struck out or appended -- the paths a libm's last bit takes once in 10^10 rows
+    if (test_flip) now = have && !was;
     // stays: the rounded p-value; goes: struck out (p = -1 marks the record until the sink is compacted)
     if (was && (unsigned long long)slot < P.out.capacity && P.out.d_pvalue) P.out.d_pvalue[slot] = now ? p : -1.0;
     const unsigned long long go_ctrl = __ballot(was && !now && sign == KMD_SIGN_CONTROL), go = __ballot(was && !now);
@@ -1697,8 +1700,9 @@ int kmd::near_list_begin(filter_params& P, hipStream_t stream)
 int kmd::near_list_end(const filter_params& P, int row_mode, hipStream_t stream)
 {
   if (!P.near) return KMD_OK;
-  if (row_mode == 1) hipLaunchKernelGGL(k_resolve_near<1>, dim3(1), dim3(64), 0, stream, P);
-  else hipLaunchKernelGGL(k_resolve_near<0>, dim3(1), dim3(64), 0, stream, P);
+  const int test_flip = std::getenv("KMD_TEST_NEAR_FLIP") != nullptr ? 1 : 0;
+  if (row_mode == 1) hipLaunchKernelGGL(k_resolve_near<1>, dim3(1), dim3(64), 0, stream, P, test_flip);
+  else hipLaunchKernelGGL(k_resolve_near<0>, dim3(1), dim3(64), 0, stream, P, test_flip);
   KMD_HIP(hipGetLastError());
   bool kept = false;
   {

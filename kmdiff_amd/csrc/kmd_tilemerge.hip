@@ -2263,7 +2263,9 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
   // pre-filter is off) in a scratch list; should the list prove too small, the merge runs again with
   // the size it reported -- nothing of the first run has reached the caller's counters or sink.
   const bool two = d_kmers_hi != nullptr;
-  size_t cap = std::max<size_t>((size_t)1 << 20, n / 8);               // (the workgroups' first chunks alone are up to 2^18 entries)
+  // (the workgroups' first chunks alone are up to 2^18 entries; measured: 0.4 % of the records on configs[2]'s rows of 26
+  // records, 1.8 % on rows of 3 -- a sixteenth leaves room, and a list that does overflow is run again below)
+  size_t cap = std::max<size_t>((size_t)1 << 20, n / 16);
   if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) cap = e;
   uint64_t entries = 0, totals[2] = { 0, 0 };
   scratch_set sc(st);
@@ -2323,6 +2325,7 @@ struct batch_streams
   hipStream_t st[kBatchStreams] = {};
   char* h_small = nullptr;                         // kBatchStreams x kBatchSlotBytes page-locked bytes
   hipEvent_t ev = nullptr;
+  hipEvent_t cand_done[kBatchStreams] = {};        // behind the candidate evaluation (and its near-threshold pass) of the slot's latest partition
 };
 std::mutex g_batch_mu;
 std::map<int, batch_streams> g_batch;              // per device
@@ -2340,6 +2343,7 @@ int batch_get(batch_streams** out)
     KMD_HIP(hipHostMalloc(&p, (size_t)kBatchStreams * kBatchSlotBytes, hipHostMallocDefault));
     B.h_small = static_cast<char*>(p);
     KMD_HIP(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+    for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipEventCreateWithFlags(&B.cand_done[i], hipEventDisableTiming));
   }
   *out = &B;
   return KMD_OK;
@@ -2366,6 +2370,33 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
   KMD_HIP(hipEventRecord(B->ev, user));
   for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipStreamWaitEvent(B->st[i], B->ev, 0));
 
+  // (every partition's pointers are looked at before anything is enqueued: an error here leaves nothing half done)
+  for (int p = 0; p < n_partitions; ++p)
+    KMD_REQUIRE(offsets[p] && d_counters[p], "kmd_merge_filter_batch: NULL offsets or counters of a partition");
+  // Partitions that share a survivor sink or counters.  The candidate evaluation of a partition ends with the pass over
+  // its near-threshold rows (k_resolve_near, kmd_filter.hip), which may strike a record and then compacts the WHOLE sink
+  // [0, counters[KMD_CNT_SIG]) in place -- assuming nothing else appends to it meanwhile.  On one stream that holds; two
+  // partitions of a batch that name the same sink run on different streams.  So: prev_alias[p] = the latest earlier
+  // partition that shares p's counters or any of its sink's arrays; p's candidate kernels wait for that partition's
+  // (an event behind them on its stream).  The merge kernels -- 90 % of a partition's time -- still overlap.
+  std::vector<int> prev_alias((size_t)n_partitions, -1);
+  std::vector<char> shares((size_t)n_partitions, 0);
+  std::vector<char> queued((size_t)n_partitions, 0);          // 1: in flight with an event behind its candidate kernels
+  {
+    auto same = [](const void* a, const void* b) { return a && a == b; };
+    for (int p = 1; p < n_partitions; ++p)
+      for (int q = p - 1; q >= 0; --q)
+      {
+        bool al = d_counters[p] == d_counters[q];
+        if (out && !al)
+        {
+          const kmd_survivors &x = out[p], &y = out[q];
+          al = same(x.d_row, y.d_row) || same(x.d_kmer_lo, y.d_kmer_lo) || same(x.d_kmer_hi, y.d_kmer_hi) || same(x.d_pvalue, y.d_pvalue) ||
+               same(x.d_sign, y.d_sign) || same(x.d_mean_control, y.d_mean_control) || same(x.d_mean_case, y.d_mean_case);
+        }
+        if (al) { prev_alias[(size_t)p] = q; shares[(size_t)p] = shares[(size_t)q] = 1; break; }
+      }
+  }
   struct in_flight { int part = -1; std::unique_ptr<merge_async> A; size_t cap = 0; void *p_k = nullptr, *p_h = nullptr, *p_c = nullptr, *p_s = nullptr, *p_w = nullptr; };
   in_flight F[kBatchStreams];
   int first_error = KMD_OK;
@@ -2379,6 +2410,10 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
   // the synchronous way, for the partitions the fast way could not finish
   auto redo = [&](int p) -> int
   {
+    // (a partition that shares its sink: nothing of the batch may be appending to it while this call's
+    // near-threshold pass compacts it -- the rare way, so simply: everything in flight first)
+    if (shares[(size_t)p]) for (int i = 0; i < kBatchStreams; ++i) KMD_HIP(hipStreamSynchronize(B->st[i]));
+    queued[(size_t)p] = 2;
     return kmd_merge_filter(m, n_samples, d_kmers[p], d_kmers_hi ? d_kmers_hi[p] : nullptr, d_counts[p], offsets[p], threshold,
                             out ? &out[p] : nullptr, d_counters[p], n_rows_out ? &n_rows_out[p] : nullptr, B->st[0]);
   };
@@ -2396,7 +2431,9 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     const uint32_t n_over = *reinterpret_cast<const uint32_t*>(h + 56), ran = *reinterpret_cast<const uint32_t*>(h + 60);
     tile_plan pl;
     std::memcpy(&pl, h, sizeof pl);
-    if (ran) { known_way = pl.g_shift == 6 ? 1 : 0; known_shape = pl.slots; }   // the way and the table shape the plan of a partition of this job took
+    // the way and the table shape the plan of a partition of this job took -- also when the guess was wrong and no merge
+    // kernel ran (k_tile_bounds wrote the plan all the same): the partitions behind it then launch what this one needed
+    if (pl.slots == kSmallSlots || pl.slots == kBigSlots) { known_way = pl.g_shift == 6 ? 1 : 0; known_shape = pl.slots; }
     const bool ok = ran != 0 && n_over == 0 && rows3[0] <= f.cap;
     f.A.reset();                                                  // the scratch goes back to the cache
     if (ok) { if (n_rows_out) n_rows_out[p] = rows3[1]; return KMD_OK; }
@@ -2408,7 +2445,6 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     rc = finish(slot);
     if (rc != KMD_OK && first_error == KMD_OK) first_error = rc;
     if (n_rows_out) n_rows_out[p] = 0;
-    KMD_REQUIRE(offsets[p] && d_counters[p], "kmd_merge_filter_batch: NULL offsets or counters of a partition");
     const uint64_t* offs = offsets[p];
     const size_t n = (size_t)offs[n_samples];
     if (n == 0) continue;
@@ -2434,7 +2470,7 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     P.counters = reinterpret_cast<unsigned long long*>(d_counters[p]);
     if (out) P.out = out[p];
     const bool two = d_kmers_hi && d_kmers_hi[p];
-    f.cap = std::max<size_t>((size_t)1 << 20, n / 8);
+    f.cap = std::max<size_t>((size_t)1 << 20, n / 16);
     if (const uint32_t e = env_u32("KMD_TILE_CAND_CAP", 0)) f.cap = e;
     hipError_t he = f.A->sc.take(&f.p_k, f.cap * 8);
     if (he == hipSuccess) he = f.A->sc.take(&f.p_c, f.cap * 8);
@@ -2445,9 +2481,16 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     const size_t cap_now = f.cap;
     auto speculate = [&](const uint64_t* d_live, const uint32_t* d_over_n) -> int
     {
-      return kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(f.p_k), static_cast<const uint64_t*>(f.p_h),
-                                           static_cast<const uint64_t*>(f.p_c), static_cast<const uint64_t*>(f.p_s), 0, 0, 0, f.p_w, cap_now, st,
-                                           d_live, d_over_n, cap_now);
+      // (the nearest earlier sharer that went the asynchronous way; one that was empty is stepped over, one that was
+      // run the synchronous way has drained everything before it)
+      int q = prev_alias[(size_t)p];
+      while (q >= 0 && queued[(size_t)q] == 0) q = prev_alias[(size_t)q];
+      if (q >= 0 && queued[(size_t)q] == 1 && q % kBatchStreams != slot) KMD_HIP(hipStreamWaitEvent(st, B->cand_done[q % kBatchStreams], 0));
+      const int rc_ = kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(f.p_k), static_cast<const uint64_t*>(f.p_h),
+                                                    static_cast<const uint64_t*>(f.p_c), static_cast<const uint64_t*>(f.p_s), 0, 0, 0, f.p_w, cap_now, st,
+                                                    d_live, d_over_n, cap_now);
+      if (rc_ == KMD_OK && shares[(size_t)p]) { KMD_HIP(hipEventRecord(B->cand_done[slot], st)); queued[(size_t)p] = 1; }
+      return rc_;
     };
     uint64_t entries = 0, totals[2] = { 0, 0 };
     rc = tile_merge(n_samples, m->nc, d_kmers[p], two ? d_kmers_hi[p] : nullptr, d_counts[p], offs, &P, static_cast<uint64_t*>(f.p_k),

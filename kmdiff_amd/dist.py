@@ -15,10 +15,9 @@ exactly one partition), so here:
     4096-bin p-value histograms (32 KB each) locates the first bin the walk cannot accept
     wholesale; only the p-values from that bin on are all-gathered and walked exactly, on
     every rank, by the device corrector (kmd_correct_from_rank).
-
-Collectives go through torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU
-tests).  Tensors are CUDA tensors under nccl and CPU tensors under gloo; nothing here
-computes p-values or decisions on the CPU -- the decisions come from kmd_correct.
+All of that is kmd_correct_sharded in the HIP library (kmd_shard.hip) since round 4; this module supplies the
+wire -- a kmd_transport whose two collectives are torch.distributed's (backend "nccl" = RCCL on ROCm, "gloo" in
+the CPU tests) -- and the small host-side reductions around it.  Nothing here computes p-values or decisions.
 """
 import numpy as np
 import torch
@@ -112,90 +111,93 @@ def barrier():
         dist.barrier()
 
 
-N_HIST_BINS = 4096
-
-
-def pvalue_histogram(K, p_t):
-    """4096-bin log-spaced histogram (device) of a CUDA float64 tensor of p-values."""
-    hist = torch.zeros(N_HIST_BINS, dtype=torch.int64, device=p_t.device)
-    if p_t.numel():
-        K._native.check(K._native.lib().kmd_pvalue_histogram(p_t.data_ptr(), int(p_t.numel()), hist.data_ptr(), None),
-                        "kmd_pvalue_histogram")
-    torch.cuda.synchronize()
-    return hist
-
-
-def critical_bin(K, correction, threshold, total_kmers, hist_global):
-    """(first bin the BH/Holm walk cannot accept wholesale, survivors before it) -- device."""
+def torch_transport(K):
+    """A kmd_transport (include/kmdiff_hip.h) whose two collectives are torch.distributed's: under backend "nccl"
+    (= RCCL) the library's device buffers are handed to RCCL as they are (zero-copy views); under "gloo" (CPU tests,
+    one-GPU dry runs of the N > 1 code) they travel through host memory.  Returns (Transport, keep-alive tuple)."""
     import ctypes as C
-    b, before = C.c_uint32(0), C.c_uint64(0)
-    K._native.check(K._native.lib().kmd_correct_critical_bin(int(correction), float(threshold), int(total_kmers),
-                                                             hist_global.data_ptr(), C.byref(b), C.byref(before), None),
-                    "kmd_correct_critical_bin")
-    return int(b.value), int(before.value)
+    N = K._native
+    lib = N.lib()
+    nccl = dist.get_backend() == "nccl"
+    world, rank = dist.get_world_size(), dist.get_rank()
+
+    def view(ptr, n, typestr, dtype):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return torch.as_tensor(_CudaView(ptr, n, typestr), device=dev) if n else torch.empty(0, dtype=dtype, device=dev)
+
+    def to_host(ptr, nbytes):
+        a = np.empty(nbytes, dtype=np.uint8)
+        if nbytes:
+            N.check(lib.kmd_memcpy_d2h(a.ctypes.data, ptr, nbytes, None), "d2h")
+        return a
+
+    def allreduce(ctx, d_buf, n, stream):
+        try:
+            if nccl:
+                t = view(d_buf, n, "<i8", torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+            else:
+                t = torch.from_numpy(to_host(d_buf, 8 * n).view(np.int64).copy())
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                a = t.numpy()
+                N.check(lib.kmd_memcpy_h2d(d_buf, a.ctypes.data, a.nbytes, None), "h2d")
+            return 0
+        except Exception:                                    # (no exception may cross the C boundary)
+            import traceback
+            traceback.print_exc()
+            return -2
+
+    def allgather(ctx, d_send, d_recv, nbytes, stream):
+        try:
+            if nbytes == 0:
+                return 0
+            if nccl:
+                src = view(d_send, nbytes, "|u1", torch.uint8)
+                dst = view(d_recv, nbytes * world, "|u1", torch.uint8)
+                dist.all_gather_into_tensor(dst, src)
+                torch.cuda.synchronize()
+            else:
+                src = torch.from_numpy(to_host(d_send, nbytes))
+                out = [torch.empty_like(src) for _ in range(world)]
+                dist.all_gather(out, src)
+                a = torch.cat(out).numpy()
+                N.check(lib.kmd_memcpy_h2d(d_recv, a.ctypes.data, a.nbytes, None), "h2d")
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -2
+
+    fa, fg = N.ALLREDUCE_FN(allreduce), N.ALLGATHER_FN(allgather)
+    return N.Transport(None, rank, world, fa, fg), (fa, fg)
 
 
-def tail_of(p_t, first_bin):
-    """Indices of the p-values whose histogram bin is >= first_bin (device ops)."""
-    bins = (p_t.view(torch.int64) >> 51) & (N_HIST_BINS - 1)
-    return torch.nonzero(bins >= first_bin, as_tuple=False).flatten()
-
-
-def walk_tail(K, correction, threshold, total_kmers, rank_offset, p_all, s_all):
-    """The exact ascending walk (kmd_correct_from_rank) over the gathered tail."""
+def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_buf, n_local, transport=None):
+    """Stage 3 across ranks: kmd_correct_sharded (kmdiff_amd/csrc/kmd_shard.hip) -- the counter all-reduce, and for
+    BH / Holm the histogram all-gather, the critical bin and the exact walk over the gathered tails -- with
+    torch.distributed as the wire (torch_transport), or the caller's `transport` (a _native.Transport).
+    Returns (keep mask for the local survivors, global counters, (n_control, n_case) kept locally)."""
     import ctypes as C
-    n = int(p_all.numel())
-    keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=p_all.device)
-    nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-    K._native.check(K._native.lib().kmd_correct_from_rank(
-        int(correction), float(threshold), int(total_kmers), int(rank_offset), p_all.data_ptr() if n else None,
-        s_all.data_ptr() if n else None, n, keep.data_ptr(), C.byref(nk), C.byref(nc), C.byref(nca), None),
-        "kmd_correct_from_rank")
-    return keep[:n]
-
-
-def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_buf, n_local):
-    """Stage 3 across ranks.  Returns (keep mask for the local survivors, global counters,
-    (n_control, n_case) kept locally).
-
-    BH / Holm walk the survivors of ALL ranks in ascending p and stop at the first rejection
-    (aggregator.hpp:286-310).  Reproduced without moving every survivor: all-gather the 32 KB
-    p-value histograms, find the first bin the walk cannot accept wholesale, all-gather only
-    the p-values from that bin on, and walk those exactly on every rank (same list, same
-    order: rank-major, then local order) starting at the rank the earlier bins consumed."""
+    N = K._native
     if isinstance(correction, str):
         correction = K.CORRECTION_BY_NAME[correction.lower()]
-    g = allreduce_counters(local_counters)
-    total_kmers = int(g[0])
+    local = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+    lc = np.asarray(local_counters, dtype=np.uint64)
+    local[:min(len(lc), N.NCOUNTERS)] = lc[:N.NCOUNTERS]
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1 or correction not in (K.CORR_BENJAMINI, K.CORR_HOLM):
-        keep, n_ctrl, n_case = K.aggregate(correction, threshold, total_kmers, pvalue_buf, sign_buf, n_local)
-        return keep, g, (n_ctrl, n_case)
-    if not torch.cuda.is_available():
-        raise RuntimeError("correct_sharded(BH/Holm) needs the HIP library: no CPU decision path")
-    dev = torch.device("cuda", torch.cuda.current_device())      # compute device (the wire may be gloo)
-    if n_local:
-        p_local = torch.as_tensor(_CudaView(pvalue_buf.ptr, n_local, "<f8"), device=dev)
-        s_local = torch.as_tensor(_CudaView(sign_buf.ptr, n_local, "<i4"), device=dev)
-    else:
-        p_local = torch.empty(0, dtype=torch.float64, device=dev)
-        s_local = torch.empty(0, dtype=torch.int32, device=dev)
-    hist = pvalue_histogram(K, p_local)
-    hists = all_gather(hist)                                       # per-rank histograms over xGMI
-    hist_global = torch.stack(hists).sum(dim=0).contiguous()
-    first_bin, before = critical_bin(K, correction, threshold, total_kmers, hist_global)
-    idx = tail_of(p_local, first_bin)
-    p_all, offs = allgather_varlen(p_local[idx].contiguous())
-    s_all, _ = allgather_varlen(s_local[idx].contiguous())
-    torch.cuda.synchronize()
-    keep_tail = walk_tail(K, correction, threshold, total_kmers, before, p_all, s_all)
-    rank = dist.get_rank()
-    keep_t = torch.ones(n_local, dtype=torch.uint8, device=dev)    # bins before the critical one: accepted
-    keep_t[idx] = keep_tail[offs[rank]:offs[rank + 1]]
-    keep = keep_t.cpu().numpy()
-    mine_sign = s_local.cpu().numpy()
-    n_ctrl = int(((mine_sign == 0) & (keep == 1)).sum())
-    return keep, g, (n_ctrl, int(keep.sum()) - n_ctrl)
+    alive = None
+    if transport is None and world > 1:
+        transport, alive = torch_transport(K)
+    g = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+    keep = K.DeviceBuffer(max(n_local, 1))
+    nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    N.check(N.lib().kmd_correct_sharded(C.byref(transport) if transport is not None else None, int(correction), float(threshold),
+                                        local.ctypes.data, g.ctypes.data, pvalue_buf.ptr if n_local else None,
+                                        sign_buf.ptr if (n_local and sign_buf) else None, int(n_local), keep.ptr,
+                                        C.byref(nk), C.byref(nc), C.byref(nca), None), "kmd_correct_sharded")
+    del alive
+    return keep.to_host(np.uint8, n_local), g[:max(len(lc), 4)], (int(nc.value), int(nca.value))
 
 
 class _CudaView:

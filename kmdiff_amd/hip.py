@@ -400,6 +400,24 @@ class StreamSet:
         return (self.kmers.ptr if t else None, self.kmers_hi.ptr if (self.two and t) else None, self.counts.ptr if t else None)
 
 
+def synth_streams(seed, partition, n_rows, nb_controls, nb_cases, kmer_limbs=1, row0=0):
+    """The synthetic partition as the per-sample streams kmtricks would write, generated on the
+    device (kmd_synth_streams): returns (StreamSet, per-sample totals)."""
+    S = nb_controls + nb_cases
+    ss = StreamSet.__new__(StreamSet)
+    ss.n_samples, ss.two = S, kmer_limbs == 2
+    ss.offs = np.zeros(S + 1, dtype=np.uint64)
+    tot = DeviceBuffer(S * 8).zero()
+    check(lib().kmd_synth_streams(int(seed), int(partition), int(row0), int(n_rows), nb_controls, nb_cases, ss.offs.ctypes.data,
+                                  None, None, None, tot.ptr, None), "kmd_synth_streams (offsets)")
+    ss.total = int(ss.offs[-1])
+    ss.kmers, ss.counts = DeviceBuffer(max(ss.total, 1) * 8), DeviceBuffer(max(ss.total, 1) * 4)
+    ss.kmers_hi = DeviceBuffer(max(ss.total, 1) * 8) if ss.two else None
+    check(lib().kmd_synth_streams(int(seed), int(partition), int(row0), int(n_rows), nb_controls, nb_cases, ss.offs.ctypes.data,
+                                  ss.kmers.ptr, ss.kmers_hi.ptr if ss.two else None, ss.counts.ptr, None, None), "kmd_synth_streams (fill)")
+    return ss, tot.to_host(np.uint64, S)
+
+
 class RowSums:
     """What kmd_merge_sums leaves on the device: n_rows rows (k-mer, control sum, case sum), compact, in no
     particular order."""

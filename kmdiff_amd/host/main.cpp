@@ -252,6 +252,7 @@ struct survivors_of_run
   uint64_t total_kmers = 0, n_sig = 0, n_sig_control = 0, n_sig_case = 0;
   uint64_t n_near = 0;                               // rows decided with correctly rounded log / exp (KMD_CNT_NEAR_THRESHOLD)
   std::vector<double> Z_device;                          // [S][10] when the device PCA ran
+  std::vector<uint64_t> worker_totals;                   // rows each GPU worker tested (empty after a resume: only their sum is on file)
 };
 
 // ---- host side of a partition ------------------------------------------------------------------
@@ -770,7 +771,7 @@ void do_diff(const run_context& C, survivors_of_run& O, const bool run_pca)
       if (want_counts) sv_all.counts.insert(sv_all.counts.end(), R.sv.counts.begin() + b * S, R.sv.counts.begin() + (b + cnt) * S);
       part_begin[p + 1] = sv_all.size();
     }
-    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; O.n_near += R.n_near; }
+    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; O.n_near += R.n_near; O.worker_totals.push_back(R.total); }
   }
   for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
   if (run_pca)                                                                             // run_eigenstrat_smartpca
@@ -964,7 +965,59 @@ void do_correction(const run_context& C, survivors_of_run& O)
   d_p.reserve(std::max<size_t>(n, 1) * 8); d_sign.reserve(std::max<size_t>(n, 1) * 4); d_keep.reserve(std::max<size_t>(n, 1));
   uint64_t kept = 0, c_controls = 0, c_cases = 0;
   std::vector<uint8_t> keep(n, 0);
-  if (n)
+  const size_t n_workers = C.n_workers;
+  if (n_workers > 1)
+  {
+    // --devices N: the survivors of partition p belong to GPU p mod N (where stage 1 found them); every GPU decides
+    // its own with kmd_correct_sharded -- the counters' all-reduce, and for BH / Holm the histogram all-gather and the
+    // exact walk over the gathered tails (aggregator.hpp:286-310, 325-339) -- over the in-process transport (one host
+    // thread per GPU; with one process per GPU it would be libkmdiff_hip_rccl.so's).  Same decisions as one list.
+    std::vector<kmd_transport> T(n_workers);
+    ck(kmd_transport_local_create((int)n_workers, T.data()), "kmd_transport_local_create");
+    std::vector<std::vector<size_t>> mine(n_workers);
+    for (size_t p = 0; p < cfg.nb_partitions; ++p)
+      for (size_t i = O.part_begin[p]; i < O.part_begin[p + 1]; ++i) mine[p % n_workers].push_back(i);
+    std::vector<std::string> errors(n_workers);
+    std::vector<uint64_t> w_ctrl(n_workers, 0), w_case(n_workers, 0);
+    auto rank_body = [&](size_t wi)
+    {
+      try
+      {
+        ck(kmd_set_device((opt.device + (int)wi) % C.ndev), "kmd_set_device");
+        const size_t m = mine[wi].size();
+        std::vector<double> lp(m); std::vector<int32_t> ls(m); std::vector<uint8_t> lk(m, 0);
+        for (size_t j = 0; j < m; ++j) { lp[j] = s_p[mine[wi][j]]; ls[j] = s_sign[mine[wi][j]]; }
+        dev_buf b_p, b_s, b_k;
+        b_p.reserve(std::max<size_t>(m, 1) * 8); b_s.reserve(std::max<size_t>(m, 1) * 4); b_k.reserve(std::max<size_t>(m, 1));
+        if (m)
+        {
+          ck(kmd_memcpy_h2d(b_p.p, lp.data(), m * 8, nullptr), "h2d");
+          ck(kmd_memcpy_h2d(b_s.p, ls.data(), m * 4, nullptr), "h2d");
+        }
+        uint64_t local[KMD_NCOUNTERS] = { 0 }, global[KMD_NCOUNTERS] = { 0 }, k_ = 0;
+        local[KMD_CNT_TOTAL] = O.worker_totals.size() == n_workers ? O.worker_totals[wi] : (wi == 0 ? total_kmers : 0);
+        local[KMD_CNT_SIG] = m;
+        ck(kmd_correct_sharded(&T[wi], correction_type(opt.correction), opt.threshold, local, global, (const double*)b_p.p, (const int32_t*)b_s.p, m,
+                               (uint8_t*)b_k.p, &k_, &w_ctrl[wi], &w_case[wi], nullptr), "kmd_correct_sharded");
+        if (global[KMD_CNT_TOTAL] != total_kmers) throw std::runtime_error("kmd_correct_sharded: the ranks' totals do not add up");
+        if (m) ck(kmd_memcpy_d2h(lk.data(), b_k.p, m, nullptr), "d2h");
+        for (size_t j = 0; j < m; ++j) keep[mine[wi][j]] = lk[j];
+      }
+      catch (const std::exception& e) { errors[wi] = e.what(); }
+    };
+    {
+      std::vector<std::thread> ranks;
+      for (size_t wi = 1; wi < n_workers; ++wi) ranks.emplace_back(rank_body, wi);
+      rank_body(0);
+      for (auto& t : ranks) t.join();
+    }
+    kmd_transport_local_destroy((int)n_workers, T.data());
+    ck(kmd_set_device(opt.device % C.ndev), "kmd_set_device");
+    for (const std::string& e : errors) if (!e.empty()) die(e);
+    for (size_t wi = 0; wi < n_workers; ++wi) { c_controls += w_ctrl[wi]; c_cases += w_case[wi]; }
+    kept = c_controls + c_cases;
+  }
+  else if (n)
   {
     ck(kmd_memcpy_h2d(d_p.p, s_p.data(), n * 8, nullptr), "h2d");
     ck(kmd_memcpy_h2d(d_sign.p, s_sign.data(), n * 4, nullptr), "h2d");

@@ -77,3 +77,17 @@ def test_command_line_fails_loudly_without_a_device(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU path" in r.stderr
     assert not (tmp_path / "o" / "control_kmers.fasta").exists()
+
+
+def test_rccl_transport_library_exports_its_header():
+    """libkmdiff_hip_rccl.so (the RCCL transport of kmd_correct_sharded) loads without a GPU and exports what
+    include/kmdiff_hip_rccl.h declares; libkmdiff_hip.so itself does not depend on librccl."""
+    import subprocess
+    assert header_functions("kmdiff_hip_rccl.h") == sorted(N.RCCL_SIGNATURES)
+    L = N.rccl_lib()
+    for name in N.RCCL_SIGNATURES:
+        assert hasattr(L, name), name
+    needed = subprocess.run(["readelf", "-d", N.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed
+    needed = subprocess.run(["readelf", "-d", N.RCCL_LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in needed

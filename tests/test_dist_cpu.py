@@ -93,7 +93,8 @@ def test_bench_starts_its_ranks_as_children_without_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=280, cwd=root, env=env)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    # (the launcher ends the sibling as soon as the first rank has failed: one of the two messages may never be written)
+    assert r.stderr.count("bench.py needs an MI355X") >= 1 and "local_rank: 1" in r.stderr, r.stderr[-2000:]
     # and a mismatch between the launcher's world size and --gpus is refused before anything touches the GPU
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                        cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))

@@ -382,14 +382,43 @@ def test_correction_matches_oracle(K, oracle, name):
     assert len(keep) == 0
 
 
-@pytest.mark.parametrize("name", ["benjamini", "holm"])
+def sharded_decisions(K, transports, name, total_per_rank, parts, thr=0.05):
+    """kmd_correct_sharded on every virtual rank at once (one host thread each, as the collectives are matched
+    calls): returns per rank (keep, global counters, n_kept, n_control, n_case)."""
+    import ctypes as C
+    import threading
+    N = K._native
+    lib = N.lib()
+    ctype = K.CORRECTION_BY_NAME[name]
+    out = [None] * len(parts)
+
+    def work(r):
+        p, s = parts[r]
+        n = len(p)
+        dp, ds = K.DeviceBuffer.from_host(p), K.DeviceBuffer.from_host(s)
+        keep = K.DeviceBuffer(max(n, 1))
+        local = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+        local[0], local[1] = total_per_rank[r], n
+        g = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+        nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = lib.kmd_correct_sharded(C.byref(transports[r]), ctype, thr, local.ctypes.data, g.ctypes.data, dp.ptr if n else None,
+                                     ds.ptr if n else None, n, keep.ptr, C.byref(nk), C.byref(nc), C.byref(nca), None)
+        out[r] = (rc, keep.to_host(np.uint8, n), g, int(nk.value), int(nc.value), int(nca.value))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(len(parts))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(o is not None and o[0] == 0 for o in out), [o and o[0] for o in out]
+    return out
+
+
+@pytest.mark.parametrize("name", ["benjamini", "holm", "bonferroni", "sidak", "nothing"])
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
-def test_sharded_bh_holm_equals_single_list(K, name, n_ranks):
-    """The histogram exchange of kmdiff_amd/dist.py, emulated with virtual ranks on one GPU
-    (the collectives replaced by local sums / concatenations): identical decisions to
-    kmd_correct over the whole list in rank-major order."""
-    import torch
-    from kmdiff_amd import dist as D
+def test_sharded_correction_equals_single_list(K, name, n_ranks):
+    """kmd_correct_sharded (kmd_shard.hip) over virtual ranks of one GPU -- one host thread per rank, the in-process
+    transport (kmd_transport_local_create) as the wire: the decisions of kmd_correct over the whole list, for every
+    corrector; ties across ranks, a rank without survivors, an early and a late stopping point."""
+    import ctypes as C
+    N = K._native
     n, nc, nk = 400_000, 4, 4
     mat = K.synth_matrix(SEED, 14, n, nc, nk, 4, K.LAYOUT_TILED)
     tot = K.column_sums(mat)
@@ -398,32 +427,79 @@ def test_sharded_bh_holm_equals_single_list(K, name, n_ranks):
     K.diff_observer(model, acc, 2e-3).process(mat)
     ns = acc.finish()
     assert ns > 500
-    ctype = K.CORRECTION_BY_NAME[name]
-    dev = torch.device("cuda", 0)
-    p_all = torch.as_tensor(D._CudaView(acc.bufs["pvalue"].ptr, ns, "<f8"), device=dev).clone()
-    s_all = torch.as_tensor(D._CudaView(acc.bufs["sign"].ptr, ns, "<i4"), device=dev).clone()
+    got = acc.get()
+    p_all, s_all = got["pvalue"].copy(), got["sign"].copy()
     p_all[5] = p_all[900]                                   # ties across ranks
     cuts = [0] + sorted(np.random.default_rng(n_ranks).choice(np.arange(1, ns), n_ranks - 1, replace=False).tolist()) + [ns]
-    for total in (n, 40 * n):                                # one late, one early stopping point
-        want, _, _ = K.aggregate(name, 0.05, total, K.DeviceBuffer.from_host(p_all.cpu().numpy()),
-                                 K.DeviceBuffer.from_host(s_all.cpu().numpy()), ns)
-        parts = [(p_all[a:b], s_all[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
-        hist = sum(D.pvalue_histogram(K, p) for p, _ in parts)          # "all-gather + sum"
-        first_bin, before = D.critical_bin(K, ctype, 0.05, total, hist.contiguous())
-        idxs = [D.tail_of(p, first_bin) for p, _ in parts]
-        tail_p = torch.cat([p[i] for (p, _), i in zip(parts, idxs)]).contiguous()   # "all-gather" of the tails
-        tail_s = torch.cat([s[i] for (_, s), i in zip(parts, idxs)]).contiguous()
-        keep_tail = D.walk_tail(K, ctype, 0.05, total, before, tail_p, tail_s)
-        got, o = [], 0
-        for (p, _), i in zip(parts, idxs):
-            k = torch.ones(p.numel(), dtype=torch.uint8, device=dev)
-            k[i] = keep_tail[o:o + i.numel()]
-            o += i.numel()
-            got.append(k)
-        got = torch.cat(got).cpu().numpy()
-        assert got.tolist() == want.tolist()
-        assert before + int(keep_tail.sum()) == int(want.sum())
-        assert int(tail_p.numel()) < ns                      # the exchange moved only a tail
+    if n_ranks == 3:
+        cuts[2] = cuts[1]                                   # rank 1 has no survivors
+    parts = [(p_all[a:b], s_all[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    T = (N.Transport * n_ranks)()
+    N.check(N.lib().kmd_transport_local_create(n_ranks, T), "kmd_transport_local_create")
+    try:
+        for total in (n, 40 * n):                            # one late, one early stopping point
+            want, w_ctrl, w_case = K.aggregate(name, 0.05, total, K.DeviceBuffer.from_host(p_all), K.DeviceBuffer.from_host(s_all), ns)
+            per = [total // n_ranks + (1 if r < total % n_ranks else 0) for r in range(n_ranks)]
+            res = sharded_decisions(K, T, name, per, parts)
+            keep = np.concatenate([o[1] for o in res])
+            assert keep.tolist() == want.tolist()
+            for r, o in enumerate(res):
+                assert int(o[2][0]) == total and int(o[2][1]) == ns                    # the counters' sums, on every rank
+                assert o[3] == int(o[1].sum()) and o[4] == int(((parts[r][1] == 0) & (o[1] == 1)).sum()) and o[5] == o[3] - o[4]
+            assert sum(o[4] for o in res) == w_ctrl and sum(o[5] for o in res) == w_case
+    finally:
+        N.lib().kmd_transport_local_destroy(n_ranks, T)
+
+
+def test_sharded_correction_one_rank_and_no_transport(K):
+    """world = 1 (a NULL transport, or a one-rank one): kmd_correct itself."""
+    import ctypes as C
+    N = K._native
+    rng = np.random.default_rng(5)
+    p = np.sort(rng.uniform(0, 1e-6, 3000)) ** 2
+    s = rng.integers(0, 3, 3000).astype(np.int32)
+    want, _, _ = K.aggregate("benjamini", 0.05, 10**9, K.DeviceBuffer.from_host(p), K.DeviceBuffer.from_host(s), len(p))
+    T = (N.Transport * 1)()
+    N.check(N.lib().kmd_transport_local_create(1, T), "create")
+    res = sharded_decisions(K, T, "benjamini", [10**9], [(p, s)])
+    assert res[0][1].tolist() == want.tolist()
+    N.lib().kmd_transport_local_destroy(1, T)
+    dp, ds, keep = K.DeviceBuffer.from_host(p), K.DeviceBuffer.from_host(s), K.DeviceBuffer(len(p))
+    local = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+    local[0] = 10**9
+    nk = C.c_uint64(0)
+    N.check(N.lib().kmd_correct_sharded(None, N.CORR_BENJAMINI, 0.05, local.ctypes.data, None, dp.ptr, ds.ptr, len(p), keep.ptr, C.byref(nk), None, None, None))
+    assert keep.to_host(np.uint8, len(p)).tolist() == want.tolist() and nk.value == int(want.sum())
+
+
+def test_sharded_correction_over_rccl_one_rank(K):
+    """libkmdiff_hip_rccl.so: a communicator of ONE rank on this GPU (ncclCommInitRank) carries the collectives of
+    kmd_correct_sharded -- what a one-GPU box can exercise of the RCCL transport (the two-rank form: tests/
+    test_gpu_bench.py, skipped without a second GPU)."""
+    import ctypes as C
+    N = K._native
+    R = N.rccl_lib()
+    ident = C.create_string_buffer(128)
+    assert R.kmd_rccl_unique_id(ident) == 0, R.kmd_rccl_last_error()
+    t = N.Transport()
+    assert R.kmd_transport_rccl_init(C.byref(t), 1, 0, ident) == 0, R.kmd_rccl_last_error()
+    try:
+        assert (t.rank, t.world) == (0, 1)
+        # the two collectives themselves (world 1: the buffers come back as they went)
+        a = K.DeviceBuffer.from_host(np.arange(16, dtype=np.uint64))
+        assert t.allreduce_u64(t.ctx, a.ptr, 16, None) == 0
+        assert a.to_host(np.uint64, 16).tolist() == list(range(16))
+        b = K.DeviceBuffer(128)
+        assert t.allgather(t.ctx, a.ptr, b.ptr, 128, None) == 0
+        assert b.to_host(np.uint64, 16).tolist() == list(range(16))
+        rng = np.random.default_rng(6)
+        p = np.sort(rng.uniform(0, 1e-6, 2000)) ** 2
+        s = rng.integers(0, 3, 2000).astype(np.int32)
+        want, _, _ = K.aggregate("holm", 0.05, 10**8, K.DeviceBuffer.from_host(p), K.DeviceBuffer.from_host(s), len(p))
+        res = sharded_decisions(K, [t], "holm", [10**8], [(p, s)])
+        assert res[0][1].tolist() == want.tolist()
+    finally:
+        R.kmd_transport_rccl_destroy(C.byref(t))
 
 
 def test_correction_golden_streams(K, golden_dir):

@@ -150,3 +150,49 @@ def test_threshold_on_a_p_value_through_the_fused_merge(K, oracle):
             assert gb["sign"].tolist() == ga["sign"][order].tolist()
             seen_near += int(cb[K._native.CNT_NEAR_THRESHOLD])
     assert seen_near >= 36
+
+
+def test_near_threshold_flips_in_a_batch_that_shares_one_sink(K, oracle):
+    """kmd_merge_filter_batch with every partition naming the SAME sink and counters: the pass over a
+    partition's near-threshold rows strikes records out and compacts the whole sink, so the candidate steps of such
+    partitions must not overlap.  Forced here (KMD_TEST_NEAR_FLIP: every listed row's decision is turned over, so each
+    partition strikes some records and appends others) with the threshold ON a p-value many rows share: the shared sink
+    of the batch holds exactly what the partitions' single calls put into sinks of their own."""
+    import os
+    n, nc, nk, parts = 30_000, 6, 6, 9
+    lf = oracle.lf_table(10000)
+    hosts = [oracle.synth_rows(SEED, 20 + p, 0, n, nc, nk, 4) for p in range(parts)]
+    tcs, tks = totals_of(np.concatenate([h[0] for h in hosts]), nc)
+    ref = oracle.diff_partition(hosts[0][0], OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), lf, 1e-2)
+    vals, cnt = np.unique(ref["pvalue"][ref["pvalue"] > 1e-300], return_counts=True)
+    thr = float(vals[np.argmax(cnt)])                                   # the p-value most rows share: many near rows per partition
+    assert cnt.max() >= 5
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, 10000)
+    sets = [K.StreamSet([(lo[h[:, s] > 0], h[h[:, s] > 0, s]) for s in range(nc + nk)]) for h, lo, _ in hosts]
+    os.environ["KMD_TEST_NEAR_FLIP"] = "1"
+    try:
+        singles, near_total, c_sum = [], 0, np.zeros(4, dtype=np.int64)
+        for ss in sets:
+            a = K.SurvivorAccumulator(n)
+            assert K.merge_filter(ss, K.diff_observer(model, a, thr)) == n
+            a.finish(by_kmer=True)
+            g, c = a.get(), a.read_counters()
+            assert int(c[K._native.CNT_NEAR_THRESHOLD]) >= 1 and int(c[K._native.CNT_NEAR_UNRESOLVED]) == 0
+            near_total += int(c[K._native.CNT_NEAR_THRESHOLD])
+            c_sum += np.array([int(x) for x in c[:4]])
+            singles.append(g)
+        assert near_total >= 3 * parts
+        for _ in range(3):                                              # (a race shows up in some runs only)
+            shared = K.SurvivorAccumulator(parts * n)
+            obs = [K.diff_observer(model, shared, thr) for _ in range(parts)]
+            assert K.merge_filter_batch(sets, obs) == [n] * parts
+            ns = shared.finish(by_kmer=True)
+            g, c = shared.get(), shared.read_counters()
+            assert [int(x) for x in c[:4]] == c_sum.tolist() and ns == int(c_sum[1])
+            want_k = np.concatenate([x["kmer_lo"] for x in singles])
+            order = np.argsort(want_k, kind="stable")
+            assert g["kmer_lo"].tolist() == want_k[order].tolist()
+            for f in ("pvalue", "sign", "mean_control", "mean_case"):
+                assert g[f].tolist() == np.concatenate([x[f] for x in singles])[order].tolist(), f
+    finally:
+        del os.environ["KMD_TEST_NEAR_FLIP"]

@@ -23,9 +23,30 @@ ap.add_argument("--fused-only", action="store_true", help="only kmd_merge_filter
 ap.add_argument("--limbs", type=int, default=1, help="2: two-limb k-mers (32 < k <= 64); fused path only")
 ap.add_argument("--overlap", type=int, default=0, help="also: this many host threads, each with a stream of its own, running the fused call on the same partition at once")
 ap.add_argument("--triples", action="store_true", help="also time kmd_merge_sums + kmd_poisson_filter_sums")
+ap.add_argument("--device", action="store_true", help="streams built on the device (kmd_synth_streams): whole configs[2] partitions (--rows 39062500) without a host copy; fused path only")
+ap.add_argument("--partition", type=int, default=0)
 a = ap.parse_args()
 S = a.nc + a.nk
 lib = K._native.lib()
+if a.device:
+    ss, tot = K.synth_streams(0x6B6D64696666, a.partition, a.rows, a.nc, a.nk, kmer_limbs=a.limbs)
+    model = K.PoissonLikelihood(a.nc, a.nk, tot[:a.nc], tot[a.nc:], 10000)
+    acc = K.SurvivorAccumulator(max(1 << 16, a.rows // 100), kmer_limbs=a.limbs)
+    obs = K.diff_observer(model, acc, 5e-7)
+    best_f = 1e9
+    for _ in range(a.iters + 1):
+        acc.counters.zero()
+        lib.kmd_stream_sync(None)
+        t0 = time.perf_counter()
+        rows_f = K.merge_filter(ss, obs)
+        lib.kmd_stream_sync(None)
+        best_f = min(best_f, time.perf_counter() - t0)
+    cf = acc.read_counters()
+    assert rows_f == int(cf[0]) == a.rows
+    bpr = 12 if a.limbs == 1 else 20
+    print("pipeline device-built S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of %d B/record  sig=%d  candidates=%d"
+          % (S, ss.total, rows_f, best_f * 1e3, rows_f / best_f, ss.total / best_f, bpr * 1e-9 * ss.total / best_f, bpr, int(cf[1]), int(cf[4])))
+    sys.exit(0)
 mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, a.nc, a.nk, 4, K.LAYOUT_ROWS)
 host = mat.to_host()
 lo = mat.kmers_to_host()[0]
