@@ -74,6 +74,24 @@ using namespace kmd::eval;
 #ifndef KMD_TILE_TIMING
 #define KMD_TILE_TIMING 0
 #endif
+#ifndef KMD_TILE_HINT
+#define KMD_TILE_HINT 0              // cache policy of the whole-wave path's record loads: 0 default, 1 nt (streaming), 2 sc1, 3 sc0 sc1
+#endif
+#if KMD_TILE_HINT == 0
+#define KMD_TILE_LOAD_HINT ""
+#elif KMD_TILE_HINT == 1
+#define KMD_TILE_LOAD_HINT " nt"
+#elif KMD_TILE_HINT == 2
+#define KMD_TILE_LOAD_HINT " sc1"
+#else
+#define KMD_TILE_LOAD_HINT " sc0 sc1"
+#endif
+#ifndef KMD_TILE_JOB_PTR
+#define KMD_TILE_JOB_PTR 0           // the merge kernel's job description through a pointer to device memory instead of ~250 bytes of kernel arguments
+#endif
+#ifndef KMD_TILE_ALIGN
+#define KMD_TILE_ALIGN 0             // whole-wave path: a run's first round starts on a 128-byte line of both arrays (its leading lanes hold the records before the run: switched off)
+#endif
 #ifndef KMD_TILE_RING
 #define KMD_TILE_RING 4              // rounds of loads in flight per wave (8, 12, 16 measured: no faster, more registers)
 #endif
@@ -608,8 +626,14 @@ struct tile_lds
 // cut window).  A low limb of all ones (the empty marker) is kept apart the same way.
 template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo, bool kWide, bool kSum32>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(KMD_TILE_WAVES(kSum32, kTwo, kWide))))
+#if KMD_TILE_JOB_PTR
+k_tile_sums(const tile_job* __restrict__ Jp)
+{
+  const tile_job& J = *Jp;
+#else
 k_tile_sums(const tile_job J)
 {
+#endif
   constexpr uint32_t kMask = kSlots - 1;
   constexpr int kShift = 32 - ilog2_c(kSlots);
   constexpr int kWaves = kThreads / 64;
@@ -823,6 +847,7 @@ k_tile_sums(const tile_job J)
           u32x4 dk = { 0u, 0u, 0u, (uint32_t)kRsrcFlags }, dc = dk, dh = dk;          // the run's buffer descriptors
           uint64_t rk[kRing][kR], rkh[kTwo ? kRing : 1][kR];
           uint32_t rcnt[kRing][kR], rrem[kRing], rctl[kRing];                         // rrem / rctl: scalar
+          [[maybe_unused]] uint32_t rlead[kRing], lead_now = 0;                        // KMD_TILE_ALIGN: lanes at the head of a run's first round that hold no record of it
           auto fetch_w = [&](const int d)
           {
             // The loads are issued and waited for BY HAND (vm_wait below): hipcc's own wait counts let a round's loads
@@ -834,10 +859,20 @@ k_tile_sums(const tile_job J)
             {
               // a new run: its description out of the lanes, its descriptors (base = its first record, extent = the run)
               const uint32_t jj = j < kBatch ? j : kBatch;                            // (lane 63 never holds a run: length 0)
-              const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)v_rb, (int)jj);
+              uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)v_rb, (int)jj);
               const uint32_t rle = (uint32_t)__builtin_amdgcn_readlane((int)v_rl, (int)jj);
               rl = rle & 0x7FFFFFFFu;
               ctl_now = rle >> 31;
+#if KMD_TILE_ALIGN
+              // Every round of a run reads 512 contiguous bytes of keys and 256 of counts.  Started wherever the run
+              // (or this wave's piece of it) starts, each round's last line is also the next round's first -- fetched
+              // twice when it has left the cache in between (PMC at configs[2] size: 1.10 x the algorithmic bytes; the
+              // runs' two ends alone account for 1.03).  So the first round starts at the record index rounded down to
+              // a multiple of 32 -- a 128-byte line of both arrays -- its first `lead` lanes switched off, and all
+              // rounds behind it are line-aligned.
+              lead_now = rl ? (rb & 31u) : 0u;
+              rb -= lead_now; rl += lead_now;
+#endif
               const uint64_t ak = (uint64_t)(uintptr_t)(J.keys + rb), ac = (uint64_t)(uintptr_t)(J.counts + rb);
               dk.x = (uint32_t)ak; dk.y = (uint32_t)(ak >> 32) & 0xFFFFu; dk.z = rl * 8u;
               dc.x = (uint32_t)ac; dc.y = (uint32_t)(ac >> 32) & 0xFFFFu; dc.z = rl * 4u;
@@ -850,12 +885,15 @@ k_tile_sums(const tile_job J)
 #pragma unroll
             for (int u = 0; u < kR; ++u)
             {
-              asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(rk[d][u]) : "v"(lane_k), "s"(dk), "s"((off + 64u * (uint32_t)u) * 8u));
-              asm volatile("buffer_load_dword %0, %1, %2, %3 offen nt" : "=v"(rcnt[d][u]) : "v"(lane_c), "s"(dc), "s"((off + 64u * (uint32_t)u) * 4u));
-              if constexpr (kTwo) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(rkh[d][u]) : "v"(lane_k), "s"(dh), "s"((off + 64u * (uint32_t)u) * 8u));
+              asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" KMD_TILE_LOAD_HINT " ; ring" : "=v"(rk[d][u]) : "v"(lane_k), "s"(dk), "s"((off + 64u * (uint32_t)u) * 8u));
+              asm volatile("buffer_load_dword %0, %1, %2, %3 offen" KMD_TILE_LOAD_HINT " ; ring" : "=v"(rcnt[d][u]) : "v"(lane_c), "s"(dc), "s"((off + 64u * (uint32_t)u) * 4u));
+              if constexpr (kTwo) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" KMD_TILE_LOAD_HINT " ; ring" : "=v"(rkh[d][u]) : "v"(lane_k), "s"(dh), "s"((off + 64u * (uint32_t)u) * 8u));
             }
             rrem[d] = rl - off;                                                       // (0 when the batch is exhausted: rl = 0, off = 0)
             rctl[d] = ctl_now;
+#if KMD_TILE_ALIGN
+            rlead[d] = lead_now; lead_now = 0;
+#endif
             off += kStep;
             if (off >= rl) { off = 0; ++j; }
           };
@@ -930,6 +968,9 @@ k_tile_sums(const tile_job J)
             uint32_t cnt = rcnt[d][u];
             bool real = true;
             if constexpr (kThere) real = real & (lane + 64u * (uint32_t)u < rrem[d]);
+#if KMD_TILE_ALIGN
+            if constexpr (kThere) real = real & (lane + 64u * (uint32_t)u >= rlead[d]);
+#endif
             if constexpr (kMarker)
             {
               if (real & (k == kEmptyKey))
@@ -1243,13 +1284,22 @@ k_tile_sums(const tile_job J)
               // A run's LAST round may hold the all-ones k-mer (also when it is a full one) and lanes without a record.
               // Without that k-mer -- almost always -- it goes the fast way too, with its empty lanes switched off
               // around it (one record per lane: the lanes that hold one are the first `rem`).
-              if (rrem[d] > kStep) insert_mid(d);
+#if KMD_TILE_ALIGN
+              const bool whole_round = rrem[d] > kStep && rlead[d] == 0;
+#else
+              const bool whole_round = rrem[d] > kStep;
+#endif
+              if (whole_round) insert_mid(d);
               else
               {
                 bool fast = false;
                 if constexpr (kR == 1 && !kTwo && kSum32 && KMD_TILE_ASM && !KMD_TILE_ABLATE && !KMD_TILE_TIMING)
                 {
+#if KMD_TILE_ALIGN
+                  const bool there = (lane < rrem[d]) & (lane >= rlead[d]);
+#else
                   const bool there = lane < rrem[d];
+#endif
                   if (!ballot(there & (rk[d][0] == kEmptyKey)))
                   {
                     fast = true;
@@ -2048,7 +2098,14 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     if (grid > tiles_at_most) grid = tiles_at_most;
     if (grid > J.n_regions) grid = J.n_regions;
     if (dbg) std::fprintf(stderr, "[tile_merge] <= %u tiles, grid %zu x %d (%d per CU), lds %zu\n", tiles_at_most, grid, threads, per_cu, lds);
+#if KMD_TILE_JOB_PTR
+    void* p_job = nullptr;
+    KMD_HIP(sc.take(&p_job, sizeof J));
+    KMD_HIP(hipMemcpyAsync(p_job, &J, sizeof J, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, static_cast<const tile_job*>(p_job));
+#else
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, J);
+#endif
     KMD_HIP(hipGetLastError());
     return KMD_OK;
   };

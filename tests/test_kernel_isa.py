@@ -42,10 +42,11 @@ def kernels(lines):
 @pytest.mark.timeout(300)
 def test_nothing_of_the_compilers_in_flight_between_the_hand_counted_loads(tile_asm):
     ks = kernels(tile_asm)
-    wide = {k: b for k, b in ks.items() if any("buffer_load_dword" in l and "offen nt" in l for l in b)}
+    # (the hand-issued loads carry the comment "; ring")
+    wide = {k: b for k, b in ks.items() if any("buffer_load_dword" in l and "; ring" in l for l in b)}
     assert len(wide) == 16, sorted(ks)            # (2 shapes) x (filter / rows) x (one / two limbs) x (32- / 64-bit sums), whole waves
     for k, b in wide.items():
-        at = [i for i, l in enumerate(b) if "buffer_load_dword" in l and "offen nt" in l]
+        at = [i for i, l in enumerate(b) if "buffer_load_dword" in l and "; ring" in l]
         span = b[at[0]:at[-1] + 1]
         assert not [l for l in span if "scratch_" in l], k
         # compiler-issued vector memory operations inside the span: none (its own loads would be counted by vmcnt too)
