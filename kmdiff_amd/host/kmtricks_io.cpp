@@ -35,6 +35,8 @@ size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const vo
 
 namespace kmd_host {
 
+constexpr uint32_t kMaxMatrixSamples = 1u << 20;       // rows of a count matrix: more samples than this is a damaged header
+
 static std::string trim(const std::string& s)
 {
   size_t b = s.find_first_not_of(" \t\r\n"), e = s.find_last_not_of(" \t\r\n");
@@ -224,6 +226,7 @@ matrix_rows read_matrix_file(const std::string& path)
   m.partition = rd<uint32_t>(d, 41);
   if (slots != 1 && slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
   if (m.count_bytes != 1 && m.count_bytes != 2 && m.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
+  if (m.nb_counts > kMaxMatrixSamples) throw std::runtime_error(path + ": implausible number of samples in the header");
   std::vector<char> raw;
   if (compressed) raw = lz4_frame_decode(d, 45, path); else raw.assign(d.begin() + 45, d.end());
   const size_t kb = 8 * (size_t)slots, rec = kb + (size_t)m.count_bytes * m.nb_counts, n = raw.size() / rec;
@@ -533,6 +536,8 @@ matrix_file_info stream_matrix_file(const std::string& path, record_sink& sink)
   std::memcpy(&f.nb_counts, head + 33, 4); std::memcpy(&f.partition, head + 41, 4);
   if (f.slots != 1 && f.slots != 2) throw std::runtime_error(path + ": k > 64 is not supported");
   if (f.count_bytes != 1 && f.count_bytes != 2 && f.count_bytes != 4) throw std::runtime_error(path + ": bad count width");
+  // (a damaged header must not size the decoder's buffers: 2^32 - 1 samples would be an 8 GB row -- found by tests/io_fuzz.cpp)
+  if (f.nb_counts > kMaxMatrixSamples) throw std::runtime_error(path + ": implausible number of samples in the header");
   if (sink.slots != f.slots || sink.nb_counts != f.nb_counts) sink.capacity = 0;   // arrays sized for rows of another shape
   sink.slots = f.slots; sink.nb_counts = f.nb_counts;
   const size_t kb = 8 * (size_t)f.slots, rec = kb + (size_t)f.count_bytes * f.nb_counts;

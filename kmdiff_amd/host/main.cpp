@@ -109,6 +109,7 @@ void usage()
             "                     matrix -- same output; --cmodel and the matrices/ feed always take the matrix path)\n"
             "  -t/--threads INT   host threads decoding the per-sample k-mer files {all}\n"
             "  -f/--kff-output    control_kmers.kff / case_kmers.kff (k-mers only) instead of the two FASTA files\n"
+            "  --covariates FILE  known to the reference's command line; refused (its load_C never terminates with a file)\n"
             "  -m, -r: accepted for compatibility, ignored");
 }
 
@@ -146,6 +147,16 @@ diff_options parse(int argc, char** argv)
     else if (a == "-t" || a == "--threads") o.threads = std::max<size_t>(1, std::stoull(need(i)));
     else if (a == "--epsilon") o.epsilon = std::stod(need(i));         // -> pop_strat_corrector::s_epsilon (popstrat.hpp:162-175,321)
     else if (a == "-v" || a == "--verbose" || a == "--gender" || a == "--learning-rate") (void)need(i);
+    else if (a == "--covariates")                                     // cli.cpp:310-315 (hidden, --pop-correction builds only)
+    {
+      // Known to the reference's command line, but not to its pop-strat code: load_C's inner loop over a sample's
+      // covariates never ends once a file is given (src/popstrat.cpp:207: `for (j = 0; ctmp[...].size(); j++)`), so no
+      // reference run with --covariates has ever produced a result to be matched.  Refused, with the reason.
+      const std::string f = need(i);
+      if (!fs::is_regular_file(f)) die("--covariates: " + f + " is not a file");       // (bc::check::is_file)
+      die("--covariates " + f + ": not supported -- the reference's pop_strat_corrector::load_C never terminates with a covariates "
+          "file (src/popstrat.cpp:207), so there is no reference behaviour to reproduce; run without it");
+    }
     else if (a == "-f" || a == "--kff-output") o.kff = true;          // cli.cpp: control_kmers.kff / case_kmers.kff
     else if (a == "-m" || a == "--in-memory" || a == "-r" || a == "--cpr" ||
              a == "--stand" || a == "--irls") {}

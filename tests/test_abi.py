@@ -71,6 +71,11 @@ def test_command_line_fails_loudly_without_a_device(tmp_path):
     assert h.returncode == 0 and "--nb-controls" in h.stdout
     u = subprocess.run([cli, "diff", "-d", "x", "-1", "1", "-2", "1", "--no-such-flag"], capture_output=True, text=True, timeout=60)
     assert u.returncode == 1 and "unknown option" in u.stderr
+    # --covariates (src/cli.cpp:310): parsed like the reference does (the value must be a file) and refused with the reason
+    c = subprocess.run([cli, "diff", "-d", "x", "-1", "1", "-2", "1", "--pop-correction", "--covariates", __file__], capture_output=True, text=True, timeout=60)
+    assert c.returncode == 1 and "unknown option" not in c.stderr and "popstrat.cpp:207" in c.stderr
+    c = subprocess.run([cli, "diff", "-d", "x", "-1", "1", "-2", "1", "--covariates", "/no/such/file"], capture_output=True, text=True, timeout=60)
+    assert c.returncode == 1 and "is not a file" in c.stderr
     if K.device_count() > 0:
         pytest.skip("GPU present")
     r = subprocess.run([cli, "diff", "-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", "1", "-2", "1", "-o", str(tmp_path / "o")],

@@ -187,3 +187,42 @@ def test_case_sum_is_printed_like_fmt_braces():
              ("9007199254740993", "9007199254740992"), ("-2.5", "-2.5")]
     out = subprocess.run([exe, "fmt"] + [c[0] for c in cases], check=True, capture_output=True, text=True).stdout.split()
     assert out == [c[1] for c in cases]
+
+
+FUZZ = os.path.join(ROOT, "kmdiff_amd", "bin", "io_fuzz")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("what", ["kmers", "kmers16", "matrix", "survivors"])
+def test_readers_on_damaged_files_under_sanitizers(tmp_path, what):
+    """stream_kmer_file / read_kmer_file, stream_matrix_file / read_matrix_file, read_survivor_file on 1 000 truncated,
+    bit-flipped, overwritten files each, in a CPU build with AddressSanitizer + UBSan (tests/io_fuzz.cpp): a reader may
+    refuse a file or deliver fewer records; any out-of-bounds access, overflow or abort fails the run.  (Round 4's
+    finding: a matrix header whose sample count was overwritten sized the decoder's row buffer -- gigabytes, half a minute under the
+    sanitizer; the header is now checked, kMaxMatrixSamples.)"""
+    if not os.path.exists(FUZZ):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kmdiff_amd", "host"), "../bin/io_fuzz"], check=True, capture_output=True)
+    rng = np.random.default_rng(11)
+    n = 12_000                                          # three 64 KB LZ4 blocks
+    km = np.sort(rng.integers(0, 1 << 62, n, dtype=np.uint64))
+    seed = tmp_path / "seed"
+    if what == "kmers":
+        KF.write_kmer_file(str(seed), 31, 3, 1, km, rng.integers(1, 300, n).astype(np.uint32))
+    elif what == "kmers16":
+        KF.write_kmer_file(str(seed), 63, 3, 1, rng.integers(0, 1 << 62, n, dtype=np.uint64), rng.integers(1, 70000, n).astype(np.uint32),
+                           kmers_hi=km)
+    elif what == "matrix":
+        KF.write_matrix_file(str(seed), 31, 2, km, rng.integers(0, 1 << 16, (n, 6), dtype=np.uint64).astype(np.uint32), 2)
+    else:
+        raw = b""
+        for i in range(1500):
+            S = 5
+            raw += struct.pack("<QdiddH", int(km[i]), 1e-9 * i, i % 3, float(i), float(2 * i), S) + np.arange(S, dtype="<f8").tobytes()
+        open(seed, "wb").write(KF.lz4_frame_encode(raw))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([FUZZ, "kmers" if what == "kmers16" else what, str(seed), str(tmp_path / "work"), "1000", "42"], capture_output=True, text=True,
+                       timeout=550, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "1000 damaged files" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    refused = int(r.stdout.split("damaged files, ")[1].split(" refused")[0])
+    assert 0 < refused < 1000                           # some mutations are caught, some leave a readable file
