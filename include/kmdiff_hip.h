@@ -263,6 +263,27 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
                         uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out, uint64_t* n_rows_out,
                         void* stream);
 
+/* ---- the compact transfer format of a partition's streams (host -> device) ----------------------------------
+ * The reference streams a partition's LZ4 files straight into its merge (include/kmdiff/merge.hpp:265-266,
+ * cmd/diff.hpp:92-95); here they are decoded on the host and cross PCIe.  A sample's stream is sorted, so it is sent
+ * as blocks of KMD_PACK_BLOCK records -- first k-mer, bit-packed deltas of the block's widest delta, one-byte counts
+ * with an escape list (kmd_pack.hip: 4-6.5 bytes per record instead of 12) -- and unpacked on the device into the
+ * (k-mer, count) arrays kmd_merge_filter takes.  One-limb k-mers (k <= 32) only.
+ *   kmd_pack_block : host, any thread: n <= KMD_PACK_BLOCK records of ONE stream -> out (room for
+ *                    kmd_pack_block_bound() bytes); returns the bytes written, a multiple of 8 (0: bad arguments).
+ *                    A stream is its blocks one after the other (all of KMD_PACK_BLOCK records but the last);
+ *                    the caller notes where each begins: block_off8 = byte offset within the stream / 8.
+ *   kmd_unpack_streams : d_packed = the streams' packed bytes, stream s at byte stream_base[s] (host array, multiples
+ *                    of 8); d_block_off8 = the streams' block tables one after the other (stream s has
+ *                    ceil(records / KMD_PACK_BLOCK) entries); offsets[n_samples + 1] = the streams' record offsets
+ *                    (host), as kmd_merge_filter takes them: d_kmers / d_counts get offsets[n_samples] records.
+ *                    Asynchronous on `stream` (put it behind the copies of the packed bytes). */
+#define KMD_PACK_BLOCK 256
+size_t kmd_pack_block_bound(void);
+size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, uint32_t n, void* out);
+int kmd_unpack_streams(int n_samples, const void* d_packed, const uint64_t* stream_base, const uint32_t* d_block_off8,
+                       const uint64_t* offsets, uint64_t* d_kmers, uint32_t* d_counts, void* stream);
+
 /* ---- stage 0 + 1 fused: streams in, survivors out ---------------------------------------------
  * km::KmerMerger<KSIZE,CMAX>::merge(diff_observer) as kmdiff runs it per partition (include/kmdiff/
  * merge.hpp:265-289 with the observer of :68-103): the S sorted streams are merged and every distinct

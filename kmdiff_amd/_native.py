@@ -99,6 +99,9 @@ SIGNATURES = {
                                  C.POINTER(_u64), _vp]),
     "kmd_transport_local_create": (_i, [_i, C.POINTER(Transport)]),
     "kmd_transport_local_destroy": (_i, [_i, C.POINTER(Transport)]),
+    "kmd_pack_block_bound": (_sz, []),
+    "kmd_pack_block": (_sz, [_vp, _vp, C.c_uint32, _vp]),
+    "kmd_unpack_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_filter": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, C.POINTER(Survivors), _vp, C.POINTER(_u64), _vp]),

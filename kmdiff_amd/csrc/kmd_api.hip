@@ -233,6 +233,7 @@ int kmd_stream_destroy(void* stream)
   {
     KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     kmd::near_list_forget(static_cast<hipStream_t>(stream));     // (a later stream may get the same handle)
+    kmd::unpack_tables_forget(static_cast<hipStream_t>(stream), false);
     KMD_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
   }
   return KMD_OK;
@@ -256,7 +257,7 @@ int kmd_memset(void* d_dst, int value, size_t bytes, void* stream)
   KMD_HIP(hipMemsetAsync(d_dst, value, bytes, static_cast<hipStream_t>(stream)));
   return KMD_OK;
 }
-int kmd_release_cache(void) { kmd::scratch_release_all(); kmd::near_lists_release(); return KMD_OK; }
+int kmd_release_cache(void) { kmd::scratch_release_all(); kmd::near_lists_release(); kmd::unpack_tables_forget(nullptr, true); return KMD_OK; }
 int kmd_stream_sync(void* stream) { KMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return KMD_OK; }
 
 int kmd_event_create(void** ev)

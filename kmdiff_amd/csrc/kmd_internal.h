@@ -74,6 +74,8 @@ void scratch_release_all();
 // the near-threshold lists kept per stream (kmd_filter.hip): one stream's (it is being destroyed), all of them
 void near_list_forget(hipStream_t stream);
 void near_lists_release();
+// the page-locked table rings of kmd_unpack_streams (kmd_pack.hip): one stream's, or all of them
+void unpack_tables_forget(hipStream_t stream, bool all);
 
 // smallest LR at which igamc(1/2, LR) <= threshold, minus a safety margin; rows with a
 // likelihood ratio below it cannot pass `p <= threshold` (kmd_filter.hip).

@@ -418,6 +418,52 @@ def synth_streams(seed, partition, n_rows, nb_controls, nb_cases, kmer_limbs=1, 
     return ss, tot.to_host(np.uint64, S)
 
 
+PACK_BLOCK = 256
+
+
+def pack_streams(streams):
+    """The compact transfer format (kmd_pack_block, kmd_pack.hip) of a list of one-limb streams [(kmers, counts)]:
+    returns (packed bytes uint8[], stream_base uint64[S], block_off8 uint32[], offsets uint64[S + 1]).  Test / tool
+    helper: the blocks are packed one by one through the C-ABI (the CLI packs while it decodes the files)."""
+    L = lib()
+    bound = int(L.kmd_pack_block_bound())
+    S = len(streams)
+    offs = np.zeros(S + 1, dtype=np.uint64)
+    chunks, base, tables, at = [], np.zeros(S, dtype=np.uint64), [], 0
+    buf = np.zeros(bound, dtype=np.uint8)
+    for s, (km, ct) in enumerate(streams):
+        km = np.ascontiguousarray(km, dtype=np.uint64)
+        ct = np.ascontiguousarray(ct, dtype=np.uint32)
+        offs[s + 1] = offs[s] + len(km)
+        base[s] = at
+        within = 0
+        for b in range(0, len(km), PACK_BLOCK):
+            n = min(PACK_BLOCK, len(km) - b)
+            got = int(L.kmd_pack_block(km[b:].ctypes.data, ct[b:].ctypes.data, n, buf.ctypes.data))
+            assert got > 0 and got % 8 == 0 and got <= bound
+            tables.append(within // 8)
+            chunks.append(buf[:got].copy())
+            within += got
+        at += within
+    packed = np.concatenate(chunks) if chunks else np.zeros(8, dtype=np.uint8)
+    return packed, base, np.asarray(tables, dtype=np.uint32), offs
+
+
+def unpack_streams(packed, stream_base, block_off8, offs, stream=None):
+    """kmd_unpack_streams: the packed bytes go to the device and come back as a StreamSet (the arrays kmd_merge_filter reads)."""
+    S = len(stream_base)
+    ss = StreamSet.__new__(StreamSet)
+    ss.n_samples, ss.two, ss.offs = S, False, np.ascontiguousarray(offs, dtype=np.uint64)
+    ss.total = int(ss.offs[-1])
+    ss.kmers, ss.counts, ss.kmers_hi = DeviceBuffer(max(ss.total, 1) * 8), DeviceBuffer(max(ss.total, 1) * 4), None
+    dp = DeviceBuffer.from_host(np.ascontiguousarray(packed, dtype=np.uint8))
+    dt = DeviceBuffer.from_host(np.ascontiguousarray(block_off8, dtype=np.uint32)) if len(block_off8) else DeviceBuffer(8)
+    sb = np.ascontiguousarray(stream_base, dtype=np.uint64)
+    check(lib().kmd_unpack_streams(S, dp.ptr, sb.ctypes.data, dt.ptr, ss.offs.ctypes.data, ss.kmers.ptr, ss.counts.ptr, stream), "kmd_unpack_streams")
+    check(lib().kmd_stream_sync(stream), "sync")
+    return ss
+
+
 class RowSums:
     """What kmd_merge_sums leaves on the device: n_rows rows (k-mer, control sum, case sum), compact, in no
     particular order."""

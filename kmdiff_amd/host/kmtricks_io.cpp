@@ -483,7 +483,7 @@ struct payload_stream
 void grow_sink(record_sink& sink, size_t have, size_t more, size_t file_size, size_t rec)
 {
   if (have + more <= sink.capacity) return;
-  const size_t guess = (file_size * 3 / 2) / rec + 1024;
+  const size_t guess = sink.consume ? 0 : (file_size * 3 / 2) / rec + 1024;       // (a consumer empties the arrays chunk by chunk)
   sink.reserve(sink, std::max({ have + more, sink.capacity + sink.capacity / 4, guess }));
   if (sink.capacity < have + more || (sink.slots == 2 && !sink.kmers_hi)) throw std::runtime_error("record sink did not grow");
 }
@@ -506,13 +506,21 @@ kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, reco
   if (sink.slots != f.slots || sink.nb_counts != 1) sink.capacity = 0;      // arrays sized for records of another shape
   sink.slots = f.slots; sink.nb_counts = 1;
   const size_t rec = 8 * (size_t)f.slots + f.count_bytes;
+  sink.file_size = ps.file_size;
+  if (sink.raw && f.slots == 1)
+  {
+    ps.records(compressed != 0, rec, sink.in, sink.out, [&](const char* p, size_t whole) { sink.raw(p, whole, f.count_bytes); f.records += whole; });
+    sink.raw(nullptr, 0, f.count_bytes);
+    return f;
+  }
+  size_t held = 0;                                        // records in the sink's arrays (all of the file's so far, unless a consumer takes them)
   // (bytes after the last whole record are dropped, as read_kmer_file does)
   ps.records(compressed != 0, rec, sink.in, sink.out, [&](const char* p, size_t whole)
   {
-    grow_sink(sink, f.records, whole, ps.file_size, rec);
-    uint64_t* km = sink.kmers + f.records;
-    uint64_t* kh = sink.kmers_hi ? sink.kmers_hi + f.records : nullptr;
-    uint32_t* ct = sink.counts + f.records;
+    grow_sink(sink, held, whole, ps.file_size, rec);
+    uint64_t* km = sink.kmers + held;
+    uint64_t* kh = sink.kmers_hi ? sink.kmers_hi + held : nullptr;
+    uint32_t* ct = sink.counts + held;
     if (f.slots == 1 && f.count_bytes == 4) split_fixed<1, 4>(p, whole, km, kh, ct);
     else if (f.slots == 1 && f.count_bytes == 2) split_fixed<1, 2>(p, whole, km, kh, ct);
     else if (f.slots == 1) split_fixed<1, 1>(p, whole, km, kh, ct);
@@ -520,7 +528,21 @@ kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, reco
     else if (f.count_bytes == 2) split_fixed<2, 2>(p, whole, km, kh, ct);
     else split_fixed<2, 1>(p, whole, km, kh, ct);
     f.records += whole;
+    held += whole;
+    if (sink.consume)
+    {
+      const size_t taken = sink.consume(sink, held, false);
+      if (taken > held) throw std::runtime_error("record sink took more than it was given");
+      if (taken && taken < held)
+      {
+        std::memmove(sink.kmers, sink.kmers + taken, (held - taken) * 8);
+        if (sink.kmers_hi) std::memmove(sink.kmers_hi, sink.kmers_hi + taken, (held - taken) * 8);
+        std::memmove(sink.counts, sink.counts + taken, (held - taken) * 4);
+      }
+      held -= taken;
+    }
   });
+  if (sink.consume && sink.consume(sink, held, true) != held) throw std::runtime_error("record sink left records behind");
   return f;
 }
 

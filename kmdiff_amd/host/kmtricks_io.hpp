@@ -56,6 +56,16 @@ struct record_sink
   uint32_t slots = 1;                                     // limbs per k-mer of the file being read (set before reserve is called)
   uint32_t nb_counts = 1;                                 // counts per record: 1 for k-mer files, the samples of a matrix row
   std::function<void(record_sink&, size_t)> reserve;
+  // optional (k-mer files): called after every decoded chunk with the number of records the arrays hold, from index 0;
+  // returns how many of them, from the front, it has taken -- the rest moves to the front and the next chunk is put
+  // behind it (last = the file is finished: what is held now is all there is).  With it the arrays need room for one
+  // chunk, not for the file: the CLI packs the records for the transfer to the device as they are decoded.
+  std::function<size_t(record_sink&, size_t held, bool last)> consume;
+  // optional (k-mer files of one-limb k-mers): the decoded records as they are in the file -- n records of
+  // [k-mer 8 bytes][count count_bytes], back to back -- instead of the split into arrays (reserve / consume are not
+  // called then); a last call with n = 0 says the file is finished.  The CLI packs from these directly.
+  std::function<void(const char* records, size_t n, uint32_t count_bytes)> raw;
+  size_t file_size = 0;                                   // set by the reader before the first record: bytes of the file being read
   std::vector<char> in, out;                              // scratch of the decoder, kept between files
 };
 struct kmer_file_info { uint32_t slots = 1, count_bytes = 4; size_t records = 0; };

@@ -64,6 +64,7 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
   size_t ploidy = 2, seed = 0;              // cli.cpp:298-302, :349-351
   size_t threads = std::max(1u, std::thread::hardware_concurrency());   // -t: host threads decoding the k-mer files (cli.cpp:72-76)
   bool verbose_timing = std::getenv("KMD_HOST_TIMING") != nullptr;   // dev: where stage 1 spends its time
+  bool raw_transfer = std::getenv("KMD_RAW_TRANSFER") != nullptr;    // --raw-transfer: the streams cross PCIe as plain 12-byte records (default: packed, kmd_pack_block)
   int device = 0, devices = 1, verbose = 1;   // first GPU, number of GPUs (0 = all): partition p on GPU (device + p % devices)
 };
 
@@ -107,6 +108,9 @@ void usage()
             "  --save-sk          write the significant rows to positive_kmer_matrix/matrices/matrix_<p>.count.lz4\n"
             "  --matrix-path      k-way merge into the count matrix, then the test (default: merge fused with the test, no\n"
             "                     matrix -- same output; --cmodel and the matrices/ feed always take the matrix path)\n"
+            "  --raw-transfer     send the decoded streams to the GPU as plain (k-mer, count) arrays, 12 bytes per record\n"
+            "                     (default for k <= 32: packed on the host as they are decoded -- first k-mer + bit-packed deltas\n"
+            "                     + one-byte counts per 256 records, ~4-6 bytes per record -- and unpacked on the GPU; same output)\n"
             "  -t/--threads INT   host threads decoding the per-sample k-mer files {all}\n"
             "  -f/--kff-output    control_kmers.kff / case_kmers.kff (k-mers only) instead of the two FASTA files\n"
             "  --covariates FILE  known to the reference's command line; refused (its load_C never terminates with a file)\n"
@@ -141,6 +145,7 @@ diff_options parse(int argc, char** argv)
     else if (a == "--save-sk") o.save_sk = true;
     else if (a == "--no-matrix") {}                       // (the default now)
     else if (a == "--matrix-path") o.matrix_path = true;
+    else if (a == "--raw-transfer") o.raw_transfer = true;
     else if (a == "--kmer-pca") o.kmer_pca = std::stod(need(i));
     else if (a == "--ploidy") o.ploidy = std::stoull(need(i));
     else if (a == "--random-seed") o.seed = std::stoull(need(i));
@@ -264,6 +269,8 @@ struct survivors_of_run
   uint64_t n_near = 0;                               // rows decided with correctly rounded log / exp (KMD_CNT_NEAR_THRESHOLD)
   std::vector<double> Z_device;                          // [S][10] when the device PCA ran
   std::vector<uint64_t> worker_totals;                   // rows each GPU worker tested (empty after a resume: only their sum is on file)
+  uint64_t records = 0, h2d_bytes = 0;                   // k-mer feed: records of the run, bytes they crossed PCIe in (packed transfer: ~4-6 each)
+  bool packed = false;
 };
 
 // ---- host side of a partition ------------------------------------------------------------------
@@ -289,6 +296,11 @@ struct sample_stream                                    // one sample's file of 
   pinned kmers, kmers_hi, counts;
   record_sink sink;
   size_t n = 0;
+  // packed transfer (kmd_pack_block): the records are packed as they are decoded -- the plain arrays above then hold
+  // one chunk of the file at a time and are ordinary memory
+  pinned packed, table;                                 // the stream's blocks one after the other; where each begins (/ 8)
+  size_t packed_bytes = 0, n_blocks = 0;
+  std::vector<char> carry;                              // records (as in the file) of a block the last chunk left open
 };
 struct partition_input
 {
@@ -305,6 +317,8 @@ public:
   partition_loader(const run_context& C, std::vector<std::string> matrix_files)
     : C_(C), mpaths_(std::move(matrix_files)), threads_(std::max<size_t>(C.opt.threads / C.n_workers, 1)) {}
   bool from_matrix() const { return !mpaths_.empty(); }
+  // the k-mer feed of one-limb k-mers crosses PCIe packed (kmd_pack.hip) unless --raw-transfer says otherwise
+  bool packed_transfer() const { return !from_matrix() && !C_.two_limbs && !C_.opt.raw_transfer; }
   const std::vector<std::string>& matrix_files() const { return mpaths_; }
 
   // The S files of partition p are decoded in parallel, each as a stream (LZ4 chunk -> records ->
@@ -325,12 +339,70 @@ private:
     const size_t S = C_.S;
     const bool two_limbs = C_.two_limbs;
     const size_t n_streams = from_matrix() ? 1 : S;
+    const bool packed = packed_transfer();
     if (in->st.size() != n_streams)
     {
       in->st = std::vector<sample_stream>(n_streams);
       for (auto& st : in->st)
       {
         sample_stream* self = &st;
+        if (packed)
+        {
+          // The records are packed for the transfer as they leave the LZ4 decoder (kmd_pack_block): a block's 256
+          // records are gathered from the file's [k-mer][count] layout into two small arrays on the stack and packed
+          // into the stream's page-locked bytes -- no pass over the data besides the decoder's own; what a chunk
+          // leaves over (< 256 records) waits in `carry` for the next one.
+          st.sink.raw = [self](const char* p, size_t n, uint32_t cb)
+          {
+            static const size_t bound = kmd_pack_block_bound();
+            const size_t rec = 8 + (size_t)cb;
+            const bool last = p == nullptr;
+            auto room = [&](size_t blocks)
+            {
+              if (self->packed_bytes + blocks * bound > self->packed.cap)
+                self->packed.reserve(std::max(self->packed_bytes + blocks * bound, self->packed.cap + self->packed.cap / 2 + (1u << 20)), self->packed_bytes);
+              if ((self->n_blocks + blocks) * 4 > self->table.cap)
+                self->table.reserve(std::max((self->n_blocks + blocks) * 4, self->table.cap * 2 + 4096), self->n_blocks * 4);
+            };
+            auto pack = [&](const char* q, uint32_t m)
+            {
+              uint64_t km[KMD_PACK_BLOCK]; uint32_t ct[KMD_PACK_BLOCK];
+              if (cb == 4) for (uint32_t i = 0; i < m; ++i) { std::memcpy(&km[i], q + i * 12, 8); std::memcpy(&ct[i], q + i * 12 + 8, 4); }
+              else if (cb == 2) for (uint32_t i = 0; i < m; ++i) { uint16_t v; std::memcpy(&km[i], q + i * 10, 8); std::memcpy(&v, q + i * 10 + 8, 2); ct[i] = v; }
+              else for (uint32_t i = 0; i < m; ++i) { std::memcpy(&km[i], q + i * 9, 8); ct[i] = (uint8_t)q[i * 9 + 8]; }
+              ((uint32_t*)self->table.p)[self->n_blocks++] = (uint32_t)(self->packed_bytes / 8);
+              const size_t got = kmd_pack_block(km, ct, m, (char*)self->packed.p + self->packed_bytes);
+              if (!got) throw std::runtime_error("kmd_pack_block failed");
+              self->packed_bytes += got;
+            };
+            if (self->n_blocks == 0 && self->packed_bytes == 0)
+            {
+              // first records of a file: room for the whole of it in one go (page-locking is the fixed cost of a run, and
+              // growing a page-locked array copies it): LZ4 leaves sorted k-mers + small counts at 0.65-0.75 of their 12
+              // bytes, packed they take 4-6.5 -- the file's own size covers it; the arrays stay for the next partition
+              const size_t guess_records = self->sink.file_size * 3 / 2 / rec + 1024;
+              // (a quarter more than asked for: the files of a sample differ by a little from partition to partition, and
+              // every growth is a page-locked allocation)
+              const size_t want_p = self->sink.file_size + (1u << 16), want_t = (guess_records / KMD_PACK_BLOCK + 2) * 4;
+              if (self->packed.cap < want_p) self->packed.reserve(want_p + want_p / 4, 0);
+              if (self->table.cap < want_t) self->table.reserve(want_t + want_t / 4, 0);
+            }
+            room(n / KMD_PACK_BLOCK + 2);
+            std::vector<char>& carry = self->carry;
+            if (!carry.empty() && n)                    // fill the block the previous chunk left open
+            {
+              const size_t have = carry.size() / rec, take = std::min(n, (size_t)KMD_PACK_BLOCK - have);
+              carry.insert(carry.end(), p, p + take * rec);
+              p += take * rec; n -= take;
+              if (carry.size() / rec == KMD_PACK_BLOCK) { pack(carry.data(), KMD_PACK_BLOCK); carry.clear(); }
+            }
+            for (; n >= KMD_PACK_BLOCK; n -= KMD_PACK_BLOCK, p += KMD_PACK_BLOCK * rec) pack(p, KMD_PACK_BLOCK);
+            if (n) carry.insert(carry.end(), p, p + n * rec);
+            if (last && !carry.empty()) { pack(carry.data(), (uint32_t)(carry.size() / rec)); carry.clear(); }
+            if (self->packed_bytes / 8 > 0xFFFFFFFFull) throw std::runtime_error("a sample's packed stream exceeds 32 GB");
+          };
+          continue;
+        }
         st.sink.reserve = [self](record_sink& k, size_t n)
         {
           const size_t keep = k.capacity;                // grows only while a file is being read: all of it is live
@@ -351,6 +423,7 @@ private:
     }
     for_samples([&](size_t s2)
     {
+      in->st[s2].packed_bytes = 0; in->st[s2].n_blocks = 0; in->st[s2].carry.clear();
       const kmer_file_info f = stream_kmer_file(kmer_file_path(C_.opt.kmtricks_dir, p, C_.fof[s2].id), C_.cfg.kmer_size, in->st[s2].sink);
       if ((f.slots == 2) != two_limbs) throw std::runtime_error("k-mer width of a sample file differs from the run's");
       in->st[s2].n = f.records;
@@ -398,6 +471,7 @@ struct worker_result
   survivor_set sv;
   std::vector<std::pair<size_t, size_t>> span;     // per partition of this worker: (begin, count) in sv
   uint64_t total = 0, n_sig = 0, n_ctrl = 0, n_case = 0, n_sampled = 0, n_near = 0;
+  uint64_t records = 0, h2d_bytes = 0;              // k-mer feed: records of this worker's partitions, bytes they crossed PCIe in
   std::vector<double> xtx;                         // the worker's PCA Gram matrix
   std::string error;
 };
@@ -438,6 +512,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   struct device_input
   {
     dev_buf kmers, kmers_hi, counts;
+    dev_buf packed, table;                               // packed transfer: the streams' blocks and block tables as they arrive
     std::vector<uint64_t> offs;                          // k-mer feed: stream s is [offs[s], offs[s + 1])
     size_t n = 0;                                        // records (k-mer feed) or rows (matrices/)
   };
@@ -505,6 +580,27 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     D.offs = in.offs;                                    // the slot is refilled while this partition is merged
     D.kmers.reserve(D.n * 8); D.counts.reserve(D.n * 4);
     if (two_limbs) D.kmers_hi.reserve(D.n * 8);
+    R.records += D.n;
+    if (loader.packed_transfer())
+    {
+      // 4-6 bytes per record cross the link instead of 12; k_unpack, behind the copies on the copy stream, writes the
+      // plain arrays the kernels read (merge.hpp:265-266: the reference streams its files straight into the merge)
+      std::vector<uint64_t> base(S + 1, 0), blk(S + 1, 0);
+      for (size_t s2 = 0; s2 < S; ++s2) { base[s2 + 1] = base[s2] + in.st[s2].packed_bytes; blk[s2 + 1] = blk[s2] + in.st[s2].n_blocks; }
+      D.packed.reserve(std::max<size_t>(base[S], 8)); D.table.reserve(std::max<size_t>(blk[S] * 4, 8));
+      for (size_t s2 = 0; s2 < S; ++s2)
+      {
+        const sample_stream& st = in.st[s2];
+        if (!st.n) continue;
+        ck(kmd_memcpy_h2d_async((char*)D.packed.p + base[s2], st.packed.p, st.packed_bytes, copy_stream), "h2d");
+        ck(kmd_memcpy_h2d_async((char*)D.table.p + blk[s2] * 4, st.table.p, st.n_blocks * 4, copy_stream), "h2d");
+      }
+      ck(kmd_unpack_streams((int)S, D.packed.p, base.data(), (const uint32_t*)D.table.p, D.offs.data(), (uint64_t*)D.kmers.p,
+                            (uint32_t*)D.counts.p, copy_stream), "kmd_unpack_streams");
+      R.h2d_bytes += base[S] + blk[S] * 4;
+      return;
+    }
+    R.h2d_bytes += D.n * (two_limbs ? 20 : 12);
     for (size_t s2 = 0; s2 < S; ++s2)                     // each stream to its place in the partition's arrays
     {
       const sample_stream& st = in.st[s2];
@@ -782,7 +878,8 @@ void do_diff(const run_context& C, survivors_of_run& O, const bool run_pca)
       if (want_counts) sv_all.counts.insert(sv_all.counts.end(), R.sv.counts.begin() + b * S, R.sv.counts.begin() + (b + cnt) * S);
       part_begin[p + 1] = sv_all.size();
     }
-    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; O.n_near += R.n_near; O.worker_totals.push_back(R.total); }
+    for (auto& R : results) { total_kmers += R.total; n_sig += R.n_sig; n_sig_control += R.n_ctrl; n_sig_case += R.n_case; O.n_near += R.n_near; O.worker_totals.push_back(R.total); O.records += R.records; O.h2d_bytes += R.h2d_bytes; }
+    O.packed = loader.packed_transfer();
   }
   for (size_t p = n_units; p < cfg.nb_partitions; ++p) part_begin[p + 1] = part_begin[n_units];
   if (run_pca)                                                                             // run_eigenstrat_smartpca
@@ -1077,7 +1174,14 @@ void do_correction(const run_context& C, survivors_of_run& O)
   js << "{\"total_kmers\": " << total_kmers << ", \"n_sig\": " << n_sig << ", \"n_sig_control\": " << n_sig_control
      << ", \"n_sig_case\": " << n_sig_case << ", \"kept\": " << kept << ", \"kept_control\": " << c_controls
      << ", \"kept_case\": " << c_cases << ", \"near_threshold\": " << O.n_near << ", \"kmer_size\": " << cfg.kmer_size
-     << ", \"nb_partitions\": " << cfg.nb_partitions << "}\n";
+     << ", \"nb_partitions\": " << cfg.nb_partitions;
+  if (O.records)                                         // (stage 1 ran on the k-mer feed)
+  {
+    char bpr[32]; std::snprintf(bpr, sizeof bpr, "%.3f", (double)O.h2d_bytes / (double)O.records);
+    js << ", \"transfer\": {\"format\": \"" << (O.packed ? "packed" : "raw") << "\", \"records\": " << O.records << ", \"h2d_bytes\": " << O.h2d_bytes
+       << ", \"bytes_per_record\": " << bpr << "}";
+  }
+  js << "}\n";
 }
 
 } // namespace

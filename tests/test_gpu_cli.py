@@ -20,7 +20,14 @@ SEED = 0x6B6D64696666
 def run_cli(args, out):
     r = subprocess.run([CLI, "diff", "-o", str(out)] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
-    return json.load(open(os.path.join(str(out), "summary.json"))), r.stderr
+    s = json.load(open(os.path.join(str(out), "summary.json")))
+    # how the k-mer feed's records crossed the link (absent when stage 1 did not run: a resume, the matrices/ feed) is
+    # kept apart: the summaries of two runs are compared as a whole all over this file
+    TRANSFER[str(out)] = s.pop("transfer", None)
+    return s, r.stderr
+
+
+TRANSFER = {}
 
 
 def read_fasta(path):
@@ -136,6 +143,7 @@ def test_cli_matrix_feed_equals_kmer_file_feed(synth_run, tmp_path):
     for p, (m, km) in enumerate(zip(mats, kms)):
         KF.write_matrix_file(str(mrun / "matrices" / ("matrix_%d.count.lz4" % p)), k, p, km, m)
     b, _ = run_cli(["-d", mrun, "-1", nc, "-2", nk, "-u", 1000], tmp_path / "b")
+    assert TRANSFER[str(tmp_path / "a")]["format"] == "packed" and TRANSFER[str(tmp_path / "b")] is None
     assert a == b and a["n_sig"] > 10
     for name in ("control_kmers.fasta", "case_kmers.fasta"):
         assert open(tmp_path / "a" / name).read() == open(tmp_path / "b" / name).read()
@@ -411,3 +419,52 @@ def test_cli_fused_path_equals_matrix_path(synth_run, tmp_path):
         s, _ = run_cli(["-d", os.path.join(ROOT, "tests", "golden", "km_out_dir"), "-1", 1, "-2", 1, "-u", 10000] + extra, tmp_path / "f")
         assert (s["total_kmers"], s["n_sig"], s["kept"]) == (320, 0, 0)
         shutil.rmtree(tmp_path / "f")
+
+
+def test_cli_packed_transfer_equals_raw_transfer(synth_run, tmp_path):
+    """The default k-mer feed (records packed on the host as they are decoded, kmd_pack_block; unpacked on the GPU,
+    kmd_unpack_streams) against --raw-transfer (plain 12-byte records): byte-identical outputs on every path that reads
+    the streams -- the fused merge, the matrix path, pop-strat's count rows and PCA sampling, --keep-tmp files -- and the
+    bytes per record that crossed the link in summary.json."""
+    run_dir, nc, nk, k, mats, kms = synth_run
+    for tag, extra in (("fused", ["--keep-tmp", "--pop-correction", "--kmer-pca", 0.05, "-c", "benjamini"]), ("matrix", ["--matrix-path"])):
+        common = ["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000] + extra
+        a, _ = run_cli(common, tmp_path / (tag + "_a"))
+        b, _ = run_cli(common + ["--raw-transfer"], tmp_path / (tag + "_b"))
+        ta, tb = TRANSFER[str(tmp_path / (tag + "_a"))], TRANSFER[str(tmp_path / (tag + "_b"))]
+        assert a == b and a["n_sig"] > 10
+        records = sum(int((m > 0).sum()) for m in mats)
+        assert ta["format"] == "packed" and tb["format"] == "raw" and ta["records"] == tb["records"] == records
+        assert tb["bytes_per_record"] == 12.0 and 3.5 < ta["bytes_per_record"] < 6.0, ta
+        names = ["control_kmers.fasta", "case_kmers.fasta"]
+        if tag == "fused":
+            names += ["popstrat/pcs.evec", "partitions/p0_uncorrected", "partitions/p2_uncorrected", "partitions/p1_popstrat_uncorrected"]
+        for name in names:
+            assert open(tmp_path / (tag + "_a") / name, "rb").read() == open(tmp_path / (tag + "_b") / name, "rb").read(), (tag, name)
+
+
+def test_cli_packed_transfer_counts_beyond_one_byte_and_tiny_files(tmp_path):
+    """Streams whose counts need the escape list (>= 255, up to 2^32 - 1), a sample without k-mers in a partition, a
+    partition of a single k-mer: the packed feed and the raw one agree."""
+    rng = np.random.default_rng(5)
+    nc, nk, k = 2, 2, 31
+    parts = []
+    uni = np.unique(rng.integers(0, 1 << 62, 3000, dtype=np.uint64))
+    st = []
+    for s in range(nc + nk):
+        pick = rng.random(len(uni)) < 0.7
+        cnt = rng.integers(1, 1000, int(pick.sum())).astype(np.uint32)
+        cnt[rng.integers(0, len(cnt), 5)] = np.uint32(2 ** 32 - 1 if s == 0 else 70000)
+        st.append((uni[pick], cnt))
+    st[2] = (np.zeros(0, np.uint64), np.zeros(0, np.uint32))                  # a sample without k-mers here
+    parts.append(st)
+    parts.append([(np.array([77], dtype=np.uint64), np.array([3], dtype=np.uint32))] + [(np.zeros(0, np.uint64), np.zeros(0, np.uint32))] * 3)
+    ids = ["C0", "C1", "K0", "K1"]
+    KF.write_run_dir(str(tmp_path / "km"), k, ids, parts)
+    common = ["-d", str(tmp_path / "km"), "-1", nc, "-2", nk, "-s", 0.9, "-u", 1, "-c", "disabled", "--keep-tmp"]
+    a, _ = run_cli(common, tmp_path / "a")
+    b, _ = run_cli(common + ["--raw-transfer"], tmp_path / "b")
+    present = len(np.unique(np.concatenate([t[0] for t in parts[0]])))
+    assert a == b and a["total_kmers"] == present + 1 and a["n_sig"] > 100
+    for name in ("control_kmers.fasta", "case_kmers.fasta", "partitions/p0_uncorrected", "partitions/p1_uncorrected"):
+        assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read(), name

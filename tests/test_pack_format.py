@@ -1,0 +1,88 @@
+"""The compact transfer format of a stream (kmd_pack_block, kmdiff_amd/csrc/kmd_pack.hip) against an independent
+decoder written from the format's description (numpy, no GPU): every block is its first k-mer, 256 bit-packed deltas of
+the block's widest delta, one-byte counts with 255 as the escape into a list of 32-bit counts."""
+import numpy as np
+import pytest
+
+import kmdiff_amd as K
+
+
+def decode_block(b, n):
+    """(k-mers, counts, bytes of the block) of a block of n records at the start of the uint8 array b"""
+    anchor = int(b[0:8].view("<u8")[0])
+    w, n_esc = int(b[8]), int(b[10:12].view("<u2")[0])
+    assert b[9] == 0 and not b[12:16].any()
+    n_words = 4 * w + 1
+    words = [int(x) for x in b[16:16 + 8 * n_words].view("<u8")]
+    big = sum(v << (64 * i) for i, v in enumerate(words))                     # the bit string as one integer
+    deltas = [(big >> (i * w)) & ((1 << w) - 1) if w else 0 for i in range(256)]
+    assert deltas[0] == 0 and not any(deltas[n:])
+    keys, k = [], anchor
+    for i in range(n):
+        k = (k + deltas[i]) & (2 ** 64 - 1)
+        keys.append(k)
+    cb = b[16 + 8 * n_words:16 + 8 * n_words + 256]
+    esc = b[16 + 8 * n_words + 256:16 + 8 * n_words + 256 + 4 * n_esc].view("<u4")
+    counts, e = [], 0
+    for i in range(n):
+        if cb[i] == 255:
+            counts.append(int(esc[e])); e += 1
+        else:
+            counts.append(int(cb[i]))
+    assert e == n_esc and not cb[n:].any()
+    size = 16 + 8 * n_words + 256 + 4 * n_esc
+    return keys, counts, (size + 7) // 8 * 8
+
+
+def roundtrip(km, ct):
+    packed, base, table, offs = K.pack_streams([(km, ct)])
+    assert base.tolist() == [0] and offs.tolist() == [0, len(km)] and len(table) == (len(km) + 255) // 256
+    keys, counts, at = [], [], 0
+    for j, b in enumerate(range(0, len(km), 256)):
+        assert int(table[j]) * 8 == at
+        k, c, size = decode_block(packed[at:], min(256, len(km) - b))
+        keys += k; counts += c; at += size
+    assert at == len(packed) or len(km) == 0
+    assert keys == [int(x) for x in km] and counts == [int(x) for x in ct]
+    return len(packed)
+
+
+@pytest.mark.parametrize("bits", [0, 1, 7, 22, 33, 45, 62, 63, 64])
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1000])
+def test_blocks_of_every_delta_width(bits, n):
+    rng = np.random.default_rng(bits * 1000 + n)
+    if bits == 64:                                       # an unsorted stream: differences wrap around 2^64
+        km = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+    elif bits == 0:
+        km = np.full(n, 12345678901234567, dtype=np.uint64)
+    else:
+        d = rng.integers(0, 1 << bits, n, dtype=np.uint64) >> np.uint64(max(0, 2 + int(np.log2(n)) - (64 - bits)) if bits > 40 else 0)
+        km = np.cumsum(d, dtype=np.uint64) + np.uint64(17)
+    ct = rng.integers(1, 400, n).astype(np.uint32)
+    ct[rng.integers(0, n, max(1, n // 50))] = np.uint32(2 ** 32 - 1)
+    ct[rng.integers(0, n, max(1, n // 50))] = np.uint32(255)
+    ct[rng.integers(0, n, max(1, n // 50))] = np.uint32(254)
+    size = roundtrip(km, ct)
+    assert size <= ((n + 255) // 256) * K._native.lib().kmd_pack_block_bound()
+
+
+def test_size_on_streams_like_the_synthetic_partitions():
+    """A sample's stream of a 2 M-row partition: k-mers every ~1.5 rows of 2^21, counts mostly below 255."""
+    rng = np.random.default_rng(1)
+    n = 100_000
+    km = np.cumsum(rng.geometric(0.65, n).astype(np.uint64) << np.uint64(21), dtype=np.uint64) + rng.integers(0, 1 << 20, n, dtype=np.uint64)
+    km.sort()
+    ct = rng.poisson(8, n).astype(np.uint32) + 1
+    ct[rng.random(n) < 0.01] = 3000
+    size = roundtrip(km, ct)
+    assert 3.5 < size / n < 5.0, size / n                # (12 as plain arrays)
+
+
+def test_bad_arguments_pack_nothing():
+    L = K._native.lib()
+    buf = np.zeros(int(L.kmd_pack_block_bound()), dtype=np.uint8)
+    km, ct = np.arange(300, dtype=np.uint64), np.ones(300, dtype=np.uint32)
+    assert L.kmd_pack_block(km.ctypes.data, ct.ctypes.data, 0, buf.ctypes.data) == 0
+    assert L.kmd_pack_block(km.ctypes.data, ct.ctypes.data, 257, buf.ctypes.data) == 0
+    assert L.kmd_pack_block(None, ct.ctypes.data, 5, buf.ctypes.data) == 0
+    assert L.kmd_pack_block_bound() == 16 + 257 * 8 + 256 + 1024

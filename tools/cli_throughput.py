@@ -25,6 +25,7 @@ ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
 ap.add_argument("--keep", default="", help="write the run directory here, keep it, and stop")
 ap.add_argument("--matrix", action="store_true", help="also write <run>/matrices: the pre-merged feed (matrix_proxy)")
+ap.add_argument("--ab", type=int, default=0, help="instead of the -t sweep: this many rounds of packed transfer against --raw-transfer at -t 16 and -t 64, alternating")
 a = ap.parse_args()
 S = a.nc + a.nk
 root = tempfile.mkdtemp(prefix="kmrun_")
@@ -58,7 +59,10 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/pro
         print(f, open(f).read().strip(), flush=True)
 print("cpus in affinity mask:", len(os.sched_getaffinity(0)), flush=True)
 cli = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
-for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64", "--devices", "2"]):
+configs = (["-t", "1"], ["-t", "8"], ["-t", "16"], ["-t", "64"], ["-t", "256"], ["-t", "64", "--devices", "2"])
+if a.ab:
+    configs = [c + m for _ in range(a.ab) for c in (["-t", "16"], ["-t", "64"]) for m in ([], ["--raw-transfer"])]
+for extra in configs:
     out = os.path.join(root, "out")
     shutil.rmtree(out, ignore_errors=True)
     t0 = time.time()
@@ -70,6 +74,13 @@ for extra in (["-t", "1"], ["-t", "8"], ["-t", "64"], ["-t", "256"], ["-t", "64"
     for l in r.stderr.split("\n"):
         if "waited" in l or "steady state" in l or "last partition" in l:
             print("   ", l)
+    try:
+        import json
+        tr = json.load(open(os.path.join(out, "summary.json"))).get("transfer")
+        if tr:
+            print("    transfer: %s, %.3f bytes per record across the link" % (tr["format"], tr["bytes_per_record"]))
+    except Exception:
+        pass
     print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s"
           % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1)), flush=True)
 shutil.rmtree(root, ignore_errors=True)
