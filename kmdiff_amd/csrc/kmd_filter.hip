@@ -886,25 +886,33 @@ __global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_pa
   if (blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
 
-  n4 buf[kFlatVecs];
-  auto issue = [&](size_t t)
+  // Two spans per wave in flight, in two sets of registers (round 4).  With one, a wave had 2.7 KB under way at 21v21
+  // -- 43 KB per CU against a loaded HBM latency of ~2.3 us: 18.5 GB/s per CU, 4.7 TB/s, exactly what was measured;
+  // the kernel's ~110 instructions per span idle between the waits.  The tile in LDS stays single: a span's registers
+  // are written to it, the set is refilled at once (the load of span t + 2 n_waves), then the tile is added up.
+#ifndef KMD_FLAT_DEPTH
+#define KMD_FLAT_DEPTH 2
+#endif
+  constexpr int kDepth = KMD_FLAT_DEPTH;
+  n4 bufs[kDepth][kFlatVecs];
+  auto issue = [&](n4 (&buf)[kFlatVecs], size_t t)
   {
+    // (every lane loads, every time: a lane past the span or the buffer re-reads the last vector inside both -- the
+    // same cache line as its neighbours'.  A load under a condition makes the number of loads in flight unknown to
+    // the compiler where the paths meet, and it then waits for ALL of them -- the other set's just-issued span
+    // included: measured, the second set bought nothing until the loads were unconditional)
     const size_t v0 = t * span_vecs;
 #pragma unroll
     for (int k = 0; k < kFlatVecs; ++k)
     {
-      const uint32_t i = (uint32_t)k * 64 + lane;
-      if ((uint32_t)k * 64 < span_vecs)                  // wave-uniform
-      {
-        const size_t v = v0 + i;
-        if (i < span_vecs && v < total_vecs) buf[k] = __builtin_nontemporal_load(base + v);   // never past the span / the buffer
-      }
+      uint32_t i = (uint32_t)k * 64 + lane;
+      i = i < span_vecs ? i : span_vecs - 1u;
+      size_t v = v0 + i;
+      v = v < total_vecs ? v : total_vecs - 1;
+      buf[k] = __builtin_nontemporal_load(base + v);
     }
   };
-
-  size_t t = (size_t)blockIdx.x * (kFlatBlock / 64) + w;
-  if (t < n_tiles) issue(t);
-  for (; t < n_tiles; t += n_waves)
+  auto consume = [&](n4 (&buf)[kFlatVecs], size_t t)
   {
     const size_t v0 = t * span_vecs;
 #pragma unroll
@@ -924,9 +932,12 @@ __global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_pa
       }
     }
     queue_fence();
-    if (t + n_waves < n_tiles) issue(t + n_waves);       // next span in flight while this one is added up
+    issue(buf, t + kDepth * n_waves < n_tiles ? t + kDepth * n_waves : t);      // this set's next span in flight while the tile is added up (past the end: this span again, unused)
     const CT* __restrict__ mine = tile_ct + (size_t)r * P.ld;
     ACC sc = 0, sk = 0;
+    // (one- and two-byte counts read as dwords with one v_sad per dword -- a quarter / half of the LDS reads -- were measured
+    // in round 4: u8 20v20 +-0 (5.17 TB/s: at 1.08e11 rows/s the per-row pre-filter is the cost, K1 tiled reaches 1.2e11),
+    // u16 21v21 5.9 -> 5.1; the count-by-count walk stays)
     // eight LDS reads in flight per lane (the walk is latency-bound otherwise)
     uint32_t e = g;
     for (; e + 7 * G < nc; e += 8 * G)
@@ -961,6 +972,19 @@ __global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_pa
     st.valid = g == 0 && st.row < P.n_rows;
     st.sum_c = sc; st.sum_k = sk;
     defer_row(P, s_lf, st, n_beyond, Q);
+  };
+
+  size_t t = (size_t)blockIdx.x * (kFlatBlock / 64) + w;
+  if (t < n_tiles)
+  {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) issue(bufs[d], t + d * n_waves < n_tiles ? t + d * n_waves : t);
+  }
+  for (; t < n_tiles; t += kDepth * n_waves)
+  {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+      if (t + d * n_waves < n_tiles) consume(bufs[d], t + d * n_waves);
   }
   drain_queue(P, s_lf, Q);
   flush_beyond(P, n_beyond);
@@ -1320,6 +1344,7 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
   // with the most rows per span (64, 32, ... 2) that fit its tile (4 KB; 8 or 16 KB for very wide rows)
   // and keep spans 16-byte aligned
   if ((((P.ld * sizeof(CT)) % 16 != 0) || std::getenv("KMD_ROWS_FLAT_ALL")) && ((reinterpret_cast<uintptr_t>(P.counts) & 15u) == 0) &&
+      P.n_rows * P.ld * sizeof(CT) >= 16 &&              // (its loads are unconditional: there must be one whole vector to read)
       std::getenv("KMD_ROWS_FLAT_OFF") == nullptr)
   {
     const size_t pitch = P.ld * sizeof(CT);
@@ -1346,8 +1371,10 @@ int launch_rows(filter_params& P, const kmd_model* m, hipStream_t stream)
       KMD_HIP(hipGetLastError());
       return KMD_OK;
     };
-    if (const uint32_t R = rows_per_span(4096)) return launch(k_filter_rows_flat<CT, 4, 1024>, 4, 1024, R);
-    if (const uint32_t R = rows_per_span(8192)) return launch(k_filter_rows_flat<CT, 8, 768>, 8, 768, R);
+    const char* force_kb = std::getenv("KMD_FLAT_TILE_KB");             // dev: 8 / 16 take the larger tiles (fewer waves) where 4 KB would do
+    const int min_kb = force_kb ? std::atoi(force_kb) : 4;
+    if (const uint32_t R = min_kb <= 4 ? rows_per_span(4096) : 0) return launch(k_filter_rows_flat<CT, 4, 1024>, 4, 1024, R);
+    if (const uint32_t R = min_kb <= 8 ? rows_per_span(8192) : 0) return launch(k_filter_rows_flat<CT, 8, 768>, 8, 768, R);
     if (const uint32_t R = rows_per_span(16384)) return launch(k_filter_rows_flat<CT, 16, 512>, 16, 512, R);
   }
   // 16-byte aligned rows: the wave-private kernel (a row's last vector may reach into the
