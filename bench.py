@@ -15,7 +15,10 @@ Sharding: partition p belongs to rank p % N (weak scaling: every rank does K ste
 The JSON line also carries
   roofline     : algorithmic bytes (168 B/row) / average kernel duration, measured with one HIP
                  event pair around the K back-to-back launches (duration / K), against the
-                 8 TB/s HBM3E peak;
+                 8 TB/s HBM3E peak (`frac` = `frac_events`: this run's events); `traffic` = HBM bytes per launch from
+                 the PMC passes in profiles/ (static), `traffic_frac` = traffic / this run's kernel time / peak;
+                 `profiled` = the kernel's average duration in the committed rocprofv3 CSV of this command and
+                 the fraction that follows from it (static; what a reader of profiles/ recomputes);
   cpu_baseline : the reference's own arithmetic (oracle/_ref, kind "reference") or the C
                  restatement (kind "port") on the host cores, on a bounded sample of the same
                  workload, tail function evaluated for every row as the reference does;
@@ -392,13 +395,24 @@ def main():
             a.free(); b.free()
         except Exception:
             pass
-        traffic, traffic_source = None, None
+        # roofline.frac / frac_events: THIS run's HIP events.  What profiles/ holds of the same command (rocprofv3 cannot
+        # run inside this process) is quoted beside it, with its source: the PMC traffic per launch, and the kernel's
+        # average duration in the committed kernel-trace CSV (tools/refresh_profiles_r04.sh makes both in one lease and
+        # checks the CSV against the HIP events of the profiled run itself: they agree to 3 %; a run under the
+        # profiler is 2-3 % slower than one without, MI355X_MICROARCH.md "DVFS give-back")
+        traffic, traffic_source, profiled = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic.json (static: %s; not measured by this run)" % tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+                if tj.get("profiled_kernel_us") and args.rows == tj.get("rows_per_launch") and args.layout == tj.get("layout", "tiled"):
+                    p_ms = tj["profiled_kernel_us"] * 1e-3
+                    profiled = {"avg_kernel_ms": p_ms, "frac": args.rows * BYTES_PER_ROW / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "events_ms_same_run": tj.get("profiled_events_ms"), "source": tj.get("profiled_source"),
+                                "what": "static: average duration of the kernel in the committed rocprofv3 --kernel-trace --stats CSV of this "
+                                        "command, and the HIP-event average of that profiled run"}
             except Exception:
                 traffic = None
         out = {
@@ -421,7 +435,10 @@ def main():
                                     "near_threshold": int(kept[3])},
                        "copy_probe_GBs": copy_gbs, "read_probe_GBs": read_gbs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_events": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_frac": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "profiled": profiled,
                          "kernel": "k_filter_%s<u32>" % ("rows" if args.layout == "rows" else "soa"), "avg_kernel_ms": avg_kernel_ms},
         }
         if world == 1 and not args.no_pipeline:

@@ -9,17 +9,23 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=4_000_000)
 ap.add_argument("--parts", type=int, default=12)
 ap.add_argument("--iters", type=int, default=4)
+ap.add_argument("--device", action="store_true", help="streams built on the device (kmd_synth_streams), four distinct partitions taken in turn: whole configs[2] partitions with --rows 39062500")
 a = ap.parse_args()
 lib = K._native.lib()
 NC = NK = 20
-mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, NC, NK, 4, K.LAYOUT_ROWS)
-host, lo = mat.to_host(), mat.kmers_to_host()[0]
-del mat
-streams = [(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(NC + NK)]
-tot = host.sum(axis=0, dtype=np.uint64)
-sets = [K.StreamSet(streams) for _ in range(a.parts)]
+if a.device:
+    made = [K.synth_streams(0x6B6D64696666, p, a.rows, NC, NK) for p in range(min(4, a.parts))]
+    tot = sum(t for _, t in made)
+    sets = [made[i % len(made)][0] for i in range(a.parts)]
+else:
+    mat = K.synth_matrix(0x6B6D64696666, 0, a.rows, NC, NK, 4, K.LAYOUT_ROWS)
+    host, lo = mat.to_host(), mat.kmers_to_host()[0]
+    del mat
+    streams = [(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(NC + NK)]
+    tot = host.sum(axis=0, dtype=np.uint64)
+    sets = [K.StreamSet(streams) for _ in range(a.parts)]
 model = K.PoissonLikelihood(NC, NK, tot[:NC], tot[NC:], 10000)
-accs = [K.SurvivorAccumulator(1 << 18) for _ in range(a.parts)]
+accs = [K.SurvivorAccumulator(max(1 << 18, a.rows // 100)) for _ in range(a.parts)]
 obs = [K.diff_observer(model, acc, 5e-7) for acc in accs]
 for o, ss in zip(obs, sets):
     K.merge_filter(ss, o)
