@@ -4,7 +4,7 @@
 #include "kmd_internal.h"
 #include "../../include/kmdiff_hip_test.h"
 #include "kmd_math.h"
-#include "kmd_synth_tables.h"
+#include "../../include/kmdiff_synth_tables.h"
 
 #include <algorithm>
 #include <cmath>
@@ -392,7 +392,7 @@ int kmd_model_lf_table(const kmd_model* m, double* out, size_t n)
 // Definition (also restated, independently, by the CPU oracle):
 //   h_row   = mix(mix(seed ^ C_PART*(part+1)) ^ C_ROW*(row+1))
 //   class   = rate class from h_row[0,16) with weights .40 .30 .15 .10 .04 .01 -> lambda index
-//             base {1,3,5,7,11,17}  (lambda_j = 0.5 * 2^(j/2), tables in kmd_synth_tables.h)
+//             base {1,3,5,7,11,17}  (lambda_j = 0.5 * 2^(j/2), tables in include/kmdiff_synth_tables.h)
 //   big     = (h_row >> 16) % 1e6 == 1   -> base index 24 (count sums beyond the lf table)
 //   planted = (h_row >> 36) % 1e4 == 0   -> +6 steps (x8) on cases, on controls if h_row bit 63
 //   depth_s = mix(seed ^ C_DEPTH*(s+1)) % 3 -> +0/+1/+2 steps per sample

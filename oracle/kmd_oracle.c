@@ -5,7 +5,7 @@
  */
 #define _GNU_SOURCE
 #include "kmd_oracle.h"
-#include "synth_tables.h"
+#include "../include/kmdiff_synth_tables.h"   /* the synthetic input's tables: data shared with the device generator */
 
 #include <math.h>
 #include <pthread.h>
@@ -340,7 +340,7 @@ size_t kmdo_aggregate(int type, double threshold, uint64_t total_kmers,
 /*   depth_s = mix(seed ^ C_DEPTH*(s+1)) % 3     -> +0/+1/+2 index steps per sample       */
 /*   cell    = h = mix(h_row ^ C_CELL*(s+1)); classes 0,1 are zero-inflated: absent when  */
 /*             (h >> 32) & 0xFFFF < 19661 (p = 0.3); else inverse-CDF Poisson draw of the */
-/*             low 32 bits of h in table j (synth_tables.h); clamped to the count type    */
+/*             low 32 bits of h in table j (kmdiff_synth_tables.h); clamped to the count type    */
 /*   all-zero rows get count 1 in sample h_row % S (the merge never emits empty rows)     */
 /*   kmer    = part*2^54 + row*2^21 + 1 + (mix(h_row ^ C_KMER) & 0xFFFFF): strictly       */
 /*             increasing in row, < 4^31; for k > 32 this is the HIGH limb and the low    */
