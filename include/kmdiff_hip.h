@@ -53,7 +53,7 @@ enum { KMD_CORR_NOTHING = 0, KMD_CORR_BONFERRONI = 1, KMD_CORR_BENJAMINI = 2,
  *                    counts prefer a multiple of 8192: 8-byte loads per lane, +16 %).
  *                    SoA inside a block, so lanes stay coalesced, but one block of rows is
  *                    one contiguous span of S*T counts: better DRAM page locality than S
- *                    far-apart columns (measured +3..10 % over plain SoA). */
+ *                    far-apart columns (measured +3..10 % over plain SoA, HISTORY.md 4 K1). */
 enum { KMD_LAYOUT_ROWS = 0, KMD_LAYOUT_SOA = 1, KMD_LAYOUT_TILED = 2 };
 
 const char* kmd_status_string(int status);
