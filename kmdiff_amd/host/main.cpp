@@ -19,8 +19,8 @@
 // --cmodel / --config load a user's IModel plugin the way plugin_manager does; its process() is
 // called row by row on the host (it is arbitrary host code), merge and correction stay on the GPU.
 //
-// Not carried over (out of scope): `count`/`infos` sub-commands, KFF output (-f is
-// accepted and FASTA is written), progress bars.
+// Not carried over (out of scope): `count`/`infos` sub-commands, progress bars; --covariates is parsed and
+// refused with the reason (the reference's load_C never terminates with a file, src/popstrat.cpp:207).
 #include <algorithm>
 #include <cinttypes>
 #include <cmath>
