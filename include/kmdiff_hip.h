@@ -125,7 +125,11 @@ int kmd_model_lf_table(const kmd_model* m, double* out, size_t n);
  * (include/kmdiff/accumulator.hpp:36-54) with SoA device arrays of `capacity` records.
  * Any array pointer may be NULL (field not recorded).  Survivors are appended in
  * unspecified order; `row` (row_base + row index in the tile) restores the reference's
- * ascending-k-mer order (kmd_survivors_sort_by_row). */
+ * ascending-k-mer order (kmd_survivors_sort_by_row).
+ * Sharing: a sink and its counters may be shared by calls on ONE stream (they accumulate), and by the partitions of one
+ * kmd_merge_filter_batch call (the library orders what must be ordered); calls in flight at the same time on DIFFERENT
+ * streams need sinks and counters of their own -- the pass over the rows within 1e-8 of the threshold may strike a
+ * record and then compacts the whole sink, which nothing else may be appending to meanwhile. */
 typedef struct {
   uint64_t* d_row;
   uint64_t* d_kmer_lo;      /* 2-bit packed k-mer, low 64 bits (k <= 32: the whole k-mer)  */
