@@ -277,11 +277,13 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
  *                    kmd_pack_block_bound() bytes); returns the bytes written, a multiple of 8 (0: bad arguments).
  *                    A stream is its blocks one after the other (all of KMD_PACK_BLOCK records but the last);
  *                    the caller notes where each begins: block_off8 = byte offset within the stream / 8.
- *   kmd_unpack_streams : d_packed = the streams' packed bytes, stream s at byte stream_base[s] (host array, multiples
- *                    of 8); d_block_off8 = the streams' block tables one after the other (stream s has
+ *   kmd_unpack_streams : d_packed = the streams' packed bytes, stream s at bytes [stream_base[s], stream_base[s + 1])
+ *                    (host array of n_samples + 1 multiples of 8); d_block_off8 = the streams' block tables one after the other (stream s has
  *                    ceil(records / KMD_PACK_BLOCK) entries); offsets[n_samples + 1] = the streams' record offsets
  *                    (host), as kmd_merge_filter takes them: d_kmers / d_counts get offsets[n_samples] records.
- *                    Asynchronous on `stream` (put it behind the copies of the packed bytes). */
+ *                    Asynchronous on `stream` (put it behind the copies of the packed bytes).  A block whose header does
+ *                    not describe exactly the bytes it has (damage in transit) comes out as zero records; nothing
+ *                    outside a block's bytes is read. */
 #define KMD_PACK_BLOCK 256
 size_t kmd_pack_block_bound(void);
 size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, uint32_t n, void* out);

@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan_u64(unsigned long l
 // block's bit-packed words (staged in LDS with coalesced loads), a wave-wide exclusive scan of the lanes' sums and
 // the anchor give the keys; the counts' escapes are numbered by a second scan.
 __global__ void __launch_bounds__(256) k_unpack(const unsigned char* __restrict__ packed, const uint32_t* __restrict__ block_off8,
-                                                const unsigned long long* __restrict__ stream_base,   // [S]: byte offset of stream s in `packed`
+                                                const unsigned long long* __restrict__ stream_base,   // [S + 1]: byte offset of stream s in `packed`; [S]: all bytes
                                                 const unsigned long long* __restrict__ rec_off,       // [S + 1]: records
                                                 const uint32_t* __restrict__ blk_prefix,              // [S + 1]: blocks
                                                 uint32_t S, uint32_t n_blocks, unsigned long long* __restrict__ kmers,
@@ -58,9 +58,27 @@ __global__ void __launch_bounds__(256) k_unpack(const unsigned char* __restrict_
   const uint32_t s = lo, b = g - blk_prefix[s];
   const unsigned long long n_s = rec_off[s + 1] - rec_off[s], first = (unsigned long long)b * kBlock;
   const uint32_t n = (uint32_t)(n_s - first < kBlock ? n_s - first : kBlock);
-  const unsigned char* blk = packed + stream_base[s] + (unsigned long long)block_off8[g] * 8ull;
+  const unsigned long long at = stream_base[s] + (unsigned long long)block_off8[g] * 8ull;
+  // where the block ends: the next block of the stream, or the stream's end
+  const unsigned long long end = g + 1 < blk_prefix[s + 1] ? stream_base[s] + (unsigned long long)block_off8[g + 1] * 8ull : stream_base[s + 1];
+  const unsigned long long out = rec_off[s] + first + 4ull * lane;
+  const unsigned char* blk = packed + at;
+  uint32_t w = 0, n_esc = 0;
+  bool sane = at + 16 <= end && end <= stream_base[S];
+  if (sane)
+  {
+    w = blk[8]; n_esc = *reinterpret_cast<const unsigned short*>(blk + 10);
+    // what kmd_pack_block wrote for this header, to the byte; anything else is damage: the block's records come out as
+    // zeros -- wrong, but nothing outside the block is read and nothing outside its records written
+    sane = w <= 64u && n_esc <= kBlock && at + ((16ull + (4ull * w + 1ull) * 8ull + kBlock + 4ull * n_esc + 7ull) & ~7ull) == end;
+  }
+  if (!sane)
+  {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (4u * lane + (uint32_t)j < n) { kmers[out + j] = 0ull; counts[out + j] = 0u; }
+    return;
+  }
   const unsigned long long anchor = *reinterpret_cast<const unsigned long long*>(blk);
-  const uint32_t w = blk[8], n_esc = *reinterpret_cast<const unsigned short*>(blk + 10);
   const unsigned long long* words = reinterpret_cast<const unsigned long long*>(blk + 16);
   const uint32_t n_words = 4u * w + 1u;
   unsigned long long* sw = s_words[wave];
@@ -90,7 +108,6 @@ __global__ void __launch_bounds__(256) k_unpack(const unsigned char* __restrict_
   uint32_t e_at = (uint32_t)wave_excl_scan_u64(my_esc, lane, esc_total);
 #pragma unroll
   for (int j = 0; j < 4; ++j) if (c[j] == kEscape) { c[j] = e_at < n_esc ? esc[e_at] : kEscape; ++e_at; }
-  const unsigned long long out = rec_off[s] + first + 4ull * lane;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (4u * lane + (uint32_t)j < n) { kmers[out + j] = before + d[j]; counts[out + j] = c[j]; }
@@ -220,7 +237,7 @@ extern "C" int kmd_unpack_streams(int n_samples, const void* d_packed, const uin
   for (size_t s = 0; s < S; ++s)
   {
     KMD_REQUIRE(offsets[s] <= offsets[s + 1], "kmd_unpack_streams: offsets must be ascending");
-    KMD_REQUIRE((stream_base[s] & 7) == 0, "kmd_unpack_streams: a stream's packed bytes must start on an 8-byte boundary");
+    KMD_REQUIRE((stream_base[s] & 7) == 0 && stream_base[s] <= stream_base[s + 1], "kmd_unpack_streams: stream_base must ascend in multiples of 8 bytes");
     const uint64_t nb = (offsets[s + 1] - offsets[s] + kBlock - 1) / kBlock;
     KMD_REQUIRE((uint64_t)blk[s] + nb < 0xFFFFFFFFull, "kmd_unpack_streams: too many blocks");
     blk[s + 1] = blk[s] + (uint32_t)nb;
@@ -229,21 +246,21 @@ extern "C" int kmd_unpack_streams(int n_samples, const void* d_packed, const uin
   if (n_blocks == 0) return KMD_OK;
   KMD_REQUIRE(d_packed && d_block_off8 && d_kmers && d_counts, "kmd_unpack_streams: NULL device buffers");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // [stream_base S | offsets S + 1 | blk_prefix S + 1 (u32)]: one upload
-  const size_t words = S + (S + 1) + (S + 2) / 2;
+  // [stream_base S + 1 | offsets S + 1 | blk_prefix S + 1 (u32)]: one upload
+  const size_t words = (S + 1) + (S + 1) + (S + 2) / 2;
   char *h = nullptr, *d = nullptr;
   hipEvent_t ev = nullptr;
   int rc = ring_slot(st, words * 8, &h, &d, &ev);
   if (rc != KMD_OK) return rc;
   uint64_t* up = reinterpret_cast<uint64_t*>(h);
-  std::memcpy(up, stream_base, S * 8);
-  std::memcpy(up + S, offsets, (S + 1) * 8);
-  std::memcpy(up + S + S + 1, blk.data(), (S + 1) * 4);
+  std::memcpy(up, stream_base, (S + 1) * 8);
+  std::memcpy(up + S + 1, offsets, (S + 1) * 8);
+  std::memcpy(up + 2 * (S + 1), blk.data(), (S + 1) * 4);
   KMD_HIP(hipMemcpyAsync(d, h, words * 8, hipMemcpyHostToDevice, st));
   KMD_HIP(hipEventRecord(ev, st));
   const unsigned long long* d_base = reinterpret_cast<const unsigned long long*>(d);
-  hipLaunchKernelGGL(k_unpack, dim3((n_blocks + 3) / 4), dim3(256), 0, st, static_cast<const unsigned char*>(d_packed), d_block_off8, d_base, d_base + S,
-                     reinterpret_cast<const uint32_t*>(d_base + S + S + 1), (uint32_t)S, n_blocks, reinterpret_cast<unsigned long long*>(d_kmers), d_counts);
+  hipLaunchKernelGGL(k_unpack, dim3((n_blocks + 3) / 4), dim3(256), 0, st, static_cast<const unsigned char*>(d_packed), d_block_off8, d_base, d_base + S + 1,
+                     reinterpret_cast<const uint32_t*>(d_base + 2 * (S + 1)), (uint32_t)S, n_blocks, reinterpret_cast<unsigned long long*>(d_kmers), d_counts);
   KMD_HIP(hipGetLastError());
   return KMD_OK;
 }

@@ -423,13 +423,13 @@ PACK_BLOCK = 256
 
 def pack_streams(streams):
     """The compact transfer format (kmd_pack_block, kmd_pack.hip) of a list of one-limb streams [(kmers, counts)]:
-    returns (packed bytes uint8[], stream_base uint64[S], block_off8 uint32[], offsets uint64[S + 1]).  Test / tool
+    returns (packed bytes uint8[], stream_base uint64[S + 1], block_off8 uint32[], offsets uint64[S + 1]).  Test / tool
     helper: the blocks are packed one by one through the C-ABI (the CLI packs while it decodes the files)."""
     L = lib()
     bound = int(L.kmd_pack_block_bound())
     S = len(streams)
     offs = np.zeros(S + 1, dtype=np.uint64)
-    chunks, base, tables, at = [], np.zeros(S, dtype=np.uint64), [], 0
+    chunks, base, tables, at = [], np.zeros(S + 1, dtype=np.uint64), [], 0
     buf = np.zeros(bound, dtype=np.uint8)
     for s, (km, ct) in enumerate(streams):
         km = np.ascontiguousarray(km, dtype=np.uint64)
@@ -445,13 +445,14 @@ def pack_streams(streams):
             chunks.append(buf[:got].copy())
             within += got
         at += within
+        base[s + 1] = at
     packed = np.concatenate(chunks) if chunks else np.zeros(8, dtype=np.uint8)
     return packed, base, np.asarray(tables, dtype=np.uint32), offs
 
 
 def unpack_streams(packed, stream_base, block_off8, offs, stream=None):
     """kmd_unpack_streams: the packed bytes go to the device and come back as a StreamSet (the arrays kmd_merge_filter reads)."""
-    S = len(stream_base)
+    S = len(stream_base) - 1
     ss = StreamSet.__new__(StreamSet)
     ss.n_samples, ss.two, ss.offs = S, False, np.ascontiguousarray(offs, dtype=np.uint64)
     ss.total = int(ss.offs[-1])

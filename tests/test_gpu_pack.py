@@ -71,7 +71,7 @@ def test_unpacked_partition_through_the_fused_merge(K, oracle):
 def test_bad_arguments(K):
     lib = K._native.lib()
     buf = K.DeviceBuffer(64)
-    base = np.array([4], dtype=np.uint64)                                            # not a multiple of 8
+    base = np.array([4, 16], dtype=np.uint64)                                        # not a multiple of 8
     offs = np.array([0, 10], dtype=np.uint64)
     assert lib.kmd_unpack_streams(1, buf.ptr, base.ctypes.data, buf.ptr, offs.ctypes.data, buf.ptr, buf.ptr, None) == -1
     base[0] = 0
@@ -79,3 +79,30 @@ def test_bad_arguments(K):
     assert lib.kmd_unpack_streams(1, buf.ptr, base.ctypes.data, buf.ptr, offs.ctypes.data, buf.ptr, buf.ptr, None) == -1
     offs[:] = [0, 10]
     assert lib.kmd_unpack_streams(1, None, base.ctypes.data, buf.ptr, offs.ctypes.data, buf.ptr, buf.ptr, None) == -1
+
+
+def test_damaged_block_headers_stay_inside_the_block(K):
+    """A delta width beyond 64 or an escape count beyond the block cannot come from kmd_pack_block; the device decoder
+    sees that the header does not describe the block's bytes and writes zero records for it -- no access outside the
+    block (the call returns, the block's neighbours and the other stream are untouched)."""
+    rng = np.random.default_rng(4)
+    a = (np.cumsum(rng.integers(1, 1 << 20, 600, dtype=np.uint64), dtype=np.uint64), rng.integers(1, 300, 600).astype(np.uint32))
+    b = (np.cumsum(rng.integers(1, 1 << 30, 300, dtype=np.uint64), dtype=np.uint64), rng.integers(1, 9, 300).astype(np.uint32))
+    packed, base, table, offs = K.pack_streams([a, b])
+    bad = packed.copy()
+    bad[8] = 200                                           # width byte of stream 0's first block
+    bad[10] = 0xFF; bad[11] = 0xFF                         # ... and its escape count
+    ss = K.unpack_streams(bad, base, table, offs)
+    km, ct = ss.kmers.to_host(np.uint64, ss.total), ss.counts.to_host(np.uint32, ss.total)
+    assert np.array_equal(km[600:], b[0]) and np.array_equal(ct[600:], b[1])          # the other stream as it was
+    assert np.array_equal(km[256:600], a[0][256:]) and np.array_equal(ct[256:600], a[1][256:])   # and stream 0's other blocks
+    assert not km[:256].any() and not ct[:256].any()                                               # the damaged one: zeros
+    # one damaged byte at a time, in every header field and in the block table's view of the lengths
+    for pos, val in ((8, 65), (8, 63), (10, 1), (11, 1)):
+        bad = packed.copy()
+        if bad[pos] == val:
+            continue
+        bad[pos] = val
+        ss = K.unpack_streams(bad, base, table, offs)
+        km = ss.kmers.to_host(np.uint64, ss.total)
+        assert np.array_equal(km[256:], np.concatenate([a[0][256:], b[0]])) and not km[:256].any(), (pos, val)
