@@ -122,6 +122,18 @@ def test_fused_merge_on_a_config4_partition(K, oracle):
     replay_windows(K, oracle, part, rows, nc, nk, 2, tot, got_rows, np.concatenate([[0, rows - 2048], rng.integers(0, rows - 2048, 6)]))
 
 
+@pytest.mark.parametrize("nc,nk,rows,part", [(4, 4, 100_000_000, 0), (100, 100, 8_000_000, 1)])
+def test_fused_merge_on_config2_and_config5_partitions(K, oracle, nc, nk, rows, part):
+    """configs[1] (10^8 rows of 4v4: 5 x 10^8 records) and configs[4]'s shape (100v100, 8 M rows: 1.05 x 10^9 records)
+    through the fused merge: K1's survivors bit for bit, oracle replay of row windows."""
+    ss, tot, model, got, c = run_both(K, part, rows, nc, nk, 1)
+    assert ss.total > 400_000_000 and int(c[0]) == rows and int(c[1]) > 500
+    got_rows = dict(got)
+    got_rows["row"] = row_of_kmer(got, 1)
+    rng = np.random.default_rng(nc)
+    replay_windows(K, oracle, part, rows, nc, nk, 1, tot, got_rows, np.concatenate([[0, rows - 2048], rng.integers(0, rows - 2048, 4)]))
+
+
 def test_runs_of_more_than_2_to_the_28_records(K, oracle):
     """Two samples v two, each with more than 2^28 records in the partition (the kernel's positions and run extents are
     32-bit: the limit is 2^29 - 1 per sample): same survivors as K1 on the matrix, every row counted."""
