@@ -35,6 +35,25 @@ assert int(D.all_gather(n)[0].item()) == 1000
 # the Gram matrix of the PCA
 g = np.random.default_rng(0).random((40, 40))
 assert (D.all_gather(torch.from_numpy(g).to(dev))[0].cpu().numpy() == g).all()
+# the wire of kmd_correct_sharded (round 4): dist.torch_transport's two collectives, called the way the library calls them
+# -- on ITS device buffers, handed to RCCL as zero-copy views
+import kmdiff_amd as K  # noqa: E402
+tr, alive = D.torch_transport(K)
+assert (tr.rank, tr.world) == (0, 1)
+a = K.DeviceBuffer.from_host(np.arange(4096, dtype=np.uint64))
+assert tr.allreduce_u64(tr.ctx, a.ptr, 4096, None) == 0
+assert a.to_host(np.uint64, 4096).tolist() == list(range(4096))
+b = K.DeviceBuffer(4096 * 8)
+assert tr.allgather(tr.ctx, a.ptr, b.ptr, 4096 * 8, None) == 0
+assert b.to_host(np.uint64, 4096).tolist() == list(range(4096))
+assert tr.allgather(tr.ctx, a.ptr, b.ptr, 0, None) == 0
+# ... and kmd_correct_sharded over it (one rank: the local walk, the counters back as they went)
+pv = np.sort(np.random.default_rng(1).uniform(0, 1e-6, 500)) ** 2
+sg = np.zeros(500, dtype=np.int32)
+dp, ds = K.DeviceBuffer.from_host(pv), K.DeviceBuffer.from_host(sg)
+keep, gc, (n_ctrl, n_case) = D.correct_sharded(K, "holm", 0.05, np.array([10 ** 8, 500, 500, 0], dtype=np.uint64), dp, ds, 500, transport=tr)
+want, _, _ = K.aggregate("holm", 0.05, 10 ** 8, dp, ds, 500)
+assert keep.tolist() == want.tolist() and int(gc[0]) == 10 ** 8 and n_ctrl == int(want.sum()) and n_case == 0
 dist.barrier()
 dist.destroy_process_group()
 print("nccl probe ok")
