@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LDS bank-conflict model of the K2t table accesses (no GPU): cycles per wave instruction from the lane groups and
 bank mapping of /opt/skills/guides/MI355X_MICROARCH.md (LDS section), for random slots (a hashed table) and for
-ascending slots with the gaps a half-loaded ordered table has.  DESIGN.md, K2t: why the ordered table was not built."""
+ascending slots with the gaps a half-loaded ordered table has.  HISTORY.md, K2t: why the ordered table was not built."""
 import numpy as np
 rng = np.random.default_rng(1)
 G128 = [ [0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27], [4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31],
