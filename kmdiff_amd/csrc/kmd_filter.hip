@@ -886,12 +886,16 @@ __global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_pa
   if (blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd(&P.counters[KMD_CNT_TOTAL], (unsigned long long)P.n_rows);
 
-  // Two spans per wave in flight, in two sets of registers (round 4).  With one, a wave had 2.7 KB under way at 21v21
-  // -- 43 KB per CU against a loaded HBM latency of ~2.3 us: 18.5 GB/s per CU, 4.7 TB/s, exactly what was measured;
-  // the kernel's ~110 instructions per span idle between the waits.  The tile in LDS stays single: a span's registers
-  // are written to it, the set is refilled at once (the load of span t + 2 n_waves), then the tile is added up.
+  // Round 4.  This kernel ran at 4.7 TB/s on 21v21 with its waves waiting 70 % of their cycles (tools/pmc_k1.sh).  What
+  // it was waiting for: every load sat under a condition (lanes past the span, spans past the buffer), so hipcc could not
+  // count the loads in flight where the paths meet and settled for vmcnt(0) -- and skipped around the loads with branches.
+  // Now EVERY lane loads EVERY time (a lane past the span or the buffer re-reads the last vector inside both: the same
+  // cache line as its neighbours'): 21v21 4.74 -> 6.09 TB/s, 3v3 4.8 -> 6.8, u8 20v20 4.1 -> 5.3, 60v61 4.6 -> 5.7
+  // (profiles/r04_ab_k1r.txt).  KMD_FLAT_DEPTH register sets hold that many spans per wave in flight: a second set
+  // measured 3-6 % SLOWER than one (5.75 / 6.65 / 5.11 / 5.58: the registers cost more than the deeper queue gives; with
+  // conditional loads it had bought nothing at all), a third spills (4.4 TB/s).  One set, as before.
 #ifndef KMD_FLAT_DEPTH
-#define KMD_FLAT_DEPTH 2
+#define KMD_FLAT_DEPTH 1
 #endif
   constexpr int kDepth = KMD_FLAT_DEPTH;
   n4 bufs[kDepth][kFlatVecs];
