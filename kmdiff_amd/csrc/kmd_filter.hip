@@ -736,14 +736,22 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
     const uint32_t cv = (row_vecs - c0) < cvb ? (row_vecs - c0) : cvb;
     const uint32_t q = 64u / cv, rem = 64u % cv;        // (row, c) of vector v+64 from those of v
     uint32_t r = lane / cv, c = lane - r * cv;
+    // The passes of 16 vectors (rows of 11 .. 15 vectors: 24v24 four-byte counts) issue every load every time -- a k past
+    // the chunk's vectors re-reads the block's last vector, the same cache line as its neighbours' --: a load under a
+    // condition makes the number in flight unknown to hipcc where the paths meet, and it waits for all of them and
+    // branches around the loads (round 4, found on k_filter_rows_flat: +28 % there; here 24v24 5.18 -> 5.56 TB/s).  The
+    // narrower instantiations, whose rows fill their passes exactly, keep the conditions: unconditional they measured
+    // 20v20 6.05 -> 5.75, 4v4 6.06 -> 5.97 (the selects cost, nothing was being skipped).
+    constexpr bool kUncond = kRowsCV >= 16;
 #pragma unroll
     for (int k = 0; k < kRowsCV; ++k)
     {
-      if ((uint32_t)k < cv)                             // wave-uniform
+      const bool in = (uint32_t)k < cv;                 // wave-uniform
+      if (kUncond || in)
       {
-        size_t row = row0 + r;
+        size_t row = row0 + ((!kUncond || in) ? r : 63u);
         if (row >= P.n_rows) row = P.n_rows - 1;
-        buf[k] = __builtin_nontemporal_load(base + row * ld_vecs + c0 + c);
+        buf[k] = __builtin_nontemporal_load(base + row * ld_vecs + c0 + ((!kUncond || in) ? c : cv - 1u));
         r += q; c += rem;
         if (c >= cv) { c -= cv; ++r; }
       }
@@ -776,9 +784,17 @@ __global__ void __launch_bounds__(kRowsWaveBlock) k_filter_rows_wave(const filte
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // next block of loads in flight while this one is added up
-      if (ch + 1 < n_chunks) issue(row0, ch + 1);
-      else if (t + n_waves < n_tiles) issue((t + n_waves) * 64, 0);
+      // next block of loads in flight while this one is added up (the wave's last block: itself once more, unused)
+      if constexpr (kRowsCV >= 16)
+      {
+        const bool more_chunks = ch + 1 < n_chunks, more_tiles = t + n_waves < n_tiles;
+        issue(more_chunks ? row0 : more_tiles ? (t + n_waves) * 64 : row0, more_chunks ? ch + 1 : 0u);
+      }
+      else
+      {
+        if (ch + 1 < n_chunks) issue(row0, ch + 1);
+        else if (t + n_waves < n_tiles) issue((t + n_waves) * 64, 0);
+      }
       const n4* __restrict__ mine = tile + lane * pitch;
       for (uint32_t c = 0; c < cv; ++c)
       {
@@ -1010,6 +1026,7 @@ __global__ void __launch_bounds__(kFlatBlock) k_filter_rows_flat(const filter_pa
 #ifndef KMD_WIDE_U
 #define KMD_WIDE_U 2
 #endif
+
 constexpr int kWideBlock = KMD_WIDE_BLOCK;
 constexpr int kWideU = KMD_WIDE_U;            // steps (of 4 rows) whose loads are issued together
 constexpr int kWideP = 4;                     // passes (of 16 vectors) of a row per chunk
@@ -1067,6 +1084,9 @@ __global__ void __launch_bounds__(kWideBlock) k_filter_rows_wide(const filter_pa
           for (int p = 0; p < kWideP; ++p)
           {
             const uint32_t c = (p0 + p) * G + q;
+            // (these loads stay under their condition: issued for every lane -- a lane past the row's vectors re-reading
+            // its last one -- the kernel lost 8-25 %: 50v50 5.26 -> 4.46 TB/s, 34v34 5.39 -> 4.06, 100v100 6.35 -> 5.8;
+            // round 4, the opposite of what the same change did for k_filter_rows_flat)
             buf[u][p] = n4{ 0, 0, 0, 0 };
             if (c < row_vecs) buf[u][p] = __builtin_nontemporal_load(rp + c);
           }
