@@ -69,6 +69,47 @@ int main(int argc, char** argv)
       bool same = n2 == f.records;
       for (size_t i = 0; same && i < n2; ++i)
         same = km[i] == km2[i] && ct[i] == ct2[i] && (f.slots == 1 || kh[i] == kh2[i]);
+      {
+        // the two other ways a caller can take the records (the CLI's packed transfer uses `raw`): chunk by chunk through
+        // `consume` (arrays sized for a chunk, whole groups of 7 records taken, the rest carried), and as they are in the
+        // file through `raw` -- both must deliver the file's records, in order, once
+        std::vector<uint64_t> ck, ckh, got_k, got_kh; std::vector<uint32_t> cc, got_c;
+        kmd_host::record_sink s2;
+        s2.reserve = [&](kmd_host::record_sink& k, size_t n)
+        {
+          ck.resize(n); cc.resize(n); if (k.slots == 2) ckh.resize(n);
+          k.kmers = ck.data(); k.counts = cc.data(); k.kmers_hi = k.slots == 2 ? ckh.data() : nullptr; k.capacity = n;
+        };
+        s2.consume = [&](kmd_host::record_sink& k, size_t held, bool last) -> size_t
+        {
+          const size_t take = last ? held : held / 7 * 7;
+          got_k.insert(got_k.end(), k.kmers, k.kmers + take); got_c.insert(got_c.end(), k.counts, k.counts + take);
+          if (k.kmers_hi) got_kh.insert(got_kh.end(), k.kmers_hi, k.kmers_hi + take);
+          return take;
+        };
+        const kmd_host::kmer_file_info f2 = kmd_host::stream_kmer_file(in, 0, s2);
+        same = same && f2.records == n2 && got_k.size() == n2 && got_c.size() == n2;
+        for (size_t i = 0; same && i < n2; ++i) same = got_k[i] == km2[i] && got_c[i] == ct2[i] && (f.slots == 1 || got_kh[i] == kh2[i]);
+        if (f.slots == 1)
+        {
+          std::vector<uint64_t> rk; std::vector<uint32_t> rc; size_t calls_after_end = 0; bool ended = false;
+          kmd_host::record_sink s3;
+          s3.raw = [&](const char* p, size_t n, uint32_t cb)
+          {
+            if (!p) { ended = true; return; }
+            if (ended) ++calls_after_end;
+            for (size_t i = 0; i < n; ++i)
+            {
+              uint64_t k; uint32_t c = 0;
+              std::memcpy(&k, p + i * (8 + cb), 8); std::memcpy(&c, p + i * (8 + cb) + 8, cb);
+              rk.push_back(k); rc.push_back(c);
+            }
+          };
+          const kmd_host::kmer_file_info f3 = kmd_host::stream_kmer_file(in, 0, s3);
+          same = same && ended && !calls_after_end && f3.records == n2 && rk.size() == n2;
+          for (size_t i = 0; same && i < n2; ++i) same = rk[i] == km2[i] && rc[i] == ct2[i];
+        }
+      }
       std::printf("records=%zu slots=%u count_bytes=%u same=%d\n", f.records, f.slots, f.count_bytes, (int)same);
       std::FILE* o = std::fopen(out.c_str(), "wb");
       if (!o) return 1;
