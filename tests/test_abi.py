@@ -96,3 +96,14 @@ def test_rccl_transport_library_exports_its_header():
     assert "rccl" not in needed
     needed = subprocess.run(["readelf", "-d", N.RCCL_LIB_PATH], capture_output=True, text=True).stdout
     assert "librccl" in needed
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: the three headers compile as C99 (no C++ in the signatures, no torch types)."""
+    import subprocess
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "kmdiff_hip.h"\n#include "kmdiff_hip_rccl.h"\n#include "kmdiff_hip_test.h"\n'
+                   'int main(void) { kmd_transport t; kmd_survivors s; kmd_tile x; (void)t; (void)s; (void)x; return KMD_PACK_BLOCK == 256 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
