@@ -181,6 +181,20 @@ int kmd_survivors_sort_by_row(const kmd_survivors* s, size_t n, void* stream);
  * (d_kmer_hi, d_kmer_lo) -- the order the merge emits rows in.  Synchronous. */
 int kmd_survivors_sort_by_kmer(const kmd_survivors* s, size_t n, void* stream);
 
+/* p-values to the reference's last bit.  The filters take the two null-hypothesis logarithms of
+ * PoissonLikelihood::process (model.hpp:155-156) and the exp / log inside igamc from the device's libm; where its last
+ * bit differs from glibc's, `k * log(lambda)` (model.hpp:137) multiplies the difference by the count sum: the p-value
+ * of a record then deviates from a glibc-built reference's by ~1e-16 x sum in LR (1e-10 absolute on p is reached at
+ * sums of ~10^4 when p is of order 1).  This pass recomputes the first n p-values from the records' own means
+ * (d_mean_case is the case sum; d_mean_control = sum_c Tk / Tc is inverted exactly) with correctly rounded log / exp:
+ * they then carry the bits glibc >= 2.28 gives the reference wherever glibc itself returned the rounded value (all but
+ * ~1 call in 10^3, where one ulp of a logarithm remains).  Records with a sum >= log_factorial_size keep their value
+ * (the reference's table term there is a k-term running sum, log_factorial_table.cpp:13-22; the device's is
+ * Stirling's series).  The DECISIONS need no such pass: rows within 1e-8 of the threshold are resolved inside every
+ * filter call.  Works on any three arrays of that meaning (a sink's, or kmd_poisson_process's outputs).  Asynchronous. */
+int kmd_pvalues_refine(const kmd_model* m, size_t n, const double* d_mean_control, const double* d_mean_case,
+                       double* d_pvalue, void* stream);
+
 /* Gather the count vectors of survivors as doubles, KmerSign::m_counts_ratio
  * (merge.hpp:91-92): d_out[i*S + s] = (double) counts[row_i - row_base][s]. */
 int kmd_survivors_gather_counts(const kmd_tile* tile, int n_samples, const uint64_t* d_rows,

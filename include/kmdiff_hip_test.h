@@ -12,6 +12,10 @@ double kmd_test_log_rounded(double x);
 double kmd_test_exp_rounded(double x);
 double kmd_test_igamc_half_rounded(double x);
 double kmd_test_row_pvalue_rounded(const kmd_model* m, uint64_t sum_control, uint64_t sum_case);
+/* the reference's log-factorial running sum (log_factorial_table.cpp:13-22) of each d_k[i] < 2^20 as the device repeats
+ * it: term by term (d_plain, may be NULL) and through the table of logarithms + the binade-wise exact integer sums of
+ * kmd_pvalues_refine (d_fast).  Device pointers; asynchronous on `stream`. */
+int kmd_test_running_sums(const uint64_t* d_k, size_t n, double* d_plain, double* d_fast, void* stream);
 #ifdef __cplusplus
 }
 #endif

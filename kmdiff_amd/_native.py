@@ -55,6 +55,7 @@ TEST_SIGNATURES = {
     "kmd_test_exp_rounded": (_d, [_d]),
     "kmd_test_igamc_half_rounded": (_d, [_d]),
     "kmd_test_row_pvalue_rounded": (_d, [_vp, _u64, _u64]),
+    "kmd_test_running_sums": (_i, [_vp, _sz, _vp, _vp, _vp]),
 }
 
 SIGNATURES = {
@@ -108,6 +109,7 @@ SIGNATURES = {
     "kmd_merge_filter_batch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, C.POINTER(Survivors), _vp, C.POINTER(_u64), _vp]),
     "kmd_survivors_gather_counts_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "kmd_survivors_sort_by_kmer": (_i, [C.POINTER(Survivors), _sz, _vp]),
+    "kmd_pvalues_refine": (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "kmd_poisson_filter_sums": (_i, [_vp, _vp, _vp, _vp, _sz, _d, C.POINTER(Survivors), _vp, _vp]),
     "kmd_popstrat_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i]),
     "kmd_popstrat_destroy": (_i, [_vp]),

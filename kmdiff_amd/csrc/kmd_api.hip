@@ -165,13 +165,20 @@ int kmd_abi_version(void) { return KMD_ABI_VERSION; }
 double kmd_test_log_rounded(double x) { return kmd::libm_rounded::log(x); }
 double kmd_test_exp_rounded(double x) { return kmd::libm_rounded::exp(x); }
 double kmd_test_igamc_half_rounded(double x) { return kmd::igamc_half<kmd::libm_rounded>(x, kmd::lngamma_half_host()); }
-// the p-value of a row with these two count sums the way the device decides a near-threshold row: table terms
-// as the model holds them, the four libm calls correctly rounded (sums inside the table only)
+// the p-value of a row with these two count sums the way the device decides a near-threshold row (and kmd_pvalues_refine
+// rewrites a survivor's): table terms as the model holds them -- beyond the table the reference's running sum
+// (log_factorial_table.cpp:13-22), for sums below 2^20 -- and the four libm calls correctly rounded.  -1: not such a row
 double kmd_test_row_pvalue_rounded(const kmd_model* m, uint64_t sum_c, uint64_t sum_k)
 {
-  if (!m || sum_c >= m->lf_n || sum_k >= m->lf_n) return -1.0;
-  const double lc = sum_c ? ::log((double)sum_c) : 0.0, lk = sum_k ? ::log((double)sum_k) : 0.0;   // the table's second column
-  const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, m->h_lf[sum_c], m->h_lf[sum_k], lc, lk, m->dT, m->dTc, m->dTk);
+  if (!m || ((sum_c >= m->lf_n || sum_k >= m->lf_n) && (sum_c >= (1ull << 20) || sum_k >= (1ull << 20)))) return -1.0;
+  auto lf_of = [&](uint64_t k) {
+    if (k < m->lf_n) return m->h_lf[k];
+    double res = 0;
+    for (; k > 1; --k) res += kmd::libm_rounded::log((double)k);
+    return res;
+  };
+  auto log_of = [&](uint64_t k) { return k < m->lf_n ? (k ? ::log((double)k) : 0.0) : kmd::libm_rounded::log((double)k); };   // the table's second column
+  const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, lf_of(sum_c), lf_of(sum_k), log_of(sum_c), log_of(sum_k), m->dT, m->dTc, m->dTk);
   return kmd::igamc_half<kmd::libm_rounded>(lr, m->lg_half);
 }
 
@@ -352,6 +359,14 @@ int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
     if (m->d_tab) (void)hipFree(m->d_tab);
     std::free(m->h_lf); delete m;
     return kmd::hip_fail(e, "upload log-factorial table", __FILE__, __LINE__);
+  }
+  m->d_log_int = nullptr;
+  const int rc_log = kmd::log_int_table(&m->d_log_int);      // (the running sums beyond the table: near-threshold rows, kmd_pvalues_refine)
+  if (rc_log != KMD_OK)
+  {
+    (void)hipFree(m->d_lf); (void)hipFree(m->d_tab);
+    std::free(m->h_lf); delete m;
+    return rc_log;
   }
   *out = m;
   return KMD_OK;

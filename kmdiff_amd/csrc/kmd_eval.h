@@ -24,6 +24,7 @@ struct filter_params
   double pf_cut;            // chi-square pre-filter cut on the likelihood ratio (or -inf: off)
   const double* lf;         // lf[k]                        (k_process_all)
   const double2* tab;       // { lf[k], log(double(k)) }    (filter kernels; head staged in LDS)
+  const double* log_int;    // correctly rounded log(j), j < kChainMax (k_resolve_near: the running sum beyond the table)
   uint32_t lf_n;
   uint32_t lds_n;           // table entries held in LDS
   kmd_survivors out;
@@ -32,6 +33,9 @@ struct filter_params
 };
 
 constexpr unsigned long long kNearCap = 4096;
+// sums up to which the reference's log-factorial running sum (log_factorial_table.cpp:13-22) is repeated term for term
+// where its bits matter (rows near the threshold, kmd_pvalues_refine): 2^20 terms = 16 K steps of one wave, ~4 ms
+constexpr unsigned long long kChainMax = 1ull << 20;
 
 // LogFactorialTable::operator[] for k >= table size (log_factorial_table.hpp:14-18 falls back
 // to the O(k) loop log(k) + log(k-1) + ... + log(2), src/log_factorial_table.cpp:13-22).
@@ -130,9 +134,10 @@ __device__ __forceinline__ row_result evaluate_core(const filter_params& P, cons
     // caller, note_near_rows); k_resolve_near, a one-wave kernel behind every filter launch, repeats its
     // four libm calls with correctly rounded log / exp (kmd_ddmath.h) and corrects the sink if the
     // decision changes.  (Inlined here, that arithmetic cost every kernel that evaluates rows registers:
-    // K1 spilled and lost 4 % at 20v20, 24 % at 4v4.)  Sums beyond the log-factorial table are left
-    // alone: their table term is Stirling's, not the reference's running sum -- no bit pattern to match
-    R.near = fabs(R.p - P.threshold) <= 1e-8 * P.threshold && !(big_c | big_k);
+    // K1 spilled and lost 4 % at 20v20, 24 % at 4v4.)  Sums beyond the log-factorial table: the table term
+    // used above is Stirling's, the reference's a k-term running sum; k_resolve_near repeats that sum for
+    // sums below kChainMax, larger ones are left alone (no bit pattern to match at a bearable cost)
+    R.near = fabs(R.p - P.threshold) <= 1e-8 * P.threshold && (!(big_c | big_k) || (st.sum_c < kChainMax && st.sum_k < kChainMax));
     R.surv = (R.p <= P.threshold);                          // merge.hpp:78
     kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, R.mean_control, R.sign);
   }

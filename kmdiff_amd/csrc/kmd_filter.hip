@@ -1283,7 +1283,7 @@ int kmd::fill_filter_params(filter_params& P, const kmd_model* m, const kmd_tile
     P.pf_cut = on ? 0.5 * P.lr_cut : -INFINITY;
     if (const char* e = std::getenv("KMD_PREFILTER")) if (e[0] == '0') P.pf_cut = -INFINITY;
   }
-  P.lf = m->d_lf; P.tab = reinterpret_cast<const double2*>(m->d_tab); P.lf_n = (uint32_t)m->lf_n;
+  P.lf = m->d_lf; P.tab = reinterpret_cast<const double2*>(m->d_tab); P.log_int = m->d_log_int; P.lf_n = (uint32_t)m->lf_n;
   P.lds_n = 0;
   P.counters = nullptr;
   P.out = kmd_survivors{};
@@ -1580,6 +1580,107 @@ extern "C" int kmd_poisson_filter_sums(const kmd_model* m, const uint64_t* d_kme
   return kmd::near_list_end(P, 0, st);
 }
 
+// LogFactorialTable::log_factorial (log_factorial_table.cpp:13-22), the reference's value for a sum beyond its table:
+// res += log(k), k-- down to 2.  By one wave for one k: 64 lanes take 64 correctly rounded logarithms, then the 64
+// additions happen in the reference's order.
+__device__ __forceinline__ double lf_running_sum_wave(uint64_t k, int lane)        // all 64 lanes, same k
+{
+  double res = 0;
+  for (uint64_t j0 = k; j0 > 1; j0 = j0 > 64 ? j0 - 64 : 0)
+  {
+    const uint64_t j = j0 > (uint64_t)lane ? j0 - (uint64_t)lane : 0;
+    const double l = j > 1 ? kmd::libm_rounded::log((double)j) : 0.0;                // (res + 0.0 == res: the lanes past k = 2)
+#pragma unroll
+    for (int t = 0; t < 64; ++t) res += __shfl(l, t, 64);
+  }
+  return res;
+}
+
+// The running sum again, fast enough for a sink full of such records (bench C3: 5 417 survivors with sums of ~1.3e5 each --
+// 1.4e9 terms; with a correctly rounded logarithm per term and 64 dependent additions per step that was 5.3 ms, twice the
+// partition's merge + test).  Two things make it cheap without changing a bit of the result:
+//  * the logarithms come from a table (log_int[j] = correctly rounded log(j), j < kChainMax: 8 MB per device, built once);
+//  * while the sum stays inside one binade [2^E, 2^(E+1)) every partial sum is a multiple of u = 2^(E-52), and
+//    fl(r + l) = r + u RN(l / u) whenever l / u is not exactly half-way between two integers (then the tie goes to the even
+//    r + ..., which depends on r): the 64 roundings are independent, their integer sum is exact, and one step of 64 terms
+//    is a load, a rounding and a wave reduction.  Steps that may cross a binade or hold a tie take the 64 additions in order.
+__device__ __forceinline__ double lf_running_sum_table(const double* __restrict__ log_int, uint64_t k, int lane)       // all 64 lanes, same k < kChainMax
+{
+  // the 64 terms of the step that starts at g: lane t holds log(g - t) (0.0 past the last term, k = 2: res + 0.0 == res)
+  auto terms = [&](uint64_t g, int step) {
+    const uint64_t off = (uint64_t)(64 * step + lane);
+    const uint64_t j = g > off ? g - off : 0;
+    return j > 1 ? log_int[j] : 0.0;
+  };
+  auto wave_sum = [](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };   // (of integers below 2^53: exact)
+  constexpr double kTwo53 = 9007199254740992.0;
+  double res = 0;
+  uint64_t g0 = k;                                              // first term not yet added
+  while (g0 > 1)
+  {
+    double u = 0, inv_u = 0, R = 0;
+    if (res >= 32.0)                                            // u >= 2^-47 > ulp(l) / 2: the scaled terms stay below 2^52
+    {
+      const int E = (int)((unsigned long long)__double_as_longlong(res) >> 52) - 1023;
+      u = __longlong_as_double((long long)(E - 52 + 1023) << 52);                        // 2^(E-52)
+      inv_u = __longlong_as_double((long long)(52 - E + 1023) << 52);
+      R = res * inv_u;                                          // res / u: an integer in [2^52, 2^53), exactly
+      // steps that cannot leave the binade: every remaining term is at most log(g0), so n_safe steps add less than
+      // 2^53 - R grid units whatever they hold.  Their roundings are summed per lane (integers as doubles: every partial sum
+      // is below 2^53, so the additions are exact), the next steps' loads in flight, and reduced across the wave once
+      const double q_max = ::ceil(log_int[g0] * inv_u) + 1.0;
+      const unsigned long long n_safe = (unsigned long long)((kTwo53 - R) / (64.0 * q_max));        // (rounded down twice)
+      unsigned long long done = 0;
+      double Q = 0;
+      constexpr int kG = 4;                                     // steps per group; the next group's loads are issued before this one is looked at
+      double nx[kG];
+#pragma unroll
+      for (int a = 0; a < kG; ++a) nx[a] = terms(g0, a);
+      while (n_safe - done >= kG && g0 > 1)
+      {
+        double x[kG], q[kG];
+        bool tie = false;
+#pragma unroll
+        for (int a = 0; a < kG; ++a) x[a] = nx[a] * inv_u;                                // exact (a power of two)
+        const uint64_t g1 = g0 > 64 * kG ? g0 - 64 * kG : 0;
+#pragma unroll
+        for (int a = 0; a < kG; ++a) nx[a] = terms(g1, a);
+#pragma unroll
+        for (int a = 0; a < kG; ++a) { q[a] = ::rint(x[a]); tie |= ::fabs(x[a] - q[a]) == 0.5; }
+        if (__ballot(tie)) break;                               // a tie rounds to the even SUM: that step goes the ordered way below
+        Q += (q[0] + q[1]) + (q[2] + q[3]);
+        static_assert(kG == 4, "the sum above");
+        done += kG;
+        g0 = g1;
+      }
+      if (done)
+      {
+        res = (R + wave_sum(Q)) * u;
+        continue;
+      }
+    }
+    // one step on its own: rounded independently if it has no tie and stays in the binade, else the 64 additions in order
+    const double l = terms(g0, 0);
+    bool fast = false;
+    if (res >= 32.0)
+    {
+      const double x = l * inv_u;
+      const double q = ::rint(x);
+      const bool tie = ::fabs(x - q) == 0.5;
+      const double Q = wave_sum(q);                             // (64 terms below 2^52 / 64 each: exact)
+      fast = !__ballot(tie) && R + Q < kTwo53;
+      if (fast) res = (R + Q) * u;
+    }
+    if (!fast)
+    {
+#pragma unroll
+      for (int t = 0; t < 64; ++t) res += __shfl(l, t, 64);
+    }
+    g0 = g0 > 64 ? g0 - 64 : 0;
+  }
+  return res;
+}
+
 // ---- the rows within 1e-8 of the threshold (kmd_eval.h: evaluate_core flags them, note_near_row lists them).
 // One wave behind every filter launch: the listed rows are re-evaluated with correctly rounded log / exp
 // (kmd_ddmath.h), and where that decision differs from the one the filter made with the device's libm the
@@ -1605,9 +1706,24 @@ __global__ void __launch_bounds__(64) k_resolve_near(const filter_params P, cons
     bool now = false;
     double p = 1.0, mean_control = 0.0;
     int sign = KMD_SIGN_NO;
+    // table terms: the model's, or -- for a sum beyond the table (below kChainMax: evaluate_core flags no others) -- the
+    // reference's running sum, one row at a time by the whole wave
+    double2 tc = make_double2(0.0, 0.0), tk = make_double2(0.0, 0.0);
+    if (have && sum_c < P.lf_n) tc = P.tab[sum_c];
+    if (have && sum_k < P.lf_n) tk = P.tab[sum_k];
+    unsigned long long chain = __ballot(have && (sum_c >= P.lf_n || sum_k >= P.lf_n));
+    while (chain)
+    {
+      const int src = __ffsll((long long)chain) - 1;
+      chain &= chain - 1;
+      const uint64_t c = (uint64_t)__shfl((unsigned long long)sum_c, src, 64), k = (uint64_t)__shfl((unsigned long long)sum_k, src, 64);
+      double2 xc = make_double2(0.0, 0.0), xk = make_double2(0.0, 0.0);
+      if (c >= P.lf_n) { xc.x = lf_running_sum_table(P.log_int, c, lane); xc.y = P.log_int[c]; }
+      if (k >= P.lf_n) { xk.x = lf_running_sum_table(P.log_int, k, lane); xk.y = P.log_int[k]; }
+      if (lane == src) { if (c >= P.lf_n) tc = xc; if (k >= P.lf_n) tk = xk; }
+    }
     if (have)
     {
-      const double2 tc = P.tab[kmd::table_index(sum_c)], tk = P.tab[kmd::table_index(sum_k)];     // (inside the table: flagged rows are)
       const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, tc.x, tk.x, tc.y, tk.y, P.dT, P.dTc, P.dTk);
       p = kmd::igamc_half<kmd::libm_rounded>(lr, P.lg_half);
       now = p <= P.threshold;                                                              // merge.hpp:78
@@ -1821,5 +1937,184 @@ extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, dou
     default: hipLaunchKernelGGL((k_process_all<uint32_t>), dim3((unsigned)grid), dim3(256), 0, st, P, tile->layout, d_pvalue, d_sign, d_mean_control, d_mean_case); break;
   }
   KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+// ---- p-values to the reference's last bit (kmd_pvalues_refine).
+// The filters evaluate the two null-hypothesis logarithms and Cephes' exp / log with the device's libm, whose last bit may
+// differ from glibc's; `k * log(lambda)` (model.hpp:137) multiplies that bit by the count sum, so the p-value of a record
+// deviates from a glibc-built reference's by ~1e-16 x sum relative in LR -- 1e-10 absolute on p is reached at sums of
+// ~10^4 when p is of order 1 (tools/soak.py found 1.1e-10 at p = 0.92, sums 7155 + 8169).  The decisions are guarded
+// separately (k_resolve_near); this pass is for the NUMBER: each record's two sums are recovered from its two means
+// (mean_case IS the case sum; mean_control = fl(fl(sc Tk) / Tc) is inverted and checked by re-evaluating it) and the chain
+// of model.hpp:147-161 is repeated with correctly rounded log / exp (kmd_ddmath.h), as k_resolve_near does for the rows
+// near the threshold.
+// A sum beyond the log-factorial table: the filters take Stirling's series there (kmd_eval.h), the reference a k-term
+// running sum res += log(k), k-- (log_factorial_table.cpp:13-22), whose rounding is its own (~sqrt(k) ulp away from
+// ln k!; it enters alt and null alike and cancels to within an ulp of k: 5e-10 relative on p measured).  Here the running
+// sum itself is repeated -- by the whole wave for one record at a time: 64 lanes take 64 logarithms, then the 64
+// additions happen in the reference's order -- for sums below kChainMax (2^20: 16 K steps of 64, ~4 ms of one
+// wave; the reference spends ~10 ms of a core on such a row); records with a larger sum keep the filter's value.
+// kernel 1: one lane per record -- the sums recovered, records inside the table rewritten, the others listed
+__global__ void __launch_bounds__(256) k_refine_pvalues(const double2* __restrict__ tab, const unsigned long long lf_n, const double dT, const double dTc,
+                                                        const double dTk, const double lg_half, const unsigned long long n,
+                                                        const double* __restrict__ mean_control, const double* __restrict__ mean_case,
+                                                        double* __restrict__ pvalue, unsigned long long* __restrict__ list)
+{
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride)      // wave-uniform trip count
+  {
+    const unsigned long long i = i0 + (unsigned long long)lane;
+    uint64_t sum_c = 0, sum_k = 0;
+    bool found = false;
+    if (i < n)
+    {
+      const double mc = mean_control[i], mk = mean_case[i];
+      if (mk >= 0.0 && mk < 9.0e15 && mc >= 0.0)
+      {
+        sum_k = (uint64_t)mk;
+        const double guess = mc * dTc / dTk;
+        if ((double)sum_k == mk && guess < 9.0e15)
+        {
+          const uint64_t g = (uint64_t)::llrint(guess);
+          for (int d = 0; d < 5 && !found; ++d)               // g, g-1, g+1, g-2, g+2
+          {
+            const long long off = (d & 1) ? -(long long)((d + 1) / 2) : (long long)(d / 2);
+            if (off < 0 && g < (uint64_t)(-off)) continue;
+            const uint64_t c = g + (uint64_t)off;
+            if ((double)c * dTk / dTc == mc) { sum_c = c; found = true; }             // model.hpp:165, as kmd::sign_of evaluates it
+          }
+        }
+      }
+    }
+    const bool beyond = found && (sum_c >= lf_n || sum_k >= lf_n);
+    if (found && !beyond)
+    {
+      const double2 tc = tab[sum_c], tk = tab[sum_k];
+      const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, tc.x, tk.x, tc.y, tk.y, dT, dTc, dTk);
+      pvalue[i] = kmd::igamc_half<kmd::libm_rounded>(lr, lg_half);
+    }
+    // the records beyond the table go on the list { count, then (index, sum_c, sum_k) }: kernel 2 gives each a wave
+    const bool listed = beyond && sum_c < kChainMax && sum_k < kChainMax;
+    const unsigned long long mask = __ballot(listed);
+    if (mask)
+    {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&list[0], (unsigned long long)__popcll(mask));
+      base = __shfl(base, 0, 64);
+      if (listed)
+      {
+        unsigned long long* e = list + 1 + 3 * (base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)));
+        e[0] = i; e[1] = sum_c; e[2] = sum_k;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_build_log_int(double* __restrict__ log_int)
+{
+  const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < kChainMax) log_int[j] = j > 0 ? kmd::libm_rounded::log((double)j) : 0.0;
+}
+
+// kernel 2: two waves per listed record (one running sum each, then the chain of model.hpp:147-161 on the first lane)
+__global__ void __launch_bounds__(128) k_refine_chain(const double2* __restrict__ tab, const unsigned long long lf_n, const double dT, const double dTc,
+                                                      const double dTk, const double lg_half, const unsigned long long* __restrict__ list,
+                                                      const double* __restrict__ log_int, double* __restrict__ pvalue)
+{
+  __shared__ double2 s_term[2];
+  const int lane = (int)(threadIdx.x & 63), half = (int)(threadIdx.x >> 6);
+  const unsigned long long count = list[0];
+  for (unsigned long long e = blockIdx.x; e < count; e += gridDim.x)
+  {
+    const unsigned long long i = list[1 + 3 * e];
+    const uint64_t c = list[2 + 3 * e], k = list[3 + 3 * e], mine = half ? k : c;
+    double2 t;
+    if (mine < lf_n) t = tab[mine]; else { t.x = lf_running_sum_table(log_int, mine, lane); t.y = log_int[mine]; }
+    if (lane == 0) s_term[half] = t;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      const double2 tc = s_term[0], tk = s_term[1];
+      const double lr = kmd::lr_from_sums<kmd::libm_rounded>(c, k, tc.x, tk.x, tc.y, tk.y, dT, dTc, dTk);
+      pvalue[i] = kmd::igamc_half<kmd::libm_rounded>(lr, lg_half);
+    }
+    __syncthreads();
+  }
+}
+
+// dev / tests: the running sum of each k[i] both ways (the term-by-term one of k_resolve_near, the table one above)
+__global__ void __launch_bounds__(64) k_test_running_sums(const unsigned long long* __restrict__ k, const unsigned long long n, const double* __restrict__ log_int,
+                                                          double* __restrict__ plain, double* __restrict__ fast)
+{
+  const int lane = (int)threadIdx.x;
+  for (unsigned long long e = blockIdx.x; e < n; e += gridDim.x)
+  {
+    const double a = plain ? lf_running_sum_wave(k[e], lane) : 0.0, b = lf_running_sum_table(log_int, k[e], lane);
+    if (lane == 0) { if (plain) plain[e] = a; fast[e] = b; }
+  }
+}
+
+namespace {
+std::mutex g_log_int_mu;
+std::map<int, double*> g_log_int;          // per device
+
+} // namespace
+
+int kmd::log_int_table(const double** out)
+{
+  int dev = 0;
+  KMD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_log_int_mu);
+  auto it = g_log_int.find(dev);
+  if (it == g_log_int.end())
+  {
+    void* p = nullptr;
+    KMD_HIP(hipMalloc(&p, kChainMax * sizeof(double)));
+    hipLaunchKernelGGL(k_build_log_int, dim3((unsigned)(kChainMax / 256)), dim3(256), 0, nullptr, static_cast<double*>(p));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);       // built once, before any stream reads it
+    if (e != hipSuccess) { (void)hipFree(p); return kmd::hip_fail(e, "k_build_log_int", __FILE__, __LINE__); }
+    it = g_log_int.emplace(dev, static_cast<double*>(p)).first;
+  }
+  *out = it->second;
+  return KMD_OK;
+}
+
+extern "C" int kmd_test_running_sums(const uint64_t* d_k, size_t n, double* d_plain, double* d_fast, void* stream)
+{
+  const double* log_int = nullptr;
+  const int rc = kmd::log_int_table(&log_int);
+  if (rc != KMD_OK) return rc;
+  if (n == 0) return KMD_OK;
+  hipLaunchKernelGGL(k_test_running_sums, dim3((unsigned)std::min<size_t>(n, 4096)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const unsigned long long*>(d_k), (unsigned long long)n, log_int, d_plain, d_fast);
+  KMD_HIP(hipGetLastError());
+  return KMD_OK;
+}
+
+extern "C" int kmd_pvalues_refine(const kmd_model* m, size_t n, const double* d_mean_control, const double* d_mean_case, double* d_pvalue, void* stream)
+{
+  KMD_REQUIRE(m != nullptr, "kmd_pvalues_refine: no model");
+  if (n == 0) return KMD_OK;
+  KMD_REQUIRE(d_mean_control && d_mean_case && d_pvalue, "kmd_pvalues_refine: the two means and the p-values are needed");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double* log_int = m->d_log_int;
+  void* list = nullptr;
+  KMD_HIP(hipMallocAsync(&list, (1 + 3 * n) * sizeof(unsigned long long), st));
+  KMD_HIP(hipMemsetAsync(list, 0, sizeof(unsigned long long), st));
+  size_t grid = (n + 255) / 256;
+  if (grid > (size_t)m->n_cu * 8) grid = (size_t)m->n_cu * 8;
+  const double2* tab = reinterpret_cast<const double2*>(m->d_tab);
+  hipLaunchKernelGGL(k_refine_pvalues, dim3((unsigned)grid), dim3(256), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
+                     (unsigned long long)n, d_mean_control, d_mean_case, d_pvalue, static_cast<unsigned long long*>(list));
+  // as many waves as the chip holds at a comfortable occupancy; those without a record leave at once
+  const size_t chain_grid = std::min<size_t>(n, (size_t)m->n_cu * 8);
+  hipLaunchKernelGGL(k_refine_chain, dim3((unsigned)chain_grid), dim3(128), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
+                     static_cast<const unsigned long long*>(list), log_int, d_pvalue);
+  const hipError_t launched = hipGetLastError();
+  KMD_HIP(hipFreeAsync(list, st));
+  KMD_HIP(launched);
   return KMD_OK;
 }

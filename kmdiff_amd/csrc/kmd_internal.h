@@ -20,6 +20,7 @@ struct kmd_model
   double* h_lf;             // host copy of the table
   double* d_lf;             // device copy
   double* d_tab;            // device: pairs { lf[k], log(double(k)) }, k < lf_n (16 B each)
+  const double* d_log_int;  // device: correctly rounded log(j), j < 2^20 (the device's one copy, kmd::log_int_table)
   int n_cu;                 // multiProcessorCount
   size_t lds_per_block_max; // sharedMemPerBlock
   // cache of lr_cut_for_threshold (host-side constant of the last threshold used); one model
@@ -74,6 +75,9 @@ void scratch_release_all();
 // the near-threshold lists kept per stream (kmd_filter.hip): one stream's (it is being destroyed), all of them
 void near_list_forget(hipStream_t stream);
 void near_lists_release();
+// the table of correctly rounded log(j), j < 2^20 (8 MB), behind the running sums of kmd_filter.hip: the current device's,
+// built at the first call and kept for the life of the process (models point into it)
+int log_int_table(const double** out);
 // the page-locked table rings of kmd_unpack_streams (kmd_pack.hip): one stream's, or all of them
 void unpack_tables_forget(hipStream_t stream, bool all);
 

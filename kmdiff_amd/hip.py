@@ -281,14 +281,20 @@ class SurvivorAccumulator:
         check(lib().kmd_stream_sync(None), "sync")
         return self.counters.to_host(np.uint64, N.NCOUNTERS)
 
-    def finish(self, sort=True, by_kmer=False):
+    def finish(self, sort=True, by_kmer=False, refine=None):
         """IAccumulator::finish: returns the number of survivors stored (sorted by row -- or by k-mer,
         for survivors of merge_filter, which have no row index -- the reference's push order).
+        refine = the PoissonLikelihood the survivors were tested with: their p-values are recomputed with correctly
+        rounded log / exp (kmd_pvalues_refine: the bits a glibc-built reference prints).
         Raises KmdError(KMD_E_OVERFLOW) if records were dropped."""
         c = self.read_counters()
         n = int(c[N.CNT_SIG])
         if n > self.capacity:
             raise KmdError("survivor capacity exceeded: %d > %d (status %d)" % (n, self.capacity, N.KMD_E_OVERFLOW))
+        if refine is not None and n:
+            check(lib().kmd_pvalues_refine(refine.handle, n, self.bufs["mean_control"].ptr, self.bufs["mean_case"].ptr,
+                                           self.bufs["pvalue"].ptr, None), "pvalues_refine")
+            check(lib().kmd_stream_sync(None), "sync")
         if sort and n > 1:
             s = self.struct()
             if by_kmer:

@@ -712,6 +712,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
         fused_cap = (size_t)c[KMD_CNT_SIG] + (size_t)c[KMD_CNT_SIG] / 4;
       }
       ns = (size_t)c[KMD_CNT_SIG];
+      ck(kmd_pvalues_refine(model, ns, (const double*)d_smc.p, (const double*)d_smk.p, (double*)d_sp.p, nullptr), "pvalues_refine");   // glibc's bits
       ck(kmd_survivors_sort_by_kmer(&sv, ns, nullptr), "sort_by_kmer");                   // reference push order
       sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
       sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);
@@ -751,6 +752,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       uint64_t c[KMD_NCOUNTERS];
       ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
       ns = (size_t)c[KMD_CNT_SIG];
+      ck(kmd_pvalues_refine(model, ns, (const double*)d_smc.p, (const double*)d_smk.p, (double*)d_sp.p, nullptr), "pvalues_refine");   // glibc's bits
       ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                     // reference push order
       sv_all.kmer.resize(base + ns); sv_all.p.resize(base + ns); sv_all.sign.resize(base + ns);
       sv_all.mean_control.resize(base + ns); sv_all.mean_case.resize(base + ns);

@@ -31,26 +31,32 @@ def survivors(K, model, mat, n, thr):
     return got["row"].astype(np.int64), got["pvalue"], acc.read_counters()
 
 
-def test_threshold_placed_on_a_p_value(K, oracle):
+@pytest.mark.parametrize("lf_n", [10000, 6])
+def test_threshold_placed_on_a_p_value(K, oracle, lf_n):
+    """lf_n = 6: most survivors have a sum beyond the log-factorial table, where the reference's table term is its running sum
+    (log_factorial_table.cpp:13-22) and the filters' Stirling's series; the guard repeats the running sum for such a row."""
     n, nc, nk = 60_000, 6, 6
     host, _, _ = oracle.synth_rows(SEED, 3, 0, n, nc, nk, 4)
     tcs, tks = totals_of(host, nc)
-    lf = oracle.lf_table(10000)
+    lf = oracle.lf_table(lf_n)
     ref = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tcs.sum()), int(tks.sum()), lf, 1e-3)
     rows, ps = ref["row"].astype(np.int64), ref["pvalue"]
     assert len(rows) > 200
-    model = K.PoissonLikelihood(nc, nk, tcs, tks, 10000)
+    model = K.PoissonLikelihood(nc, nk, tcs, tks, lf_n)
     mat = K.CountMatrix.from_host(host, K.LAYOUT_ROWS)
     lib = K._native.lib()
     # every reference p-value as the device would compute it for a near-threshold row: correctly rounded libm
     sc = host[rows][:, :nc].sum(axis=1, dtype=np.uint64)
     sk = host[rows][:, nc:].sum(axis=1, dtype=np.uint64)
     p_rounded = np.array([lib.kmd_test_row_pvalue_rounded(C.c_void_p(model.handle), int(a), int(b)) for a, b in zip(sc, sk)])
-    inside = p_rounded >= 0                                          # (sums inside the log-factorial table)
+    inside = p_rounded >= 0                                          # (sums inside the log-factorial table, or below 2^20)
+    assert inside.all()
+    beyond = (sc >= lf_n) | (sk >= lf_n)
     agree = inside & (p_rounded == ps)
     assert agree.sum() >= 0.95 * inside.sum()                        # glibc gave the rounded value itself
     order = np.argsort(ps)
     picks = [i for i in order[:: max(1, len(order) // 40)] if inside[i] and ps[i] > 1e-300][:40]
+    assert lf_n >= 100 or sum(bool(beyond[i]) for i in picks) >= 20
     n_checked = 0
     for i in picks:
         for thr in (ps[i], np.nextafter(ps[i], 0.0), np.nextafter(ps[i], 1.0)):
@@ -196,3 +202,45 @@ def test_near_threshold_flips_in_a_batch_that_shares_one_sink(K, oracle):
                 assert g[f].tolist() == np.concatenate([x[f] for x in singles])[order].tolist(), f
     finally:
         del os.environ["KMD_TEST_NEAR_FLIP"]
+
+
+def test_threshold_on_a_p_value_of_a_row_beyond_the_table(K, oracle):
+    """Count sums of thousands against --log-factorial 300: the filters take Stirling's series for ln k!, the reference its
+    k-term running sum (log_factorial_table.cpp:13-22) -- 5e-10 apart on p.  A threshold ON such a row's p-value (and one ulp
+    to either side) is decided by the guard, which repeats the running sum: the survivor set is the oracle's wherever glibc
+    gave the oracle the rounded logarithms, and the row on the threshold reports the rounded p-value."""
+    from test_gpu_tilemerge import make_streams
+    rng = np.random.default_rng(77)
+    S, nc, lf_n = 40, 20, 300
+    universe = np.unique(rng.integers(0, 1 << 62, 4000, dtype=np.uint64))
+    streams = make_streams(rng, universe, S, rng.uniform(0.3, 1.0, S), count_hi=300)
+    want, wlo = oracle.merge_partition(streams)
+    tcs, tks = totals_of(want, nc)
+    ref = oracle.diff_partition(want, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(lf_n), 1.0)
+    ps = ref["pvalue"]
+    sc, sk = want[:, :nc].sum(axis=1, dtype=np.uint64), want[:, nc:].sum(axis=1, dtype=np.uint64)
+    assert ((sc >= lf_n) & (sk >= lf_n)).all() and int(sc.max()) > 2000
+    model = K.PoissonLikelihood(nc, S - nc, tcs, tks, lf_n)
+    lib = K._native.lib()
+    p_rounded = np.array([lib.kmd_test_row_pvalue_rounded(C.c_void_p(model.handle), int(a), int(b)) for a, b in zip(sc, sk)])
+    agree = p_rounded == ps
+    assert agree.mean() > 0.97
+    ss = K.StreamSet(streams)
+    picks = [i for i in np.argsort(ps)[:: len(ps) // 14] if 1e-300 < ps[i] < 0.9][:12]
+    n_oracle = 0
+    for i in picks:
+        for thr in (float(ps[i]), float(np.nextafter(ps[i], 0.0)), float(np.nextafter(ps[i], 1.0))):
+            acc = K.SurvivorAccumulator(len(ps))
+            K.merge_filter(ss, K.diff_observer(model, acc, thr))
+            acc.finish(by_kmer=True)
+            got, c = acc.get(), acc.read_counters()
+            assert int(c[K._native.CNT_NEAR_THRESHOLD]) >= 1
+            assert got["kmer_lo"].tolist() == wlo[p_rounded <= thr].tolist()
+            near_band = np.abs(ps - thr) <= 1e-8 * thr
+            if agree[near_band].all():
+                assert got["kmer_lo"].tolist() == wlo[ps <= thr].tolist()
+                n_oracle += 1
+            k = np.nonzero(got["kmer_lo"] == wlo[i])[0]
+            if len(k):
+                assert got["pvalue"][k[0]] == p_rounded[i]
+    assert n_oracle >= 30

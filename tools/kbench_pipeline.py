@@ -43,6 +43,16 @@ if a.device:
         best_f = min(best_f, time.perf_counter() - t0)
     cf = acc.read_counters()
     assert rows_f == int(cf[0]) == a.rows
+    # the pass that gives the survivors' p-values the reference's last bit (kmd_pvalues_refine), on this partition's sink
+    e0, e1 = K.Event(), K.Event()
+    ns, best_r = int(cf[1]), 1e9
+    for _ in range(4):
+        e0.record()
+        K._native.check(lib.kmd_pvalues_refine(model.handle, ns, acc.bufs["mean_control"].ptr, acc.bufs["mean_case"].ptr, acc.bufs["pvalue"].ptr, None))
+        e1.record()
+        lib.kmd_stream_sync(None)
+        best_r = min(best_r, e0.elapsed_ms(e1))
+    print("kmd_pvalues_refine on the %d survivors: %.3f ms" % (ns, best_r))
     bpr = 12 if a.limbs == 1 else 20
     print("pipeline device-built S=%d records=%d rows=%d  fused merge+test (kmd_merge_filter) %.3f ms  %.3e rows/s  %.3e records/s  %.0f GB/s of %d B/record  sig=%d  candidates=%d"
           % (S, ss.total, rows_f, best_f * 1e3, rows_f / best_f, ss.total / best_f, bpr * 1e-9 * ss.total / best_f, bpr, int(cf[1]), int(cf[4])))

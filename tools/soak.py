@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""GPU box: a randomized soak of the product paths against the oracle, beyond the committed (seeded, small) tests:
+  * kmd_merge_filter on random partitions (2..260 samples, 0..60 000 k-mers, spread / clustered / consecutive keys, empty
+    samples, huge counts, thresholds 1 .. 1e-9) == oracle merge + diff_partition       (tests/test_gpu_tilemerge.run_fused)
+  * kmd_pack_block / kmd_unpack_streams round trips on random streams
+  * kmd_correct_sharded over 2..9 virtual ranks == kmd_correct over the whole list, all correctors
+usage: python3 tools/soak.py [--seconds 300] [--seed N]      (prints one line per 50 cases; any mismatch raises)"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kmdiff_amd as K                     # noqa: E402
+import oracle_lib as OL                    # noqa: E402
+from test_gpu_parity import totals_of, sharded_decisions       # noqa: E402
+from test_gpu_tilemerge import make_streams, run_fused         # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=300)
+ap.add_argument("--seed", type=int, default=int(time.time()))
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+oracle = OL.load()
+N = K._native
+print("soak seed", a.seed, flush=True)
+DEV = {"raw_abs": 0.0, "raw_rel": 0.0, "ref_rel_in": 0.0, "ref_abs_in": 0.0, "in_rows": 0, "in_equal": 0, "beyond_abs": 0.0, "beyond_rel": 0.0, "beyond_rows": 0}
+
+
+def fused_case(streams, nc, thr, lf_n):
+    """tests/test_gpu_tilemerge.run_fused with the p-values MEASURED: everything else exact; p as the filter wrote it, then
+    after kmd_pvalues_refine -- rows with both sums inside the table apart from the others"""
+    S = len(streams)
+    want, wlo = oracle.merge_partition(streams)
+    tcs, tks = totals_of(want, nc)
+    ref = oracle.diff_partition(want, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(lf_n), thr)
+    model = K.PoissonLikelihood(nc, S - nc, tcs, tks, lf_n)
+    acc = K.SurvivorAccumulator(max(want.shape[0], 1))
+    K.merge_filter(K.StreamSet(streams), K.diff_observer(model, acc, thr))
+    n = acc.finish(by_kmer=True)
+    got = acc.get()
+    c = acc.read_counters()
+    assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == ref["counters"] and int(c[0]) == want.shape[0]
+    rr = ref["row"].astype(np.int64)
+    assert n == len(rr) and got["kmer_lo"].tolist() == wlo[rr].tolist() and got["sign"].tolist() == ref["sign"].tolist()
+    assert got["mean_control"].tolist() == ref["mean_control"].tolist() and got["mean_case"].tolist() == ref["mean_case"].tolist()
+    if n == 0:
+        return
+    w = ref["pvalue"]
+    d = np.abs(got["pvalue"] - w)
+    DEV["raw_abs"] = max(DEV["raw_abs"], float(d.max()))
+    nz = w > 0
+    if nz.any():
+        DEV["raw_rel"] = max(DEV["raw_rel"], float((d[nz] / w[nz]).max()))
+    check_ = K._native.check
+    check_(K._native.lib().kmd_pvalues_refine(model.handle, n, acc.bufs["mean_control"].ptr, acc.bufs["mean_case"].ptr, acc.bufs["pvalue"].ptr, None))
+    check_(K._native.lib().kmd_stream_sync(None))
+    p2 = acc.bufs["pvalue"].to_host(np.float64, n)
+    sc, sk = want[rr, :nc].astype(np.uint64).sum(axis=1), want[rr, nc:].astype(np.uint64).sum(axis=1)
+    inside = (sc < lf_n) & (sk < lf_n)
+    d2 = np.abs(p2 - w)
+    if inside.any():
+        DEV["in_rows"] += int(inside.sum()); DEV["in_equal"] += int((p2[inside] == w[inside]).sum())
+        DEV["ref_abs_in"] = max(DEV["ref_abs_in"], float(d2[inside].max()))
+        m = inside & nz
+        if m.any():
+            DEV["ref_rel_in"] = max(DEV["ref_rel_in"], float((d2[m] / w[m]).max()))
+    if (~inside).any():
+        DEV["beyond_equal"] = DEV.get("beyond_equal", 0) + int((p2[~inside] == w[~inside]).sum())
+        DEV["beyond_rows"] += int((~inside).sum())
+        DEV["beyond_abs"] = max(DEV["beyond_abs"], float(d2[~inside].max()))
+        m = ~inside & nz
+        if m.any():
+            DEV["beyond_rel"] = max(DEV["beyond_rel"], float((d2[m] / w[m]).max()))
+t0, n_fused, n_pack, n_shard = time.time(), 0, 0, 0
+while time.time() - t0 < a.seconds:
+    kind = rng.integers(0, 10)
+    if kind < 6:
+        S = int(rng.choice([2, 3, 5, 8, 16, 40, 41, 64, 65, 100, 200, 260]))
+        nc = int(rng.integers(1, S))
+        n = int(rng.integers(0, 60000 if S <= 64 else 8000))
+        mode = rng.integers(0, 4)
+        if mode == 0:
+            base = int(rng.integers(0, 1 << 60))
+            universe = np.unique(np.uint64(base) + rng.integers(0, 3 * n + 8, n).astype(np.uint64))
+        elif mode == 1:                                    # a few dense clusters
+            starts = rng.integers(0, 1 << 61, 7, dtype=np.uint64)
+            universe = np.unique((starts[:, None] + rng.integers(0, 4 * (n // 7 + 1), (7, n // 7 + 1)).astype(np.uint64)).ravel())
+        else:
+            universe = np.unique(rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64))
+        if rng.random() < 0.15 and len(universe):
+            universe = np.unique(np.concatenate([universe, np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
+        pres = rng.uniform(0.01, 1.0, S) if rng.random() < 0.5 else np.full(S, rng.uniform(0.02, 0.9))
+        empty = tuple(int(x) for x in rng.choice(S, size=int(rng.integers(0, max(1, S // 3))), replace=False)) if S > 2 else ()
+        streams = make_streams(rng, universe, S, pres, count_hi=int(rng.integers(2, 3000)), empty=empty)
+        if sum(len(t[0]) for t in streams) == 0:
+            continue
+        if rng.random() < 0.2:
+            for s in range(S):
+                km, cnt = streams[s]
+                if len(cnt):
+                    cnt = cnt.copy()
+                    cnt[rng.integers(0, len(cnt), 2)] = np.uint32(3_000_000_000)
+                    streams[s] = (km, cnt)
+        want, _ = oracle.merge_partition(streams)
+        tcs, tks = totals_of(want, nc)
+        if int(tcs.sum()) == 0 or int(tks.sum()) == 0:
+            continue
+        thr, lf_n = float(rng.choice([1.0, 0.3, 1e-2, 1e-4, 1e-6, 1e-9])), int(rng.choice([10000, 300, 50]))
+        try:
+            fused_case(streams, nc, thr, lf_n)
+        except AssertionError:
+            np.savez("gpurun_out/soak_fail.npz", nc=nc, thr=thr, lf_n=lf_n, **{"k%d" % i: t[0] for i, t in enumerate(streams)},
+                     **{"c%d" % i: t[1] for i, t in enumerate(streams)})
+            print("FAILED: S=%d nc=%d n=%d mode=%d thr=%g lf_n=%d count max %d" % (S, nc, n, mode, thr, lf_n, max(int(t[1].max(initial=0)) for t in streams)), flush=True)
+            raise
+        n_fused += 1
+    elif kind < 8:
+        streams = []
+        for _ in range(int(rng.integers(1, 12))):
+            n = int(rng.integers(0, 3000))
+            bits = int(rng.integers(0, 65))
+            if bits == 64:
+                km = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+            elif bits == 0:
+                km = np.full(n, int(rng.integers(0, 2 ** 63)), dtype=np.uint64)
+            else:
+                km = np.cumsum(rng.integers(0, 1 << min(bits, 52), n, dtype=np.uint64), dtype=np.uint64)
+            ct = rng.integers(0, int(rng.choice([3, 254, 256, 70000, 2 ** 32])), n).astype(np.uint32)
+            streams.append((km, ct))
+        packed, base, table, offs = K.pack_streams(streams)
+        ss = K.unpack_streams(packed, base, table, offs)
+        km, ct = ss.kmers.to_host(np.uint64, ss.total), ss.counts.to_host(np.uint32, ss.total)
+        assert np.array_equal(km, np.concatenate([s[0] for s in streams])) and np.array_equal(ct, np.concatenate([s[1] for s in streams]))
+        n_pack += 1
+    else:
+        n = int(rng.integers(0, 5000))
+        p = rng.uniform(0, 1, n) ** int(rng.integers(1, 40))
+        if n > 10 and rng.random() < 0.5:
+            p[rng.integers(0, n, n // 5)] = p[rng.integers(0, n)]            # ties
+        s = rng.integers(0, 3, n).astype(np.int32)
+        world = int(rng.integers(2, 10))
+        cuts = [0] + sorted(rng.integers(0, n + 1, world - 1).tolist()) + [n]
+        parts = [(p[x:y], s[x:y]) for x, y in zip(cuts[:-1], cuts[1:])]
+        total = int(rng.choice([max(n, 1), 10 * max(n, 1), 10 ** 7, 10 ** 10]))
+        name = str(rng.choice(["benjamini", "holm", "bonferroni", "sidak", "nothing"]))
+        thr = float(rng.choice([0.05, 0.5, 1e-3]))
+        T = (N.Transport * world)()
+        N.check(N.lib().kmd_transport_local_create(world, T))
+        try:
+            want, _, _ = K.aggregate(name, thr, total, K.DeviceBuffer.from_host(p), K.DeviceBuffer.from_host(s), n)
+            per = [total // world + (1 if r < total % world else 0) for r in range(world)]
+            res = sharded_decisions(K, T, name, per, parts, thr=thr)
+            assert np.concatenate([o[1] for o in res]).tolist() == want.tolist(), (name, world, n, total, thr)
+        finally:
+            N.lib().kmd_transport_local_destroy(world, T)
+        n_shard += 1
+    if (n_fused + n_pack + n_shard) % 50 == 0:
+        print("  %.0f s: %d fused, %d pack, %d sharded cases" % (time.time() - t0, n_fused, n_pack, n_shard), flush=True)
+print("p-values vs the oracle:", DEV)
+print("soak ok: %d fused merge cases, %d pack round trips, %d sharded corrections in %.0f s (seed %d)" % (n_fused, n_pack, n_shard, time.time() - t0, a.seed))
