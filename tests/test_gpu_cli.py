@@ -174,6 +174,9 @@ def test_cli_keep_tmp_files_resume_and_save_sk(synth_run, tmp_path):
     assert got["kmer"] == surv["kmer"] and got["sign"] == surv["sign"]
     assert got["mc"] == surv["mc"] and got["mk"] == surv["mk"]
     assert np.allclose(got["p"], surv["p"], rtol=0, atol=1e-10)
+    # ... and since the CLI passes its survivors through kmd_pvalues_refine: the oracle's bits (glibc's own log is the rounded
+    # one in all but ~1 call in 10^3)
+    assert (np.array(got["p"]) == np.array(surv["p"])).mean() >= 0.99 and np.allclose(got["p"], surv["p"], rtol=1e-9, atol=0)
     lut = [{int(v): i for i, v in enumerate(km)} for km in kms]
     want_rows = np.array([next(m[l[kv]] for m, l in zip(mats, lut) if kv in l) for kv in surv["kmer"]])
     assert (np.array(got["counts"]) == want_rows).all() and (np.concatenate(sk_rows) == want_rows).all()
@@ -218,6 +221,7 @@ def test_cli_two_limb_kmers_k63(tmp_path):
         f = KF.read_survivor_file(str(tmp_path / "o" / "partitions" / ("p%d_uncorrected" % p)), kmer_bytes=16)
         assert f["kmer"] == los[p][idx].tolist() and f["kmer_hi"] == his[p][idx].tolist()
         assert np.allclose(f["p"], out["pvalue"], rtol=0, atol=1e-10)
+        assert (np.array(f["p"]) == out["pvalue"]).mean() >= 0.98                   # kmd_pvalues_refine: the oracle's bits
         for i, sg, pv in zip(idx, out["sign"], out["pvalue"]):
             if pv < 0.05:                                                    # "disabled" = threshold corrector
                 want["control" if sg == 0 else "case"].append(KF.kmer_to_string2(his[p][i], los[p][i], k))
