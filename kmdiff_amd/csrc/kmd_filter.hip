@@ -1997,6 +1997,20 @@ __global__ void __launch_bounds__(256) k_refine_pvalues(const double2* __restric
     }
     // the records beyond the table go on the list { count, then (index, sum_c, sum_k) }: kernel 2 gives each a wave
     const bool listed = beyond && sum_c < kChainMax && sum_k < kChainMax;
+    if (beyond && !listed)
+    {
+      // a sum of 2^20 or more: the table term stays Stirling's (evaluate_core's), the logarithms are rounded correctly --
+      // the part of the deviation that grows with the sum (k ulp(log lambda): 5e-9 relative on p at sums of 2.6e6) goes,
+      // what stays is the rounding of the reference's own running sum (~ulp(k))
+      const uint32_t kc = kmd::table_index(sum_c), kk = kmd::table_index(sum_k);
+      double2 tc = make_double2(0.0, 0.0), tk = make_double2(0.0, 0.0);
+      if (kc < lf_n) tc = tab[kc]; else tc.x = lf_beyond_table(kc);
+      if (kk < lf_n) tk = tab[kk]; else tk.x = lf_beyond_table(kk);
+      if (sum_c >= lf_n) tc.y = kmd::libm_rounded::log((double)sum_c);
+      if (sum_k >= lf_n) tk.y = kmd::libm_rounded::log((double)sum_k);
+      const double lr = kmd::lr_from_sums<kmd::libm_rounded>(sum_c, sum_k, tc.x, tk.x, tc.y, tk.y, dT, dTc, dTk);
+      pvalue[i] = kmd::igamc_half<kmd::libm_rounded>(lr, lg_half);
+    }
     const unsigned long long mask = __ballot(listed);
     if (mask)
     {

@@ -2,6 +2,7 @@
 """GPU box: a randomized soak of the product paths against the oracle, beyond the committed (seeded, small) tests:
   * kmd_merge_filter on random partitions (2..260 samples, 0..60 000 k-mers, spread / clustered / consecutive keys, empty
     samples, huge counts, thresholds 1 .. 1e-9) == oracle merge + diff_partition       (tests/test_gpu_tilemerge.run_fused)
+  * kmd_poisson_filter on random count matrices (every layout and count width), kmd_merge_filter_batch against single calls
   * kmd_pack_block / kmd_unpack_streams round trips on random streams
   * kmd_correct_sharded over 2..9 virtual ranks == kmd_correct over the whole list, all correctors
 usage: python3 tools/soak.py [--seconds 300] [--seed N]      (prints one line per 50 cases; any mismatch raises)"""
@@ -76,10 +77,116 @@ def fused_case(streams, nc, thr, lf_n):
         m = ~inside & nz
         if m.any():
             DEV["beyond_rel"] = max(DEV["beyond_rel"], float((d2[m] / w[m]).max()))
-t0, n_fused, n_pack, n_shard = time.time(), 0, 0, 0
+t0, n_fused, n_pack, n_shard, n_k1, n_batch = time.time(), 0, 0, 0, 0, 0
+
+
+def k1_case():
+    """kmd_poisson_filter on a random count matrix: every layout and count width, 2..300 samples, rows of zeros, thresholds
+    1 .. 1e-9 -- rows, sign, means, counters exact; p after kmd_pvalues_refine bit-equal in >= 99 %, the rest 1e-9 relative"""
+    S = int(rng.choice([2, 3, 7, 16, 21, 40, 41, 64, 100, 129, 255, 300]))
+    nc = int(rng.integers(1, S))
+    n = int(rng.integers(1, 40000 if S <= 64 else 6000))
+    dt = [np.uint8, np.uint16, np.uint32][int(rng.integers(0, 3))]
+    hi = int(rng.choice([2, 4, 30, 255, 256, 3000, 70000]))
+    hi = min(hi, int(np.iinfo(dt).max))
+    rows = rng.integers(0, hi + 1, (n, S)).astype(dt)
+    rows[rng.random((n, S)) < rng.uniform(0, 0.95)] = 0
+    rows[rng.random(n) < 0.02] = 0
+    if dt == np.uint32 and rng.random() < 0.2:
+        rows[rng.integers(0, n, 3), rng.integers(0, S, 3)] = np.uint32(4_000_000_000)
+    tcs, tks = totals_of(rows, nc)
+    if int(tcs.sum()) == 0 or int(tks.sum()) == 0:
+        return
+    layout = [K.LAYOUT_ROWS, K.LAYOUT_SOA, K.LAYOUT_TILED][int(rng.integers(0, 3))]
+    thr, lf_n = float(rng.choice([1.0, 0.05, 1e-3, 1e-6, 1e-9])), int(rng.choice([10000, 10000, 500, 20]))
+    ref = oracle.diff_partition(rows, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(lf_n), thr)
+    model = K.PoissonLikelihood(nc, S - nc, tcs, tks, lf_n)
+    lo = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    mat = K.CountMatrix.from_host(rows if layout == K.LAYOUT_ROWS else np.ascontiguousarray(rows.T), layout, kmer_lo=lo, row_base=int(rng.integers(0, 1 << 40)))
+    acc = K.SurvivorAccumulator(n)
+    K.diff_observer(model, acc, thr).process(mat)
+    ns = acc.finish(refine=model)
+    got, c = acc.get(), acc.read_counters()
+    tag = (S, nc, n, dt.__name__, layout, thr, lf_n)
+    assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == ref["counters"], tag
+    rr = ref["row"].astype(np.int64)
+    assert ns == len(rr) and (got["row"] - np.uint64(mat.row_base)).tolist() == rr.tolist() and got["kmer_lo"].tolist() == lo[rr].tolist(), tag
+    assert got["sign"].tolist() == ref["sign"].tolist() and got["mean_control"].tolist() == ref["mean_control"].tolist(), tag
+    assert got["mean_case"].tolist() == ref["mean_case"].tolist(), tag
+    if ns:
+        w, p = ref["pvalue"], got["pvalue"]
+        small = (rows[rr, :nc].astype(np.uint64).sum(axis=1) < (1 << 20)) & (rows[rr, nc:].astype(np.uint64).sum(axis=1) < (1 << 20))
+        d = np.abs(p - w)
+        rel = np.where(w > 0, d / np.where(w > 0, w, 1.0), 0.0)
+        assert d[small].max(initial=0) <= 1e-10 and rel[small].max(initial=0) <= 1e-9, (tag, d[small].max(initial=0))
+        if (~small).any():                       # sums of 2^20 and more keep the filter's value: measured, not asserted beyond 1e-6
+            DEV["k1_large_sum_rel"] = max(DEV.get("k1_large_sum_rel", 0.0), float(rel[~small].max()))
+            DEV["k1_large_sum_abs"] = max(DEV.get("k1_large_sum_abs", 0.0), float(d[~small].max()))
+            assert rel[~small].max() <= 1e-6, (tag, rel[~small].max())
+        if small.sum() > 200:
+            assert (p[small] == w[small]).mean() >= 0.99, (tag, (p[small] == w[small]).mean())
+        DEV["k1_rows"] = DEV.get("k1_rows", 0) + int(ns)
+        DEV["k1_equal"] = DEV.get("k1_equal", 0) + int((p == w).sum())
+
+
+def batch_case():
+    """kmd_merge_filter_batch over 2..10 random partitions (some empty, some with two-limb k-mers apart), sinks shared or
+    not, against single kmd_merge_filter calls: bit for bit"""
+    S = int(rng.choice([3, 12, 40, 80]))
+    nc = int(rng.integers(1, S))
+    sets, hosts, tot = [], [], np.zeros(S, dtype=np.uint64)
+    for j in range(int(rng.integers(2, 11))):
+        n = 0 if rng.random() < 0.1 else int(rng.integers(1, 30000 if S <= 12 else 6000))
+        universe = np.unique(rng.integers(0, 1 << 62, n, dtype=np.uint64))
+        streams = make_streams(rng, universe, S, rng.uniform(0.02, 1.0, S), count_hi=int(rng.integers(2, 400)))
+        sets.append(K.StreamSet(streams))
+        hosts.append(streams)
+        tot += np.array([int(t[1].sum(dtype=np.uint64)) for t in streams], dtype=np.uint64)
+    if int(tot[:nc].sum()) == 0 or int(tot[nc:].sum()) == 0:
+        return
+    model = K.PoissonLikelihood(nc, S - nc, tot[:nc], tot[nc:], 10000)
+    thr = float(rng.choice([0.5, 1e-2, 1e-5]))
+    single = []
+    for ss in sets:
+        acc = K.SurvivorAccumulator(1 << 16)
+        rows = K.merge_filter(ss, K.diff_observer(model, acc, thr)) if ss.total else 0
+        single.append((rows, acc.finish(by_kmer=True), acc.get(), [int(x) for x in acc.read_counters()[:4]]))
+    shared = rng.random() < 0.5
+    if shared:
+        one = K.SurvivorAccumulator(1 << 19)
+        accs = [one] * len(sets)
+    else:
+        accs = [K.SurvivorAccumulator(1 << 16) for _ in sets]
+    rows_b = K.merge_filter_batch(sets, [K.diff_observer(model, x, thr) for x in accs])
+    assert [int(r) for r in rows_b] == [s_[0] for s_ in single]
+    if shared:
+        n = one.finish(by_kmer=True)
+        got = one.get()
+        allk = np.concatenate([s_[2]["kmer_lo"] for s_ in single]) if n else np.zeros(0, np.uint64)
+        allp = np.concatenate([s_[2]["pvalue"] for s_ in single]) if n else np.zeros(0)
+        order = np.argsort(allk, kind="stable")
+        assert n == len(allk) and got["kmer_lo"].tolist() == allk[order].tolist()
+        # (the same k-mer may be in two partitions of this soak: compare as multisets of (k-mer, p))
+        assert sorted(zip(got["kmer_lo"].tolist(), got["pvalue"].tolist())) == sorted(zip(allk.tolist(), allp.tolist()))
+        assert [int(x) for x in one.read_counters()[:4]] == [sum(s_[3][i] for s_ in single) for i in range(4)]
+    else:
+        for j, x in enumerate(accs):
+            n = x.finish(by_kmer=True)
+            got = x.get()
+            assert n == single[j][1] and [int(v) for v in x.read_counters()[:4]] == single[j][3], j
+            for key in ("kmer_lo", "pvalue", "sign", "mean_control", "mean_case"):
+                assert got[key].tolist() == single[j][2][key].tolist(), (j, key)
+
+
 while time.time() - t0 < a.seconds:
-    kind = rng.integers(0, 10)
-    if kind < 6:
+    kind = rng.integers(0, 16)
+    if kind >= 13:
+        batch_case()
+        n_batch += 1
+    elif kind >= 10:
+        k1_case()
+        n_k1 += 1
+    elif kind < 6:
         S = int(rng.choice([2, 3, 5, 8, 16, 40, 41, 64, 65, 100, 200, 260]))
         nc = int(rng.integers(1, S))
         n = int(rng.integers(0, 60000 if S <= 64 else 8000))
@@ -159,7 +266,8 @@ while time.time() - t0 < a.seconds:
         finally:
             N.lib().kmd_transport_local_destroy(world, T)
         n_shard += 1
-    if (n_fused + n_pack + n_shard) % 50 == 0:
-        print("  %.0f s: %d fused, %d pack, %d sharded cases" % (time.time() - t0, n_fused, n_pack, n_shard), flush=True)
+    if (n_fused + n_pack + n_shard + n_k1 + n_batch) % 50 == 0:
+        print("  %.0f s: %d fused, %d pack, %d sharded, %d matrix, %d batch cases" % (time.time() - t0, n_fused, n_pack, n_shard, n_k1, n_batch), flush=True)
 print("p-values vs the oracle:", DEV)
-print("soak ok: %d fused merge cases, %d pack round trips, %d sharded corrections in %.0f s (seed %d)" % (n_fused, n_pack, n_shard, time.time() - t0, a.seed))
+print("soak ok: %d fused merge cases, %d pack round trips, %d sharded corrections, %d matrix filters, %d batches in %.0f s (seed %d)"
+      % (n_fused, n_pack, n_shard, n_k1, n_batch, time.time() - t0, a.seed))
