@@ -78,6 +78,8 @@ class PoissonLikelihoodHip : public kmdiff::IModel<MAX_C>
     kmd_tile t { m_d_row, (int)sizeof(count_type), KMD_LAYOUT_ROWS, m_nc + m_nk, nullptr, nullptr, 1, 0 };
     int rc = kmd_memcpy_h2d(m_d_row, row.data(), row.size() * sizeof(count_type), nullptr);
     if (rc == KMD_OK) rc = kmd_poisson_process(m_model, &t, (double*)m_d_p, (int32_t*)m_d_sign, (double*)m_d_mc, (double*)m_d_mk, nullptr);
+    // the reference decides `p <= threshold` on this number itself (merge.hpp:78): give it glibc's bits
+    if (rc == KMD_OK) rc = kmd_pvalues_refine(m_model, 1, (const double*)m_d_mc, (const double*)m_d_mk, (double*)m_d_p, nullptr);
     if (rc == KMD_OK) rc = kmd_memcpy_d2h(&p, m_d_p, 8, nullptr);
     if (rc == KMD_OK) rc = kmd_memcpy_d2h(&sign, m_d_sign, 4, nullptr);
     if (rc == KMD_OK) rc = kmd_memcpy_d2h(&mc, m_d_mc, 8, nullptr);

@@ -543,11 +543,26 @@ double kmdo_bench_partitions(uint64_t seed, int n_parts, size_t rows_per_part, i
 /* Matrices are dense row-major doubles.                                                 */
 /* ------------------------------------------------------------------------------------ */
 
+/* Test instrument, not the reference's code: when armed (kmdo_sigmoid_jitter), the pow() below is moved by one ulp, up or
+ * down, in about one call in 2^log2_every -- the difference two correct libms may show.  It answers "is this row's p-value
+ * a property of the data or of the last bit of pow()": pop-strat's default design is not standardised (a column of ~1e7
+ * beside one of ~1e-6, Hessian condition number beyond 1e16), and IRLS on it can amplify one ulp to any size. */
+static uint64_t g_jitter_state = 0;
+static int g_jitter_log2 = 0;
+void kmdo_sigmoid_jitter(uint64_t seed, int log2_every) { g_jitter_state = seed; g_jitter_log2 = log2_every; }
+
 /* src/linear_model.cpp:191-195 */
 double kmdo_sigmoid(double x)
 {
   double e = M_E;
-  return 1.0 / (1.0 + pow(e, -x));
+  double pw = pow(e, -x);
+  if (g_jitter_state)
+  {
+    g_jitter_state ^= g_jitter_state << 13; g_jitter_state ^= g_jitter_state >> 7; g_jitter_state ^= g_jitter_state << 17;
+    if ((g_jitter_state >> 20 & ((1ull << g_jitter_log2) - 1)) == 0)
+      pw = nextafter(pw, (g_jitter_state >> 60 & 1) ? INFINITY : 0.0);
+  }
+  return 1.0 / (1.0 + pw);
 }
 
 /* src/linear_model.cpp:94-132 -- Doolittle, no pivoting */

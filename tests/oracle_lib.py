@@ -39,6 +39,8 @@ class Oracle:
         L.kmdo_synth_rows.argtypes = [u64, C.c_uint32, u64, sz, i, i, i, i, sz, vp, vp, vp]
         L.kmdo_sigmoid.restype = d
         L.kmdo_sigmoid.argtypes = [d]
+        L.kmdo_sigmoid_jitter.restype = None
+        L.kmdo_sigmoid_jitter.argtypes = [C.c_uint64, i]
         L.kmdo_lu.argtypes = [vp, i, vp, vp]
         L.kmdo_inverse.restype = i
         L.kmdo_inverse.argtypes = [vp, i, vp]

@@ -361,6 +361,8 @@ def test_imodel_plugin_loaded_like_the_reference_does(tmp_path, bits, dtype):
     for i, g in enumerate(got):
         assert int(g[1]) == s[i] and float.fromhex(g[2]) == mc[i] and float.fromhex(g[3]) == mk[i]
         assert abs(float.fromhex(g[0]) - p[i]) <= 1e-10 and abs(float.fromhex(g[0]) - p[i]) <= 1e-9 * p[i] + 1e-300
+    # the plugin passes every p-value through kmd_pvalues_refine (the reference compares THIS number with its threshold)
+    assert sum(float.fromhex(g[0]) == p[i] for i, g in enumerate(got)) >= 0.98 * n
 
 
 def test_cli_empty_sample_files_and_an_empty_partition(tmp_path):

@@ -27,7 +27,12 @@ def oracle_setup(oracle, nc, nk, tc, tk, Z, npc, stand, max_iter, Y):
     return alt, w, tot
 
 
-def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_scale=1.0, seed=3, want_spread=True):
+def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_scale=1.0, seed=3, want_spread=True, libm_rows=None):
+    """libm_rows: a list -- rows outside the bars are then allowed IF the oracle's own p-value for them moves by more than
+    the bars when the pow() inside its sigmoid is jittered by one ulp (kmdo_sigmoid_jitter): their p-value is a property of
+    libm's last bit, not of the data (the default design is not standardised: a column of ~1e7 beside one of ~1e-6, and
+    IRLS without pivoting on a Hessian of condition number > 1e16 amplifies one ulp to anything).  Their indices are
+    appended to the list."""
     S = nc + nk
     rng = np.random.default_rng(seed)
     if Z is None:
@@ -43,17 +48,58 @@ def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_
     alt_d, null_d, _ = pop.info()
     assert alt_d.tolist() == alt_o.tolist()
     both_nan = np.isnan(null_d) & np.isnan(null_o)
-    assert (np.abs(null_d - null_o)[~both_nan] <= 1e-9 * max(1.0, np.abs(null_o[~both_nan]).max(initial=0.0))).all()
+    null_scale = max(1.0, np.abs(null_o[~both_nan]).max(initial=0.0))
+    null_dev = np.abs(null_d - null_o)[~both_nan].max(initial=0.0)
+    if null_dev > 1e-9 * null_scale:
+        # the null model itself: allowed (libm_rows given) if the oracle's own fit moves as much under one ulp of jitter;
+        # the design is then marked (-1) and its rows are not compared -- every one of them inherits the null fit's doubt
+        assert libm_rows is not None, null_dev
+        spread = 0.0
+        for sd in range(1, 9):
+            oracle.L.kmdo_sigmoid_jitter(sd * 7919, 1)
+            try:
+                _, n2, _ = oracle_setup(oracle, nc, nk, tc, tk, Z, npc, stand, it, Yv)
+            finally:
+                oracle.L.kmdo_sigmoid_jitter(0, 0)
+            with np.errstate(invalid="ignore"):
+                spread = max(spread, float(np.nanmax(np.abs(n2 - null_o))))
+        assert null_dev <= 8 * spread + 1e-9 * null_scale, (null_dev, spread)
+        libm_rows.append(-1)
+        return None
     rows = np.ascontiguousarray(rows, dtype=np.float64)
     n = len(rows)
     p_dev = pop.apply(K.DeviceBuffer.from_host(rows), n)
-    p_ref = np.array([oracle.L.kmdo_popstrat_pvalue(alt_o.ctypes.data, S, alt_o.shape[1], Yv.ctypes.data, tot_o.ctypes.data,
-                                                    r.ctypes.data, null_o.ctypes.data, it) for r in rows])
-    assert np.isfinite(p_dev).all() == np.isfinite(p_ref).all()
-    ok = np.isfinite(p_ref)
-    assert np.abs(p_dev[ok] - p_ref[ok]).max(initial=0.0) <= 1e-10
-    nz = ok & (p_ref > 1e-300)
-    assert (np.abs(p_dev[nz] - p_ref[nz]) / p_ref[nz]).max(initial=0.0) <= 1e-7
+
+    def ref_of(r):
+        return oracle.L.kmdo_popstrat_pvalue(alt_o.ctypes.data, S, alt_o.shape[1], Yv.ctypes.data, tot_o.ctypes.data,
+                                             r.ctypes.data, null_o.ctypes.data, it)
+    p_ref = np.array([ref_of(r) for r in rows])
+    fin_d, fin_r = np.isfinite(p_dev), np.isfinite(p_ref)
+    with np.errstate(invalid="ignore"):
+        d = np.abs(p_dev - p_ref)
+        bad = (fin_d != fin_r) | (fin_r & fin_d & ((d > 1e-10) | (d > 1e-7 * np.abs(p_ref))))
+    if libm_rows is None:
+        assert np.isfinite(p_dev).all() == np.isfinite(p_ref).all()
+        assert not bad.any(), (int(bad.sum()), np.nanmax(d))
+    else:
+        for i in np.nonzero(bad)[0]:
+            seen = [p_ref[i]]
+            for lg in (0, 1, 2):
+                for sd in range(1, 17):
+                    oracle.L.kmdo_sigmoid_jitter(sd * 104729 + lg, lg)
+                    try:
+                        seen.append(ref_of(rows[i]))
+                    finally:
+                        oracle.L.kmdo_sigmoid_jitter(0, 0)
+            seen = np.array(seen)
+            if np.isfinite(seen).all() and np.isfinite(p_dev[i]):
+                lo, hi = seen.min(), seen.max()
+                assert hi - lo > 1e-10 or hi - lo > 1e-7 * lo, (i, p_dev[i], p_ref[i], lo, hi)      # the oracle itself is unsure
+                assert 0.9 * lo - 1e-12 <= p_dev[i] <= 1.1 * hi + 1e-12, (i, p_dev[i], lo, hi)       # ... and the device is in its range
+            else:
+                assert not np.isfinite(seen).all() or len(np.unique(seen)) > 1, (i, p_dev[i], seen[:4])
+            libm_rows.append(int(i))
+    ok = fin_r
     if want_spread:
         assert len(np.unique(p_ref[ok])) > min(10, n // 4)
     return p_ref
@@ -186,3 +232,17 @@ def test_group_kernel_equals_lane_kernel(K, oracle, monkeypatch, nc, nk, npc, st
         assert (pop.apply(buf_t, len(rows), sample_major=True, ld=len(rows)) == out[kind]).all()
     assert (out["lane"] == out["group"]).all()
     assert len(np.unique(out["lane"])) > 50 or max_iter == 1
+
+
+@pytest.mark.parametrize("nc,nk,npc,seed", [(43, 3, 4, 1), (43, 3, 4, 2), (50, 2, 3, 3), (12, 40, 6, 4)])
+def test_rows_whose_p_value_hangs_on_the_last_bit_of_pow(K, oracle, nc, nk, npc, seed):
+    """tools/soak.py's find: the DEFAULT design (no --stand) with a few samples on one side.  One row in ~3000 came out at
+    p = 5e-5 on the device and p = 1 in the oracle -- and the oracle itself gives either, depending on one ulp of the pow()
+    in its sigmoid (kmdo_sigmoid_jitter).  Such rows are no parity failure and no parity success: they are counted.  Every
+    other row keeps the bars (1e-10 absolute, 1e-7 relative), and there are few of the former."""
+    rng = np.random.default_rng(9000 + seed)
+    rows = count_rows(rng, 3000, nc, nk, effect=float(rng.choice([1.2, 3.0])))
+    Z = rng.normal(0, 0.1, size=(nc + nk, 10))
+    libm_rows = []
+    check(K, oracle, nc, nk, npc, False, 0, rows, Z=Z, seed=seed, want_spread=False, libm_rows=libm_rows)
+    assert len(libm_rows) <= 30, len(libm_rows)
