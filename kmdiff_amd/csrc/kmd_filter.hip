@@ -1959,7 +1959,8 @@ extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, dou
 __global__ void __launch_bounds__(256) k_refine_pvalues(const double2* __restrict__ tab, const unsigned long long lf_n, const double dT, const double dTc,
                                                         const double dTk, const double lg_half, const unsigned long long n,
                                                         const double* __restrict__ mean_control, const double* __restrict__ mean_case,
-                                                        double* __restrict__ pvalue, unsigned long long* __restrict__ list)
+                                                        double* __restrict__ pvalue, unsigned long long* __restrict__ list,
+                                                        const double* __restrict__ log_int)
 {
   const int lane = (int)(threadIdx.x & 63);
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -2012,7 +2013,26 @@ __global__ void __launch_bounds__(256) k_refine_pvalues(const double2* __restric
       pvalue[i] = kmd::igamc_half<kmd::libm_rounded>(lr, lg_half);
     }
     const unsigned long long mask = __ballot(listed);
-    if (mask)
+    if (mask && !list)
+    {
+      // a small call (no list was allocated): the wave takes its records beyond the table one at a time, here
+      unsigned long long todo = mask;
+      while (todo)
+      {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint64_t c = (uint64_t)__shfl((unsigned long long)sum_c, src, 64), k = (uint64_t)__shfl((unsigned long long)sum_k, src, 64);
+        double2 tc, tk;
+        if (c < lf_n) tc = tab[c]; else { tc.x = lf_running_sum_table(log_int, c, lane); tc.y = log_int[c]; }
+        if (k < lf_n) tk = tab[k]; else { tk.x = lf_running_sum_table(log_int, k, lane); tk.y = log_int[k]; }
+        if (lane == src)
+        {
+          const double lr = kmd::lr_from_sums<kmd::libm_rounded>(c, k, tc.x, tk.x, tc.y, tk.y, dT, dTc, dTk);
+          pvalue[i] = kmd::igamc_half<kmd::libm_rounded>(lr, lg_half);
+        }
+      }
+    }
+    else if (mask)
     {
       unsigned long long base = 0;
       if (lane == 0) base = atomicAdd(&list[0], (unsigned long long)__popcll(mask));
@@ -2115,14 +2135,22 @@ extern "C" int kmd_pvalues_refine(const kmd_model* m, size_t n, const double* d_
   KMD_REQUIRE(d_mean_control && d_mean_case && d_pvalue, "kmd_pvalues_refine: the two means and the p-values are needed");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double* log_int = m->d_log_int;
+  const double2* tab = reinterpret_cast<const double2*>(m->d_tab);
+  size_t grid = (n + 255) / 256;
+  if (grid > (size_t)m->n_cu * 8) grid = (size_t)m->n_cu * 8;
+  if (n <= 2048)
+  {
+    // a handful of records (the IModel plugin refines one per call): one launch, nothing allocated
+    hipLaunchKernelGGL(k_refine_pvalues, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
+                       (unsigned long long)n, d_mean_control, d_mean_case, d_pvalue, static_cast<unsigned long long*>(nullptr), log_int);
+    KMD_HIP(hipGetLastError());
+    return KMD_OK;
+  }
   void* list = nullptr;
   KMD_HIP(hipMallocAsync(&list, (1 + 3 * n) * sizeof(unsigned long long), st));
   KMD_HIP(hipMemsetAsync(list, 0, sizeof(unsigned long long), st));
-  size_t grid = (n + 255) / 256;
-  if (grid > (size_t)m->n_cu * 8) grid = (size_t)m->n_cu * 8;
-  const double2* tab = reinterpret_cast<const double2*>(m->d_tab);
   hipLaunchKernelGGL(k_refine_pvalues, dim3((unsigned)grid), dim3(256), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
-                     (unsigned long long)n, d_mean_control, d_mean_case, d_pvalue, static_cast<unsigned long long*>(list));
+                     (unsigned long long)n, d_mean_control, d_mean_case, d_pvalue, static_cast<unsigned long long*>(list), log_int);
   // as many waves as the chip holds at a comfortable occupancy; those without a record leave at once
   const size_t chain_grid = std::min<size_t>(n, (size_t)m->n_cu * 8);
   hipLaunchKernelGGL(k_refine_chain, dim3((unsigned)chain_grid), dim3(128), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
