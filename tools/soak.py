@@ -33,15 +33,18 @@ print("soak seed", a.seed, flush=True)
 DEV = {"raw_abs": 0.0, "raw_rel": 0.0, "ref_rel_in": 0.0, "ref_abs_in": 0.0, "in_rows": 0, "in_equal": 0, "beyond_abs": 0.0, "beyond_rel": 0.0, "beyond_rows": 0}
 
 
-def fused_case(streams, nc, thr, lf_n):
+def fused_case(streams, nc, thr, lf_n, two=False):
     """tests/test_gpu_tilemerge.run_fused with the p-values MEASURED: everything else exact; p as the filter wrote it, then
     after kmd_pvalues_refine -- rows with both sums inside the table apart from the others"""
     S = len(streams)
-    want, wlo = oracle.merge_partition(streams)
+    if two:
+        want, wlo, whi = oracle.merge_partition2(streams)
+    else:
+        want, wlo = oracle.merge_partition(streams)
     tcs, tks = totals_of(want, nc)
     ref = oracle.diff_partition(want, OL.LAYOUT_ROWS, nc, S - nc, int(tcs.sum()), int(tks.sum()), oracle.lf_table(lf_n), thr)
     model = K.PoissonLikelihood(nc, S - nc, tcs, tks, lf_n)
-    acc = K.SurvivorAccumulator(max(want.shape[0], 1))
+    acc = K.SurvivorAccumulator(max(want.shape[0], 1), kmer_limbs=2 if two else 1)
     K.merge_filter(K.StreamSet(streams), K.diff_observer(model, acc, thr))
     n = acc.finish(by_kmer=True)
     got = acc.get()
@@ -49,6 +52,8 @@ def fused_case(streams, nc, thr, lf_n):
     assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == ref["counters"] and int(c[0]) == want.shape[0]
     rr = ref["row"].astype(np.int64)
     assert n == len(rr) and got["kmer_lo"].tolist() == wlo[rr].tolist() and got["sign"].tolist() == ref["sign"].tolist()
+    if two:
+        assert got["kmer_hi"].tolist() == whi[rr].tolist()
     assert got["mean_control"].tolist() == ref["mean_control"].tolist() and got["mean_case"].tolist() == ref["mean_case"].tolist()
     if n == 0:
         return
@@ -242,26 +247,34 @@ while time.time() - t0 < a.seconds:
             universe = np.unique(np.concatenate([universe, np.array([0, 2 ** 64 - 1], dtype=np.uint64)]))
         pres = rng.uniform(0.01, 1.0, S) if rng.random() < 0.5 else np.full(S, rng.uniform(0.02, 0.9))
         empty = tuple(int(x) for x in rng.choice(S, size=int(rng.integers(0, max(1, S // 3))), replace=False)) if S > 2 else ()
-        streams = make_streams(rng, universe, S, pres, count_hi=int(rng.integers(2, 3000)), empty=empty)
+        two = rng.random() < 0.25                          # two-limb k-mers (32 < k <= 64): a few high limbs, sorted (hi, lo)
+        hi = None
+        if two and len(universe):
+            hi = np.sort(rng.integers(0, int(rng.choice([2, 5, 1 << 62])), len(universe), dtype=np.uint64))
+            order = np.lexsort((universe, hi))
+            universe, hi = universe[order], hi[order]
+        else:
+            two = False
+        streams = make_streams(rng, universe, S, pres, count_hi=int(rng.integers(2, 3000)), empty=empty, hi=hi)
         if sum(len(t[0]) for t in streams) == 0:
             continue
         if rng.random() < 0.2:
             for s in range(S):
-                km, cnt = streams[s]
+                km, cnt = streams[s][0], streams[s][1]
                 if len(cnt):
                     cnt = cnt.copy()
                     cnt[rng.integers(0, len(cnt), 2)] = np.uint32(3_000_000_000)
-                    streams[s] = (km, cnt)
-        want, _ = oracle.merge_partition(streams)
+                    streams[s] = (km, cnt) + tuple(streams[s][2:])
+        want = oracle.merge_partition2(streams)[0] if two else oracle.merge_partition(streams)[0]
         tcs, tks = totals_of(want, nc)
         if int(tcs.sum()) == 0 or int(tks.sum()) == 0:
             continue
         thr, lf_n = float(rng.choice([1.0, 0.3, 1e-2, 1e-4, 1e-6, 1e-9])), int(rng.choice([10000, 300, 50]))
         try:
-            fused_case(streams, nc, thr, lf_n)
+            fused_case(streams, nc, thr, lf_n, two=two)
         except AssertionError:
             np.savez("gpurun_out/soak_fail.npz", nc=nc, thr=thr, lf_n=lf_n, **{"k%d" % i: t[0] for i, t in enumerate(streams)},
-                     **{"c%d" % i: t[1] for i, t in enumerate(streams)})
+                     **{"c%d" % i: t[1] for i, t in enumerate(streams)}, **({"h%d" % i: t[2] for i, t in enumerate(streams)} if two else {}))
             print("FAILED: S=%d nc=%d n=%d mode=%d thr=%g lf_n=%d count max %d" % (S, nc, n, mode, thr, lf_n, max(int(t[1].max(initial=0)) for t in streams)), flush=True)
             raise
         n_fused += 1
