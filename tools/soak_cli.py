@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: `kmdiff-hip diff` on random kmtricks run directories against the oracle's pipeline (per-partition merge +
 PoissonLikelihood::process + threshold, then the corrector), beyond the fixed-seed cases of tests/test_gpu_cli.py:
-1..12 samples a side, 1..6 partitions of 0..20 000 k-mers (some samples or whole partitions empty), k = 11..32, counts to
+1..12 samples a side, 1..6 partitions of 0..20 000 k-mers (some samples or whole partitions empty), k = 11..64 (one and two limbs), counts to
 70 000, all five corrections, thresholds, -t, --devices 1|2, packed or --raw-transfer, fused or --matrix-path.
 Held: summary counts, and both FASTA files record by record (k-mer, rank, means; p as printed, 6 digits).
 usage: python3 tools/soak_cli.py [--seconds 300] [--seed N]"""
@@ -34,15 +34,22 @@ try:
     while time.time() - t0 < a.seconds:
         nc, nk = int(rng.integers(1, 13)), int(rng.integers(1, 13))
         S = nc + nk
-        k = int(rng.choice([11, 15, 20, 27, 31, 32]))
+        k = int(rng.choice([11, 15, 20, 27, 31, 32, 33, 47, 63, 64]))
+        two = k > 32
         n_parts = int(rng.integers(1, 7))
         count_hi = int(rng.choice([3, 40, 255, 256, 1000, 70000]))
         effect = float(rng.choice([1.0, 2.0, 6.0]))
-        parts, mats, kms = [], [], []
+        parts, mats, kms, his = [], [], [], []
         for p in range(n_parts):
             n = 0 if rng.random() < 0.1 else int(rng.integers(1, 20001))
             lo = np.unique(rng.integers(0, 1 << (2 * k), n, dtype=np.uint64)) if 2 * k < 64 else np.unique(rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64))
             n = len(lo)
+            hi = None
+            if two:                                           # the high limb holds the 2 (k - 32) bits above the low 64; sorted (hi, lo)
+                top = 1 << (2 * (k - 32))
+                hi = np.sort(rng.integers(0, min(top, int(rng.choice([2, 7, top]))), n, dtype=np.uint64) if top < (1 << 63) else rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2))
+                order = np.lexsort((lo, hi))
+                lo, hi = lo[order], hi[order]
             host = rng.integers(1, count_hi + 1, (n, S)).astype(np.uint32)
             if effect > 1.0:
                 up = rng.random(n) < 0.02
@@ -53,9 +60,14 @@ try:
                     host[:, s] = 0                            # a sample without k-mers in this partition
             keep = host.sum(axis=1) > 0                       # a k-mer nobody holds is in no file
             host, lo = host[keep], lo[keep]
-            parts.append([(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(S)])
+            if two:
+                hi = hi[keep]
+                parts.append([(lo[host[:, s] > 0], host[host[:, s] > 0, s], hi[host[:, s] > 0]) for s in range(S)])
+            else:
+                parts.append([(lo[host[:, s] > 0], host[host[:, s] > 0, s]) for s in range(S)])
             mats.append(host)
             kms.append(lo)
+            his.append(hi)
         totals = np.sum([m.sum(axis=0, dtype=np.uint64) for m in mats], axis=0) if mats else np.zeros(S, np.uint64)
         if int(totals[:nc].sum()) == 0 or int(totals[nc:].sum()) == 0:
             continue
@@ -73,7 +85,11 @@ try:
             args += ["--matrix-path"]
         out = os.path.join(tmp, "out%d" % n_runs)
         s, _ = run_cli(args, out)
-        surv, keep, total = oracle_pipeline(o, nc, nk, mats, kms, alpha / cutoff, correction, alpha)
+        # (oracle_pipeline carries one limb per survivor: give it the row's index in the job, look both limbs up afterwards)
+        base_of = np.cumsum([0] + [len(x) for x in kms])
+        surv, keep, total = oracle_pipeline(o, nc, nk, mats, [np.arange(base_of[i], base_of[i + 1], dtype=np.uint64) for i in range(len(kms))], alpha / cutoff, correction, alpha)
+        all_lo = np.concatenate(kms) if kms else np.zeros(0, np.uint64)
+        all_hi = np.concatenate(his) if two else None
         tag = (a.seed, n_runs, args)
         assert s["total_kmers"] == total and s["n_sig"] == len(surv["p"]) and s["kept"] == int(keep.sum()), (tag, s, total, len(surv["p"]), int(keep.sum()))
         order = list(range(len(keep)))
@@ -87,7 +103,8 @@ try:
             got = read_fasta(os.path.join(out, "%s_kmers.fasta" % name))
             assert len(got) == len(want[name]), (tag, name, len(got), len(want[name]))
             for j, (i, (hdr, seq)) in enumerate(zip(want[name], got)):
-                assert seq == KF.kmer_to_string(surv["kmer"][i], k), (tag, name, j)
+                at = int(surv["kmer"][i])
+                assert seq == (KF.kmer_to_string2(all_hi[at], all_lo[at], k) if two else KF.kmer_to_string(all_lo[at], k)), (tag, name, j)
                 f = hdr[1:].split("_")
                 assert f[0] == str(j) and f[2] == "control=%d" % int(surv["mc"][i]) and f[3] == "case=" + fmt_shortest(surv["mk"][i]), (tag, hdr)
                 pv = float(f[1].split("=")[1])
