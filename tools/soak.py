@@ -25,6 +25,7 @@ from test_gpu_tilemerge import make_streams, run_fused         # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=300)
 ap.add_argument("--seed", type=int, default=int(time.time()))
+ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: by --seconds alone): the same cases on every box")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 oracle = OL.load()
@@ -219,7 +220,9 @@ def popstrat_case():
 
 
 n_ps = 0
-while time.time() - t0 < a.seconds:
+n_cases = 0
+while time.time() - t0 < a.seconds and (a.cases == 0 or n_cases < a.cases):
+    n_cases += 1
     kind = rng.integers(0, 19)
     if kind >= 16:
         popstrat_case()

@@ -24,6 +24,7 @@ from test_gpu_cli import run_cli, read_fasta, fmt_shortest, oracle_pipeline     
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=300)
 ap.add_argument("--seed", type=int, default=int(time.time()))
+ap.add_argument("--cases", type=int, default=0, help="stop after this many runs (0: by --seconds alone): the same runs on every box")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 o = OL.load()
@@ -31,7 +32,7 @@ print("cli soak seed", a.seed, flush=True)
 t0, n_runs, n_kept = time.time(), 0, 0
 tmp = tempfile.mkdtemp(prefix="kmd_soak_")
 try:
-    while time.time() - t0 < a.seconds:
+    while time.time() - t0 < a.seconds and (a.cases == 0 or n_runs < a.cases):
         nc, nk = int(rng.integers(1, 13)), int(rng.integers(1, 13))
         S = nc + nk
         k = int(rng.choice([11, 15, 20, 27, 31, 32, 33, 47, 63, 64]))
