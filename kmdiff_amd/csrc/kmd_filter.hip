@@ -1944,7 +1944,7 @@ extern "C" int kmd_poisson_process(const kmd_model* m, const kmd_tile* tile, dou
 // The filters evaluate the two null-hypothesis logarithms and Cephes' exp / log with the device's libm, whose last bit may
 // differ from glibc's; `k * log(lambda)` (model.hpp:137) multiplies that bit by the count sum, so the p-value of a record
 // deviates from a glibc-built reference's by ~1e-16 x sum relative in LR -- 1e-10 absolute on p is reached at sums of
-// ~10^4 when p is of order 1 (tools/soak.py found 1.1e-10 at p = 0.92, sums 7155 + 8169).  The decisions are guarded
+// ~10^4 when p is of order 1 (tests/soak.py found 1.1e-10 at p = 0.92, sums 7155 + 8169).  The decisions are guarded
 // separately (k_resolve_near); this pass is for the NUMBER: each record's two sums are recovered from its two means
 // (mean_case IS the case sum; mean_control = fl(fl(sc Tk) / Tc) is inverted and checked by re-evaluating it) and the chain
 // of model.hpp:147-161 is repeated with correctly rounded log / exp (kmd_ddmath.h), as k_resolve_near does for the rows

@@ -6,7 +6,7 @@
   * kmd_popstrat_apply on random designs (samples, principal components, iteration limits, effect sizes)
   * kmd_pack_block / kmd_unpack_streams round trips on random streams
   * kmd_correct_sharded over 2..9 virtual ranks == kmd_correct over the whole list, all correctors
-usage: python3 tools/soak.py [--seconds 300] [--seed N]      (prints one line per 50 cases; any mismatch raises)"""
+usage: python3 tests/soak.py [--seconds 300] [--seed N]      (prints one line per 50 cases; any mismatch raises)"""
 import argparse
 import os
 import sys

@@ -4,7 +4,7 @@ PoissonLikelihood::process + threshold, then the corrector), beyond the fixed-se
 1..12 samples a side, 1..6 partitions of 0..20 000 k-mers (some samples or whole partitions empty), k = 11..64 (one and two limbs), counts to
 70 000, all five corrections, thresholds, -t, --devices 1|2, packed or --raw-transfer, fused or --matrix-path.
 Held: summary counts, and both FASTA files record by record (k-mer, rank, means; p as printed, 6 digits).
-usage: python3 tools/soak_cli.py [--seconds 300] [--seed N]"""
+usage: python3 tests/soak_cli.py [--seconds 300] [--seed N]"""
 import argparse
 import os
 import shutil

@@ -238,7 +238,7 @@ def test_group_kernel_equals_lane_kernel(K, oracle, monkeypatch, nc, nk, npc, st
 
 @pytest.mark.parametrize("nc,nk,npc,seed", [(43, 3, 4, 1), (43, 3, 4, 2), (50, 2, 3, 3), (12, 40, 6, 4)])
 def test_rows_whose_p_value_hangs_on_the_last_bit_of_pow(K, oracle, nc, nk, npc, seed):
-    """tools/soak.py's find: the DEFAULT design (no --stand) with a few samples on one side.  One row in ~3000 came out at
+    """tests/soak.py's find: the DEFAULT design (no --stand) with a few samples on one side.  One row in ~3000 came out at
     p = 5e-5 on the device and p = 1 in the oracle -- and the oracle itself gives either, depending on one ulp of the pow()
     in its sigmoid (kmdo_sigmoid_jitter).  Such rows are no parity failure and no parity success: they are counted.  Every
     other row keeps the bars (1e-10 absolute, 1e-7 relative), and there are few of the former."""

@@ -2,7 +2,7 @@
 a glibc-built reference gives them (PoissonLikelihood::process, include/kmdiff/model.hpp:142-176, with
 LogFactorialTable::operator[], log_factorial_table.hpp:14-18 / log_factorial_table.cpp:13-22).
 The bar of the other parity tests (1e-10 absolute / 1e-9 relative on p) is what the filters' own p-values meet in the
-regimes those tests cover; tools/soak.py found its edge (1.1e-10 at p = 0.92 with count sums of ~7000; 4.7e-10 relative
+regimes those tests cover; tests/soak.py found its edge (1.1e-10 at p = 0.92 with count sums of ~7000; 4.7e-10 relative
 with sums beyond the table).  After this pass the bar is: bit-equal to the oracle in >= 99 % of the records, and the rest
 (where glibc's own log is one ulp off the rounded value) within 1e-9 relative / 1e-10 absolute (measured over 1.2 x 10^7 soak records: 2.5e-10 / 2.6e-11)."""
 import ctypes as C

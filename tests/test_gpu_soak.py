@@ -1,4 +1,4 @@
-"""The randomized soaks (tools/soak.py: every library entry point against the oracle on random inputs; tools/soak_cli.py:
+"""The randomized soaks (tests/soak.py: every library entry point against the oracle on random inputs; tests/soak_cli.py:
 `kmdiff-hip diff` on random run directories against the oracle's pipeline) for a fixed number of cases at a fixed seed (the same cases on every box) -- the tools
 stay runnable, and every GPU test run adds a few dozen random cases to the fixed ones.  PARITY.md has what the long runs found."""
 import os
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_soak_tools_run_clean(tool, cases, word, tmp_path):
     env = dict(os.environ)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)          # (where a failing case would be saved)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--cases", str(cases), "--seconds", "600", "--seed", "20261003"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", tool), "--cases", str(cases), "--seconds", "600", "--seed", "20261003"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert word in r.stdout
