@@ -15,6 +15,9 @@
 #include <mutex>
 #include <new>
 #include <vector>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 namespace {
 thread_local std::string g_last_error;
@@ -803,3 +806,51 @@ int kmd_copy_probe(void* d_dst, const void* d_src, size_t bytes, void* stream)
 }
 
 } // extern "C"
+
+// dev (KMD_ABORT_TRACE=1 | <file> | fd:<n>): the native stack of whoever calls abort() -- the HIP runtime, libstdc++'s
+// terminate, an assert -- written to stderr, and to <file> (appended) or descriptor <n> if one is named (a test runner may
+// have fd 2 captured), before the handler that was there before (Python's faulthandler, say) or the default takes over.
+#include <fcntl.h>
+namespace {
+int g_abort_trace_fd = -1;
+struct sigaction g_abort_prev;
+void abort_trace(int sig, siginfo_t* info, void* ctx)
+{
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\n[kmdiff_hip] SIGABRT: native backtrace of the aborting thread:\n";
+  for (int fd : { 2, g_abort_trace_fd })
+  {
+    if (fd < 0) continue;
+    (void)!write(fd, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, fd);
+  }
+  if ((g_abort_prev.sa_flags & SA_SIGINFO) && g_abort_prev.sa_sigaction) { g_abort_prev.sa_sigaction(sig, info, ctx); }
+  else if (!(g_abort_prev.sa_flags & SA_SIGINFO) && g_abort_prev.sa_handler != SIG_DFL && g_abort_prev.sa_handler != SIG_IGN) g_abort_prev.sa_handler(sig);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct abort_trace_installer
+{
+  abort_trace_installer()
+  {
+    const char* e = std::getenv("KMD_ABORT_TRACE");
+    if (!e || !*e) return;
+    if (std::strncmp(e, "fd:", 3) == 0)
+    {
+      g_abort_trace_fd = std::atoi(e + 3);
+      // (a child process inherits the variable, not the descriptor: only one that is open NOW is written to)
+      if (g_abort_trace_fd <= 2 || fcntl(g_abort_trace_fd, F_GETFD) == -1) g_abort_trace_fd = -1;
+    }
+    else if (e[0] == '/' || e[0] == '.') g_abort_trace_fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    void* warm[4];
+    (void)backtrace(warm, 4);                                  // (loads libgcc now, not inside the handler)
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = abort_trace;
+    sa.sa_flags = SA_SIGINFO;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGABRT, &sa, &g_abort_prev);
+  }
+} g_abort_trace_installer;
+} // namespace

@@ -4,13 +4,23 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-
+# An abort() of the test process was seen three times in ~45 full GPU suite runs of round 4 -- always in
+# test_merge_filter_partitions_in_flight, never with `-s`, never when the test is looped on its own 300 times -- and nothing
+# of it reached the log but Python's own frames: stderr is captured.  The library writes the native stack of the aborting
+# thread to a descriptor it is told (kmd_api.hip, abort_trace): the one pytest keeps of the real stderr (pytest_configure).
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if "KMD_ABORT_TRACE" not in os.environ:
+        fd = 2
+        try:                                     # the saved real stderr of the global capture (private to pytest: best effort)
+            cap = config.pluginmanager.getplugin("capturemanager")._global_capturing
+            if cap is not None and cap.err is not None and hasattr(cap.err, "targetfd_save"):
+                fd = os.dup(cap.err.targetfd_save)
+                os.set_inheritable(fd, False)
+        except Exception:
+            fd = 2
+        os.environ["KMD_ABORT_TRACE"] = "fd:%d" % fd
 
 
 @pytest.fixture(scope="session")

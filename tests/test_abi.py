@@ -107,3 +107,29 @@ def test_headers_are_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_abort_trace_reaches_the_descriptor_it_is_given(tmp_path):
+    """KMD_ABORT_TRACE=fd:<n> (tests/conftest.py gives the library pytest's saved real stderr): a process that aborts with
+    the library loaded leaves the native backtrace of the aborting thread there -- here a file -- and still dies of SIGABRT."""
+    import subprocess
+    import sys
+    out = tmp_path / "trace.txt"
+    code = "\n".join(["import os, sys",
+                      "fd = os.open(%r, os.O_WRONLY | os.O_CREAT, 0o644)" % str(out),
+                      "os.environ['KMD_ABORT_TRACE'] = 'fd:%d' % fd",
+                      "sys.path.insert(0, %r)" % ROOT,
+                      "from kmdiff_amd import _native",
+                      "_native.lib()",
+                      "os.abort()"])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == -6, (r.returncode, r.stderr[-500:])
+    text = out.read_text()
+    assert "[kmdiff_hip] SIGABRT: native backtrace" in text and "abort" in text
+
+
+def test_conftest_names_a_descriptor_for_the_abort_trace():
+    v = os.environ.get("KMD_ABORT_TRACE", "")
+    assert v.startswith("fd:") or v.startswith("/") or v == "1", v
+    if v.startswith("fd:"):
+        os.fstat(int(v[3:]))                      # open
