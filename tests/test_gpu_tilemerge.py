@@ -326,9 +326,14 @@ def test_merge_filter_partitions_in_flight(K, oracle):
         jobs.append({"ss": K.StreamSet(streams), "obs": K.diff_observer(model, acc, 0.01), "acc": acc, "st": st,
                      "want_rows": want.shape[0], "want_kmers": wlo[ref["row"].astype(np.int64)].tolist(), "ref": ref, "rows": []})
 
+    # (the threads leave together: when this test aborted -- 3 times in ~45 suite runs, DESIGN 10 -- ONE worker was still
+    # inside its call and the others had just exited; a thread's exit tears down the HIP runtime's per-thread state)
+    all_done = threading.Barrier(len(jobs))
+
     def work(job, reps):
         for _ in range(reps):
             job["rows"].append(K.merge_filter(job["ss"], job["obs"], stream=job["st"]))
+        all_done.wait()
     th = [threading.Thread(target=work, args=(job, 4)) for job in jobs]
     [t.start() for t in th]
     [t.join() for t in th]

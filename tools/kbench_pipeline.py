@@ -139,11 +139,13 @@ if a.overlap > 1:
         K._native.check(lib.kmd_stream_create(C.byref(st)), "stream")
         acc_t = K.SurvivorAccumulator(1 << 20)
         workers.append((st, acc_t, K.diff_observer(model, acc_t, 5e-7)))
-    def work(w, k):
+    def work(w, k, all_done):
         for _ in range(k):
             K.merge_filter(ss, w[2], stream=w[0])
+        all_done.wait()                                    # (the threads leave together: DESIGN 10)
     def run_all(k):
-        th = [threading.Thread(target=work, args=(w, k)) for w in workers]
+        all_done = threading.Barrier(len(workers))
+        th = [threading.Thread(target=work, args=(w, k, all_done)) for w in workers]
         for x in th: x.start()
         for x in th: x.join()
         for w in workers: lib.kmd_stream_sync(w[0])
