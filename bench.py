@@ -188,13 +188,11 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
         acc_t = K.SurvivorAccumulator(cap)
         workers.append((st, acc_t, K.diff_observer(model, acc_t, THRESHOLD / CUTOFF, NC, NK), sets[w_i % n_distinct]))
 
-    def work(w, k, all_done):
+    def work(w, k):
         for _ in range(k):
             K.merge_filter(w[3], w[2], stream=w[0])
-        all_done.wait()                                    # (no thread exits while another is inside a call: tests/test_gpu_tilemerge.py)
     def run_all(k):
-        all_done = threading.Barrier(len(workers))
-        threads = [threading.Thread(target=work, args=(w, k, all_done)) for w in workers]
+        threads = [threading.Thread(target=work, args=(w, k)) for w in workers]
         for t in threads:
             t.start()
         for t in threads:

@@ -24,7 +24,10 @@
 extern "C" {
 #endif
 
-#define KMD_ABI_VERSION 2
+/* 3: kmd_transport gained `abort`; kmd_transport_abort; (2 -> 3 also covers round 4's additions: kmd_correct_sharded,
+ * kmd_pack_block(_bound), kmd_unpack_streams, kmd_pvalues_refine, kmd_synth_streams, kmd_transport_local_*).  A host
+ * checks kmd_abi_version() == KMD_ABI_VERSION before it binds anything else. */
+#define KMD_ABI_VERSION 3
 
 typedef enum {
   KMD_OK = 0,
@@ -239,7 +242,7 @@ int kmd_correct_from_rank(int correction, double threshold, uint64_t total_kmers
  * The wire: two collectives over DEVICE buffers, called by every rank in the same order; each returns when the result
  * is in the caller's buffer (they synchronise `stream` themselves).  Two transports come with the library --
  * kmd_transport_local_create (N host threads of one process: `kmdiff-hip diff --devices N`) and, in
- * libkmdiff_hip_rccl.so, kmd_transport_rccl_create (one process per GPU: ncclAllReduce / ncclAllGather over xGMI); a
+ * libkmdiff_hip_rccl.so, kmd_transport_rccl_init (one process per GPU: ncclAllReduce / ncclAllGather over xGMI); a
  * host with a wire of its own fills the struct itself (kmdiff_amd/dist.py does, with torch.distributed). */
 typedef struct kmd_transport {
   void* ctx;
@@ -248,6 +251,9 @@ typedef struct kmd_transport {
   int (*allreduce_u64)(void* ctx, uint64_t* d_buf, size_t n, void* stream);
   /* d_recv[r * bytes .. (r + 1) * bytes) = rank r's d_send; `bytes` is the same on every rank */
   int (*allgather)(void* ctx, const void* d_send, void* d_recv, size_t bytes, void* stream);
+  /* optional (may be NULL): this rank cannot go on -- the other ranks' pending and later collectives return an error
+   * instead of waiting for it (kmd_correct_sharded calls it on every error return once world > 1) */
+  void (*abort)(void* ctx);
 } kmd_transport;
 
 /* kmd_correct for the survivors of THIS rank in a run of t->world ranks (t == NULL: one rank):
@@ -263,6 +269,9 @@ int kmd_correct_sharded(const kmd_transport* t, int correction, double threshold
  * are called by a host thread of its own that has made rank r's device current (several ranks may share a device). */
 int kmd_transport_local_create(int world, kmd_transport* out);
 int kmd_transport_local_destroy(int world, kmd_transport* t);
+/* A rank that fails OUTSIDE a collective (its device could not be set, an allocation failed before the exchange ...)
+ * says so, so that the others do not wait for it for ever: t->abort(t->ctx) if the transport has one. */
+int kmd_transport_abort(const kmd_transport* t);
 
 /* ---- stage 0: k-way merge of one partition -------------------------------------------------
  * Replaces km::KmerMerger<KSIZE,CMAX>(paths, ab_mins = 1.., k, r_min = 1, save_if = 0).merge(obs)

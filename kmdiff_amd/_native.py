@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KMD_LIB") or os.path.join(_HERE, "lib", "libkmdiff_hip.so")
 
 KMD_OK = 0
+ABI_VERSION = 3           # KMD_ABI_VERSION of include/kmdiff_hip.h (tests/test_abi.py holds the two together)
 KMD_E_OVERFLOW = -4
 SIGN_CONTROL, SIGN_CASE, SIGN_NO = 0, 1, 2
 CORR_NOTHING, CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM = 0, 1, 2, 3, 4
@@ -39,11 +40,12 @@ class Tile(C.Structure):
 # kmd_transport (include/kmdiff_hip.h): the wire of kmd_correct_sharded -- two collectives over device buffers
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ABORT_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class Transport(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int),
-                ("allreduce_u64", ALLREDUCE_FN), ("allgather", ALLGATHER_FN)]
+                ("allreduce_u64", ALLREDUCE_FN), ("allgather", ALLGATHER_FN), ("abort", ABORT_FN)]
 
 
 # name -> (restype, argtypes); the list mirrors include/kmdiff_hip.h and is what
@@ -100,6 +102,7 @@ SIGNATURES = {
                                  C.POINTER(_u64), _vp]),
     "kmd_transport_local_create": (_i, [_i, C.POINTER(Transport)]),
     "kmd_transport_local_destroy": (_i, [_i, C.POINTER(Transport)]),
+    "kmd_transport_abort": (_i, [C.POINTER(Transport)]),
     "kmd_pack_block_bound": (_sz, []),
     "kmd_pack_block": (_sz, [_vp, _vp, C.c_uint32, _vp]),
     "kmd_unpack_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -154,6 +157,15 @@ def lib():
             L = C.CDLL(LIB_PATH)
         except OSError as e:
             raise KmdError("cannot load %s: %s" % (LIB_PATH, e))
+        # (the version first: a stale .so says so instead of failing on the first name it lacks)
+        try:
+            L.kmd_abi_version.restype = C.c_int
+            have = int(L.kmd_abi_version())
+        except AttributeError:
+            have = -1
+        if have != ABI_VERSION:
+            raise KmdError("%s has ABI version %d, this package binds version %d: rebuild it (python -c 'import "
+                           "__graft_entry__ as g; g.build()')" % (LIB_PATH, have, ABI_VERSION))
         for name, (res, args) in list(SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
             fn = getattr(L, name)
             fn.restype = res

@@ -356,6 +356,7 @@ int kmd_model_create(kmd_model** out, int nb_controls, int nb_cases,
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_tab), 2 * n * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m->d_lf, m->h_lf, n * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tab, tab.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);     // (the tables are read from streams that are not ordered against the null stream)
   if (e != hipSuccess)
   {
     if (m->d_lf) (void)hipFree(m->d_lf);
@@ -442,6 +443,8 @@ int ensure_tables(synth_tables& t)
   int dev = 0;
   KMD_HIP(hipGetDevice(&dev));
   KMD_REQUIRE(dev < 16, "kmd_synth: device index >= 16");
+  static std::mutex mu;                                  // (bench's ranks-in-one-process generate from several threads)
+  std::lock_guard<std::mutex> lock(mu);
   if (!g_tables_ready[dev])
   {
     uint32_t* d = nullptr;
@@ -451,6 +454,7 @@ int ensure_tables(synth_tables& t)
     KMD_HIP(hipMemcpy(d + KMD_SYNTH_NJ, KMD_SYNTH_C0, KMD_SYNTH_NJ * 4, hipMemcpyHostToDevice));
     KMD_HIP(hipMemcpy(d + 2 * KMD_SYNTH_NJ, KMD_SYNTH_LEN, KMD_SYNTH_NJ * 4, hipMemcpyHostToDevice));
     KMD_HIP(hipMemcpy(d + 3 * KMD_SYNTH_NJ, KMD_SYNTH_THR, KMD_SYNTH_NTHR * 4, hipMemcpyHostToDevice));
+    KMD_HIP(hipStreamSynchronize(nullptr));
     g_tables[dev] = synth_tables{ d, d + KMD_SYNTH_NJ, d + 2 * KMD_SYNTH_NJ, d + 3 * KMD_SYNTH_NJ };
     g_tables_ready[dev] = true;
   }

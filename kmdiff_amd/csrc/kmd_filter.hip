@@ -1849,9 +1849,22 @@ int kmd::near_list_begin(filter_params& P, hipStream_t stream)
     if (it != g_near_lists.end()) { P.near = it->second; return KMD_OK; }
     if (g_near_lists.size() < kNearListsMax)
     {
+      // The list's count is zeroed ON THE STREAM the filter kernels run on.  (Round 4 zeroed it with hipMemset -- the
+      // null stream, which the library's and its callers' non-blocking streams are not ordered against, and which
+      // returns before the fill has run: a filter launch on a NEW stream could find whatever the fresh allocation held,
+      // k_resolve_near then "resolved" up to 4096 entries of garbage -- log_int[garbage] -- and the queue died of a
+      // memory aperture violation, taking the process with it: the abort of DESIGN 10, seen when several host threads
+      // made their first call on fresh streams right after kmd_release_cache had handed used memory back.)
       void* p = nullptr;
       if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return KMD_OK; }
-      if (hipMemset(p, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return KMD_OK; }
+      static const int init_mode = [] { const char* e = std::getenv("KMD_TEST_NEAR_INIT"); return e ? std::atoi(e) : 0; }();
+      hipError_t e = hipSuccess;
+      // dev / tests: 1 = the fresh list is filled with ones first (what used memory may look like: an initialisation that
+      // is not ordered before the kernels then fails every time, not once in fifteen runs); 2 = that, and round 4's
+      // initialisation on the null stream (the regression test's "old tree")
+      if (init_mode >= 1) { e = hipMemsetAsync(p, 0xFF, bytes, stream); if (e == hipSuccess) e = hipStreamSynchronize(stream); }     // (the ones are THERE before the count is zeroed)
+      if (e == hipSuccess) e = init_mode == 2 ? hipMemset(p, 0, sizeof(unsigned long long)) : hipMemsetAsync(p, 0, sizeof(unsigned long long), stream);
+      if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return KMD_OK; }
       g_near_lists[{ dev, stream }] = static_cast<unsigned long long*>(p);
       P.near = static_cast<unsigned long long*>(p);
       return KMD_OK;

@@ -33,6 +33,7 @@ int rccl_allreduce_u64(void* ctx, uint64_t* d_buf, size_t n, void* stream)
 {
   rccl_ctx* R = static_cast<rccl_ctx*>(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!R->comm) return fail("kmd_transport_rccl", "the communicator was aborted");
   KMD_NCCL(ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, R->comm, st));
   KMD_HIPR(hipStreamSynchronize(st));
   return KMD_OK;
@@ -42,9 +43,18 @@ int rccl_allgather(void* ctx, const void* d_send, void* d_recv, size_t bytes, vo
 {
   rccl_ctx* R = static_cast<rccl_ctx*>(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!R->comm) return fail("kmd_transport_rccl", "the communicator was aborted");
   if (bytes) KMD_NCCL(ncclAllGather(d_send, d_recv, bytes, ncclInt8, R->comm, st));
   KMD_HIPR(hipStreamSynchronize(st));
   return KMD_OK;
+}
+
+// kmd_transport::abort: this rank cannot go on.  ncclCommAbort tears the communicator down without waiting for the
+// peers; theirs then fail (or time out) in RCCL instead of waiting for a collective this rank will never join.
+void rccl_abort(void* ctx)
+{
+  rccl_ctx* R = static_cast<rccl_ctx*>(ctx);
+  if (R->comm) { (void)ncclCommAbort(R->comm); R->comm = nullptr; }
 }
 
 } // namespace
@@ -72,7 +82,7 @@ int kmd_transport_rccl_init(kmd_transport* out, int world, int rank, const void*
   KMD_NCCL(ncclCommInitRank(&comm, world, id, rank));            // (the calling thread's current device)
   rccl_ctx* R = new rccl_ctx { comm, true };
   out->ctx = R; out->rank = rank; out->world = world;
-  out->allreduce_u64 = rccl_allreduce_u64; out->allgather = rccl_allgather;
+  out->allreduce_u64 = rccl_allreduce_u64; out->allgather = rccl_allgather; out->abort = rccl_abort;
   return KMD_OK;
 }
 
@@ -85,7 +95,7 @@ int kmd_transport_rccl_wrap(kmd_transport* out, void* nccl_comm)
   KMD_NCCL(ncclCommCount(comm, &world));
   rccl_ctx* R = new rccl_ctx { comm, false };
   out->ctx = R; out->rank = rank; out->world = world;
-  out->allreduce_u64 = rccl_allreduce_u64; out->allgather = rccl_allgather;
+  out->allreduce_u64 = rccl_allreduce_u64; out->allgather = rccl_allgather; out->abort = rccl_abort;
   return KMD_OK;
 }
 
@@ -93,7 +103,7 @@ int kmd_transport_rccl_destroy(kmd_transport* t)
 {
   if (!t || !t->ctx) return KMD_OK;
   rccl_ctx* R = static_cast<rccl_ctx*>(t->ctx);
-  if (R->own) (void)ncclCommDestroy(R->comm);
+  if (R->own && R->comm) (void)ncclCommDestroy(R->comm);
   delete R;
   t->ctx = nullptr;
   return KMD_OK;

@@ -142,9 +142,10 @@ struct scratch
 
 } // namespace
 
-extern "C" int kmd_correct_sharded(const kmd_transport* t, int correction, double threshold, const uint64_t* counters_local,
-                                   uint64_t* counters_global, const double* d_pvalue, const int32_t* d_sign, size_t n,
-                                   uint8_t* d_keep, uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream)
+namespace {
+int correct_sharded(const kmd_transport* t, int correction, double threshold, const uint64_t* counters_local,
+                    uint64_t* counters_global, const double* d_pvalue, const int32_t* d_sign, size_t n,
+                    uint8_t* d_keep, uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream)
 {
   KMD_REQUIRE(counters_local, "kmd_correct_sharded: NULL counters");
   KMD_REQUIRE(correction >= KMD_CORR_NOTHING && correction <= KMD_CORR_HOLM, "kmd_correct_sharded: bad correction type");
@@ -263,6 +264,25 @@ extern "C" int kmd_correct_sharded(const kmd_transport* t, int correction, doubl
   if (n_case) *n_case = h_t[0] - h_t[1];
   return KMD_OK;
 }
+} // namespace
+
+// Every rank calls this, and the collectives inside are matched calls: a rank that leaves early -- an argument refused,
+// an allocation that failed, a collective that returned an error -- would leave the others waiting for it.  It tells them
+// (kmd_transport::abort) on every error return once there is more than one rank.
+extern "C" int kmd_correct_sharded(const kmd_transport* t, int correction, double threshold, const uint64_t* counters_local,
+                                   uint64_t* counters_global, const double* d_pvalue, const int32_t* d_sign, size_t n,
+                                   uint8_t* d_keep, uint64_t* n_kept, uint64_t* n_control, uint64_t* n_case, void* stream)
+{
+  const int rc = correct_sharded(t, correction, threshold, counters_local, counters_global, d_pvalue, d_sign, n, d_keep, n_kept, n_control, n_case, stream);
+  if (rc != KMD_OK && t && t->world > 1 && t->abort) t->abort(t->ctx);
+  return rc;
+}
+
+extern "C" int kmd_transport_abort(const kmd_transport* t)
+{
+  if (t && t->abort) t->abort(t->ctx);
+  return KMD_OK;
+}
 
 // ---- the in-process transport: N host threads of one process, one per rank -----------------------------------
 // Every rank's thread calls the collective; a generation barrier lines them up, the data moves with device
@@ -277,13 +297,23 @@ struct local_hub
   unsigned long long generation = 0;
   std::vector<const void*> send;
   std::vector<int> dev;
-  bool failed = false;
-  void barrier()
+  bool failed = false;                            // a rank's copy failed inside a collective (everybody still arrives)
+  bool aborted = false;                           // a rank left for good (kmd_transport::abort): nobody waits any more
+  // false: a rank has given up -- the collective in progress, and every later one, fails on all ranks
+  bool barrier()
   {
     std::unique_lock<std::mutex> lock(mu);
+    if (aborted) return false;
     const unsigned long long gen = generation;
     if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-    else cv.wait(lock, [&] { return generation != gen; });
+    else cv.wait(lock, [&] { return generation != gen || aborted; });
+    return !aborted;
+  }
+  void abort()
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    aborted = true;
+    cv.notify_all();
   }
 };
 
@@ -306,15 +336,20 @@ int local_allgather(void* ctx, const void* d_send, void* d_recv, size_t bytes, v
     H.dev[(size_t)R->rank] = dev;
     if (e != hipSuccess) H.failed = true;
   }
-  H.barrier();
+  if (!H.barrier()) { kmd::set_error("kmd_transport_local: another rank gave up"); return KMD_E_HIP; }
+  // (on the caller's stream, and waited for there: a device-to-device hipMemcpy on the null stream may return before
+  // the copy has run, and the callers' non-blocking streams are not ordered against the null stream)
+  hipStream_t st = static_cast<hipStream_t>(stream);
   for (int q = 0; q < H.world && e == hipSuccess && bytes; ++q)
   {
     char* dst = static_cast<char*>(d_recv) + (size_t)q * bytes;
-    if (H.dev[(size_t)q] == dev) e = hipMemcpy(dst, H.send[(size_t)q], bytes, hipMemcpyDeviceToDevice);
-    else e = hipMemcpyPeer(dst, dev, H.send[(size_t)q], H.dev[(size_t)q], bytes);
+    if (H.dev[(size_t)q] == dev) e = hipMemcpyAsync(dst, H.send[(size_t)q], bytes, hipMemcpyDeviceToDevice, st);
+    else e = hipMemcpyPeerAsync(dst, dev, H.send[(size_t)q], H.dev[(size_t)q], bytes, st);
   }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) { std::lock_guard<std::mutex> lock(H.mu); H.failed = true; }
-  H.barrier();                                                 // nobody's send buffer is still being read
+  const bool all_here = H.barrier();                           // nobody's send buffer is still being read
+  if (!all_here) { kmd::set_error("kmd_transport_local: another rank gave up"); return KMD_E_HIP; }
   if (e != hipSuccess) return kmd::hip_fail(e, "kmd_transport_local: copy", __FILE__, __LINE__);
   if (H.failed) { kmd::set_error("kmd_transport_local: another rank failed"); return KMD_E_HIP; }
   return KMD_OK;
@@ -325,7 +360,10 @@ int local_allreduce_u64(void* ctx, uint64_t* d_buf, size_t n, void* stream)
   local_rank* R = static_cast<local_rank*>(ctx);
   const int world = R->hub->world;
   void* d_all = nullptr;
-  KMD_HIP(kmd::scratch_alloc(&d_all, (size_t)world * n * 8));
+  {
+    const hipError_t e_alloc = kmd::scratch_alloc(&d_all, (size_t)world * n * 8);
+    if (e_alloc != hipSuccess) { R->hub->abort(); return kmd::hip_fail(e_alloc, "kmd_transport_local: scratch", __FILE__, __LINE__); }
+  }
   int rc = local_allgather(ctx, d_buf, d_all, n * 8, stream);
   if (rc == KMD_OK)
   {
@@ -340,6 +378,8 @@ int local_allreduce_u64(void* ctx, uint64_t* d_buf, size_t n, void* stream)
   kmd::scratch_free(d_all);
   return rc;
 }
+
+void local_abort(void* ctx) { static_cast<local_rank*>(ctx)->hub->abort(); }
 
 } // namespace
 
@@ -357,6 +397,7 @@ extern "C" int kmd_transport_local_create(int world, kmd_transport* out)
     out[r].ctx = R; out[r].rank = r; out[r].world = world;
     out[r].allreduce_u64 = local_allreduce_u64;
     out[r].allgather = local_allgather;
+    out[r].abort = local_abort;
   }
   return KMD_OK;
 }

@@ -170,7 +170,7 @@ def torch_transport(K):
             return -2
 
     fa, fg = N.ALLREDUCE_FN(allreduce), N.ALLGATHER_FN(allgather)
-    return N.Transport(None, rank, world, fa, fg), (fa, fg)
+    return N.Transport(None, rank, world, fa, fg, N.ABORT_FN()), (fa, fg)      # (no abort: torch.distributed's own timeouts apply)
 
 
 def correct_sharded(K, correction, threshold, local_counters, pvalue_buf, sign_buf, n_local, transport=None):

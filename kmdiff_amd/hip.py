@@ -64,6 +64,7 @@ class DeviceBuffer:
 
     def zero(self):
         check(lib().kmd_memset(self.ptr, 0, self.nbytes, None), "memset")
+        check(lib().kmd_stream_sync(None), "sync")          # (the buffer may next be used on a stream that is not ordered against the null stream)
         return self
 
     def to_host(self, dtype, count=None, offset_bytes=0):

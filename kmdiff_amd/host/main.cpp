@@ -661,6 +661,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
                                 (const uint32_t*)Dp.counts.p, Dp.offs.data(), nullptr), "kmd_pca_sample_streams");
     }
     else if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");        // merge.hpp:150-152
+    bool unresolved_redo = false;                         // the fused pass left near-threshold rows undecided: the matrix way, in pieces
     if (n_rows && plugin)
     {
       // diff_observer::process with the user's model (merge.hpp:68-103): the merged rows come
@@ -711,6 +712,26 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
         if (c[KMD_CNT_SIG] <= fused_cap) break;
         fused_cap = (size_t)c[KMD_CNT_SIG] + (size_t)c[KMD_CNT_SIG] / 4;
       }
+      if (c[KMD_CNT_NEAR_UNRESOLVED] != 0)
+      {
+        // More rows within 1e-8 of the threshold than one launch can list (4096; include/kmdiff_hip.h): the rows beyond
+        // kept the device libm's decision.  The guard's guarantee is restored the long way: the partition is merged
+        // into a matrix and its rows are tested in pieces small enough for every near row to be listed (below).
+        if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] partition %zu: %llu near-threshold rows beyond the list: again, as a matrix in pieces\n", p, (unsigned long long)c[KMD_CNT_NEAR_UNRESOLVED]);
+        const size_t n = D.n;
+        d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
+        if (two_limbs) d_kmer_col_hi.reserve(n * 8);
+        ck(kmd_merge_partition((int)S, (const uint64_t*)D.kmers.p, two_limbs ? (const uint64_t*)D.kmers_hi.p : nullptr,
+                               (const uint32_t*)D.counts.p, D.offs.data(), 4, KMD_LAYOUT_TILED, T, n, d_matrix.p,
+                               (uint64_t*)d_kmer_col.p, two_limbs ? (uint64_t*)d_kmer_col_hi.p : nullptr, &n_rows, nullptr),
+           "kmd_merge_partition");
+        tile = kmd_tile { d_matrix.p, 4, KMD_LAYOUT_TILED, T, (const uint64_t*)d_kmer_col.p,
+                          two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
+        sums_done = false;
+        unresolved_redo = true;
+      }
+      else
+      {
       ns = (size_t)c[KMD_CNT_SIG];
       ck(kmd_pvalues_refine(model, ns, (const double*)d_smc.p, (const double*)d_smk.p, (double*)d_sp.p, nullptr), "pvalues_refine");   // glibc's bits
       ck(kmd_survivors_sort_by_kmer(&sv, ns, nullptr), "sort_by_kmer");                   // reference push order
@@ -738,8 +759,9 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       }
       total_kmers += c[KMD_CNT_TOTAL]; n_sig += ns; n_sig_control += c[KMD_CNT_SIG_CONTROL]; n_sig_case += c[KMD_CNT_SIG_CASE];
       n_near += c[KMD_CNT_NEAR_THRESHOLD];
+      }
     }
-    else if (n_rows)
+    if (n_rows && !plugin && !sums_done)
     {
       // survivor sink sized for the worst case of this partition (every row)
       d_srow.reserve(n_rows * 8); d_skmer.reserve(n_rows * 8); d_sp.reserve(n_rows * 8); d_ssign.reserve(n_rows * 4);
@@ -748,9 +770,35 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
       kmd_survivors sv { (uint64_t*)d_srow.p, (uint64_t*)d_skmer.p, two_limbs ? (uint64_t*)d_skmer_hi.p : nullptr, (double*)d_sp.p, (int32_t*)d_ssign.p,
                          (double*)d_smc.p, (double*)d_smk.p, (size_t)n_rows };
-      ck(kmd_poisson_filter(model, &tile, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
+      // One launch lists up to 4096 rows within 1e-8 of the threshold for the correctly rounded second look; more than
+      // that (KMD_CNT_NEAR_UNRESOLVED) and the partition is tested again in pieces, twice as many each time -- a piece
+      // of 4096 rows cannot overflow the list.  (0 such rows in 10^10 synthetic ones; a threshold that IS some row's
+      // p-value with thousands of equal rows gets here.)
       uint64_t c[KMD_NCOUNTERS];
-      ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+      const size_t unit = tile.layout == KMD_LAYOUT_TILED ? tile.ld : 1;                  // pieces begin on a block of the tiled layout
+      for (size_t pieces = unresolved_redo ? 2 : 1;; pieces *= 2)
+      {
+        size_t rows_per = ((size_t)n_rows + pieces - 1) / pieces;
+        rows_per = std::max<size_t>((rows_per + unit - 1) / unit * unit, unit);
+        if (pieces > 1) ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
+        for (size_t r0 = 0; r0 < (size_t)n_rows; r0 += rows_per)
+        {
+          kmd_tile piece = tile;
+          piece.n_rows = std::min(rows_per, (size_t)n_rows - r0);
+          piece.row_base = tile.row_base + r0;
+          const char* cp = (const char*)tile.d_counts;
+          if (tile.layout == KMD_LAYOUT_TILED) cp += (r0 / tile.ld) * S * tile.ld * (size_t)tile.count_bytes;
+          else if (tile.layout == KMD_LAYOUT_ROWS) cp += r0 * tile.ld * (size_t)tile.count_bytes;
+          else cp += r0 * (size_t)tile.count_bytes;
+          piece.d_counts = cp;
+          if (tile.d_kmer_lo) piece.d_kmer_lo = tile.d_kmer_lo + r0;
+          if (tile.d_kmer_hi) piece.d_kmer_hi = tile.d_kmer_hi + r0;
+          ck(kmd_poisson_filter(model, &piece, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
+        }
+        ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+        if (c[KMD_CNT_NEAR_UNRESOLVED] == 0) break;
+        if (rows_per <= 4096) die("kmd_poisson_filter: near-threshold rows left undecided in a piece of <= 4096 rows");
+      }
       ns = (size_t)c[KMD_CNT_SIG];
       ck(kmd_pvalues_refine(model, ns, (const double*)d_smc.p, (const double*)d_smk.p, (double*)d_sp.p, nullptr), "pvalues_refine");   // glibc's bits
       ck(kmd_survivors_sort_by_row(&sv, ns, nullptr), "sort_by_row");                     // reference push order
@@ -1094,6 +1142,8 @@ void do_correction(const run_context& C, survivors_of_run& O)
       try
       {
         ck(kmd_set_device((opt.device + (int)wi) % C.ndev), "kmd_set_device");
+        if (const char* e = std::getenv("KMD_TEST_FAIL_RANK"))          // dev / tests: this rank fails before the exchange
+          if ((size_t)std::atoi(e) == wi) throw std::runtime_error("KMD_TEST_FAIL_RANK: rank " + std::to_string(wi) + " fails before the exchange");
         const size_t m = mine[wi].size();
         std::vector<double> lp(m); std::vector<int32_t> ls(m); std::vector<uint8_t> lk(m, 0);
         for (size_t j = 0; j < m; ++j) { lp[j] = s_p[mine[wi][j]]; ls[j] = s_sign[mine[wi][j]]; }
@@ -1113,7 +1163,12 @@ void do_correction(const run_context& C, survivors_of_run& O)
         if (m) ck(kmd_memcpy_d2h(lk.data(), b_k.p, m, nullptr), "d2h");
         for (size_t j = 0; j < m; ++j) keep[mine[wi][j]] = lk[j];
       }
-      catch (const std::exception& e) { errors[wi] = e.what(); }
+      catch (const std::exception& e)
+      {
+        // (the other ranks may be inside a collective, waiting for this one: they are told, and fail instead)
+        errors[wi] = e.what();
+        kmd_transport_abort(&T[wi]);
+      }
     };
     {
       std::vector<std::thread> ranks;

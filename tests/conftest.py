@@ -4,10 +4,12 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# An abort() of the test process was seen three times in ~45 full GPU suite runs of round 4 -- always in
-# test_merge_filter_partitions_in_flight, never with `-s`, never when the test is looped on its own 300 times -- and nothing
-# of it reached the log but Python's own frames: stderr is captured.  The library writes the native stack of the aborting
-# thread to a descriptor it is told (kmd_api.hip, abort_trace): the one pytest keeps of the real stderr (pytest_configure).
+for _p in (ROOT, os.path.join(ROOT, "tests")):           # plain `pytest tests/...` from anywhere, not only `python -m pytest` from the root
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+# Should the process ever die under a test (round 4: a GPU queue error, whose message pytest's capture of fd 2 swallowed --
+# tests/test_gpu_tilemerge.py::test_first_filter_launch_on_fresh_streams), the library writes the aborting thread's native
+# stack to a descriptor it is told (kmd_api.hip, abort_trace): the one pytest keeps of the real stderr (pytest_configure).
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_version_without_gpu():
     L = N.lib()
-    assert L.kmd_abi_version() == 2
+    assert L.kmd_abi_version() == 3 == N.ABI_VERSION
     assert L.kmd_status_string(0) == b"ok"
     assert L.kmd_status_string(-4) == b"survivor capacity exceeded"
 
