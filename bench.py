@@ -28,9 +28,12 @@ The JSON line also carries
                  back-to-back calls; `overlapped` = the same with six partitions in flight on streams (and host threads) of
                  their own, per partition; `batched` = twelve partitions (four distinct ones in turn) through
                  kmd_merge_filter_batch (one host thread, six in flight inside the library); `small` = the 4 M-row
-                 partition earlier rounds quoted (single calls only);
-  h2d_inclusive: (N = 1) the headline step with the host-to-device copy of the partition (from page-locked
-                 memory) inside the timed loop -- never `value`.
+                 partition earlier rounds quoted (single calls only); `sparse` = a partition of the MIXED presence profile (every
+                 second row in one or two samples, the others in 95 % of them), single calls and the batch, its own roofline
+                 block; `feed_inclusive` = the first partition again WITH the link: packed streams in page-locked memory ->
+                 async copies -> kmd_unpack_streams -> kmd_merge_filter, double-buffered, beside the link's ceiling;
+  h2d_inclusive: (N = 1) the MATRIX-feed case only (`matrices/` input): the headline step with the host-to-device copy
+                 of the partition's count matrix (from page-locked memory) inside the timed loop, serial -- never `value`.
 """
 import argparse
 import ctypes as C
@@ -125,7 +128,7 @@ def cpu_baseline(rows_per_part, tc, tk):
                       "with the tail function for every row; %d survivors" % (cores, n, c.n_sig)}
 
 
-def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=True):
+def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=True, profile=0, keep=None):
     """Streams -> survivors on one partition of `rows` rows: the per-sample (k-mer, count) streams kmtricks writes
     (records of sample s = the rows with a non-zero count in column s), built on the device (kmd_synth_streams),
     resident in HBM, through kmd_merge_filter.  12 algorithmic bytes per record (8-byte k-mer + 4-byte count, each
@@ -133,11 +136,13 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
     (merge.hpp:265-289)."""
     sets, tot = [], None
     for p in range(n_distinct):
-        ss_p, tot_p = K.synth_streams(SEED, p, rows, NC, NK)
+        ss_p, tot_p = K.synth_streams(SEED, p, rows, NC, NK, profile=profile)
         sets.append(ss_p)
         tot = tot_p if tot is None else tot + tot_p
     ss = sets[0]
     model = K.PoissonLikelihood(NC, NK, tot[:NC], tot[NC:], LOG_FACTORIAL)
+    if keep is not None:                                   # (the feed-inclusive leg sends this partition across the link again)
+        keep["ss"], keep["model"] = ss, model
     cap = max(1 << 16, rows // 100)
     acc = K.SurvivorAccumulator(cap)
     obs = K.diff_observer(model, acc, THRESHOLD / CUTOFF, NC, NK)
@@ -158,11 +163,30 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
                    "fused with the Poisson test; tile plan + boundary search + merge kernel + candidate evaluation, host "
                    "round trip included)",
            "config": {"workload": "%s: 20v20, k=31, %d rows, %d records of 12 bytes (8-byte k-mer + 4-byte count) in 40 per-sample "
-                                  "streams, built on the device (kmd_synth_streams)"
-                                  % ("one configs[2] partition (10^10 rows / 256)" if rows == ROWS_PER_PARTITION else "a reduced partition", rows, ss.total),
+                                  "streams, built on the device (kmd_synth_streams)%s"
+                                  % ("one configs[2] partition (10^10 rows / 256)" if rows == ROWS_PER_PARTITION else "a reduced partition", rows, ss.total,
+                                     "; MIXED presence profile: every second row in one or two samples, the others in 95 % of the samples "
+                                     "(%.1f records per row on average)" % (ss.total / float(rows)) if profile else ""),
                       "rows": rows, "records": ss.total, "samples": NC + NK},
            "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),
            "records_per_s": ss.total / (ms * 1e-3), "bytes_algorithmic": 12 * ss.total, "roofline": roof(gbs), "n_sig": n_sig0}
+    if with_extras == "batched":
+        # (the sparse leg: single calls above, and the batch entry point -- no host threads, no refine timing)
+        accs = [K.SurvivorAccumulator(cap) for _ in range(n_batch)]
+        obs_b = [K.diff_observer(model, a_, THRESHOLD / CUTOFF, NC, NK) for a_ in accs]
+        b_sets = [sets[i % n_distinct] for i in range(n_batch)]
+        K.merge_filter_batch(b_sets, obs_b)
+        K._native.check(lib.kmd_stream_sync(None))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rows_b = K.merge_filter_batch(b_sets, obs_b)
+        ms_b = (time.perf_counter() - t0) / (3 * n_batch) * 1e3
+        assert rows_b == [rows] * n_batch
+        rec_avg = sum(x.total for x in sets) / float(n_distinct)
+        out["batched"] = {"partitions": n_batch, "in_flight": 6, "ms_per_partition": ms_b, "kmers_per_s": rows / (ms_b * 1e-3),
+                          "records_per_s": rec_avg / (ms_b * 1e-3), "what": "kmd_merge_filter_batch, one host thread",
+                          "roofline": roof(12.0 * rec_avg / (ms_b * 1e-3) / 1e9)}
+        return out
     if not with_extras:
         return out
     # beside it, not inside: the optional pass that gives the survivors' p-values the reference's last bit
@@ -239,6 +263,102 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
     return out
 
 
+def feed_leg(K, lib, ss, model, n_parts=4, threads=8):
+    """The path `kmdiff-hip diff` takes, link included: one whole partition's streams as the host hands them over -- packed
+    per 256 records (kmd_pack_stream: what the command's decoder threads write into page-locked memory), kmd_memcpy_h2d_async
+    on a copy stream, kmd_unpack_streams behind the copies, kmd_merge_filter on the unpacked arrays -- double-buffered:
+    the copy of partition i + 1 runs beside the kernels of partition i.  Never `value`."""
+    from concurrent.futures import ThreadPoolExecutor
+    S, offs = ss.n_samples, ss.offs
+    bound = int(lib.kmd_pack_block_bound())
+    t_pack0 = time.perf_counter()
+
+    def pack(s_):
+        a_, b_ = int(offs[s_]), int(offs[s_ + 1])
+        n_ = b_ - a_
+        nb_ = (n_ + 255) // 256
+        if n_ == 0:
+            return np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+        km = ss.kmers.to_host(np.uint64, n_, offset_bytes=a_ * 8)
+        ct = ss.counts.to_host(np.uint32, n_, offset_bytes=a_ * 4)
+        out_ = np.empty(nb_ * bound, dtype=np.uint8)
+        tab_ = np.empty(nb_, dtype=np.uint32)
+        got = int(lib.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, n_, out_.ctypes.data, out_.nbytes, tab_.ctypes.data))
+        assert got > 0 and got % 8 == 0
+        return out_[:got].copy(), tab_
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(pack, range(S)))
+    t_pack = time.perf_counter() - t_pack0
+    base = np.zeros(S + 1, dtype=np.uint64)
+    for s_ in range(S):
+        base[s_ + 1] = base[s_] + parts[s_][0].nbytes
+    P = int(base[S])
+    table = np.concatenate([t for _, t in parts]) if S else np.zeros(0, np.uint32)
+    h = C.c_void_p()
+    K._native.check(lib.kmd_malloc_host(C.byref(h), P + table.nbytes + 64), "kmd_malloc_host")
+    st = C.c_void_p()
+    K._native.check(lib.kmd_stream_create(C.byref(st)), "kmd_stream_create")
+    try:
+        hb = (C.c_uint8 * (P + table.nbytes)).from_address(h.value)
+        hv = np.frombuffer(hb, dtype=np.uint8)
+        for s_ in range(S):
+            hv[int(base[s_]):int(base[s_ + 1])] = parts[s_][0]
+        hv[P:P + table.nbytes] = table.view(np.uint8)
+        del parts
+        d_packed = [K.DeviceBuffer(P + table.nbytes + 64) for _ in range(2)]
+        outs = []
+        for _ in range(2):
+            o = K.StreamSet.__new__(K.StreamSet)
+            o.n_samples, o.two, o.offs, o.total = S, False, offs, ss.total
+            o.kmers, o.counts, o.kmers_hi = K.DeviceBuffer(ss.total * 8), K.DeviceBuffer(ss.total * 4), None
+            outs.append(o)
+        cap = max(1 << 16, int(offs[-1]) // 2000)
+        acc = K.SurvivorAccumulator(cap)
+        obs = K.diff_observer(model, acc, THRESHOLD / CUTOFF, NC, NK)
+        # the link alone: the packed partition, page-locked source, one copy at a time
+        K._native.check(lib.kmd_memcpy_h2d(d_packed[0].ptr, h, P + table.nbytes, st), "h2d")
+        t0 = time.perf_counter()
+        for _ in range(2):
+            K._native.check(lib.kmd_memcpy_h2d(d_packed[0].ptr, h, P + table.nbytes, st), "h2d")
+        link_gbs = 2 * (P + table.nbytes) / (time.perf_counter() - t0) / 1e9
+
+        def enqueue(i):
+            slot = i % 2
+            K._native.check(lib.kmd_memcpy_h2d_async(d_packed[slot].ptr, h, P + table.nbytes, st), "h2d_async")
+            K._native.check(lib.kmd_unpack_streams(S, d_packed[slot].ptr, base.ctypes.data, d_packed[slot].ptr + P, offs.ctypes.data,
+                                                   outs[slot].kmers.ptr, outs[slot].counts.ptr, st), "kmd_unpack_streams")
+        # untimed: one partition through (first-use costs, the survivors it must reproduce)
+        enqueue(0)
+        K._native.check(lib.kmd_stream_sync(st))
+        rows0 = K.merge_filter(outs[0], obs)
+        n_sig0 = int(acc.read_counters()[1])
+        acc.counters.zero()
+        enqueue(0)
+        t0 = time.perf_counter()
+        rows_seen = 0
+        for i in range(n_parts):
+            K._native.check(lib.kmd_stream_sync(st))        # partition i lies unpacked in HBM
+            if i + 1 < n_parts:
+                enqueue(i + 1)                              # the next one crosses the link beside this one's kernels
+            rows_seen += K.merge_filter(outs[i % 2], obs)
+        K._native.check(lib.kmd_stream_sync(None))
+        dt = (time.perf_counter() - t0) / n_parts
+        c = acc.read_counters()
+        assert rows_seen == n_parts * rows0 and int(c[1]) == n_parts * n_sig0, (rows_seen, rows0, int(c[1]), n_sig0)
+    finally:
+        lib.kmd_stream_destroy(st)
+        lib.kmd_free_host(h)
+    bpr = (P + table.nbytes) / float(ss.total)
+    ceiling = link_gbs * 1e9 / ((P + table.nbytes) / float(rows0))
+    return {"what": "one whole configs[2] partition per step: packed streams (kmd_pack_stream) in page-locked memory -> kmd_memcpy_h2d_async "
+                    "on a copy stream -> kmd_unpack_streams -> kmd_merge_filter, double-buffered (the copy of partition i + 1 beside the kernels "
+                    "of partition i): what `kmdiff-hip diff` does per partition once its files are decoded; never `value`",
+            "partitions": n_parts, "rows": int(rows0), "records": int(ss.total), "packed_bytes": P + table.nbytes, "bytes_per_record": bpr,
+            "ms_per_partition": dt * 1e3, "kmers_per_s": rows0 / dt, "records_per_s": ss.total / dt, "link_GBs": link_gbs,
+            "h2d_GBs_sustained": (P + table.nbytes) / dt / 1e9, "link_ceiling_kmers_per_s": ceiling, "frac_of_link_ceiling": (rows0 / dt) / ceiling,
+            "n_sig": n_sig0, "host_pack_seconds": t_pack, "host_pack_threads": threads}
+
+
 def h2d_leg(K, lib, obs, mat, steps=3):
     """The headline step with the partition's host-to-device copy (page-locked source) in the loop."""
     nbytes = mat.counts.nbytes
@@ -312,10 +432,14 @@ def main():
     backend = os.environ.get("KMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # a collective that a peer never joins (it died, it hangs) fails after this long instead of after the backends'
+        # 10 / 30 minutes: every rank then leaves with an error, and the launcher with a non-zero status
+        import datetime
+        patience = datetime.timedelta(seconds=float(os.environ.get("KMD_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=patience)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=patience)
     # how many ranks the collective library really connected: an all-reduce of 1 over the job's backend
     n_ranks_seen = world
     if world > 1:
@@ -364,6 +488,8 @@ def main():
     for i in range(args.steps):
         obs.process(mats[i % n_res])
     ev1.record()
+    if os.environ.get("KMD_BENCH_TEST_DIE_RANK") == str(rank) and world > 1:     # tests: a rank dies before the exchange
+        os._exit(3)
     n_surv = acc.finish(sort=True)
     keep, g_counters, (n_ctrl, n_case) = D.correct_sharded(K, args.correction, THRESHOLD, acc.read_counters(),
                                                           acc.bufs["pvalue"], acc.bufs["sign"], n_surv)
@@ -461,9 +587,18 @@ def main():
             # the resident matrices of the headline leg make room for the streams of whole partitions (4 x 12 GB)
             del mats[1:]
             K._native.check(lib.kmd_release_cache())
-            out["pipeline"] = pipeline_leg(K, lib, args.pipeline_rows, iters=6, n_distinct=args.pipeline_partitions)
+            kept = {}
+            out["pipeline"] = pipeline_leg(K, lib, args.pipeline_rows, iters=6, n_distinct=args.pipeline_partitions, keep=kept)
+            try:
+                out["pipeline"]["feed_inclusive"] = feed_leg(K, lib, kept["ss"], kept["model"], threads=min(8, usable_cpus()[0]))
+            except Exception as e:                          # (a host without the memory for the packed copy)
+                out["pipeline"]["feed_inclusive"] = {"error": repr(e)}
+            kept.clear()
+            K._native.check(lib.kmd_release_cache())
             if args.pipeline_rows > 4_000_000:
                 out["pipeline"]["small"] = pipeline_leg(K, lib, 4_000_000, iters=6, n_distinct=1, with_extras=False)
+            # rows of few records beside rows of many: the MIXED profile at the same size, with a roofline block of its own
+            out["pipeline"]["sparse"] = pipeline_leg(K, lib, args.pipeline_rows, iters=6, n_distinct=1, with_extras="batched", profile=K.SYNTH_MIXED)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.rows, int(totals[:NC].sum()), int(totals[NC:].sum()))
         print(json.dumps(out), flush=True)

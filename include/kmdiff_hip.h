@@ -196,7 +196,8 @@ int kmd_survivors_sort_by_kmer(const kmd_survivors* s, size_t n, void* stream);
  * running sum itself, term for term in the reference's order, for sums below 2^20 (same bits; 0.1 us per 64 terms).  Sums
  * of 2^20 and more get the rounded logarithms but keep Stirling's term (within ~ulp(sum) of the reference: 5e-10
  * relative on p at sums of 10^6).  The DECISIONS need no such pass: rows within 1e-8 of the threshold are resolved inside every
- * filter call.  Works on any three arrays of that meaning (a sink's, or kmd_poisson_process's outputs).  Asynchronous. */
+ * filter call.  Works on any three arrays of that meaning (a sink's, or kmd_poisson_process's outputs).  Up to 2048
+ * records: asynchronous; more: returns when the stream has drained (its work list goes back to the library's cache). */
 int kmd_pvalues_refine(const kmd_model* m, size_t n, const double* d_mean_control, const double* d_mean_case,
                        double* d_pvalue, void* stream);
 
@@ -312,6 +313,10 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
 #define KMD_PACK_BLOCK 256
 size_t kmd_pack_block_bound(void);
 size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, uint32_t n, void* out);
+/* A whole stream, block by block (host, any thread): n records -> out (room for out_capacity bytes; ceil(n / 256) x
+ * kmd_pack_block_bound() always suffices), block_off8[ceil(n / 256)] = where each block begins / 8.  Returns the bytes
+ * written (a multiple of 8); 0 with n > 0: out too small or bad arguments. */
+size_t kmd_pack_stream(const uint64_t* kmers, const uint32_t* counts, size_t n, void* out, size_t out_capacity, uint32_t* block_off8);
 int kmd_unpack_streams(int n_samples, const void* d_packed, const uint64_t* stream_base, const uint32_t* d_block_off8,
                        const uint64_t* offsets, uint64_t* d_kmers, uint32_t* d_counts, void* stream);
 
@@ -445,7 +450,14 @@ int kmd_pca_eigen(int n_samples, const double* xtx_host, int n_out, double* evec
 
 /* ---- synthetic count matrices (benchmark / test support) ------------------
  * Counter-based generator, every cell a pure function of (seed, partition, row, sample);
- * the CPU oracle replays it.  d_kmer_lo / d_kmer_hi may be NULL. */
+ * the CPU oracle replays it.  d_kmer_lo / d_kmer_hi may be NULL.
+ * partition: bits 0-7 the partition (< 256), bits 8-15 the PRESENCE PROFILE of the rows: 0 = SURVEY 8d's (every sample
+ * absent with probability 0.3 in the two low rate classes: ~26 of 40 samples hold a row); KMD_SYNTH_MIXED (1) = every
+ * second row RARE (present in one or two samples) and the others COMMON (in 95 % of the samples) -- the shape of a
+ * real partition's two populations, sample-specific k-mers and shared ones (bench.py's pipeline.sparse; not replayed
+ * by the oracle: the device-built streams are held against the device-built matrix). */
+#define KMD_SYNTH_MIXED 1u
+#define KMD_SYNTH_PARTITION(partition, profile) ((uint32_t)(partition) | ((uint32_t)(profile) << 8))
 int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_rows, int nc,
                    int nk, int count_bytes, int layout, size_t ld, void* d_counts,
                    uint64_t* d_kmer_lo, uint64_t* d_kmer_hi, void* stream);

@@ -16,6 +16,16 @@ double kmd_test_row_pvalue_rounded(const kmd_model* m, uint64_t sum_control, uin
  * it: term by term (d_plain, may be NULL) and through the table of logarithms + the binade-wise exact integer sums of
  * kmd_pvalues_refine (d_fast).  Device pointers; asynchronous on `stream`. */
 int kmd_test_running_sums(const uint64_t* d_k, size_t n, double* d_plain, double* d_fast, void* stream);
+/* Stage 2's device linear algebra on inputs of the caller's (host pointers; synchronous) -- so that the vectors the
+ * reference's own tests hold (tests/linear_test.cpp:29-31, 80-151: sigmoid(1), predict, the 4 x 4 LU and inverse) go
+ * through the code K3 runs.  a: F x F row-major, b: F.  lane_out / group_out (2 F F + F + 1 doubles each; the lane
+ * kernel's lu_solve, the group kernel's group_lu_solve): [LU in place: L below the diagonal, U on and above | the
+ * inverse, row-major | w = a^-1 b | status: 0 ok, 1 det == 0, 2 det NaN (group: 1 for either)]. */
+int kmd_test_popstrat_linear(int F, const double* a, const double* b, double* lane_out, double* group_out);
+/* out[i] = sigmoid(x[i]) as K3 evaluates linear_model.cpp:191-195 */
+int kmd_test_popstrat_sigmoid(const double* x, size_t n, double* out);
+/* *eta_out = sum_j x[j] w[j] in index order, *p_out = its sigmoid: linear_predictor / predict (linear_model.cpp:197-211) */
+int kmd_test_popstrat_predict(const double* w, const double* x, int n, double* eta_out, double* p_out);
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("KMD_LIB") or os.path.join(_HERE, "lib", "libkmdiff_hi
 
 KMD_OK = 0
 ABI_VERSION = 3           # KMD_ABI_VERSION of include/kmdiff_hip.h (tests/test_abi.py holds the two together)
+KMD_E_INVALID = -1
 KMD_E_OVERFLOW = -4
 SIGN_CONTROL, SIGN_CASE, SIGN_NO = 0, 1, 2
 CORR_NOTHING, CORR_BONFERRONI, CORR_BENJAMINI, CORR_SIDAK, CORR_HOLM = 0, 1, 2, 3, 4
@@ -58,6 +59,9 @@ TEST_SIGNATURES = {
     "kmd_test_igamc_half_rounded": (_d, [_d]),
     "kmd_test_row_pvalue_rounded": (_d, [_vp, _u64, _u64]),
     "kmd_test_running_sums": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "kmd_test_popstrat_linear": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "kmd_test_popstrat_sigmoid": (_i, [_vp, _sz, _vp]),
+    "kmd_test_popstrat_predict": (_i, [_vp, _vp, _i, C.POINTER(_d), C.POINTER(_d)]),
 }
 
 SIGNATURES = {
@@ -105,6 +109,7 @@ SIGNATURES = {
     "kmd_transport_abort": (_i, [C.POINTER(Transport)]),
     "kmd_pack_block_bound": (_sz, []),
     "kmd_pack_block": (_sz, [_vp, _vp, C.c_uint32, _vp]),
+    "kmd_pack_stream": (_sz, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "kmd_unpack_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),
     "kmd_merge_sums": (_i, [_i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), _vp]),

@@ -471,10 +471,17 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, uint32_t part, uin
   const int S = nc + nk;
   constexpr uint32_t cmax = sizeof(CT) == 1 ? 0xFFu : sizeof(CT) == 2 ? 0xFFFFu : 0xFFFFFFFFu;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // bits 8.. of `part`: the presence profile (include/kmdiff_hip.h, kmd_synth_fill).  1 = MIXED: every second row (by a
+  // bit of its hash) is RARE -- present in one or two samples, picked by the hash -- the others are COMMON: present in
+  // 95 % of the samples.  The counts are the default profile's draws (at least 1 where the row is present).
+  const uint32_t profile = part >> 8;
+  part &= 0xFFu;
   for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
   {
     const uint64_t row = row0 + r;
     const uint64_t h = mix64(mix64(seed ^ (C_PART * ((uint64_t)part + 1))) ^ (C_ROW * (row + 1)));
+    const bool rare = profile == 1 && ((h >> 41) & 1ull) != 0;
+    const int rare_s0 = (int)((h >> 8) % (uint64_t)S), rare_s1 = ((h >> 42) & 1ull) ? (int)((h >> 24) % (uint64_t)S) : rare_s0;
     const uint32_t u16 = (uint32_t)(h & 0xFFFF);
     int cls = u16 < 26214 ? 0 : u16 < 45875 ? 1 : u16 < 55705 ? 2 : u16 < 62259 ? 3 : u16 < 64880 ? 4 : 5;
     int jbase = cls == 0 ? 1 : cls == 1 ? 3 : cls == 2 ? 5 : cls == 3 ? 7 : cls == 4 ? 11 : 17;
@@ -486,7 +493,9 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, uint32_t part, uin
     {
       const uint64_t hc = mix64(h ^ (C_CELL * ((uint64_t)s + 1)));
       uint32_t v = 0;
-      if (!(cls <= 1 && ((hc >> 32) & 0xFFFF) < 19661))
+      const bool absent = profile == 1 ? (rare ? (s != rare_s0 && s != rare_s1) : ((hc >> 48) % 20ull) == 0)
+                                       : (cls <= 1 && ((hc >> 32) & 0xFFFF) < 19661);
+      if (!absent)
       {
         int j = jbase + (int)(mix64(seed ^ (C_DEPTH * ((uint64_t)s + 1))) % 3);
         const int is_case = s >= nc;
@@ -501,6 +510,7 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, uint32_t part, uin
           if (thr[mid] <= u) lo = mid + 1; else hi = mid;
         }
         v = T.c0[j] + lo;
+        if (profile == 1 && v == 0) v = 1;                    // (mixed profile: presence is the profile's, not the draw's)
       }
       any |= (v != 0);
       if (v > cmax) v = cmax;
@@ -684,7 +694,7 @@ int kmd_synth_fill(uint64_t seed, uint32_t partition, uint64_t row0, size_t n_ro
   KMD_REQUIRE(count_bytes == 1 || count_bytes == 2 || count_bytes == 4, "kmd_synth_fill: count_bytes");
   KMD_REQUIRE(kmd::layout_ok(layout), "kmd_synth_fill: layout");
   KMD_REQUIRE(layout != KMD_LAYOUT_TILED || (ld > 0 && ld % 4096 == 0), "kmd_synth_fill: tiled ld % 4096");
-  KMD_REQUIRE(partition < 256, "kmd_synth_fill: partition >= 256");
+  KMD_REQUIRE((partition >> 8) <= 1, "kmd_synth_fill: partition >= 256 or an unknown presence profile");
   if (n_rows == 0) return KMD_OK;
   synth_tables T;
   int rc = ensure_tables(T);
@@ -708,7 +718,7 @@ int kmd_synth_streams(uint64_t seed, uint32_t partition, uint64_t row0, size_t n
 {
   KMD_REQUIRE(offsets, "kmd_synth_streams: NULL offsets");
   KMD_REQUIRE(nc > 0 && nk > 0 && nc + nk <= 1024, "kmd_synth_streams: nc, nk");
-  KMD_REQUIRE(partition < 256, "kmd_synth_streams: partition >= 256");
+  KMD_REQUIRE((partition >> 8) <= 1, "kmd_synth_streams: partition >= 256 or an unknown presence profile");
   KMD_REQUIRE((d_kmers == nullptr) == (d_counts == nullptr), "kmd_synth_streams: d_kmers and d_counts go together");
   KMD_REQUIRE(d_kmers || !d_kmers_hi, "kmd_synth_streams: d_kmers_hi without d_kmers");
   const int S = nc + nk;

@@ -2159,9 +2159,14 @@ extern "C" int kmd_pvalues_refine(const kmd_model* m, size_t n, const double* d_
     KMD_HIP(hipGetLastError());
     return KMD_OK;
   }
+  // (the list from the library's scratch cache: a hipMallocAsync / hipFreeAsync pair per call bypassed it; the block is
+  // parked again once the stream has drained -- the two kernels take microseconds on a sink's worth of records)
   void* list = nullptr;
-  KMD_HIP(hipMallocAsync(&list, (1 + 3 * n) * sizeof(unsigned long long), st));
-  KMD_HIP(hipMemsetAsync(list, 0, sizeof(unsigned long long), st));
+  KMD_HIP(kmd::scratch_alloc(&list, (1 + 3 * n) * sizeof(unsigned long long)));
+  {
+    const hipError_t e0 = hipMemsetAsync(list, 0, sizeof(unsigned long long), st);
+    if (e0 != hipSuccess) { kmd::scratch_free(list); return kmd::hip_fail(e0, "hipMemsetAsync", __FILE__, __LINE__); }
+  }
   hipLaunchKernelGGL(k_refine_pvalues, dim3((unsigned)grid), dim3(256), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
                      (unsigned long long)n, d_mean_control, d_mean_case, d_pvalue, static_cast<unsigned long long*>(list), log_int);
   // as many waves as the chip holds at a comfortable occupancy; those without a record leave at once
@@ -2169,7 +2174,9 @@ extern "C" int kmd_pvalues_refine(const kmd_model* m, size_t n, const double* d_
   hipLaunchKernelGGL(k_refine_chain, dim3((unsigned)chain_grid), dim3(128), 0, st, tab, (unsigned long long)m->lf_n, m->dT, m->dTc, m->dTk, m->lg_half,
                      static_cast<const unsigned long long*>(list), log_int, d_pvalue);
   const hipError_t launched = hipGetLastError();
-  KMD_HIP(hipFreeAsync(list, st));
+  const hipError_t drained = hipStreamSynchronize(st);          // nothing reads the list any more: back to the cache
+  kmd::scratch_free(list);
   KMD_HIP(launched);
+  KMD_HIP(drained);
   return KMD_OK;
 }

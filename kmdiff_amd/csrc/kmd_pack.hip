@@ -166,6 +166,32 @@ extern "C" size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, 
   return bytes;
 }
 
+// a whole stream: its blocks one behind the other (what a host does while it decodes a sample's file)
+extern "C" size_t kmd_pack_stream(const uint64_t* kmers, const uint32_t* counts, size_t n, void* out, size_t out_capacity, uint32_t* block_off8)
+{
+  if (n == 0) return 0;
+  if (!kmers || !counts || !out || !block_off8) return 0;
+  const size_t bound = kmd_pack_block_bound();
+  char* o = static_cast<char*>(out);
+  size_t at = 0, b = 0;
+  alignas(8) char tmp[16 + (4 * 64 + 1) * 8 + kBlock + 4 * kBlock];
+  for (size_t i = 0; i < n; i += kBlock, ++b)
+  {
+    const uint32_t m = (uint32_t)std::min<size_t>(kBlock, n - i);
+    if (at / 8 > 0xFFFFFFFFull) return 0;                                  // (block_off8 is 32-bit: 32 GB of one stream)
+    block_off8[b] = (uint32_t)(at / 8);
+    if (out_capacity - at >= bound) at += kmd_pack_block(kmers + i, counts + i, m, o + at);
+    else
+    {
+      const size_t got = kmd_pack_block(kmers + i, counts + i, m, tmp);    // the last blocks of a tight buffer: packed aside, copied if they fit
+      if (got == 0 || got > out_capacity - at) return 0;
+      std::memcpy(o + at, tmp, got);
+      at += got;
+    }
+  }
+  return at;
+}
+
 // The kernel's small tables (where each stream starts, in bytes, records and blocks) travel through a page-locked
 // ring kept per (device, stream): the upload is a true asynchronous copy -- a pageable source would make the call wait
 // for the copies the caller has just enqueued on the stream -- and nothing is allocated per call.  A slot is reused

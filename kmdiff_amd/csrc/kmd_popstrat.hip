@@ -323,6 +323,74 @@ template <int F> struct group_shape
   static constexpr int kLds = L * kSample + F * F + 3 * F + F * F + 8;
 };
 
+// The linear algebra of one IRLS step of the group kernel, on the group's LDS: no-pivot LU of Hm in place, the F column
+// solves of inverse() one per lane (xc, column-major), det, and wv = H^-1 bv.  `active` goes false on det == 0 / NaN
+// (:366-373).  A function of its own so that the reference's vectors (tests/linear_test.cpp:80-151) can be pushed through
+// the very code the kernel runs (kmd_test_popstrat_linear).
+template <int F>
+__device__ __forceinline__ void group_lu_solve(double* const Hm, const double* const bv, double* const xc, double* const wv, bool& active, const int l)
+{
+  // no-pivot Doolittle LU in place (:94-132): row i of U across the lanes, then column i of L
+  for (int i = 0; i < F; ++i)
+  {
+    if (active && l >= i && l < F)
+    {
+      const int k = l;
+      double sum = 0.0;
+      for (int j = 0; j < i; ++j) sum += Hm[i * F + j] * Hm[j * F + k];
+      Hm[i * F + k] = Hm[i * F + k] - sum;
+    }
+    group_sync();
+    if (active && l > i && l < F)
+    {
+      const int k = l;
+      double sum = 0;
+      for (int j = 0; j < i; ++j) sum += Hm[k * F + j] * Hm[j * F + i];
+      Hm[k * F + i] = (Hm[k * F + i] - sum) / Hm[i * F + i];
+    }
+    group_sync();
+  }
+  // inverse() (:134-189): lane c solves column c; det is the running product over every column solve
+  if (active && l < F)
+  {
+    const int c = l;
+    double y[F], x[F];
+    y[0] = (c == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int row = 1; row < F; ++row)
+    {
+      double sum = 0;
+      for (int col = 0; col < row; ++col) sum += Hm[row * F + col] * y[col];
+      y[row] = ((c == row) ? 1.0 : 0.0) - sum;
+    }
+    x[F - 1] = y[F - 1] / Hm[(F - 1) * F + (F - 1)];
+#pragma unroll
+    for (int row = F - 2; row > -1; --row)
+    {
+      double sum = 0;
+      for (int col = row + 1; col < F; ++col) sum += Hm[row * F + col] * x[col];
+      x[row] = (y[row] - sum) / Hm[row * F + row];
+    }
+#pragma unroll
+    for (int p = 0; p < F; ++p) xc[c * F + p] = x[p];
+  }
+  group_sync();
+  if (active)
+  {
+    double det = 1;
+    for (int c = 0; c < F; ++c)
+      for (int row = F - 1; row > -1; --row) det *= Hm[row * F + row];
+    if (det == 0 || det != det) active = false;                  // :366-373
+  }
+  if (active && l < F)
+  {
+    double r = 0.0;
+    for (int c = 0; c < F; ++c) r = r + xc[c * F + l] * bv[c];   // :381
+    wv[l] = r;
+  }
+  group_sync();
+}
+
 template <int F>
 __global__ void __launch_bounds__(64) k_popstrat_group(irls_args A, size_t n_surv, double null_likelihood,
                                                        double lg_half, double epsilon, double* __restrict__ out_p)
@@ -469,65 +537,7 @@ __global__ void __launch_bounds__(64) k_popstrat_group(irls_args A, size_t n_sur
         else prev_error = error;
       }
     }
-    // no-pivot Doolittle LU in place (:94-132): row i of U across the lanes, then column i of L
-    for (int i = 0; i < F; ++i)
-    {
-      if (active && l >= i && l < F)
-      {
-        const int k = l;
-        double sum = 0.0;
-        for (int j = 0; j < i; ++j) sum += Hm[i * F + j] * Hm[j * F + k];
-        Hm[i * F + k] = Hm[i * F + k] - sum;
-      }
-      group_sync();
-      if (active && l > i && l < F)
-      {
-        const int k = l;
-        double sum = 0;
-        for (int j = 0; j < i; ++j) sum += Hm[k * F + j] * Hm[j * F + i];
-        Hm[k * F + i] = (Hm[k * F + i] - sum) / Hm[i * F + i];
-      }
-      group_sync();
-    }
-    // inverse() (:134-189): lane c solves column c; det is the running product over every column solve
-    if (active && l < F)
-    {
-      const int c = l;
-      double y[F], x[F];
-      y[0] = (c == 0) ? 1.0 : 0.0;
-#pragma unroll
-      for (int row = 1; row < F; ++row)
-      {
-        double sum = 0;
-        for (int col = 0; col < row; ++col) sum += Hm[row * F + col] * y[col];
-        y[row] = ((c == row) ? 1.0 : 0.0) - sum;
-      }
-      x[F - 1] = y[F - 1] / Hm[(F - 1) * F + (F - 1)];
-#pragma unroll
-      for (int row = F - 2; row > -1; --row)
-      {
-        double sum = 0;
-        for (int col = row + 1; col < F; ++col) sum += Hm[row * F + col] * x[col];
-        x[row] = (y[row] - sum) / Hm[row * F + row];
-      }
-#pragma unroll
-      for (int p = 0; p < F; ++p) xc[c * F + p] = x[p];
-    }
-    group_sync();
-    if (active)
-    {
-      double det = 1;
-      for (int c = 0; c < F; ++c)
-        for (int row = F - 1; row > -1; --row) det *= Hm[row * F + row];
-      if (det == 0 || det != det) active = false;                  // :366-373
-    }
-    if (active && l < F)
-    {
-      double r = 0.0;
-      for (int c = 0; c < F; ++c) r = r + xc[c * F + l] * bv[c];   // :381
-      wv[l] = r;
-    }
-    group_sync();
+    group_lu_solve<F>(Hm, bv, xc, wv, active, l);
     if (active)
     {
 #pragma unroll
@@ -681,7 +691,10 @@ int kmd_popstrat_create(kmd_popstrat** out, int nb_controls, int nb_cases,
   if (standardize)
   {
     // pop_strat_corrector::standardize (popstrat.cpp:327-370), quirks included
-    std::vector<double> means(fn, 0.0), stddev(n, 0.0);
+    // (the reference sizes stddev by ROWS and fills it by COLUMN, popstrat.cpp:330,349: with more columns than rows --
+    // fewer than 4 + npc samples -- it writes past the vector's end, undefined behaviour there; here those entries
+    // exist, and nothing reads them: the division below indexes rows.  tests/soak.py found this one: glibc's heap check)
+    std::vector<double> means(fn, 0.0), stddev(std::max(n, fn), 0.0);
     for (int i = 0; i < n; ++i) for (int j = 0; j < fn; ++j) means[j] += nul[(size_t)i * fn + j];
     for (int j = 1; j < fn; ++j) means[j] /= fn;                                   // :342 (ncols, not nrows)
     for (int i = 0; i < n; ++i) for (int j = 1; j < fn; ++j)
@@ -823,6 +836,133 @@ int kmd_popstrat_apply(const kmd_popstrat* ps, const double* d_counts, int sampl
     if (e == hipSuccess) e = e2;
   }
   if (e != hipSuccess) return kmd::hip_fail(e, "kmd_popstrat_apply", __FILE__, __LINE__);
+  return KMD_OK;
+}
+
+// ---- test hooks (include/kmdiff_hip_test.h): the reference's own linear-algebra vectors through the DEVICE routines of
+// stage 2 -- lu_solve (the lane kernel's), group_lu_solve (the group kernel's), sigmoid_ref and the dot product of
+// eta = X w -- tests/linear_test.cpp:29-31,80-151 are the only numbers of R9 the reference itself holds.
+} // extern "C"
+namespace {
+template <int F>
+__global__ void __launch_bounds__(64) k_test_linear(const double* __restrict__ a_in, const double* __restrict__ b_in, double* __restrict__ out)
+{
+  // out: [0, F*F) LU in place (lane) | [F*F, 2F*F) inverse row-major (lane) | [2F*F, 2F*F+F) w (lane) | status (lane)
+  //      | the same four of the group routine
+  using G = group_shape<F>;
+  __shared__ double s_h[F * F], s_b[F], s_xc[F * F], s_w[F];
+  const int lane = (int)threadIdx.x;
+  double* lane_out = out;
+  double* grp_out = out + 2 * F * F + F + 1;
+  if (lane == 0)
+  {
+    double a[F][F], b[F], w[F];
+    for (int c = 0; c < F; ++c)
+    {
+      // column c of the inverse: the routine's w for b = e_c (w[p] = sum_c inv[p][c] b[c]: the other terms are +-0)
+      for (int i = 0; i < F; ++i) { b[i] = i == c ? 1.0 : 0.0; for (int j = 0; j < F; ++j) a[i][j] = a_in[i * F + j]; }
+      (void)lu_solve<F>(a, b, w);
+      for (int p = 0; p < F; ++p) lane_out[F * F + p * F + c] = w[p];
+    }
+    for (int i = 0; i < F; ++i) { b[i] = b_in[i]; for (int j = 0; j < F; ++j) a[i][j] = a_in[i * F + j]; }
+    const int st = lu_solve<F>(a, b, w);
+    for (int i = 0; i < F; ++i) for (int j = 0; j < F; ++j) lane_out[i * F + j] = a[i][j];
+    for (int p = 0; p < F; ++p) lane_out[2 * F * F + p] = w[p];
+    lane_out[2 * F * F + F] = (double)st;
+  }
+  // the group routine: lanes [0, L) of the wave are one group
+  for (int i = lane; i < F * F; i += 64) s_h[i] = a_in[i];
+  if (lane < F) s_b[lane] = b_in[lane];
+  group_sync();
+  bool active = true;
+  if (lane < G::L) group_lu_solve<F>(s_h, s_b, s_xc, s_w, active, lane);
+  group_sync();
+  if (lane == 0)
+  {
+    for (int i = 0; i < F * F; ++i) grp_out[i] = s_h[i];
+    for (int c = 0; c < F; ++c) for (int p = 0; p < F; ++p) grp_out[F * F + p * F + c] = s_xc[c * F + p];
+    for (int p = 0; p < F; ++p) grp_out[2 * F * F + p] = active ? s_w[p] : 0.0;
+    grp_out[2 * F * F + F] = active ? 0.0 : 1.0;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_test_sigmoid(const double* __restrict__ x, size_t n, double* __restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i < n) out[i] = sigmoid_ref(x[i]);
+}
+
+// predict() (linear_model.cpp:197-211): sigmoid of the dot product, summed in index order as irls_fit forms eta
+__global__ void __launch_bounds__(64) k_test_predict(const double* __restrict__ w, const double* __restrict__ x, int n, double* __restrict__ out)
+{
+  if (threadIdx.x != 0) return;
+  double eta = 0;
+  for (int j = 0; j < n; ++j) eta += x[j] * w[j];
+  out[0] = eta; out[1] = sigmoid_ref(eta);
+}
+} // namespace
+extern "C" {
+
+int kmd_test_popstrat_linear(int F, const double* a, const double* b, double* lane_out, double* group_out)
+{
+  KMD_REQUIRE(a && b && lane_out && group_out, "kmd_test_popstrat_linear: NULL");
+  KMD_REQUIRE(F >= 2 && F <= 13, "kmd_test_popstrat_linear: F");
+  const size_t each = 2 * (size_t)F * F + F + 1;
+  double *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_a), (size_t)F * F * 8));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_b), (size_t)F * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_o), 2 * each * 8);
+  if (e == hipSuccess) e = hipMemcpy(d_a, a, (size_t)F * F * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_b, b, (size_t)F * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+  {
+    switch (F)
+    {
+#define KMD_TL(N) case N: hipLaunchKernelGGL((k_test_linear<N>), dim3(1), dim3(64), 0, nullptr, d_a, d_b, d_o); break;
+      KMD_TL(2) KMD_TL(3) KMD_TL(4) KMD_TL(5) KMD_TL(6) KMD_TL(7) KMD_TL(8) KMD_TL(9) KMD_TL(10) KMD_TL(11) KMD_TL(12) KMD_TL(13)
+#undef KMD_TL
+    }
+    e = hipGetLastError();
+  }
+  std::vector<double> h(2 * each);
+  if (e == hipSuccess) e = hipMemcpy(h.data(), d_o, 2 * each * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+  if (e != hipSuccess) return kmd::hip_fail(e, "kmd_test_popstrat_linear", __FILE__, __LINE__);
+  std::copy(h.begin(), h.begin() + each, lane_out);
+  std::copy(h.begin() + each, h.end(), group_out);
+  return KMD_OK;
+}
+
+int kmd_test_popstrat_sigmoid(const double* x, size_t n, double* out)
+{
+  KMD_REQUIRE(x && out, "kmd_test_popstrat_sigmoid: NULL");
+  if (n == 0) return KMD_OK;
+  double *d_x = nullptr, *d_o = nullptr;
+  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_x), n * 8));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 8);
+  if (e == hipSuccess) e = hipMemcpy(d_x, x, n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_test_sigmoid, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, d_x, n, d_o); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpy(out, d_o, n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d_x); (void)hipFree(d_o);
+  if (e != hipSuccess) return kmd::hip_fail(e, "kmd_test_popstrat_sigmoid", __FILE__, __LINE__);
+  return KMD_OK;
+}
+
+int kmd_test_popstrat_predict(const double* w, const double* x, int n, double* eta_out, double* p_out)
+{
+  KMD_REQUIRE(w && x && eta_out && p_out && n > 0, "kmd_test_popstrat_predict: arguments");
+  double *d_w = nullptr, *d_x = nullptr, *d_o = nullptr;
+  KMD_HIP(hipMalloc(reinterpret_cast<void**>(&d_w), (size_t)n * 8));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_x), (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_o), 16);
+  if (e == hipSuccess) e = hipMemcpy(d_w, w, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_x, x, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_test_predict, dim3(1), dim3(64), 0, nullptr, d_w, d_x, n, d_o); e = hipGetLastError(); }
+  double h[2] = { 0, 0 };
+  if (e == hipSuccess) e = hipMemcpy(h, d_o, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d_w); (void)hipFree(d_x); (void)hipFree(d_o);
+  if (e != hipSuccess) return kmd::hip_fail(e, "kmd_test_popstrat_predict", __FILE__, __LINE__);
+  *eta_out = h[0]; *p_out = h[1];
   return KMD_OK;
 }
 

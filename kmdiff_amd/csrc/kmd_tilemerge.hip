@@ -72,7 +72,7 @@ using namespace kmd::eval;
 #define KMD_TILE_ASM 1               // whole-wave path: stages 1 and 2 of a round in the middle of a run as hand-written gfx950 code
 #endif
 #ifndef KMD_TILE_TIMING
-#define KMD_TILE_TIMING 0
+#define KMD_TILE_TIMING 0            // dev: 1 = cycles per LDS round trip inside the hand-written round + the phases of one tile (printf); 2 = the phases only
 #endif
 #ifndef KMD_TILE_HINT
 #define KMD_TILE_HINT 0              // cache policy of the whole-wave path's record loads: 0 default, 1 nt (streaming), 2 sc1, 3 sc0 sc1
@@ -804,7 +804,7 @@ k_tile_sums(const tile_job J)
         //  * a lane's state in the table is ONE number (insert_w).
         uint32_t cmax = 0;                                                            // largest count this lane met (kSum32: one look per tile)
         bool gave_up = false;
-#if KMD_TILE_TIMING   // dev: cycles a wave sits out per LDS round trip (bucket reads, swap), printed by one wave
+#if KMD_TILE_TIMING == 1   // dev: cycles a wave sits out per LDS round trip (bucket reads, swap), printed by one wave
         uint32_t tm_read = 0, tm_nread = 0, tm_cas = 0, tm_ncas = 0;
         const unsigned long long tm_t0 = __builtin_readcyclecounter();
 #endif
@@ -1173,7 +1173,7 @@ k_tile_sums(const tile_job J)
                   "v_bfe_u32 %[a1], %[se], %[sh1], %[nb]\n\t"                   // bucket 1: the bits below them
                   "v_lshl_add_u32 %[a0], %[a0], 4, %[kb]\n\t"
                   "v_lshl_add_u32 %[a1], %[a1], 4, %[kb]\n\t"
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
                   "s_memtime s[90:91]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
 #endif
@@ -1184,7 +1184,7 @@ k_tile_sums(const tile_job J)
                   "v_add_u32 %[t1], 8, %[a1]\n\t"
                   "v_lshl_add_u32 %[se], %[se], 3, %[sb]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
                   "s_memtime s[92:93]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
                   "s_sub_u32 s92, s92, s90\n\t"
@@ -1210,13 +1210,13 @@ k_tile_sums(const tile_job J)
                   "v_cndmask_b32 %[se], %[se], %[a1], %[m1]\n\t"
                   "v_cndmask_b32 %[se], %[se], %[t0], %[m2]\n\t"
                   "v_cndmask_b32 %[se], %[se], %[a0], vcc\n\t"
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
                   "s_memtime s[90:91]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
 #endif
                   "ds_cmpst_rtn_b64 v[40:41], %[se], %[empty], %[k]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
                   "s_memtime s[92:93]\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
                   "s_sub_u32 s92, s92, s90\n\t"
@@ -1238,14 +1238,14 @@ k_tile_sums(const tile_job J)
                   "ds_add_u32 %[t0], %[cnt]"
                   : [sl] "=&v"(sl), [a0] "=&v"(a0), [a1] "=&v"(a1), [se] "=&v"(se), [t0] "=&v"(t0), [t1] "=&v"(t1),
                     [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [sv] "=&s"(sv)
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
                     , [tr] "+s"(tm_read), [nr] "+s"(tm_nread), [tc] "+s"(tm_cas), [nc_] "+s"(tm_ncas)
 #endif
                   : [k] "v"(k), [klo] "v"((uint32_t)k), [khi] "v"((uint32_t)(k >> 32)), [none] "v"(kNone), [empty] "v"(empty), [cnt] "v"(cnt), [sbase] "s"(sums_lds),
                     [kb] "s"(key_lds), [sb] "s"(key_lds + kSlots * 8u), [c1] "s"(kHashMul), [sh0] "n"(32 - kBucketBits), [sh1] "n"(32 - 2 * kBucketBits),
                     [nb] "n"(kBucketBits), [nsec] "n"(ilog2_c(kSec))
                   : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47"
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
                     , "s90", "s91", "s92", "s93"
 #endif
                   );
@@ -1293,7 +1293,7 @@ k_tile_sums(const tile_job J)
               else
               {
                 bool fast = false;
-                if constexpr (kR == 1 && !kTwo && kSum32 && KMD_TILE_ASM && !KMD_TILE_ABLATE && !KMD_TILE_TIMING)
+                if constexpr (kR == 1 && !kTwo && kSum32 && KMD_TILE_ASM && !KMD_TILE_ABLATE && KMD_TILE_TIMING != 1)
                 {
 #if KMD_TILE_ALIGN
                   const bool there = (lane < rrem[d]) & (lane >= rlead[d]);
@@ -1320,7 +1320,7 @@ k_tile_sums(const tile_job J)
           // landed before their registers serve anything else)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#if KMD_TILE_TIMING
+#if KMD_TILE_TIMING == 1
         if (blockIdx.x == 77 && tid == 64 && tm_nread)
           printf("[tile timing] tile %u: %u rounds, bucket reads %.0f cycles each, %u swaps %.0f cycles each, whole insert loop %llu cycles (%.0f per round)\n",
                  tile, tm_nread, (double)tm_read / tm_nread, tm_ncas, tm_ncas ? (double)tm_cas / tm_ncas : 0.0,
@@ -1868,8 +1868,8 @@ k_tile_sums(const tile_job J)
     if constexpr (kFilter) lds_barrier(); else __syncthreads();
 #if KMD_TILE_TIMING
     if (blockIdx.x == 77 && tid == 64)
-      printf("[tile phases] tile %u: inserts -> barrier %llu, next segments %llu, walk %llu (rows mode: pass 1 %llu, reservation %llu), last barrier %llu\n",
-             tile, tp_bar1 - tp_ins, tp_seg - tp_bar1, tp_walk2 - tp_seg, tp_walk1 ? tp_walk1 - tp_seg : 0ull, tp_resv ? tp_resv - tp_walk1 : 0ull,
+      printf("[tile phases] tile %u (%u records): inserts %llu, inserts -> barrier %llu, next segments %llu, walk %llu (rows mode: pass 1 %llu, reservation %llu), last barrier %llu\n",
+             tile, n, tp_ins - tp_tile, tp_bar1 - tp_ins, tp_seg - tp_bar1, tp_walk2 - tp_seg, tp_walk1 ? tp_walk1 - tp_seg : 0ull, tp_resv ? tp_resv - tp_walk1 : 0ull,
              __builtin_readcyclecounter() - tp_walk2);
 #endif
   }

@@ -282,7 +282,7 @@ class SurvivorAccumulator:
         check(lib().kmd_stream_sync(None), "sync")
         return self.counters.to_host(np.uint64, N.NCOUNTERS)
 
-    def finish(self, sort=True, by_kmer=False, refine=None):
+    def finish(self, sort=True, by_kmer=False, refine=None, allow_unresolved=False):
         """IAccumulator::finish: returns the number of survivors stored (sorted by row -- or by k-mer,
         for survivors of merge_filter, which have no row index -- the reference's push order).
         refine = the PoissonLikelihood the survivors were tested with: their p-values are recomputed with correctly
@@ -292,6 +292,10 @@ class SurvivorAccumulator:
         n = int(c[N.CNT_SIG])
         if n > self.capacity:
             raise KmdError("survivor capacity exceeded: %d > %d (status %d)" % (n, self.capacity, N.KMD_E_OVERFLOW))
+        if len(c) > N.CNT_NEAR_UNRESOLVED and int(c[N.CNT_NEAR_UNRESOLVED]) and not allow_unresolved:
+            # (include/kmdiff_hip.h, KMD_CNT_NEAR_UNRESOLVED: the guard of `p <= threshold` could not list them all)
+            raise KmdError("%d rows within 1e-8 of the threshold were left with the device libm's decision (more than 4096 "
+                           "in one launch): run the partition again in smaller pieces" % int(c[N.CNT_NEAR_UNRESOLVED]))
         if refine is not None and n:
             check(lib().kmd_pvalues_refine(refine.handle, n, self.bufs["mean_control"].ptr, self.bufs["mean_case"].ptr,
                                            self.bufs["pvalue"].ptr, None), "pvalues_refine")
@@ -407,10 +411,11 @@ class StreamSet:
         return (self.kmers.ptr if t else None, self.kmers_hi.ptr if (self.two and t) else None, self.counts.ptr if t else None)
 
 
-def synth_streams(seed, partition, n_rows, nb_controls, nb_cases, kmer_limbs=1, row0=0):
+def synth_streams(seed, partition, n_rows, nb_controls, nb_cases, kmer_limbs=1, row0=0, profile=0):
     """The synthetic partition as the per-sample streams kmtricks would write, generated on the
-    device (kmd_synth_streams): returns (StreamSet, per-sample totals)."""
+    device (kmd_synth_streams): returns (StreamSet, per-sample totals).  `profile`: as synth_matrix."""
     S = nb_controls + nb_cases
+    partition = int(partition) | (int(profile) << 8)
     ss = StreamSet.__new__(StreamSet)
     ss.n_samples, ss.two = S, kmer_limbs == 2
     ss.offs = np.zeros(S + 1, dtype=np.uint64)
@@ -648,12 +653,16 @@ def aggregate(correction, threshold, total_kmers, pvalue_buf, sign_buf, n):
     return keep.to_host(np.uint8, n), int(nc.value), int(nca.value)
 
 
+SYNTH_MIXED = 1          # KMD_SYNTH_MIXED: every second row in one or two samples, the others in 95 % of them
+
+
 def synth_matrix(seed, partition, n_rows, nb_controls, nb_cases, count_bytes=4,
-                 layout=N.LAYOUT_SOA, kmer_limbs=1, row0=0, with_kmers=True, stream=None):
-    """Synthetic partition generated on the device."""
+                 layout=N.LAYOUT_SOA, kmer_limbs=1, row0=0, with_kmers=True, stream=None, profile=0):
+    """Synthetic partition generated on the device; `profile`: the rows' presence profile
+    (include/kmdiff_hip.h, kmd_synth_fill)."""
     m = CountMatrix(n_rows, nb_controls + nb_cases, count_bytes, layout, with_kmers=with_kmers,
                     kmer_limbs=kmer_limbs, row_base=row0)
-    check(lib().kmd_synth_fill(int(seed), int(partition), int(row0), m.n_rows, nb_controls, nb_cases,
+    check(lib().kmd_synth_fill(int(seed), int(partition) | (int(profile) << 8), int(row0), m.n_rows, nb_controls, nb_cases,
                                count_bytes, layout, m.ld, m.counts.ptr,
                                m.kmer_lo.ptr if m.kmer_lo else None,
                                m.kmer_hi.ptr if m.kmer_hi else None, stream), "kmd_synth_fill")

@@ -507,7 +507,10 @@ kmer_file_info stream_kmer_file(const std::string& path, size_t expected_k, reco
   sink.slots = f.slots; sink.nb_counts = 1;
   const size_t rec = 8 * (size_t)f.slots + f.count_bytes;
   sink.file_size = ps.file_size;
-  if (sink.raw && f.slots == 1)
+  // (a packed-transfer sink takes one-limb records only and has no arrays to grow: a two-limb file in a k <= 32 run is
+  // refused here, by name -- it used to fall through to an empty sink.reserve and die of std::bad_function_call)
+  if (sink.raw && f.slots != 1) throw std::runtime_error(path + ": k-mer width of a sample file differs from the run's");
+  if (sink.raw)
   {
     ps.records(compressed != 0, rec, sink.in, sink.out, [&](const char* p, size_t whole) { sink.raw(p, whole, f.count_bytes); f.records += whole; });
     sink.raw(nullptr, 0, f.count_bytes);

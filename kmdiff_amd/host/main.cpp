@@ -717,7 +717,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
         // More rows within 1e-8 of the threshold than one launch can list (4096; include/kmdiff_hip.h): the rows beyond
         // kept the device libm's decision.  The guard's guarantee is restored the long way: the partition is merged
         // into a matrix and its rows are tested in pieces small enough for every near row to be listed (below).
-        if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] partition %zu: %llu near-threshold rows beyond the list: again, as a matrix in pieces\n", p, (unsigned long long)c[KMD_CNT_NEAR_UNRESOLVED]);
+        std::fprintf(stderr, "[kmdiff-hip] partition %zu: %llu near-threshold rows beyond the list: again, as a matrix in pieces\n", p, (unsigned long long)c[KMD_CNT_NEAR_UNRESOLVED]);
         const size_t n = D.n;
         d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);
         if (two_limbs) d_kmer_col_hi.reserve(n * 8);
@@ -796,7 +796,11 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
           ck(kmd_poisson_filter(model, &piece, first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter");
         }
         ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
-        if (c[KMD_CNT_NEAR_UNRESOLVED] == 0) break;
+        if (c[KMD_CNT_NEAR_UNRESOLVED] == 0)
+        {
+          if (pieces > 1) std::fprintf(stderr, "[kmdiff-hip] partition %zu: every near-threshold row decided in %zu pieces of %zu rows\n", p, pieces, rows_per);
+          break;
+        }
         if (rows_per <= 4096) die("kmd_poisson_filter: near-threshold rows left undecided in a piece of <= 4096 rows");
       }
       ns = (size_t)c[KMD_CNT_SIG];
@@ -1178,6 +1182,8 @@ void do_correction(const run_context& C, survivors_of_run& O)
     }
     kmd_transport_local_destroy((int)n_workers, T.data());
     ck(kmd_set_device(opt.device % C.ndev), "kmd_set_device");
+    // (the rank that failed first, not the ones that came back because it had: "another rank gave up")
+    for (const std::string& e : errors) if (!e.empty() && e.find("another rank gave up") == std::string::npos) die(e);
     for (const std::string& e : errors) if (!e.empty()) die(e);
     for (size_t wi = 0; wi < n_workers; ++wi) { c_controls += w_ctrl[wi]; c_cases += w_case[wi]; }
     kept = c_controls + c_cases;

@@ -778,7 +778,9 @@ void kmdo_popstrat_features(int nc, int nk, const uint64_t* totals_c, const uint
   }
   if (!standardize) return;
   double* means = calloc((size_t)fn, sizeof(double));
-  double* stddev = calloc((size_t)n, sizeof(double));                            /* :330 sized by ROWS */
+  /* :330 sized by ROWS -- and filled by column (:349): with fn > n the reference writes past the end (undefined behaviour
+   * there); the entries beyond n exist here and are never read (the division indexes rows) */
+  double* stddev = calloc((size_t)(n > fn ? n : fn), sizeof(double));
   for (int i = 0; i < n; i++) for (int j = 0; j < fn; j++) means[j] += null_out[i * fn + j];
   for (int j = 1; j < fn; j++) means[j] /= fn;                                   /* :342 divides by ncols */
   for (int i = 0; i < n; i++) for (int j = 1; j < fn; j++)

@@ -26,6 +26,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=300)
 ap.add_argument("--seed", type=int, default=int(time.time()))
 ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: by --seconds alone): the same cases on every box")
+ap.add_argument("--only", default="", help="'popstrat': pop-strat designs only")
+ap.add_argument("--tally", action="store_true", help="pop-strat rows outside the bars that jitter does not explain are counted (with the worst) instead of ending the run")
+ap.add_argument("--popstrat-stand", default="both", choices=["both", "true", "false"],
+                help="'true': standardised designs only -- the only mode the reference can reach (s_stand starts true and set_params can "
+                     "only turn it on, popstrat.hpp:155,174-175); 'false' is a stress case")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 oracle = OL.load()
@@ -200,19 +205,44 @@ def popstrat_case():
     Z = rng.normal(0, zs, size=(nc + nk, 10))
     Z[:nc, 0] += zshift
     stand, max_iter, scale, seed = bool(rng.integers(0, 2)), int(rng.choice([0, 0, 1, 2, 5, 25])), float(rng.choice([1.0, 0.01, 100.0])), int(rng.integers(0, 1 << 30))
-    libm_rows = []
+    if a.popstrat_stand != "both":
+        stand = a.popstrat_stand == "true"
+    libm_rows, outside = [], []
     try:
-        ps_check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=Z, totals_scale=scale, seed=seed, want_spread=False, libm_rows=libm_rows)
+        ps_check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=Z, totals_scale=scale, seed=seed, want_spread=False, libm_rows=libm_rows,
+                 outside=outside if a.tally else None)
     except AssertionError:
         np.savez("gpurun_out/soak_ps_fail.npz", nc=nc, nk=nk, npc=npc, stand=stand, max_iter=max_iter, rows=rows, Z=Z, scale=scale, seed=seed)
         print("FAILED pop-strat: nc=%d nk=%d npc=%d stand=%s max_iter=%d n=%d effect=%g sparse=%s zs=%g zshift=%g scale=%g seed=%d"
               % (nc, nk, npc, stand, max_iter, n, effect, sparse, zs, zshift, scale, seed), flush=True)
         raise
+    if outside and outside[0][0] == -1:       # --tally: a null fit that differs by more than the jitter explains
+        tag = "stand" if stand else "nostand"
+        DEV["popstrat_unexplained_null_fits_" + tag] = DEV.get("popstrat_unexplained_null_fits_" + tag, 0) + 1
+        print("  unexplained null fit (%s): nc=%d nk=%d npc=%d max_iter=%d scale=%g: |dev - oracle| %.3g of weights up to %.3g, jitter spread %.3g"
+              % (tag, nc, nk, npc, max_iter, scale, outside[0][1], outside[0][2], outside[0][3]), flush=True)
+        return
     if -1 in libm_rows:                       # the null fit itself hangs on libm's last bit: the design is counted, its rows are not compared
         key = "popstrat_libm_designs_stand" if stand else "popstrat_libm_designs_nostand"
         DEV[key] = DEV.get(key, 0) + 1
         return
+    if outside:
+        # rows outside the bars that one ulp of the oracle's pow() does not explain (--tally: counted, with the worst of them)
+        tag = "stand" if stand else "nostand"
+        DEV["popstrat_unexplained_rows_" + tag] = DEV.get("popstrat_unexplained_rows_" + tag, 0) + len(outside)
+        DEV["popstrat_unexplained_designs_" + tag] = DEV.get("popstrat_unexplained_designs_" + tag, 0) + 1
+        for (i, pd, pr, lo, hi) in outside:
+            d_abs = abs(pd - pr)
+            if d_abs > DEV.get("popstrat_unexplained_max_abs_" + tag, (0.0,))[0]:
+                DEV["popstrat_unexplained_max_abs_" + tag] = (d_abs, pd, pr)
+            d_rel = d_abs / abs(pr) if pr else float("inf")
+            if pr <= 0.05 and d_rel > DEV.get("popstrat_unexplained_max_rel_at_p_le_0.05_" + tag, (0.0,))[0]:
+                DEV["popstrat_unexplained_max_rel_at_p_le_0.05_" + tag] = (d_rel, pd, pr)
+            if pr <= 0.05:
+                DEV["popstrat_unexplained_rows_p_le_0.05_" + tag] = DEV.get("popstrat_unexplained_rows_p_le_0.05_" + tag, 0) + 1
     DEV["popstrat_rows"] = DEV.get("popstrat_rows", 0) + n
+    DEV["popstrat_rows_stand" if stand else "popstrat_rows_nostand"] = DEV.get("popstrat_rows_stand" if stand else "popstrat_rows_nostand", 0) + n
+    DEV["popstrat_designs_stand" if stand else "popstrat_designs_nostand"] = DEV.get("popstrat_designs_stand" if stand else "popstrat_designs_nostand", 0) + 1
     DEV["popstrat_libm_rows"] = DEV.get("popstrat_libm_rows", 0) + len(libm_rows)
     if libm_rows:
         key = "popstrat_libm_rows_stand" if stand else "popstrat_libm_rows_nostand"
@@ -224,6 +254,8 @@ n_cases = 0
 while time.time() - t0 < a.seconds and (a.cases == 0 or n_cases < a.cases):
     n_cases += 1
     kind = rng.integers(0, 19)
+    if a.only == "popstrat":
+        kind = 16
     if kind >= 16:
         popstrat_case()
         n_ps += 1

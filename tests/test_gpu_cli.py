@@ -239,11 +239,79 @@ def test_cli_partitions_sharded_over_gpus(synth_run, tmp_path):
     a, _ = run_cli(common + ["--devices", 1], tmp_path / "a")
     b, err = run_cli(common + ["--devices", 2], tmp_path / "b")
     c, _ = run_cli(common + ["--devices", 5], tmp_path / "c")           # more workers than partitions
-    assert a == b == c and a["n_sig"] > 10
+    d, _ = run_cli(common + ["--devices", 8], tmp_path / "d")           # the width of the node the job is sold for
+    assert a == b == c == d and a["n_sig"] > 10
     for name in ("control_kmers.fasta", "case_kmers.fasta", "popstrat/pcs.evec", "partitions/p0_uncorrected", "partitions/p2_uncorrected",
                  "partitions/p1_popstrat_uncorrected"):
         ref = open(tmp_path / "a" / name, "rb").read()
-        assert open(tmp_path / "b" / name, "rb").read() == ref and open(tmp_path / "c" / name, "rb").read() == ref, name
+        for other in "bcd":
+            assert open(tmp_path / other / name, "rb").read() == ref, (other, name)
+
+
+def test_cli_a_rank_that_fails_ends_the_run_with_its_error(synth_run, tmp_path):
+    """--devices 4 with one rank's thread failing before the exchange of stage 3 (KMD_TEST_FAIL_RANK): the run ends
+    with that rank's message and a non-zero status within seconds -- it used to hang in the other ranks' barrier."""
+    run_dir, nc, nk, k, mats, kms = synth_run
+    env = dict(os.environ, KMD_TEST_FAIL_RANK="2")
+    r = subprocess.run([CLI, "diff", "-o", str(tmp_path / "o"), "-d", run_dir, "-1", str(nc), "-2", str(nk), "-u", "1000", "-c", "benjamini",
+                        "--devices", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "KMD_TEST_FAIL_RANK: rank 2" in r.stderr, r.stderr[-2000:]
+
+
+def test_cli_more_near_threshold_rows_than_one_launch_lists(tmp_path):
+    """KMD_CNT_NEAR_UNRESOLVED read by the host: 6 000 rows with the same two count sums and the
+    first threshold put ON their p-value -- more rows within 1e-8 of the threshold than one launch can list for the
+    correctly rounded second look (4096).  The fused pass reports the rest unresolved; the command merges the partition
+    into a matrix and tests it in pieces until none is (stderr says so), and --matrix-path gets there by halving: both
+    write what the oracle decides."""
+    import kmdiff_amd as K
+    import ctypes as C
+    o = OL.load()
+    nc, nk, k, n_bg, n_same = 4, 4, 31, 30_000, 6_000
+    host, lo, _ = o.synth_rows(SEED, 9, 0, n_bg, nc, nk, 4)
+    rng = np.random.default_rng(11)
+    extra_km = np.setdiff1d(np.unique(rng.integers(int(lo.min()), int(lo.max()), 2 * n_same, dtype=np.uint64)), lo)[:n_same]
+    assert len(extra_km) == n_same
+    tcs, tks = host[:, :nc].sum(axis=0, dtype=np.uint64), host[:, nc:].sum(axis=0, dtype=np.uint64)
+    lf = o.lf_table(10000)
+    lib = K._native.lib()
+    # a row shape whose correctly rounded p-value (what the device decides a near row by) is the oracle's own double
+    chosen = None
+    cands = [[c0, 0, 0, 0, a, b, 2, 1] for c0 in (0, 1) for a in (2, 3, 4, 5) for b in (1, 2, 3)]
+    for cand in cands:
+        row = np.array(cand, dtype=np.uint32)
+        full = np.vstack([host, np.tile(row, (n_same, 1))])
+        tot_c = int(tcs.sum()) + n_same * int(row[:nc].sum()); tot_k = int(tks.sum()) + n_same * int(row[nc:].sum())
+        one = o.diff_partition(row[None, :], OL.LAYOUT_ROWS, nc, nk, tot_c, tot_k, lf, 1.0)
+        p_star = float(one["pvalue"][0])
+        tot = full.sum(axis=0, dtype=np.uint64)
+        model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+        p_rounded = lib.kmd_test_row_pvalue_rounded(C.c_void_p(model.handle), int(row[:nc].sum()), int(row[nc:].sum()))
+        if p_rounded == p_star and 1e-12 < p_star < 1e-2:
+            chosen = (row, full, p_star)
+            break
+    assert chosen is not None
+    row, full, p_star = chosen
+    km_all = np.concatenate([lo, extra_km])
+    order = np.argsort(km_all, kind="stable")
+    full, km_all = full[order], km_all[order]
+    part = [(km_all[full[:, s] > 0], full[full[:, s] > 0, s]) for s in range(nc + nk)]
+    ids = ["C%d" % i for i in range(nc)] + ["K%d" % i for i in range(nk)]
+    KF.write_run_dir(str(tmp_path / "km"), k, ids, [part])
+    tot = full.sum(axis=0, dtype=np.uint64)
+    want = o.diff_partition(full, OL.LAYOUT_ROWS, nc, nk, int(tot[:nc].sum()), int(tot[nc:].sum()), lf, p_star)
+    assert (want["pvalue"] == p_star).sum() >= n_same                       # the reference keeps them: p <= threshold (merge.hpp:78)
+    want_km = sorted(km_all[want["row"].astype(np.int64)].tolist())
+    outs = {}
+    for name, extra in (("fused", []), ("matrix", ["--matrix-path"])):
+        s, err = run_cli(["-d", str(tmp_path / "km"), "-1", nc, "-2", nk, "-s", repr(p_star), "-u", 1, "-c", "disabled", "--keep-tmp"] + extra,
+                         tmp_path / name)
+        assert "every near-threshold row decided in" in err, err[-1500:]
+        assert ("again, as a matrix in pieces" in err) == (name == "fused")
+        assert s["near_threshold"] >= n_same and s["n_sig"] == len(want_km)
+        recs = KF.read_survivor_file(str(tmp_path / name / "partitions" / "p0_uncorrected"))
+        outs[name] = sorted(int(v) for v in recs["kmer"])
+        assert outs[name] == want_km
 
 
 def test_cli_partitions_on_two_real_gpus(synth_run, tmp_path):

@@ -451,6 +451,64 @@ def test_sharded_correction_equals_single_list(K, name, n_ranks):
         N.lib().kmd_transport_local_destroy(n_ranks, T)
 
 
+@pytest.mark.parametrize("how", ["abort_before", "bad_argument", "leaves_mid_way"])
+def test_sharded_correction_a_rank_that_fails_does_not_hang_the_others(K, how):
+    """The in-process transport's barrier is abortable (a rank that failed outside a collective left the
+    others in local_hub::barrier for ever, `kmdiff-hip diff --devices N` hung in join).  One of four virtual ranks
+    gives up -- before its first collective (kmd_transport_abort: what the CLI's rank thread does when it throws), on
+    an argument kmd_correct_sharded refuses (the entry point tells the others itself), or after the counters'
+    all-reduce -- and every other rank comes back with an error within seconds."""
+    import ctypes as C
+    import threading
+    import time
+    N = K._native
+    lib = N.lib()
+    n_ranks, bad = 4, 2
+    rng = np.random.default_rng(77)
+    T = (N.Transport * n_ranks)()
+    N.check(lib.kmd_transport_local_create(n_ranks, T), "create")
+    rcs, msgs = [None] * n_ranks, [None] * n_ranks
+
+    def work(r):
+        p = np.sort(rng.uniform(0, 1e-6, 2000)) ** 2
+        s = np.zeros(len(p), dtype=np.int32)
+        dp, ds, keep = K.DeviceBuffer.from_host(p), K.DeviceBuffer.from_host(s), K.DeviceBuffer(len(p))
+        local = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+        local[0], local[1] = 10**8, len(p)
+        g = np.zeros(N.NCOUNTERS, dtype=np.uint64)
+        nk, nc, nca = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        if r == bad and how == "abort_before":
+            time.sleep(0.3)                                  # (the others are inside the all-reduce by now)
+            rcs[r] = lib.kmd_transport_abort(C.byref(T[r]))
+            return
+        corr = K.CORRECTION_BY_NAME["benjamini"]
+        if r == bad and how == "bad_argument":
+            time.sleep(0.3)
+            corr = 99                                        # refused before any collective
+        if r == bad and how == "leaves_mid_way":
+            # the counters' all-reduce by hand, then nothing more
+            buf = K.DeviceBuffer.from_host(local)
+            assert T[r].allreduce_u64(T[r].ctx, buf.ptr, N.NCOUNTERS, None) == 0
+            time.sleep(0.3)
+            rcs[r] = lib.kmd_transport_abort(C.byref(T[r]))
+            return
+        rcs[r] = lib.kmd_correct_sharded(C.byref(T[r]), corr, 0.05, local.ctypes.data, g.ctypes.data, dp.ptr, ds.ptr, len(p), keep.ptr,
+                                         C.byref(nk), C.byref(nc), C.byref(nca), None)
+        msgs[r] = lib.kmd_last_error().decode()
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(n_ranks)]
+    t0 = time.time()
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for the one that gave up"
+    assert time.time() - t0 < 30
+    for r in range(n_ranks):
+        if r == bad:
+            assert rcs[r] == (N.KMD_E_INVALID if how == "bad_argument" else 0)
+        else:
+            assert rcs[r] not in (None, 0) and "another rank gave up" in msgs[r], (r, rcs[r], msgs[r])
+    lib.kmd_transport_local_destroy(n_ranks, T)
+
+
 def test_sharded_correction_one_rank_and_no_transport(K):
     """world = 1 (a NULL transport, or a one-rank one): kmd_correct itself."""
     import ctypes as C

@@ -67,12 +67,12 @@ def test_synth_streams_are_the_matrix_column_by_column(K, nc, nk, limbs, rows, c
             assert np.array_equal(kh[a:b], hi[sel])
 
 
-def run_both(K, part, rows, nc, nk, limbs, thr=THR):
+def run_both(K, part, rows, nc, nk, limbs, thr=THR, profile=0):
     """K1 on the matrix and K2t (single call, then a batch of two) on the streams of one synthetic partition"""
-    ss, tot = K.synth_streams(SEED, part, rows, nc, nk, kmer_limbs=limbs)
+    ss, tot = K.synth_streams(SEED, part, rows, nc, nk, kmer_limbs=limbs, profile=profile)
     model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
     cap = max(rows // 200, 1 << 16)
-    mat = K.synth_matrix(SEED, part, rows, nc, nk, 4, K.LAYOUT_TILED, kmer_limbs=limbs)
+    mat = K.synth_matrix(SEED, part, rows, nc, nk, 4, K.LAYOUT_TILED, kmer_limbs=limbs, profile=profile)
     assert K.column_sums(mat).tolist() == tot.tolist()
     a = K.SurvivorAccumulator(cap, kmer_limbs=limbs)
     K.diff_observer(model, a, thr).process(mat)
@@ -109,6 +109,49 @@ def test_fused_merge_on_a_config3_partition(K, oracle):
         assert x.finish(by_kmer=True) == len(got["sign"])
         same_survivors(x.get(), got)
         assert [int(v) for v in x.read_counters()[:4]] == [int(v) for v in c[:4]]
+
+
+def test_mixed_partition_rare_and_common_rows(K, oracle):
+    """The MIXED presence profile (KMD_SYNTH_MIXED: bench.py's pipeline.sparse): every second row in one or two samples,
+    the others in ~95 % of them.  Small: the device-built streams are the device-built matrix column by column, and the
+    fused merge's survivors are the ORACLE's on that matrix (bit-exact identity, sign, means, counters; p within 1e-10).
+    Whole configs[2] size (39 062 500 rows, ~7.7 x 10^8 records): K2t == K1 bit for bit, single call and batch."""
+    import oracle_lib as OL
+    from test_gpu_parity import assert_p_close
+    nc, nk, rows = 20, 20, 120_000
+    S = nc + nk
+    mat = K.synth_matrix(SEED, 7, rows, nc, nk, 4, K.LAYOUT_ROWS, profile=K.SYNTH_MIXED)
+    host, (lo, _) = mat.to_host(), mat.kmers_to_host()
+    present = (host > 0).sum(axis=1)
+    rare = present <= 2
+    assert 0.45 < rare.mean() < 0.55 and present[rare].min() >= 1 and present[~rare].mean() > 0.93 * S and present[~rare].min() > 0.7 * S
+    ss, tot = K.synth_streams(SEED, 7, rows, nc, nk, profile=K.SYNTH_MIXED)
+    assert tot.tolist() == host.sum(axis=0, dtype=np.uint64).tolist() and ss.total == int(present.sum())
+    km, cn = ss.kmers.to_host(np.uint64, ss.total), ss.counts.to_host(np.uint32, ss.total)
+    for s in range(S):
+        sel = host[:, s] > 0
+        a, b = int(ss.offs[s]), int(ss.offs[s + 1])
+        assert np.array_equal(km[a:b], lo[sel]) and np.array_equal(cn[a:b], host[sel, s])
+    thr = 1e-4
+    model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+    acc = K.SurvivorAccumulator(rows)
+    assert K.merge_filter(ss, K.diff_observer(model, acc, thr)) == rows
+    n = acc.finish(by_kmer=True)
+    got, c = acc.get(), acc.read_counters()
+    want = oracle.diff_partition(host, OL.LAYOUT_ROWS, nc, nk, int(tot[:nc].sum()), int(tot[nc:].sum()), oracle.lf_table(10000), thr)
+    rr = want["row"].astype(np.int64)
+    assert n == len(rr) > 20 and tuple(int(v) for v in c[:4]) == want["counters"]
+    assert got["kmer_lo"].tolist() == lo[rr].tolist() and got["sign"].tolist() == want["sign"].tolist()
+    assert got["mean_control"].tolist() == want["mean_control"].tolist() and got["mean_case"].tolist() == want["mean_case"].tolist()
+    assert_p_close(got["pvalue"], want["pvalue"])
+    del mat, ss, acc
+    ss, tot, model, got, c = run_both(K, 7, 39_062_500, nc, nk, 1, profile=K.SYNTH_MIXED)
+    assert 600_000_000 < ss.total < 900_000_000 and int(c[0]) == 39_062_500 and int(c[1]) > 100
+    accs = [K.SurvivorAccumulator(1 << 17), K.SurvivorAccumulator(1 << 17)]
+    assert K.merge_filter_batch([ss, ss], [K.diff_observer(model, x, THR) for x in accs]) == [39_062_500] * 2
+    for x in accs:
+        assert x.finish(by_kmer=True) == len(got["sign"])
+        same_survivors(x.get(), got)
 
 
 def test_fused_merge_on_a_config4_partition(K, oracle):

@@ -27,12 +27,15 @@ def oracle_setup(oracle, nc, nk, tc, tk, Z, npc, stand, max_iter, Y):
     return alt, w, tot
 
 
-def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_scale=1.0, seed=3, want_spread=True, libm_rows=None):
+def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_scale=1.0, seed=3, want_spread=True, libm_rows=None, outside=None):
     """libm_rows: a list -- rows outside the bars are then allowed IF the oracle's own p-value for them moves by more than
     the bars when the pow() inside its sigmoid is jittered by one ulp (kmdo_sigmoid_jitter): their p-value is a property of
-    libm's last bit, not of the data (the default design is not standardised: a column of ~1e7 beside one of ~1e-6, and
-    IRLS without pivoting on a Hessian of condition number > 1e16 amplifies one ulp to anything).  Their indices are
-    appended to the list."""
+    libm's last bit, not of the data (an unstandardised design -- stand=False, which the reference cannot reach -- has a
+    column of ~1e7 beside one of ~1e-6, and IRLS without pivoting on a Hessian of condition number > 1e16 amplifies one
+    ulp to anything; the reference's own standardize() leaves the k-mer column unscaled too, so separation cases exist in
+    the reachable mode as well).  Their indices are appended to the list.
+    outside: a list (tests/soak.py's tally) -- a row outside the bars that the jitter does NOT explain is then appended as
+    (index, p_dev, p_ref, jitter lo, jitter hi) instead of failing the check."""
     S = nc + nk
     rng = np.random.default_rng(seed)
     if Z is None:
@@ -63,6 +66,10 @@ def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_
                 oracle.L.kmdo_sigmoid_jitter(0, 0)
             with np.errstate(invalid="ignore"):
                 spread = max(spread, float(np.nanmax(np.abs(n2 - null_o))))
+        if not (null_dev <= 8 * spread + 1e-9 * null_scale) and outside is not None:
+            outside.append((-1, float(null_dev), float(null_scale), float(spread), 0.0))      # (tally: the null fit itself, unexplained)
+            libm_rows.append(-1)
+            return None
         assert null_dev <= 8 * spread + 1e-9 * null_scale, (null_dev, spread)
         libm_rows.append(-1)
         return None
@@ -94,10 +101,13 @@ def check(K, oracle, nc, nk, npc, stand, max_iter, rows, Z=None, Y=None, totals_
             seen = np.array(seen)
             if np.isfinite(seen).all() and np.isfinite(p_dev[i]):
                 lo, hi = seen.min(), seen.max()
-                # the oracle itself is unsure: one ulp moves it by at least a quarter of what the device differs by ...
-                assert hi - lo >= 0.25 * abs(p_dev[i] - p_ref[i]), (i, p_dev[i], p_ref[i], lo, hi)
-                # ... and the device is no further from the oracle's range than a few times its width
-                assert lo - 4 * (hi - lo) <= p_dev[i] <= hi + 4 * (hi - lo), (i, p_dev[i], lo, hi)
+                # the oracle itself is unsure: one ulp moves it by at least a quarter of what the device differs by,
+                # and the device is no further from the oracle's range than a few times its width
+                explained = hi - lo >= 0.25 * abs(p_dev[i] - p_ref[i]) and lo - 4 * (hi - lo) <= p_dev[i] <= hi + 4 * (hi - lo)
+                if not explained and outside is not None:
+                    outside.append((int(i), float(p_dev[i]), float(p_ref[i]), float(lo), float(hi)))
+                    continue
+                assert explained, (i, p_dev[i], p_ref[i], lo, hi)
             else:
                 assert not np.isfinite(seen).all() or len(np.unique(seen)) > 1, (i, p_dev[i], seen[:4])
             libm_rows.append(int(i))
@@ -132,6 +142,15 @@ def test_principal_components_and_standardisation(K, oracle, npc, stand):
     nc, nk = (20, 20) if npc < 8 else (35, 30)
     # unstandardised totals of 1e7 make the Hessian wildly scaled: the no-pivot LU still has to agree
     check(K, oracle, nc, nk, npc, stand, 0, count_rows(rng, 400, nc, nk), want_spread=stand)
+
+
+def test_more_features_than_samples(K, oracle):
+    """Fewer samples than columns of the design (6 samples, 8 PCs: 10 null features): standardize() fills stddev -- sized
+    by rows -- by column (popstrat.cpp:330,349), past its end in the reference; here and in the oracle the entries
+    exist (tests/soak.py met glibc's heap check on such a design).  The Hessian is singular: every fit stops at once."""
+    rng = np.random.default_rng(15)
+    check(K, oracle, 3, 3, 8, True, 0, count_rows(rng, 100, 3, 3), want_spread=False)
+    check(K, oracle, 2, 2, 10, True, 0, count_rows(rng, 100, 2, 2), want_spread=False)
 
 
 def test_singular_hessian_leaves_the_weights_at_one(K, oracle):
@@ -238,13 +257,75 @@ def test_group_kernel_equals_lane_kernel(K, oracle, monkeypatch, nc, nk, npc, st
 
 @pytest.mark.parametrize("nc,nk,npc,seed", [(43, 3, 4, 1), (43, 3, 4, 2), (50, 2, 3, 3), (12, 40, 6, 4)])
 def test_rows_whose_p_value_hangs_on_the_last_bit_of_pow(K, oracle, nc, nk, npc, seed):
-    """tests/soak.py's find: the DEFAULT design (no --stand) with a few samples on one side.  One row in ~3000 came out at
-    p = 5e-5 on the device and p = 1 in the oracle -- and the oracle itself gives either, depending on one ulp of the pow()
-    in its sigmoid (kmdo_sigmoid_jitter).  Such rows are no parity failure and no parity success: they are counted.  Every
-    other row keeps the bars (1e-10 absolute, 1e-7 relative), and there are few of the former."""
+    """A STRESS case, not a mode the reference can reach: the unstandardised design (stand=False) with a few samples on
+    one side.  (In the reference s_stand starts true and set_params can only turn it on, popstrat.hpp:155,174-175: every
+    reference run standardises -- with standardize()'s bugs, which kmd_popstrat_create repeats; the CLI ignores --stand
+    accordingly.  Round 4 called this design "the default": wrong; PARITY.md 2 has the tally of the
+    reachable mode alone.)  tests/soak.py found it: one row in ~3000 came out at p = 5e-5 on the device and p = 1 in the
+    oracle -- and the oracle itself gives either, depending on one ulp of the pow() in its sigmoid (kmdo_sigmoid_jitter).
+    Such rows are no parity failure and no parity success: they are counted.  Every other row keeps the bars (1e-10
+    absolute, 1e-7 relative), and there are few of the former."""
     rng = np.random.default_rng(9000 + seed)
     rows = count_rows(rng, 3000, nc, nk, effect=float(rng.choice([1.2, 3.0])))
     Z = rng.normal(0, 0.1, size=(nc + nk, 10))
     libm_rows = []
     check(K, oracle, nc, nk, npc, False, 0, rows, Z=Z, seed=seed, want_spread=False, libm_rows=libm_rows)
     assert len(libm_rows) <= 30, len(libm_rows)
+
+
+def test_reference_linear_vectors_through_the_device_routines(K):
+    """The only numbers of stage 2 the reference's own tests hold (tests/linear_test.cpp:29-31 sigmoid(1) and predict,
+    :80-151 the 4 x 4 LU factors and inverse at 1e-15) pushed through the DEVICE routines K3 runs (kmd_test_popstrat_*:
+    lu_solve of the lane kernel, group_lu_solve of the group kernel, sigmoid_ref, the dot product of eta = X w) -- until
+    now they reached the GPU only through the oracle (missing 1)."""
+    import ctypes as C
+    lib = K._native.lib()
+    # linear_test.cpp:29: EXPECT_TRUE(is_equal_d(sigmoid(1.0), 0.7310585786300048792512))  (is_equal_d: |a - b| < 1e-15 by default)
+    x = np.array([1.0, 0.0, -1.0, 14.0, -745.0, 745.0, 40.0])
+    out = np.zeros_like(x)
+    K._native.check(lib.kmd_test_popstrat_sigmoid(x.ctypes.data, len(x), out.ctypes.data), "sigmoid")
+    assert abs(out[0] - 0.7310585786300048792512) < 1e-15 and out[1] == 0.5 and abs(out[2] - (1 - 0.7310585786300048792512)) < 1e-15
+    assert 0.0 <= out[4] < 1e-300 and out[5] == 1.0 and out[6] == 1.0
+    # :30-31: linear_predictor({1,2,3},{1,2,3}) == 14; predict(...) == 0.9999991684719723358679
+    w = np.array([1.0, 2.0, 3.0])
+    eta, pr = C.c_double(0), C.c_double(0)
+    K._native.check(lib.kmd_test_popstrat_predict(w.ctypes.data, w.ctypes.data, 3, C.byref(eta), C.byref(pr)), "predict")
+    assert eta.value == 14.0 and abs(pr.value - 0.9999991684719723358679) < 1e-15
+    # :80-151: the 4 x 4 matrix, its no-pivot LU factors (exact: small integers) and its inverse (1e-15)
+    m = np.array([[1, 2, 1, 1], [1, 1, 6, 1], [1, 0, 1, 0], [1, 0, 1, 1]], dtype=np.float64)
+    lower = np.array([[1, 0, 0, 0], [1, 1, 0, 0], [1, 2, 1, 0], [1, 2, 1, 1]], dtype=np.float64)
+    upper = np.array([[1, 2, 1, 1], [0, -1, 5, 0], [0, 0, -10, -1], [0, 0, 0, 1]], dtype=np.float64)
+    inv = np.array([[0.1, -0.2, 1, 0.1], [0.5, 0, 0, -0.5], [-0.1, 0.2, 0, -0.1], [0, 0, -1, 1]])
+    b = np.array([3.0, -1.0, 0.5, 2.0])
+    F = 4
+    each = 2 * F * F + F + 1
+    lane, grp = np.zeros(each), np.zeros(each)
+    K._native.check(lib.kmd_test_popstrat_linear(F, m.ctypes.data, b.ctypes.data, lane.ctypes.data, grp.ctypes.data), "linear")
+    for name, o in (("lane", lane), ("group", grp)):
+        lu = o[:F * F].reshape(F, F)
+        got_l = np.tril(lu, -1) + np.eye(F)
+        got_u = np.triu(lu)
+        assert (got_l == lower).all() and (got_u == upper).all(), name
+        got_inv = o[F * F:2 * F * F].reshape(F, F)
+        assert np.abs(got_inv - inv).max() < 1e-15, (name, got_inv)
+        assert o[2 * F * F + F] == 0.0
+        assert np.abs(o[2 * F * F:2 * F * F + F] - inv @ b).max() < 1e-14, name
+    # the two device routines agree bit for bit (as the two kernels' p-values do), also on an ill-scaled Hessian
+    assert (lane == grp).all()
+    rng = np.random.default_rng(4)
+    for F in (3, 5, 7, 13):
+        X = rng.normal(0, 1, (40, F)) * np.array([1.0] + [10.0 ** rng.integers(-6, 7) for _ in range(F - 1)])
+        H = X.T @ X
+        bb = rng.normal(0, 1, F)
+        each = 2 * F * F + F + 1
+        lane, grp = np.zeros(each), np.zeros(each)
+        K._native.check(lib.kmd_test_popstrat_linear(F, np.ascontiguousarray(H).ctypes.data, bb.ctypes.data, lane.ctypes.data, grp.ctypes.data), "linear")
+        assert (lane[:each - 1] == grp[:each - 1]).all(), F
+        with np.errstate(all="ignore"):
+            resid = H @ lane[F * F:2 * F * F].reshape(F, F) - np.eye(F)
+        assert lane[each - 1] == 0 and np.abs(resid).max() < 1e-2, (F, np.abs(resid).max())      # (no pivoting, columns up to 10^12 apart)
+    # a singular matrix: det == 0 -> status 1 (the fit then stops before its first update, linear_model.cpp:366-372)
+    sing = np.array([[1.0, 2.0, 3.0], [2.0, 4.0, 6.0], [1.0, 0.0, 1.0]])
+    lane, grp = np.zeros(2 * 9 + 4), np.zeros(2 * 9 + 4)
+    K._native.check(lib.kmd_test_popstrat_linear(3, sing.ctypes.data, np.ones(3).ctypes.data, lane.ctypes.data, grp.ctypes.data), "linear")
+    assert lane[-1] in (1.0, 2.0) and grp[-1] == 1.0

@@ -25,11 +25,12 @@ ap.add_argument("--overlap", type=int, default=0, help="also: this many host thr
 ap.add_argument("--triples", action="store_true", help="also time kmd_merge_sums + kmd_poisson_filter_sums")
 ap.add_argument("--device", action="store_true", help="streams built on the device (kmd_synth_streams): whole configs[2] partitions (--rows 39062500) without a host copy; fused path only")
 ap.add_argument("--partition", type=int, default=0)
+ap.add_argument("--profile", type=int, default=0, help="--device: the rows' presence profile (1: mixed -- every second row in one or two samples, the others in 95 %%)")
 a = ap.parse_args()
 S = a.nc + a.nk
 lib = K._native.lib()
 if a.device:
-    ss, tot = K.synth_streams(0x6B6D64696666, a.partition, a.rows, a.nc, a.nk, kmer_limbs=a.limbs)
+    ss, tot = K.synth_streams(0x6B6D64696666, a.partition, a.rows, a.nc, a.nk, kmer_limbs=a.limbs, profile=a.profile)
     model = K.PoissonLikelihood(a.nc, a.nk, tot[:a.nc], tot[a.nc:], 10000)
     acc = K.SurvivorAccumulator(max(1 << 16, a.rows // 100), kmer_limbs=a.limbs)
     obs = K.diff_observer(model, acc, 5e-7)
