@@ -165,8 +165,8 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
            "config": {"workload": "%s: 20v20, k=31, %d rows, %d records of 12 bytes (8-byte k-mer + 4-byte count) in 40 per-sample "
                                   "streams, built on the device (kmd_synth_streams)%s"
                                   % ("one configs[2] partition (10^10 rows / 256)" if rows == ROWS_PER_PARTITION else "a reduced partition", rows, ss.total,
-                                     "; MIXED presence profile: every second row in one or two samples, the others in 95 % of the samples "
-                                     "(%.1f records per row on average)" % (ss.total / float(rows)) if profile else ""),
+                                     ("; MIXED presence profile: every second row in one or two samples, the others in 95 %% of the samples "
+                                      "(%.1f records per row on average)" % (ss.total / float(rows))) if profile else ""),
                       "rows": rows, "records": ss.total, "samples": NC + NK},
            "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),
            "records_per_s": ss.total / (ms * 1e-3), "bytes_algorithmic": 12 * ss.total, "roofline": roof(gbs), "n_sig": n_sig0}
@@ -263,11 +263,11 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
     return out
 
 
-def feed_leg(K, lib, ss, model, n_parts=4, threads=8):
+def feed_leg(K, lib, ss, model, n_parts=6, threads=8):
     """The path `kmdiff-hip diff` takes, link included: one whole partition's streams as the host hands them over -- packed
     per 256 records (kmd_pack_stream: what the command's decoder threads write into page-locked memory), kmd_memcpy_h2d_async
-    on a copy stream, kmd_unpack_streams behind the copies, kmd_merge_filter on the unpacked arrays -- double-buffered:
-    the copy of partition i + 1 runs beside the kernels of partition i.  Never `value`."""
+    on a copy stream, kmd_unpack_streams on a second stream behind an event of its copy, kmd_merge_filter on the unpacked
+    arrays: the copies of partitions i + 1 and i + 2 run beside the kernels of partition i.  Never `value`."""
     from concurrent.futures import ThreadPoolExecutor
     S, offs = ss.n_samples, ss.offs
     bound = int(lib.kmd_pack_block_bound())
@@ -296,8 +296,9 @@ def feed_leg(K, lib, ss, model, n_parts=4, threads=8):
     table = np.concatenate([t for _, t in parts]) if S else np.zeros(0, np.uint32)
     h = C.c_void_p()
     K._native.check(lib.kmd_malloc_host(C.byref(h), P + table.nbytes + 64), "kmd_malloc_host")
-    st = C.c_void_p()
-    K._native.check(lib.kmd_stream_create(C.byref(st)), "kmd_stream_create")
+    st, st_u = C.c_void_p(), C.c_void_p()
+    K._native.check(lib.kmd_stream_create(C.byref(st)), "kmd_stream_create")          # the copies
+    K._native.check(lib.kmd_stream_create(C.byref(st_u)), "kmd_stream_create")        # kmd_unpack_streams, behind an event of the copy it reads
     try:
         hb = (C.c_uint8 * (P + table.nbytes)).from_address(h.value)
         hv = np.frombuffer(hb, dtype=np.uint8)
@@ -305,7 +306,10 @@ def feed_leg(K, lib, ss, model, n_parts=4, threads=8):
             hv[int(base[s_]):int(base[s_ + 1])] = parts[s_][0]
         hv[P:P + table.nbytes] = table.view(np.uint8)
         del parts
-        d_packed = [K.DeviceBuffer(P + table.nbytes + 64) for _ in range(2)]
+        # three packed buffers (two copies queued behind each other: the link never waits for an unpack), two sets of
+        # unpacked arrays (one being merged, one being written)
+        d_packed = [K.DeviceBuffer(P + table.nbytes + 64) for _ in range(3)]
+        copied = [K.Event() for _ in range(3)]
         outs = []
         for _ in range(2):
             o = K.StreamSet.__new__(K.StreamSet)
@@ -322,31 +326,40 @@ def feed_leg(K, lib, ss, model, n_parts=4, threads=8):
             K._native.check(lib.kmd_memcpy_h2d(d_packed[0].ptr, h, P + table.nbytes, st), "h2d")
         link_gbs = 2 * (P + table.nbytes) / (time.perf_counter() - t0) / 1e9
 
-        def enqueue(i):
-            slot = i % 2
-            K._native.check(lib.kmd_memcpy_h2d_async(d_packed[slot].ptr, h, P + table.nbytes, st), "h2d_async")
-            K._native.check(lib.kmd_unpack_streams(S, d_packed[slot].ptr, base.ctypes.data, d_packed[slot].ptr + P, offs.ctypes.data,
-                                                   outs[slot].kmers.ptr, outs[slot].counts.ptr, st), "kmd_unpack_streams")
+        def enqueue_copy(k):
+            K._native.check(lib.kmd_memcpy_h2d_async(d_packed[k % 3].ptr, h, P + table.nbytes, st), "h2d_async")
+            copied[k % 3].record(st)
+
+        def enqueue_unpack(k):
+            K._native.check(lib.kmd_stream_wait_event(st_u, copied[k % 3].ptr), "kmd_stream_wait_event")
+            K._native.check(lib.kmd_unpack_streams(S, d_packed[k % 3].ptr, base.ctypes.data, d_packed[k % 3].ptr + P, offs.ctypes.data,
+                                                   outs[k % 2].kmers.ptr, outs[k % 2].counts.ptr, st_u), "kmd_unpack_streams")
         # untimed: one partition through (first-use costs, the survivors it must reproduce)
-        enqueue(0)
-        K._native.check(lib.kmd_stream_sync(st))
+        enqueue_copy(0)
+        enqueue_unpack(0)
+        K._native.check(lib.kmd_stream_sync(st_u))
         rows0 = K.merge_filter(outs[0], obs)
         n_sig0 = int(acc.read_counters()[1])
         acc.counters.zero()
-        enqueue(0)
+        enqueue_copy(0)
+        enqueue_copy(1)
+        enqueue_unpack(0)
         t0 = time.perf_counter()
         rows_seen = 0
         for i in range(n_parts):
-            K._native.check(lib.kmd_stream_sync(st))        # partition i lies unpacked in HBM
+            K._native.check(lib.kmd_stream_sync(st_u))      # partition i lies unpacked in HBM
+            if i + 2 < n_parts:
+                enqueue_copy(i + 2)                         # (its buffer held partition i - 1: unpacked long since)
             if i + 1 < n_parts:
-                enqueue(i + 1)                              # the next one crosses the link beside this one's kernels
-            rows_seen += K.merge_filter(outs[i % 2], obs)
+                enqueue_unpack(i + 1)                       # behind its copy; into the arrays partition i - 1 was merged from
+            rows_seen += K.merge_filter(outs[i % 2], obs)   # beside the copies of partitions i + 1, i + 2
         K._native.check(lib.kmd_stream_sync(None))
         dt = (time.perf_counter() - t0) / n_parts
         c = acc.read_counters()
         assert rows_seen == n_parts * rows0 and int(c[1]) == n_parts * n_sig0, (rows_seen, rows0, int(c[1]), n_sig0)
     finally:
         lib.kmd_stream_destroy(st)
+        lib.kmd_stream_destroy(st_u)
         lib.kmd_free_host(h)
     bpr = (P + table.nbytes) / float(ss.total)
     ceiling = link_gbs * 1e9 / ((P + table.nbytes) / float(rows0))

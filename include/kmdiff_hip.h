@@ -93,6 +93,9 @@ int kmd_release_cache(void);
 int kmd_event_create(void** ev);
 int kmd_event_destroy(void* ev);
 int kmd_event_record(void* ev, void* stream);
+/* work enqueued on `stream` after this call waits for what `ev` recorded (hipStreamWaitEvent): copies on one stream,
+ * the kernels that read them on another, no host round trip between */
+int kmd_stream_wait_event(void* stream, void* ev);
 int kmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* syncs on ev_stop */
 
 /* ---- the model ------------------------------------------------------------------------
@@ -453,7 +456,7 @@ int kmd_pca_eigen(int n_samples, const double* xtx_host, int n_out, double* evec
  * the CPU oracle replays it.  d_kmer_lo / d_kmer_hi may be NULL.
  * partition: bits 0-7 the partition (< 256), bits 8-15 the PRESENCE PROFILE of the rows: 0 = SURVEY 8d's (every sample
  * absent with probability 0.3 in the two low rate classes: ~26 of 40 samples hold a row); KMD_SYNTH_MIXED (1) = every
- * second row RARE (present in one or two samples) and the others COMMON (in 95 % of the samples) -- the shape of a
+ * second row RARE (present in one or two samples, counts of the two low rate classes) and the others COMMON (in 95 % of the samples) -- the shape of a
  * real partition's two populations, sample-specific k-mers and shared ones (bench.py's pipeline.sparse; not replayed
  * by the oracle: the device-built streams are held against the device-built matrix). */
 #define KMD_SYNTH_MIXED 1u

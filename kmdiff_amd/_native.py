@@ -86,6 +86,7 @@ SIGNATURES = {
     "kmd_event_create": (_i, [C.POINTER(_vp)]),
     "kmd_event_destroy": (_i, [_vp]),
     "kmd_event_record": (_i, [_vp, _vp]),
+    "kmd_stream_wait_event": (_i, [_vp, _vp]),
     "kmd_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "kmd_model_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _vp, _sz]),
     "kmd_model_destroy": (_i, [_vp]),

@@ -284,6 +284,12 @@ int kmd_event_record(void* ev, void* stream)
   KMD_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)));
   return KMD_OK;
 }
+int kmd_stream_wait_event(void* stream, void* ev)
+{
+  KMD_REQUIRE(ev, "kmd_stream_wait_event: NULL event");
+  KMD_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0));
+  return KMD_OK;
+}
 int kmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms)
 {
   KMD_REQUIRE(ms, "kmd_event_elapsed_ms: NULL");
@@ -486,7 +492,10 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, uint32_t part, uin
     int cls = u16 < 26214 ? 0 : u16 < 45875 ? 1 : u16 < 55705 ? 2 : u16 < 62259 ? 3 : u16 < 64880 ? 4 : 5;
     int jbase = cls == 0 ? 1 : cls == 1 ? 3 : cls == 2 ? 5 : cls == 3 ? 7 : cls == 4 ? 11 : 17;
     if ((h >> 16) % 1000000ull == 1) { jbase = 24; cls = 6; }
-    const bool planted = (h >> 36) % 10000ull == 0;
+    // (a rare row is a low-abundance one: the two low rate classes, no planted signal -- a k-mer seen 300 times in one
+    // sample and nowhere else would be "significant", and one row in forty would be)
+    if (rare && cls > 1) { cls = 1; jbase = 3; }
+    const bool planted = !rare && (h >> 36) % 10000ull == 0;
     const int boost_controls = (int)(h >> 63);
     bool any = false;
     for (int s = 0; s < S; ++s)

@@ -229,8 +229,21 @@ def popstrat_case():
     if outside:
         # rows outside the bars that one ulp of the oracle's pow() does not explain (--tally: counted, with the worst of them)
         tag = "stand" if stand else "nostand"
+        if nc + nk < npc + 3:
+            # fewer samples than columns of the alternative design (F = 3 + npc): X^T G X is singular by construction, the
+            # no-pivot LU divides by rounding noise, and the p-value is noise in the reference and here alike (with fewer
+            # samples than NULL columns the reference has already written past its stddev vector: undefined behaviour there)
+            tag += "_rank_deficient"
         DEV["popstrat_unexplained_rows_" + tag] = DEV.get("popstrat_unexplained_rows_" + tag, 0) + len(outside)
         DEV["popstrat_unexplained_designs_" + tag] = DEV.get("popstrat_unexplained_designs_" + tag, 0) + 1
+        nd = DEV["popstrat_unexplained_designs_" + tag]
+        worst = max(outside, key=lambda t: abs(t[1] - t[2]))
+        print("  unexplained rows (%s): %d of %d in nc=%d nk=%d npc=%d max_iter=%d effect=%g sparse=%s zs=%g zshift=%g scale=%g seed=%d; worst p_dev %.17g p_ref %.17g jitter [%.17g, %.17g]"
+              % (tag, len(outside), n, nc, nk, npc, max_iter, effect, sparse, zs, zshift, scale, seed, worst[1], worst[2], worst[3], worst[4]), flush=True)
+        if nd <= 12:
+            idx = np.array([t[0] for t in outside])
+            np.savez("gpurun_out/soak_ps_unexplained_%s_%d.npz" % (tag, nd), nc=nc, nk=nk, npc=npc, stand=stand, max_iter=max_iter, rows=rows[idx], Z=Z, scale=scale, seed=seed,
+                     p_dev=np.array([t[1] for t in outside]), p_ref=np.array([t[2] for t in outside]), idx=idx, n_rows=n)
         for (i, pd, pr, lo, hi) in outside:
             d_abs = abs(pd - pr)
             if d_abs > DEV.get("popstrat_unexplained_max_abs_" + tag, (0.0,))[0]:
