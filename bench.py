@@ -548,7 +548,7 @@ def main():
             pass
         # roofline.frac / frac_events: THIS run's HIP events.  What profiles/ holds of the same command (rocprofv3 cannot
         # run inside this process) is quoted beside it, with its source: the PMC traffic per launch, and the kernel's
-        # average duration in the committed kernel-trace CSV (tools/refresh_profiles_r04.sh makes both in one lease and
+        # average duration in the committed kernel-trace CSV (tools/refresh_profiles_r05.sh makes both in one lease and
         # checks the CSV against the HIP events of the profiled run itself: they agree to 3 %; a run under the
         # profiler is 2-3 % slower than one without, MI355X_MICROARCH.md "DVFS give-back")
         traffic, traffic_source, profiled = None, None, None
