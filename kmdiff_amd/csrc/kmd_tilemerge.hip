@@ -100,6 +100,15 @@ using namespace kmd::eval;
 #ifndef KMD_TILE_WAVES
 #define KMD_TILE_WAVES(sum32, two, wide) ((sum32) && !(two) && (wide) ? 8 : 1)
 #endif
+#ifndef KMD_TILE_WAVES_BIG
+#define KMD_TILE_WAVES_BIG(sum32, two, wide) (KMD_TILE_BIG_THREADS == 1024 ? KMD_TILE_WAVES(sum32, two, wide) : ((sum32) && !(two) && (wide) ? 4 : 1))
+#endif
+#ifndef KMD_TILE_BIG_THREADS
+#define KMD_TILE_BIG_THREADS 1024    // threads of the workgroup that takes the 4096-slot table (dev: 512 = eight waves with twice the registers each)
+#endif
+#ifndef KMD_TILE_RING_BIG
+#define KMD_TILE_RING_BIG KMD_TILE_RING   // rounds in flight per wave under the 4096-slot shape
+#endif
 #ifndef KMD_TILE_ABORT_EVERY
 #define KMD_TILE_ABORT_EVERY 4       // rounds between two looks at the tile's give-up flag (a power of two <= KMD_TILE_RING)
 #endif
@@ -625,7 +634,7 @@ struct tile_lds
 // differ, so some slice boundary falls between them; at the latest when a slice is a single value of the
 // cut window).  A low limb of all ones (the empty marker) is kept apart the same way.
 template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo, bool kWide, bool kSum32>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(KMD_TILE_WAVES(kSum32, kTwo, kWide))))
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kSlots == kBigSlots ? KMD_TILE_WAVES_BIG(kSum32, kTwo, kWide) : KMD_TILE_WAVES(kSum32, kTwo, kWide))))
 #if KMD_TILE_JOB_PTR
 k_tile_sums(const tile_job* __restrict__ Jp)
 {
@@ -783,7 +792,7 @@ k_tile_sums(const tile_job J)
     {
       if (process)
       {
-        constexpr int kRing = KMD_TILE_RING;
+        constexpr int kRing = kSlots == kBigSlots ? KMD_TILE_RING_BIG : KMD_TILE_RING;
         constexpr int kR = KMD_TILE_RPL;                                              // records per lane and round (lane l: records l, 64 + l, ...)
         constexpr uint32_t kStep = 64u * kR;                                          // records per round
         constexpr uint32_t kBatch = 63;                                               // runs of a wave whose description its lanes hold at a time
@@ -2126,8 +2135,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   uint32_t shape_known = sh.slots;                               // levels > 0: the plan's, read back
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
   // (what the instantiations that can be launched take of the 160 KB of LDS, 1024 samples' segment tables included)
-  static_assert(sizeof(tile_lds<kBigSlots, 16, true, true>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, two limbs, 32-bit sums");
-  static_assert(sizeof(tile_lds<kBigSlots, 16, false, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, one limb, 64-bit sums");
+  static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, true, true>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, two limbs, 32-bit sums");
+  static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, false, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, one limb, 64-bit sums");
   static_assert(sizeof(tile_lds<kSmallSlots, 8, true, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "2048 slots, two limbs, 64-bit sums");
   auto run = [&](uint32_t tiles_at_most) -> int
   {
@@ -2163,14 +2172,14 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     };
     const uint32_t which = J.n_tiles ? shape_known : shape_level0;     // 0: both (level 0 only)
     if (which != 0 && which != kSmallSlots && which != kBigSlots) { kmd::set_error("kmd: KMD_TILE_SHAPE not built"); return KMD_E_INVALID; }
-    if (sh.threads && !((sh.threads == 512 && sh.slots == kSmallSlots) || (sh.threads == 1024 && sh.slots == kBigSlots)))
+    if (sh.threads && !((sh.threads == 512 && sh.slots == kSmallSlots) || (sh.threads == KMD_TILE_BIG_THREADS && sh.slots == kBigSlots)))
     {
       kmd::set_error("kmd: KMD_TILE_SHAPE not built");
       return KMD_E_INVALID;
     }
     int rc_ = KMD_OK;
     if (which == 0 || which == kSmallSlots) rc_ = pick(shape_tag<512, kSmallSlots>());
-    if (rc_ == KMD_OK && (which == 0 || which == kBigSlots)) rc_ = pick(shape_tag<1024, kBigSlots>());
+    if (rc_ == KMD_OK && (which == 0 || which == kBigSlots)) rc_ = pick(shape_tag<KMD_TILE_BIG_THREADS, kBigSlots>());
     return rc_;
   };
 
