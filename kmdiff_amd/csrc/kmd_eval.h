@@ -137,7 +137,9 @@ __device__ __forceinline__ row_result evaluate_core(const filter_params& P, cons
     // K1 spilled and lost 4 % at 20v20, 24 % at 4v4.)  Sums beyond the log-factorial table: the table term
     // used above is Stirling's, the reference's a k-term running sum; k_resolve_near repeats that sum for
     // sums below kChainMax, larger ones are left alone (no bit pattern to match at a bearable cost)
-    R.near = fabs(R.p - P.threshold) <= 1e-8 * P.threshold && (!(big_c | big_k) || (st.sum_c < kChainMax && st.sum_k < kChainMax));
+    // (a threshold of 1 or more keeps every row whatever its last bit -- the tail function never exceeds 1 --: nothing to
+    // guard, and thousands of rows with p = 1 exactly would fill the list for nothing: tests/soak.py, round 5)
+    R.near = P.threshold < 1.0 && fabs(R.p - P.threshold) <= 1e-8 * P.threshold && (!(big_c | big_k) || (st.sum_c < kChainMax && st.sum_k < kChainMax));
     R.surv = (R.p <= P.threshold);                          // merge.hpp:78
     kmd::sign_of(st.sum_c, st.sum_k, P.dTc, P.dTk, R.mean_control, R.sign);
   }

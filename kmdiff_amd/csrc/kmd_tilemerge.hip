@@ -136,6 +136,7 @@ constexpr uint32_t kBigBit = 0x40000000u;        // over list: the tile holds a 
 constexpr uint64_t kMaxRecords = 0xFFFFFFFFull - 128ull;
 constexpr uint64_t kMaxRun = 1ull << 29;
 constexpr uint32_t kBigCount = 1u << 22;
+constexpr uint64_t kBigFromRecords = 200000000ull;   // partitions of this many records take the 4096-slot table whatever their runs (make_plan)
 constexpr uint32_t kStage = 32;                  // candidates mode: rows of a tile parked in LDS on their way to the list
 constexpr uint32_t kOutChunk = 256;              // candidates mode: entries of the list a workgroup takes at a time
 constexpr unsigned long long kHole = ~0ull;      // sum_c of an entry that holds no row (no sum of 32-bit counts reaches it)         // 1024 samples of counts below this cannot overflow a 32-bit sum
@@ -403,7 +404,14 @@ __device__ __forceinline__ tile_plan make_plan(const uint32_t* __restrict__ mult
   // records per run down (measured, whole call, small / large shape: runs of 665 records 0.42 / 0.46 ms, 400
   // 0.46 / 0.50, 200 0.59 / 0.58, 133 0.72 / 0.67, 73 1.06 / 0.94; 8 or 200 samples with runs of 665: 0.52 / 0.55,
   // 0.59 / 0.61).
-  const uint32_t slots = slots_fixed ? slots_fixed : (rho * (double)load * (double)kSmallSlots / (double)S < 160.0 ? kBigSlots : kSmallSlots);
+  // Round 5: ... and from ~2 x 10^8 records up whatever the runs' length.  The measurements above were taken on 4 M-row
+  // partitions; at the size of the job the larger shape wins (whole call, small / large, same box: 20v20 2 M rows 0.305 /
+  // 0.315 ms, 4 M 0.396 / 0.425, 8 M 0.657 / 0.652, 16 M 1.157 / 1.142, 39 M -- one configs[2] partition -- 2.59 / 2.42;
+  // the MIXED partition 2.15 / 1.97; 100v100 1.6 M rows 0.797 / 0.772, 7.8 M 3.10 / 2.66; 4v4 16 M rows 0.418 / 0.447,
+  // 78 M 1.54 / 1.47: profiles/r05_shape_size.txt): half the tiles -- half the boundary searches, half the per-tile
+  // barriers and walks' fixed parts -- once there are enough of them to keep every workgroup of either grid busy to the end.
+  const bool many_records = n >= kBigFromRecords;
+  const uint32_t slots = slots_fixed ? slots_fixed : ((many_records || rho * (double)load * (double)kSmallSlots / (double)S < 160.0) ? kBigSlots : kSmallSlots);
   const uint32_t grid_hint = slots == kBigSlots ? grid_hint_big : grid_hint_small;
   double fill = rho * (double)load * (double)slots;
   const double fill_max = 24.0 * (double)slots;                      // ~0.6 MB of records per tile at most

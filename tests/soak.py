@@ -130,7 +130,19 @@ def k1_case():
         small = (rows[rr, :nc].astype(np.uint64).sum(axis=1) < (1 << 20)) & (rows[rr, nc:].astype(np.uint64).sum(axis=1) < (1 << 20))
         d = np.abs(p - w)
         rel = np.where(w > 0, d / np.where(w > 0, w, 1.0), 0.0)
-        assert d[small].max(initial=0) <= 1e-10 and rel[small].max(initial=0) <= 1e-9, (tag, d[small].max(initial=0))
+        # (the bar on the relative deviation: 1e-9, or -- count sums beyond 5e5 -- one ulp of each of the two logarithms of
+        # model.hpp:155-156 times its count sum: kmd_pvalues_refine takes correctly rounded logarithms, glibc's own is one ulp
+        # off that in ~1 call in 10^3, and `k log(lambda)` multiplies the ulp by the sum: 1.9e-9 at sums of 7e5, PARITY.md 1)
+        sums = rows[rr, :].astype(np.uint64).sum(axis=1).astype(np.float64)
+        rel_bar = np.maximum(1e-9, 2.0e-15 * sums)
+        if not (d[small].max(initial=0) <= 1e-10 and (rel[small] <= rel_bar[small]).all()):
+            k = int(np.argmax(np.where(small, rel, 0.0)))
+            sc_k, sk_k = int(rows[rr[k], :nc].astype(np.uint64).sum()), int(rows[rr[k], nc:].astype(np.uint64).sum())
+            print("FAILED k1 p-value: %r worst row %d: p_dev %.17g p_ref %.17g rel %.3g sums %d %d (Tc %d Tk %d); %d of %d rows beyond 1e-9 relative"
+                  % (tag, k, p[k], w[k], rel[k], sc_k, sk_k, int(tcs.sum()), int(tks.sum()), int((rel[small] > 1e-9).sum()), int(small.sum())), flush=True)
+            np.savez("gpurun_out/soak_k1_fail.npz", rows=rows, nc=nc, thr=thr, lf_n=lf_n, layout=layout, p_dev=p, p_ref=w, rr=rr)
+        assert d[small].max(initial=0) <= 1e-10 and (rel[small] <= rel_bar[small]).all(), (tag, d[small].max(initial=0))
+        DEV["k1_rel_beyond_1e-9"] = DEV.get("k1_rel_beyond_1e-9", 0) + int((rel[small] > 1e-9).sum())
         if (~small).any():                       # sums of 2^20 and more keep the filter's value: measured, not asserted beyond 1e-6
             DEV["k1_large_sum_rel"] = max(DEV.get("k1_large_sum_rel", 0.0), float(rel[~small].max()))
             DEV["k1_large_sum_abs"] = max(DEV.get("k1_large_sum_abs", 0.0), float(d[~small].max()))
