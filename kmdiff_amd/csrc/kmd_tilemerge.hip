@@ -1997,6 +1997,9 @@ struct merge_async
   explicit merge_async(hipStream_t st) : sc(st) {}
 };
 constexpr size_t kUpWords = (size_t)kMaxStreams + 1 + ((size_t)kMaxStreams + 2) / 2;
+// the table shape the last plan on each device took (a job's partitions are alike): what level 0 of the next call -- and
+// the first partitions of the next batch -- launch alone; the read-back says whether that was right
+std::atomic<uint32_t> g_last_shape[64];
 int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi, const uint32_t* d_counts,
                const uint64_t* offsets, const filter_params* pf, uint64_t* d_kmer_out, uint64_t* d_kmer_hi_out,
                uint64_t* d_sum_c, uint64_t* d_sum_k, size_t row_capacity, uint64_t* n_entries, uint64_t totals[2], hipStream_t st,
@@ -2138,7 +2141,6 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   // once, but not for free (its turn in the stream: ~5 us): level 0 launches the shape the last plan on this device
   // took -- a job's partitions are alike -- and the read-back says whether that was right (bytes 60..63: did a merge
   // kernel run); if not, level 0 is launched again with the shape the plan did take.  The batch keeps its own guess.
-  static std::atomic<uint32_t> g_last_shape[64];
   uint32_t shape_level0 = sh.slots ? sh.slots : async ? async->shape : g_last_shape[dev & 63].load(std::memory_order_relaxed);   // 0: both
   uint32_t shape_known = sh.slots;                               // levels > 0: the plan's, read back
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
@@ -2480,7 +2482,12 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
   // with the rest of its stream behind it: once a partition of the batch has come back, the others launch only the
   // way its plan took -- the read-back says whether that was right, and the synchronous way stands behind it.
   int known_way = -1;
-  uint32_t known_shape = 0;
+  // (the shape the last plan on this device took -- round 5: a batch used to start from "both", and each launch of the
+  // instantiation that only leaves again waited ~120 us for its turn among the other partitions' kernels, with the rest of
+  // its stream behind it: 19 such launches in a trace of 36 partitions)
+  int dev_b = 0;
+  KMD_HIP(hipGetDevice(&dev_b));
+  uint32_t known_shape = g_last_shape[dev_b & 63].load(std::memory_order_relaxed);
   // the synchronous way, for the partitions the fast way could not finish
   auto redo = [&](int p) -> int
   {
@@ -2507,7 +2514,11 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     std::memcpy(&pl, h, sizeof pl);
     // the way and the table shape the plan of a partition of this job took -- also when the guess was wrong and no merge
     // kernel ran (k_tile_bounds wrote the plan all the same): the partitions behind it then launch what this one needed
-    if (pl.slots == kSmallSlots || pl.slots == kBigSlots) { known_way = pl.g_shift == 6 ? 1 : 0; known_shape = pl.slots; }
+    if (pl.slots == kSmallSlots || pl.slots == kBigSlots)
+    {
+      known_way = pl.g_shift == 6 ? 1 : 0; known_shape = pl.slots;
+      if (!pick_shape().slots) g_last_shape[dev_b & 63].store(pl.slots, std::memory_order_relaxed);
+    }
     const bool ok = ran != 0 && n_over == 0 && rows3[0] <= f.cap;
     f.A.reset();                                                  // the scratch goes back to the cache
     if (ok) { if (n_rows_out) n_rows_out[p] = rows3[1]; return KMD_OK; }

@@ -79,26 +79,26 @@ def main():
         out += lines
         rd = wr = None
         for l in lines:
-            if l.startswith("FETCH_SIZE") and "k_tile_sums<512" in l:
+            if l.startswith("FETCH_SIZE") and "k_tile_sums<1024" in l:
                 rd = float(l.split("-> ")[1].split(" B")[0])
-            if l.startswith("WRITE_SIZE") and "k_tile_sums<512" in l:
+            if l.startswith("WRITE_SIZE") and "k_tile_sums<1024" in l:
                 wr = float(l.split("-> ")[1].split(" B")[0])
         if wr is None:                                   # (not among the pass's top four: straight from its CSV)
             acc, n = 0.0, 0
             for c in glob.glob(os.path.join(SRC, "c3", "pmc_WRITE_SIZE", "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(c)):
-                    if "k_tile_sums<512" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE":
+                    if "k_tile_sums<1024" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE":
                         acc += float(r["Counter_Value"]); n += 1
             if n:
                 wr = acc / n * 1024
-                out.append("WRITE_SIZE k_tile_sums<512, 2048u, true, false, true, true> %.1f KB/launch (%d launches) -> %.4e B (x1024 x1)" % (acc / n, n, wr))
+                out.append("WRITE_SIZE k_tile_sums<1024, 4096u, true, false, true, true> %.1f KB/launch (%d launches) -> %.4e B (x1024 x1)" % (acc / n, n, wr))
         if rd:
             alg = 12.0 * 1014558591
             out += ["", "merge kernel HBM bytes per launch = %.4e read + %.4e written; algorithmic 12 B x 1 014 558 591 records = %.4e B -> x%.3f"
                     % (rd, wr or 0.0, alg, (rd + (wr or 0.0)) / alg)]
     f = os.path.join(SRC, "pmc_tile_sq.txt")
     if os.path.exists(f):
-        out += ["", "# SQ counters per launch of k_tile_sums<512, 2048, filter, one limb, whole waves, 32-bit sums>, whole GPU (tools/pmc_ab.sh)"]
+        out += ["", "# SQ counters per launch of k_tile_sums<1024, 4096, filter, one limb, whole waves, 32-bit sums>, whole GPU (tools/pmc_ab.sh)"]
         out += [l.rstrip() for l in open(f) if l.strip()]
     open(os.path.join(DST, "r05_pmc_tile.txt"), "w").write("\n".join(out) + "\n")
     print("  r05_pmc_tile.txt")

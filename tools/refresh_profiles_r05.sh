@@ -31,7 +31,7 @@ fi
 if has c3; then
   # kmd_merge_filter on a whole configs[2] partition: kernel trace, FETCH_SIZE / WRITE_SIZE, SQ counters of the merge kernel
   bash tools/prof_c3.sh $O/c3 > $O/c3_summary.txt 2>&1
-  bash tools/pmc_ab.sh -a "--device --rows 39062500" kmdiff_amd/lib/libkmdiff_hip.so > $O/pmc_tile_sq.txt 2>&1
+  bash tools/pmc_ab.sh -a "--device --rows 39062500" -k "k_tile_sums<1024" kmdiff_amd/lib/libkmdiff_hip.so > $O/pmc_tile_sq.txt 2>&1      # (the plan takes the 4096-slot / 1024-thread shape at this size since round 5)
   rm -rf $O/prof_batch
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_batch -o batch -- python3 tools/kbench_batch.py --iters 2 --device --rows 39062500 --parts 6 \
     > $O/prof_batch.log 2>&1 < /dev/null
@@ -45,7 +45,7 @@ if has sparse; then
     > $O/prof_mixed.log 2>&1 < /dev/null
   { bash tools/pmc_ab.sh -a "--fused-only --sparse 0.1 --rows 40000000 --iters 2" -k "k_tile_sums<1024" kmdiff_amd/lib/libkmdiff_hip.so
     bash tools/pmc_ab.sh -a "--fused-only --sparse 0.3 --rows 13333333 --iters 2" -k "k_tile_sums<512" kmdiff_amd/lib/libkmdiff_hip.so
-    bash tools/pmc_ab.sh -a "--device --rows 39062500 --profile 1" -k "k_tile_sums<512" kmdiff_amd/lib/libkmdiff_hip.so; } > $O/pmc_tile_sparse.txt 2>&1
+    bash tools/pmc_ab.sh -a "--device --rows 39062500 --profile 1" -k "k_tile_sums<1024" kmdiff_amd/lib/libkmdiff_hip.so; } > $O/pmc_tile_sparse.txt 2>&1
 fi
 if has hunt; then
   # the concurrent single-call path in fresh processes (round 4's abort: tests/test_gpu_tilemerge.py::test_first_filter_launch_on_fresh_streams)
