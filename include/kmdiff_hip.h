@@ -343,7 +343,7 @@ int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_t* d_kmers,
                      const uint32_t* d_counts, const uint64_t* offsets, double threshold,
                      const kmd_survivors* out, uint64_t* d_counters, uint64_t* n_rows_out, void* stream);
 
-/* A batch of partitions through kmd_merge_filter, up to six of them in flight on streams of the library's own: a job
+/* A batch of partitions through kmd_merge_filter, two or three of them in flight on streams of the library's own: a job
  * (one ThreadPool task per partition, merge.hpp:259-307) has hundreds, and a quarter of a single call is not the merge
  * kernel -- index, probe and boundary searches, candidate evaluation, launches, the read-back.  Enqueued without a
  * host round trip, those run beside the merge kernel of another partition; the host waits once per partition.

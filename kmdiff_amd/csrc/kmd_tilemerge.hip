@@ -2390,11 +2390,14 @@ extern "C" int kmd_merge_filter(const kmd_model* m, int n_samples, const uint64_
 // boundary searches, candidate evaluation, launches, the read-back and its wake-up).  Here the calls of up to
 // kBatchStreams partitions are in flight on streams of the library's own -- everything a partition needs is enqueued
 // without a host round trip (tile_merge, async), so the small kernels of one run beside the merge kernel of another
-// -- and the host waits once per partition, in turn, when its stream slot is needed again.  A partition whose first
+// -- and the host waits once per partition, in turn, when its stream slot is needed again (two or three slots are used: below).  A partition whose first
 // pass did not finish every tile, or whose candidate list overflowed (both rare), is run again the synchronous way:
 // nothing of its first run has reached the caller's counters or sink.
 namespace {
-constexpr int kBatchStreams = 6;
+#ifndef KMD_BATCH_STREAMS
+#define KMD_BATCH_STREAMS 6          // partitions of a batch in flight (dev: A/B)
+#endif
+constexpr int kBatchStreams = KMD_BATCH_STREAMS;
 constexpr size_t kBatchSlotBytes = 64 + kUpWords * 8;      // page-locked, per stream: [read-back | upload staging]
 struct batch_streams
 {
@@ -2524,9 +2527,18 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
     if (ok) { if (n_rows_out) n_rows_out[p] = rows3[1]; return KMD_OK; }
     return redo(p);
   };
+  // How many partitions are in flight (round 5; kBatchStreams is the most): three -- two when partitions are of the job's
+  // size.  A merge kernel fills the chip by itself; what a second partition in flight adds is its small kernels and its
+  // first tiles in the other's tail, and more than that only has the persistent grids of several partitions take turns
+  // on the same CUs.  Measured, per partition, in flight 6 / 3 / 2 (profiles/r05_ab_k2t.txt): 39 M rows 2.33-2.35 /
+  // 2.20-2.21 / 2.15-2.17 ms, 16 M 0.98 / 0.96 / 0.95, 8 M 0.524 / 0.490 / 0.536, 4 M 0.30 / 0.29 / 0.31.
+  int n_fly = 3;
+  for (int p = 0; p < n_partitions; ++p)
+    if (offsets[p][n_samples] != 0) { n_fly = offsets[p][n_samples] >= 500000000ull ? 2 : 3; break; }
+  if (const uint32_t e = env_u32("KMD_BATCH_IN_FLIGHT", 0)) n_fly = (int)std::min<uint32_t>(e, kBatchStreams);      // dev: A/B
   for (int p = 0; p < n_partitions; ++p)
   {
-    const int slot = p % kBatchStreams;
+    const int slot = p % n_fly;
     rc = finish(slot);
     if (rc != KMD_OK && first_error == KMD_OK) first_error = rc;
     if (n_rows_out) n_rows_out[p] = 0;
@@ -2570,7 +2582,7 @@ extern "C" int kmd_merge_filter_batch(const kmd_model* m, int n_partitions, int 
       // run the synchronous way has drained everything before it)
       int q = prev_alias[(size_t)p];
       while (q >= 0 && queued[(size_t)q] == 0) q = prev_alias[(size_t)q];
-      if (q >= 0 && queued[(size_t)q] == 1 && q % kBatchStreams != slot) KMD_HIP(hipStreamWaitEvent(st, B->cand_done[q % kBatchStreams], 0));
+      if (q >= 0 && queued[(size_t)q] == 1 && q % n_fly != slot) KMD_HIP(hipStreamWaitEvent(st, B->cand_done[q % n_fly], 0));
       const int rc_ = kmd::launch_filter_candidates(P, m, static_cast<const uint64_t*>(f.p_k), static_cast<const uint64_t*>(f.p_h),
                                                     static_cast<const uint64_t*>(f.p_c), static_cast<const uint64_t*>(f.p_s), 0, 0, 0, f.p_w, cap_now, st,
                                                     d_live, d_over_n, cap_now);

@@ -531,7 +531,7 @@ def merge_filter(streams, observer, stream=None):
 
 def merge_filter_batch(stream_sets, observers, stream=None):
     """km::KmerMerger::merge(diff_observer) for a batch of partitions (global_merge's loop over the partitions,
-    merge.hpp:259-307): kmd_merge_filter_batch keeps up to six of them in flight on streams of the library's own.
+    merge.hpp:259-307): kmd_merge_filter_batch keeps two or three of them in flight on streams of the library's own.
     `stream_sets`: one StreamSet per partition; `observers`: one diff_observer per partition (several may share an
     accumulator: survivors and counters add up).  Returns the partitions' numbers of distinct k-mers."""
     P = len(stream_sets)
