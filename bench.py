@@ -204,7 +204,7 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
     # partitions in flight: a job has hundreds of partitions; with six of them on streams (and host threads) of
     # their own, the boundary searches, the candidate evaluation and the read-back of one run beside the merge
     # kernel of another
-    in_flight, per = 6, max(4, iters)
+    in_flight, per = int(os.environ.get("KMD_BENCH_OVERLAP_THREADS", "6")), max(4, iters)      # (dev: the host threads of the overlapped leg)
     workers = []
     for w_i in range(in_flight):
         st = C.c_void_p()
