@@ -101,7 +101,10 @@ using namespace kmd::eval;
 #define KMD_TILE_WAVES(sum32, two, wide) ((sum32) && !(two) && (wide) ? 8 : 1)
 #endif
 #ifndef KMD_TILE_WAVES_BIG
-#define KMD_TILE_WAVES_BIG(sum32, two, wide) (KMD_TILE_BIG_THREADS == 1024 ? KMD_TILE_WAVES(sum32, two, wide) : ((sum32) && !(two) && (wide) ? 4 : 1))
+#ifndef KMD_TILE_BIG_WPE
+#define KMD_TILE_BIG_WPE (KMD_TILE_BIG_THREADS == 1024 ? 8 : 4)     // waves per SIMD the 4096-slot shape's registers are held to
+#endif
+#define KMD_TILE_WAVES_BIG(sum32, two, wide) ((sum32) && !(two) && (wide) ? KMD_TILE_BIG_WPE : 1)
 #endif
 #ifndef KMD_TILE_BIG_THREADS
 #define KMD_TILE_BIG_THREADS 1024    // threads of the workgroup that takes the 4096-slot table (dev: 512 = eight waves with twice the registers each)
@@ -124,7 +127,10 @@ constexpr int kRsrcFlags = 0x00020000;           // buffer descriptor, dword 3: 
 // the lanes' predicate as a mask, straight from the compare (HIP's __ballot takes an int: a select and a second compare)
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr uint32_t kMaxStreams = 1024;           // segment tables of a tile live in LDS (16 KB at 1024 streams)
-constexpr uint32_t kSmallSlots = 2048, kBigSlots = 4096;   // the two table shapes built (512 / 1024 threads); make_plan picks one per partition
+#ifndef KMD_TILE_BIG_SLOTS
+#define KMD_TILE_BIG_SLOTS 4096      // dev: 8192 = one workgroup per CU (one-limb k-mers, 32-bit sums, few samples only: the others do not fit the LDS)
+#endif
+constexpr uint32_t kSmallSlots = 2048, kBigSlots = KMD_TILE_BIG_SLOTS;   // the two table shapes built (512 / 1024 threads); make_plan picks one per partition
 constexpr uint32_t kProbes = 512;                // records sampled for the records-per-row estimate (+-5 % at worst; 2048 cost 39 us, 4x this)
 // ... fewer with many samples -- a probe is a search in every stream, 100 000 of them at 200 samples (0.1 ms), and
 // the multiplicities it averages scatter less there: <= 32 768 searches, never under 128 probes
@@ -2145,8 +2151,10 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   uint32_t shape_known = sh.slots;                               // levels > 0: the plan's, read back
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
   // (what the instantiations that can be launched take of the 160 KB of LDS, 1024 samples' segment tables included)
+#if KMD_TILE_BIG_SLOTS == 4096
   static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, true, true>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, two limbs, 32-bit sums");
   static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, false, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, one limb, 64-bit sums");
+#endif
   static_assert(sizeof(tile_lds<kSmallSlots, 8, true, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "2048 slots, two limbs, 64-bit sums");
   auto run = [&](uint32_t tiles_at_most) -> int
   {
