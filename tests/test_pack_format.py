@@ -86,3 +86,28 @@ def test_bad_arguments_pack_nothing():
     assert L.kmd_pack_block(km.ctypes.data, ct.ctypes.data, 257, buf.ctypes.data) == 0
     assert L.kmd_pack_block(None, ct.ctypes.data, 5, buf.ctypes.data) == 0
     assert L.kmd_pack_block_bound() == 16 + 257 * 8 + 256 + 1024
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 5000])
+def test_pack_stream_is_its_blocks_one_behind_the_other(n):
+    """kmd_pack_stream (a whole stream in one call: what bench.py's feed-inclusive leg and a host's decoder thread use) writes
+    exactly what kmd_pack_block writes block by block, with the block table beside it; a buffer that is too small is
+    refused (0 bytes), one that is just large enough is filled to the byte."""
+    from kmdiff_amd import _native as N
+    L = N.lib()
+    rng = np.random.default_rng(n)
+    km = np.cumsum(rng.integers(1, 1 << 23, n, dtype=np.uint64), dtype=np.uint64)
+    ct = rng.integers(1, 400, n).astype(np.uint32)
+    packed, base, table, offs = K.pack_streams([(km, ct)])                  # block by block (kmd_pack_block)
+    nb = (n + 255) // 256
+    bound = int(L.kmd_pack_block_bound())
+    out = np.zeros(nb * bound, dtype=np.uint8)
+    tab = np.zeros(nb, dtype=np.uint32)
+    got = int(L.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, n, out.ctypes.data, out.nbytes, tab.ctypes.data))
+    assert got == len(packed) and np.array_equal(out[:got], packed) and tab.tolist() == table.tolist()
+    tight = np.zeros(got, dtype=np.uint8)
+    assert int(L.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, n, tight.ctypes.data, tight.nbytes, tab.ctypes.data)) == got
+    assert np.array_equal(tight, packed)
+    small = np.zeros(max(got - 8, 1), dtype=np.uint8)
+    assert int(L.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, n, small.ctypes.data, small.nbytes, tab.ctypes.data)) == 0
+    assert int(L.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, 0, out.ctypes.data, out.nbytes, tab.ctypes.data)) == 0
