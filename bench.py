@@ -224,18 +224,19 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
         for w in workers:
             K._native.check(lib.kmd_stream_sync(w[0]))
     run_all(2)                                             # untimed: the scratch of six concurrent calls gets allocated here
-    ms_o, n_timed = 1e9, 2                                 # the better of two timed rounds (six host threads: the one measurement here the host's scheduler has a say in)
+    n_timed, rounds_o = 3, []                              # the MEDIAN of three timed rounds (six host threads: the one measurement here the host's scheduler has a say in)
     for _ in range(n_timed):
         t0 = time.perf_counter()
         run_all(per)
-        ms_o = min(ms_o, (time.perf_counter() - t0) / (in_flight * per) * 1e3)
+        rounds_o.append((time.perf_counter() - t0) / (in_flight * per) * 1e3)
+    ms_o = sorted(rounds_o)[n_timed // 2]
     for w in workers:
         cw = w[1].read_counters()
         assert int(cw[0]) == (n_timed * per + 2) * rows, int(cw[0])
         lib.kmd_stream_destroy(w[0])
     rec_avg = sum(x.total for x in sets) / float(n_distinct)
     gbs_o = 12.0 * rec_avg / (ms_o * 1e-3) / 1e9
-    out["overlapped"] = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "kmers_per_s": rows / (ms_o * 1e-3),
+    out["overlapped"] = {"partitions_in_flight": in_flight, "ms_per_partition": ms_o, "ms_rounds": rounds_o, "kmers_per_s": rows / (ms_o * 1e-3),
                          "records_per_s": rec_avg / (ms_o * 1e-3), "roofline": roof(gbs_o)}
     # the same through ONE host thread: kmd_merge_filter_batch keeps two or three partitions in flight on streams of the
     # library's own and waits once per partition (n_distinct different partitions in HBM, taken in turn)

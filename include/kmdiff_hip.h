@@ -171,6 +171,12 @@ typedef struct {
   uint64_t        row_base;   /* global index of row 0 within its partition                */
 } kmd_tile;
 
+/* TOLERANCE of the p-values this call (and kmd_merge_filter / _batch / kmd_poisson_filter_sums) writes to the sink:
+ * the set of survivors, their k-mers, rows, signs, means and the counters are exact at every threshold; the p-values
+ * are within 1e-10 (absolute) of the reference's for thresholds < 1.  At a threshold of 1 or more every row is kept, and
+ * rows with p of order 1 and count sums of ~10^4 deviate by up to 1.1e-10 (4.7e-10 beyond the log-factorial table):
+ * `k * log(lambda)` multiplies the last bit of the device's logarithm by the sum (PARITY.md 1).  A caller that needs
+ * the 1e-10 bar there follows the call with kmd_pvalues_refine (below) on the sink, as the CLI and the IModel plugin do. */
 int kmd_poisson_filter(const kmd_model* m, const kmd_tile* tile, double threshold,
                        const kmd_survivors* out, uint64_t* d_counters, void* stream);
 

@@ -24,6 +24,8 @@ extern "C" {
 const char* kmd_rccl_last_error(void);
 int kmd_rccl_unique_id(void* id128);
 int kmd_transport_rccl_init(kmd_transport* out, int world, int rank, const void* id128);
+/* (a wrapped communicator stays the host's: kmd_transport.abort on it only makes this transport refuse further
+ * collectives -- it never calls ncclCommAbort on a handle it does not own; _destroy leaves it alone as well) */
 int kmd_transport_rccl_wrap(kmd_transport* out, void* nccl_comm);
 int kmd_transport_rccl_destroy(kmd_transport* t);
 

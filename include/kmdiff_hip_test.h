@@ -22,6 +22,12 @@ int kmd_test_running_sums(const uint64_t* d_k, size_t n, double* d_plain, double
  * kernel's lu_solve, the group kernel's group_lu_solve): [LU in place: L below the diagonal, U on and above | the
  * inverse, row-major | w = a^-1 b | status: 0 ok, 1 det == 0, 2 det NaN (group: 1 for either)]. */
 int kmd_test_popstrat_linear(int F, const double* a, const double* b, double* lane_out, double* group_out);
+/* glm_irls (src/linear_model.cpp:297-410) on a design of the caller's -- X: n x f row-major, y: n (host pointers;
+ * synchronous) -- through the loops K3 runs: the lane kernel's (irls_fit) and the group kernel's (k_popstrat_group, whose
+ * k-mer column is count / total: it gets counts = the design's last column and totals of 1.0).  Each returns the weights
+ * as glm_irls returns them (f doubles) and the iteration count it reports (:385).  2 <= f <= 13. */
+int kmd_test_popstrat_irls(const double* X, const double* y, int n, int f, int max_iter, double* w_lane, int* iters_lane,
+                           double* w_group, int* iters_group);
 /* out[i] = sigmoid(x[i]) as K3 evaluates linear_model.cpp:191-195 */
 int kmd_test_popstrat_sigmoid(const double* x, size_t n, double* out);
 /* *eta_out = sum_j x[j] w[j] in index order, *p_out = its sigmoid: linear_predictor / predict (linear_model.cpp:197-211) */

@@ -62,6 +62,7 @@ TEST_SIGNATURES = {
     "kmd_test_popstrat_linear": (_i, [_i, _vp, _vp, _vp, _vp]),
     "kmd_test_popstrat_sigmoid": (_i, [_vp, _sz, _vp]),
     "kmd_test_popstrat_predict": (_i, [_vp, _vp, _i, C.POINTER(_d), C.POINTER(_d)]),
+    "kmd_test_popstrat_irls": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp, C.POINTER(_i)]),
 }
 
 SIGNATURES = {

@@ -159,7 +159,7 @@ struct design_rows
 // glm_irls (linear_model.cpp:297-410) over F features.  KMER: feature F-1 of each sample is
 // counts/totals (popstrat.hpp:254-257), else all F features come from `alt`.
 template <int F, bool KMER, bool LDSD>
-__device__ __forceinline__ void irls_fit(const irls_args& A, const double* s_d, size_t surv, double (&weight)[F])
+__device__ __forceinline__ void irls_fit(const irls_args& A, const double* s_d, size_t surv, double (&weight)[F], int* iters_out = nullptr)
 {
   const design_rows<F, LDSD> D { A, s_d };
   double w[F];
@@ -234,6 +234,7 @@ __device__ __forceinline__ void irls_fit(const irls_args& A, const double* s_d, 
 #pragma unroll
     for (int j = 0; j < F; ++j) weight[j] = w[j];                // :394-395
   }
+  if (iters_out) *iters_out = iter;                              // (the test hook's: what glm_irls counts, :385)
 }
 
 // pop_strat_corrector::apply(KmerSign&) (popstrat.hpp:249-333) for one survivor per lane
@@ -393,7 +394,8 @@ __device__ __forceinline__ void group_lu_solve(double* const Hm, const double* c
 
 template <int F>
 __global__ void __launch_bounds__(64) k_popstrat_group(irls_args A, size_t n_surv, double null_likelihood,
-                                                       double lg_half, double epsilon, double* __restrict__ out_p)
+                                                       double lg_half, double epsilon, double* __restrict__ out_p,
+                                                       double* __restrict__ out_w = nullptr, int* __restrict__ out_iter = nullptr)
 {
   using G = group_shape<F>;
   constexpr int L = G::L, kGroups = 64 / L;
@@ -553,6 +555,9 @@ __global__ void __launch_bounds__(64) k_popstrat_group(irls_args A, size_t n_sur
   double model[F];
 #pragma unroll
   for (int j = 0; j < F; ++j) model[j] = weight[j];
+  // (kmd_test_popstrat_irls: the loop's own result -- weights as returned, iterations as glm_irls counts them)
+  if (out_w && live && l < F) out_w[surv * F + l] = weight[l];
+  if (out_iter && live && l == 0) out_iter[surv] = iter;
   double alt_l = 1.0;
   for (int c0 = 0; c0 < A.n; c0 += L)
   {
@@ -892,6 +897,20 @@ __global__ void __launch_bounds__(64) k_test_sigmoid(const double* __restrict__ 
   if (i < n) out[i] = sigmoid_ref(x[i]);
 }
 
+// glm_irls (linear_model.cpp:297-410) on a design of the caller's, through the lane kernel's loop (irls_fit: every column
+// from the design, as the null model is fitted)
+template <int F>
+__global__ void __launch_bounds__(64) k_test_irls_lane(irls_args A, double* __restrict__ out_w, int* __restrict__ out_iter)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double model[F];
+  int it = 0;
+  irls_fit<F, false, false>(A, nullptr, 0, model, &it);
+#pragma unroll
+  for (int j = 0; j < F; ++j) out_w[j] = model[j];
+  *out_iter = it;
+}
+
 // predict() (linear_model.cpp:197-211): sigmoid of the dot product, summed in index order as irls_fit forms eta
 __global__ void __launch_bounds__(64) k_test_predict(const double* __restrict__ w, const double* __restrict__ x, int n, double* __restrict__ out)
 {
@@ -930,6 +949,55 @@ int kmd_test_popstrat_linear(int F, const double* a, const double* b, double* la
   if (e != hipSuccess) return kmd::hip_fail(e, "kmd_test_popstrat_linear", __FILE__, __LINE__);
   std::copy(h.begin(), h.begin() + each, lane_out);
   std::copy(h.begin() + each, h.end(), group_out);
+  return KMD_OK;
+}
+
+// The IRLS loop itself on a design of the caller's: X (n x f row-major), y (n) -> weights and glm_irls's iteration count
+// from (a) the lane kernel's loop and (b) the group kernel's.  The group kernel takes its last column as count / total
+// (popstrat.hpp:254-257): it is handed counts = that column and totals of 1.0 -- the division is exact.
+int kmd_test_popstrat_irls(const double* X, const double* y, int n, int f, int max_iter, double* w_lane, int* iters_lane,
+                           double* w_group, int* iters_group)
+{
+  KMD_REQUIRE(X && y && w_lane && iters_lane && w_group && iters_group, "kmd_test_popstrat_irls: NULL");
+  KMD_REQUIRE(n > 0 && f >= 2 && f <= 13 && max_iter > 0, "kmd_test_popstrat_irls: arguments");
+  std::vector<double> last((size_t)n), ones((size_t)n, 1.0);
+  for (int i = 0; i < n; ++i) last[(size_t)i] = X[(size_t)i * f + f - 1];
+  double *d_x = nullptr, *d_y = nullptr, *d_c = nullptr, *d_t = nullptr, *d_o = nullptr;
+  int* d_it = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_x), (size_t)n * f * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_y), (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_c), (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_t), (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_o), (size_t)(2 * f + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_it), 2 * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(d_x, X, (size_t)n * f * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_y, y, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_c, last.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_t, ones.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+  {
+    // one survivor, its counts survivor-major: counts[i * si + v * ss] with (si, ss) = (1, n)
+    const irls_args A { d_x, f, d_y, d_t, d_c, 1, (size_t)n, n, max_iter };
+    switch (f)
+    {
+#define KMD_TI(N) case N: \
+        hipLaunchKernelGGL((k_test_irls_lane<N>), dim3(1), dim3(64), 0, nullptr, A, d_o, d_it); \
+        hipLaunchKernelGGL((k_popstrat_group<N>), dim3(1), dim3(64), (size_t)(64 / group_shape<N>::L) * group_shape<N>::kLds * sizeof(double), nullptr, \
+                           A, (size_t)1, 1.0, 0.0, 1e-30, d_o + 2 * f, d_o + f, d_it + 1); break;
+      KMD_TI(2) KMD_TI(3) KMD_TI(4) KMD_TI(5) KMD_TI(6) KMD_TI(7) KMD_TI(8) KMD_TI(9) KMD_TI(10) KMD_TI(11) KMD_TI(12) KMD_TI(13)
+#undef KMD_TI
+    }
+    e = hipGetLastError();
+  }
+  std::vector<double> h((size_t)(2 * f + 1));
+  int h_it[2] = { 0, 0 };
+  if (e == hipSuccess) e = hipMemcpy(h.data(), d_o, h.size() * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h_it, d_it, sizeof h_it, hipMemcpyDeviceToHost);
+  (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_c); (void)hipFree(d_t); (void)hipFree(d_o); (void)hipFree(d_it);
+  if (e != hipSuccess) return kmd::hip_fail(e, "kmd_test_popstrat_irls", __FILE__, __LINE__);
+  std::copy(h.begin(), h.begin() + f, w_lane);
+  std::copy(h.begin() + f, h.begin() + 2 * f, w_group);
+  *iters_lane = h_it[0]; *iters_group = h_it[1];
   return KMD_OK;
 }
 

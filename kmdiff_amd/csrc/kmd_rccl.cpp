@@ -27,13 +27,13 @@ int fail(const char* what, const char* msg)
 #define KMD_NCCL(call) do { const ncclResult_t r__ = (call); if (r__ != ncclSuccess) return fail(#call, ncclGetErrorString(r__)); } while (0)
 #define KMD_HIPR(call) do { const hipError_t e__ = (call); if (e__ != hipSuccess) return fail(#call, hipGetErrorString(e__)); } while (0)
 
-struct rccl_ctx { ncclComm_t comm; bool own; };
+struct rccl_ctx { ncclComm_t comm; bool own; bool aborted; };
 
 int rccl_allreduce_u64(void* ctx, uint64_t* d_buf, size_t n, void* stream)
 {
   rccl_ctx* R = static_cast<rccl_ctx*>(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!R->comm) return fail("kmd_transport_rccl", "the communicator was aborted");
+  if (!R->comm || R->aborted) return fail("kmd_transport_rccl", "the communicator was aborted");
   KMD_NCCL(ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, R->comm, st));
   KMD_HIPR(hipStreamSynchronize(st));
   return KMD_OK;
@@ -43,7 +43,7 @@ int rccl_allgather(void* ctx, const void* d_send, void* d_recv, size_t bytes, vo
 {
   rccl_ctx* R = static_cast<rccl_ctx*>(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!R->comm) return fail("kmd_transport_rccl", "the communicator was aborted");
+  if (!R->comm || R->aborted) return fail("kmd_transport_rccl", "the communicator was aborted");
   if (bytes) KMD_NCCL(ncclAllGather(d_send, d_recv, bytes, ncclInt8, R->comm, st));
   KMD_HIPR(hipStreamSynchronize(st));
   return KMD_OK;
@@ -51,10 +51,14 @@ int rccl_allgather(void* ctx, const void* d_send, void* d_recv, size_t bytes, vo
 
 // kmd_transport::abort: this rank cannot go on.  ncclCommAbort tears the communicator down without waiting for the
 // peers; theirs then fail (or time out) in RCCL instead of waiting for a collective this rank will never join.
+// A communicator that was only WRAPPED (kmd_transport_rccl_wrap) belongs to the host -- torch.distributed's, say --
+// which will destroy it itself: aborting it here would leave the host a freed handle.  This transport then
+// only refuses further collectives; the peers are released by the host's own timeout or abort.
 void rccl_abort(void* ctx)
 {
   rccl_ctx* R = static_cast<rccl_ctx*>(ctx);
-  if (R->comm) { (void)ncclCommAbort(R->comm); R->comm = nullptr; }
+  R->aborted = true;
+  if (R->own && R->comm) { (void)ncclCommAbort(R->comm); R->comm = nullptr; }
 }
 
 } // namespace
@@ -80,7 +84,7 @@ int kmd_transport_rccl_init(kmd_transport* out, int world, int rank, const void*
   std::memcpy(&id, id128, sizeof id);
   ncclComm_t comm = nullptr;
   KMD_NCCL(ncclCommInitRank(&comm, world, id, rank));            // (the calling thread's current device)
-  rccl_ctx* R = new rccl_ctx { comm, true };
+  rccl_ctx* R = new rccl_ctx { comm, true, false };
   out->ctx = R; out->rank = rank; out->world = world;
   out->allreduce_u64 = rccl_allreduce_u64; out->allgather = rccl_allgather; out->abort = rccl_abort;
   return KMD_OK;
@@ -93,7 +97,7 @@ int kmd_transport_rccl_wrap(kmd_transport* out, void* nccl_comm)
   int rank = 0, world = 0;
   KMD_NCCL(ncclCommUserRank(comm, &rank));
   KMD_NCCL(ncclCommCount(comm, &world));
-  rccl_ctx* R = new rccl_ctx { comm, false };
+  rccl_ctx* R = new rccl_ctx { comm, false, false };
   out->ctx = R; out->rank = rank; out->world = world;
   out->allreduce_u64 = rccl_allreduce_u64; out->allgather = rccl_allgather; out->abort = rccl_abort;
   return KMD_OK;

@@ -299,6 +299,7 @@ struct local_hub
   std::vector<int> dev;
   bool failed = false;                            // a rank's copy failed inside a collective (everybody still arrives)
   bool aborted = false;                           // a rank left for good (kmd_transport::abort): nobody waits any more
+  int copying = 0;                                // ranks between the two barriers of a collective: reading the others' send buffers
   // false: a rank has given up -- the collective in progress, and every later one, fails on all ranks
   bool barrier()
   {
@@ -315,6 +316,11 @@ struct local_hub
     aborted = true;
     cv.notify_all();
   }
+  // a rank's copies out of the others' send buffers: counted in and out, so that a rank the abort wakes at the second
+  // barrier does not return -- and have its caller free its send buffer -- while a peer's copy still reads it
+  void copies_begin() { std::lock_guard<std::mutex> lock(mu); ++copying; }
+  void copies_end() { std::lock_guard<std::mutex> lock(mu); --copying; cv.notify_all(); }
+  void wait_for_copies() { std::unique_lock<std::mutex> lock(mu); cv.wait(lock, [&] { return copying == 0; }); }
 };
 
 struct local_rank
@@ -340,16 +346,25 @@ int local_allgather(void* ctx, const void* d_send, void* d_recv, size_t bytes, v
   // (on the caller's stream, and waited for there: a device-to-device hipMemcpy on the null stream may return before
   // the copy has run, and the callers' non-blocking streams are not ordered against the null stream)
   hipStream_t st = static_cast<hipStream_t>(stream);
+  H.copies_begin();
   for (int q = 0; q < H.world && e == hipSuccess && bytes; ++q)
   {
     char* dst = static_cast<char*>(d_recv) + (size_t)q * bytes;
     if (H.dev[(size_t)q] == dev) e = hipMemcpyAsync(dst, H.send[(size_t)q], bytes, hipMemcpyDeviceToDevice, st);
     else e = hipMemcpyPeerAsync(dst, dev, H.send[(size_t)q], H.dev[(size_t)q], bytes, st);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  const hipError_t e_sync = hipStreamSynchronize(st);           // (also after a failed enqueue: the copies before it have run)
+  if (e == hipSuccess) e = e_sync;
+  H.copies_end();
   if (e != hipSuccess) { std::lock_guard<std::mutex> lock(H.mu); H.failed = true; }
   const bool all_here = H.barrier();                           // nobody's send buffer is still being read
-  if (!all_here) { kmd::set_error("kmd_transport_local: another rank gave up"); return KMD_E_HIP; }
+  if (!all_here)
+  {
+    // (woken by an abort: the ranks that passed the first barrier with this one may still be copying)
+    H.wait_for_copies();
+    kmd::set_error("kmd_transport_local: another rank gave up");
+    return KMD_E_HIP;
+  }
   if (e != hipSuccess) return kmd::hip_fail(e, "kmd_transport_local: copy", __FILE__, __LINE__);
   if (H.failed) { kmd::set_error("kmd_transport_local: another rank failed"); return KMD_E_HIP; }
   return KMD_OK;

@@ -86,9 +86,6 @@ using namespace kmd::eval;
 #else
 #define KMD_TILE_LOAD_HINT " sc0 sc1"
 #endif
-#ifndef KMD_TILE_JOB_PTR
-#define KMD_TILE_JOB_PTR 0           // the merge kernel's job description through a pointer to device memory instead of ~250 bytes of kernel arguments
-#endif
 #ifndef KMD_TILE_ALIGN
 #define KMD_TILE_ALIGN 0             // whole-wave path: a run's first round starts on a 128-byte line of both arrays (its leading lanes hold the records before the run: switched off)
 #endif
@@ -143,7 +140,12 @@ constexpr uint64_t kMaxRecords = 0xFFFFFFFFull - 128ull;
 constexpr uint64_t kMaxRun = 1ull << 29;
 constexpr uint32_t kBigCount = 1u << 22;
 constexpr uint64_t kBigFromRecords = 200000000ull;   // partitions of this many records take the 4096-slot table whatever their runs (make_plan)
-constexpr uint32_t kStage = 32;                  // candidates mode: rows of a tile parked in LDS on their way to the list
+// candidates mode: rows of a tile parked in LDS on their way to the list (rows of 3 records: ~90 of a 4096-slot tile's
+// ~1900 leave; configs[2]'s rows of 26: one or two)
+constexpr uint32_t stage_rows(uint32_t slots) { return slots >= 4096u ? 128u : 64u; }
+constexpr uint32_t kGroup = 63;                  // runs per group of a tile's segment table (one lane each; lane 63 holds none)
+constexpr uint32_t kMaxGroups = 17;              // (kMaxStreams + kGroup - 1) / kGroup
+constexpr uint32_t kQueue = 128;                 // candidates mode: live slots a wave has queued for its next full pass (< 64 + 64)
 constexpr uint32_t kOutChunk = 256;              // candidates mode: entries of the list a workgroup takes at a time
 constexpr unsigned long long kHole = ~0ull;      // sum_c of an entry that holds no row (no sum of 32-bit counts reaches it)         // 1024 samples of counts below this cannot overflow a 32-bit sum
 
@@ -207,16 +209,17 @@ struct tile_job
 // <= 0.07, ten times that is allowed for, and a row is dropped only if it stays below the candidate cut with it --
 // rows that pass are evaluated exactly as before (k_cand_eval, kmd_filter.hip), rows dropped were no candidates: every
 // exposed number is unchanged.  Sums at or beyond the log-factorial table (or 2^16) pass on the first stage alone.
-__device__ __forceinline__ bool row_may_pass_kl(const tile_job& J, unsigned long long sum_c, unsigned long long sum_k)
+struct kl_consts { float qc, qk, cut; uint32_t max; };
+__device__ __forceinline__ bool row_may_pass_kl(const kl_consts& J, unsigned long long sum_c, unsigned long long sum_k)
 {
-  if (sum_c >= J.kl_max || sum_k >= J.kl_max) return true;          // (also: stage off, kl_max = 0)
+  if (sum_c >= J.max || sum_k >= J.max) return true;                // (also: stage off, max = 0)
   const float sc = (float)(uint32_t)sum_c, sk = (float)(uint32_t)sum_k, n = sc + sk;
-  const float lc = __builtin_amdgcn_logf(sc * __builtin_amdgcn_rcpf(n * J.kl_qc));
-  const float lk = __builtin_amdgcn_logf(sk * __builtin_amdgcn_rcpf(n * J.kl_qk));
+  const float lc = __builtin_amdgcn_logf(sc * __builtin_amdgcn_rcpf(n * J.qc));
+  const float lk = __builtin_amdgcn_logf(sk * __builtin_amdgcn_rcpf(n * J.qk));
   const float tc = sum_c ? sc * lc : 0.0f, tk = sum_k ? sk * lk : 0.0f;        // (base 2)
   const float lr = 0.69314718f * (tc + tk);
   const float slack = 5e-6f * n + 2e-6f * (__builtin_fabsf(tc) + __builtin_fabsf(tk)) + 1e-3f;
-  return !(lr + slack < J.kl_cut);
+  return !(lr + slack < J.cut);
 }
 
 __host__ __device__ inline uint64_t mix64(uint64_t x)
@@ -592,6 +595,21 @@ __global__ void __launch_bounds__(256) k_tile_refine(const uint64_t* __restrict_
 
 constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 
+// inclusive prefix sum over the wave's 64 lanes, six DPP adds: shifts by 1, 2, 4, 8 within rows of 16 lanes, then a row's
+// last lane into the next row (row_bcast:15, rows 1 and 3) and lane 31 into the upper half (row_bcast:31).  A lane
+// without a source, or masked out of a step, adds 0.  (Written with shuffles and `lane >= o` it was six LDS-crossbar
+// round trips and six lane masks the compiler kept in scalar registers for the life of the kernel.)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 // LDS of one workgroup, carved from the dynamic allocation (the segment tables follow it)
 // kSum32: a slot's two sums are 32-bit (16 bytes per slot with the key: four workgroups per CU instead of three,
 // half the bytes per atomic add); kmd_tilemerge keeps 64-bit sums for the tiles that need them.
@@ -603,22 +621,30 @@ struct tile_lds
   // whole-wave path lets lanes that have nothing to add add it: its key is 0, never the empty marker, and nothing
   // reads its sums
   static constexpr uint32_t kAll = kSlots + kSlots / 16;
-  unsigned long long key[kAll + 2];
-  unsigned long long sc[kSum32 ? 2 : kAll + 2];
-  unsigned long long sk[kSum32 ? 2 : kAll + 2];
-  uint32_t c32[kSum32 ? kAll + 4 : 4];                   // kSum32: control sum of slot i (arrays of their own: a round adds to ONE
-  uint32_t k32[kSum32 ? kAll + 4 : 4];                   // of them -- the run is a control's or a case's -- so its lanes spread over all banks)
-  unsigned long long key_hi[kTwo ? kAll + 2 : 2];
-  unsigned long long hi_min[kTwo ? kAll + 2 : 2];        // see k_tile_sums: every record's high limb must agree with its slot's
+  static constexpr uint32_t kStage = stage_rows(kSlots);
+  using stage_sum_t = typename std::conditional<kSum32, uint32_t, unsigned long long>::type;
+  // (the small fields FIRST: a DS instruction's offset field is 16 bits, and the address of a field that lies beyond
+  // 64 KB -- behind a 4096-slot table -- is a scalar the compiler computes once, keeps for the life of the kernel and,
+  // out of scalar registers, spills into vector lanes: round 5's build read eight such addresses back per walk)
   unsigned long long maxsum[2];
   unsigned long long max_hi[2];                          // kTwo: min / max high limb of the records whose low limb is all ones
   unsigned long long base;
-  unsigned long long out_base, late_base;          // candidates mode: the workgroup's current chunk of the list; where late entries go
-  uint32_t out_used, out_cap, late_cnt, stage_n;
-  unsigned long long stage_key[kStage], stage_c[kStage], stage_k[kStage], stage_hi[kTwo ? kStage : 1];   // rows parked for the list (k_tile_sums, the walk)
+  unsigned long long out_base;                           // candidates mode: the workgroup's current chunk of the list
+  uint32_t out_used, out_cap, stage_n, pad0;
   uint32_t n[2], fresh[2], abort[2], big[2];
   uint32_t hasmax, bad;
   uint32_t wcnt[kWaves];
+  uint32_t grp[2][kMaxGroups + 1];                       // records of each group of kGroup runs of the current / the next tile
+  unsigned long long stage_key[kStage], stage_hi[kTwo ? kStage : 1];     // rows parked for the list (k_tile_sums, the walk)
+  stage_sum_t stage_c[kStage], stage_k[kStage];
+  uint16_t queue[kWaves][kQueue];                        // candidates mode, the walk: live slots of each wave, 64 of them evaluated at a time
+  alignas(16) unsigned long long key[kAll + 2];
+  uint32_t c32[kSum32 ? kAll + 4 : 4];                   // kSum32: control sum of slot i (arrays of their own: a round adds to ONE
+  uint32_t k32[kSum32 ? kAll + 4 : 4];                   // of them -- the run is a control's or a case's -- so its lanes spread over all banks)
+  unsigned long long sc[kSum32 ? 2 : kAll + 2];
+  unsigned long long sk[kSum32 ? 2 : kAll + 2];
+  unsigned long long key_hi[kTwo ? kAll + 2 : 2];
+  unsigned long long hi_min[kTwo ? kAll + 2 : 2];        // see k_tile_sums: every record's high limb must agree with its slot's
 };
 
 // One workgroup per tile on a persistent grid.  Per tile, candidates mode (kFilter):
@@ -649,14 +675,8 @@ struct tile_lds
 // cut window).  A low limb of all ones (the empty marker) is kept apart the same way.
 template <int kThreads, uint32_t kSlots, bool kFilter, bool kTwo, bool kWide, bool kSum32>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kSlots == kBigSlots ? KMD_TILE_WAVES_BIG(kSum32, kTwo, kWide) : KMD_TILE_WAVES(kSum32, kTwo, kWide))))
-#if KMD_TILE_JOB_PTR
-k_tile_sums(const tile_job* __restrict__ Jp)
-{
-  const tile_job& J = *Jp;
-#else
 k_tile_sums(const tile_job J)
 {
-#endif
   constexpr uint32_t kMask = kSlots - 1;
   constexpr int kShift = 32 - ilog2_c(kSlots);
   constexpr int kWaves = kThreads / 64;
@@ -669,20 +689,39 @@ k_tile_sums(const tile_job J)
   static_assert((kSlots & kMask) == 0 && kSlots % kThreads == 0, "shape");
   static_assert(kWalk <= 32, "walk bits");
   using lds_t = tile_lds<kSlots, kWaves, kTwo, kSum32>;
+  constexpr uint32_t kStage = lds_t::kStage;
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_raw[];      // (16: a bucket of two keys is one ds_read_b128)
   lds_t& M = *reinterpret_cast<lds_t*>(s_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // The job description is 250 bytes of kernel arguments.  Read through `J`, every field is fetched once at the top and
+  // kept for the life of the kernel -- with 64 VGPRs per wave (8 waves per SIMD) that is ~80 scalar registers for ~110
+  // live values: round 5's build spilled 121 of them into vector lanes and read them back with v_readlane in the middle
+  // of the walk (83 reloads per tile and wave).  So only what the insert loop needs lives in `J`'s registers (the
+  // streams, S, nc, the boundary table); everything a colder phase needs -- the pre-filter's constants, the list's
+  // pointers, the over list -- is read where it is used, with s_load, through a pointer to the kernel arguments the
+  // compiler cannot see through (job(): it cannot hoist the loads above the statement that made the pointer).
+  typedef __attribute__((address_space(4))) const tile_job job_c;
+  auto job = [&]() -> job_c*
+  {
+    job_c* p = (job_c*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; job" : "+s"(p));
+    return p;
+  };
   const uint32_t S = J.S;
+  {
+    job_c* const J0 = job();
+    const uint32_t g_shift0 = J0->n_tiles ? J0->g_shift : J0->force_wide ? 6u : J0->plan->g_shift;
+    // two instantiations, both launched at level 0 where the plan is on the device: the one whose way of
+    // streaming a tile (kWide: whole waves per run, g_shift 6; else sub-groups of lanes) the plan did
+    // not choose returns at once
+    if ((g_shift0 == 6) != kWide) return;
+    // ... and so does the one of the table shape the plan did not choose
+    if (!J0->n_tiles && J0->plan->slots != kSlots) return;
+    if (blockIdx.x == 0 && tid == 0) *J0->ran = 1u;
+  }
   const uint32_t n_tiles = J.n_tiles ? J.n_tiles : J.plan->nb;
-  const uint32_t g_shift = J.n_tiles ? J.g_shift : J.force_wide ? 6u : J.plan->g_shift;
-  // two instantiations, both launched at level 0 where the plan is on the device: the one whose way of
-  // streaming a tile (kWide: whole waves per run, g_shift 6; else sub-groups of lanes) the plan did
-  // not choose returns at once
-  if ((g_shift == 6) != kWide) return;
-  // ... and so does the one of the table shape the plan did not choose
-  if (!J.n_tiles && J.plan->slots != kSlots) return;
-  if (blockIdx.x == 0 && tid == 0) *J.ran = 1u;
-  // segment tables of the current and the next tile, behind the fixed part: [2][begin[S] | length[S]]
+  [[maybe_unused]] const uint32_t g_shift = J.n_tiles ? J.g_shift : J.force_wide ? 6u : J.plan->g_shift;
+  // segment tables of the current and the next tile, behind the fixed part: [2][begin[S] | length[S] | prefix[S]]
   uint32_t* const s_seg = reinterpret_cast<uint32_t*>(s_raw + (sizeof(lds_t) + 7) / 8);
 
   // this workgroup's tiles: tile_first, tile_first + stride, ... below tile_end
@@ -714,27 +753,34 @@ k_tile_sums(const tile_job J)
   if (tid == 0)
   {
     M.key[kAll] = 0; M.key[kAll + 1] = 0;                  // the spare slot: never the empty marker
-    M.out_base = J.first_base + (unsigned long long)blockIdx.x * kOutChunk; M.out_used = 0; M.out_cap = kOutChunk; M.late_cnt = 0; M.stage_n = 0;
+    M.out_base = job()->first_base + (unsigned long long)blockIdx.x * kOutChunk; M.out_used = 0; M.out_cap = kOutChunk; M.stage_n = 0;
     M.n[0] = 0; M.n[1] = 0; M.fresh[0] = 0; M.fresh[1] = 0; M.abort[0] = 0; M.abort[1] = 0; M.big[0] = 0; M.big[1] = 0;
     M.hasmax = 0; M.bad = 0; M.maxsum[0] = 0; M.maxsum[1] = 0;
     M.max_hi[0] = ~0ull; M.max_hi[1] = 0;
   }
   __syncthreads();
+  // The segment table of a tile: where each stream's run begins, how long it is, and -- ONE scan per tile, by the
+  // wave that fetches the run (round 5: every wave of the workgroup scanned the tile's runs for itself at the top of
+  // its inserts, 16 x 6 shuffle steps per tile) -- how many records the runs up to and including it hold, counted
+  // within groups of kGroup runs (one wave, one lane per run; grp[] = a group's records, n = the tile's).
   auto load_segments = [&](uint32_t tile, uint32_t buf)
   {
     if (tile >= tile_end) return;
 #if KMD_TILE_ABLATE & 32   // dev: every workgroup streams the same 32 tiles again and again (cache-resident: the inserts alone; results wrong)
     tile &= 31u;
 #endif
-    uint32_t* beg = s_seg + (size_t)buf * 2 * S;
-    uint32_t mine = 0;
-    for (uint32_t s = tid; s < S; s += kThreads)
+    uint32_t* const beg = s_seg + (size_t)buf * 3 * S;
+    const uint32_t n_grp = (S + kGroup - 1u) / kGroup;
+    for (uint32_t g = wave; g < n_grp; g += (uint32_t)kWaves)
     {
-      const uint32_t b = J.start[(size_t)tile * S + s], e = J.start[((size_t)tile + 1) * S + s];
-      beg[s] = b; beg[S + s] = e - b;
-      mine += e - b;
+      const uint32_t s = g * kGroup + lane;
+      const bool ok = lane < kGroup && s < S;
+      uint32_t b = 0, e = 0;
+      if (ok) { b = J.start[(size_t)tile * S + s]; e = J.start[((size_t)tile + 1) * S + s]; }
+      const uint32_t incl = wave_scan_incl(e - b);
+      if (ok) { beg[s] = b; beg[S + s] = e - b; beg[2 * S + s] = incl; }
+      if (lane == 63) { M.grp[buf][g] = incl; if (incl) atomicAdd(&M.n[buf], incl); }
     }
-    if (mine) atomicAdd(&M.n[buf], mine);
   };
   load_segments(tile_first, 0);
   __syncthreads();
@@ -750,26 +796,30 @@ k_tile_sums(const tile_job J)
       if (wave != 0) return;
       const uint32_t n_st = M.stage_n < kStage ? M.stage_n : kStage;
       if (n_st == 0) return;
+      job_c* const Jf = job();
       unsigned long long base = M.out_base;
       uint32_t used = M.out_used < M.out_cap ? M.out_used : M.out_cap;
       const uint32_t cap = M.out_cap;
+      const unsigned long long row_cap = Jf->row_capacity;
+      unsigned long long* const sum_c_out = Jf->sum_c_out;
       if (used + n_st > cap)
       {
         for (unsigned long long e = base + used + lane; e < base + cap; e += 64)
-          if (e < J.row_capacity) J.sum_c_out[e] = kHole;
+          if (e < row_cap) sum_c_out[e] = kHole;
         unsigned long long fresh = 0;
-        if (lane == 0) fresh = atomicAdd(J.n_rows, (unsigned long long)kOutChunk);
+        if (lane == 0) fresh = atomicAdd(Jf->n_rows, (unsigned long long)kOutChunk);
         base = __shfl(fresh, 0, 64);
         used = 0;
         if (lane == 0) { M.out_base = base; M.out_cap = kOutChunk; }
       }
-      if (lane < n_st)
+      static_assert(kStage <= kOutChunk, "a tile's parked rows fit one chunk");
+      for (uint32_t i = lane; i < n_st; i += 64)
       {
-        const unsigned long long e = base + used + lane;
-        if (e < J.row_capacity)
+        const unsigned long long e = base + used + i;
+        if (e < row_cap)
         {
-          J.kmer_out[e] = M.stage_key[lane]; J.sum_c_out[e] = M.stage_c[lane]; J.sum_k_out[e] = M.stage_k[lane];
-          if constexpr (kTwo) J.kmer_hi_out[e] = M.stage_hi[lane];
+          Jf->kmer_out[e] = M.stage_key[i]; sum_c_out[e] = M.stage_c[i]; Jf->sum_k_out[e] = M.stage_k[i];
+          if constexpr (kTwo) Jf->kmer_hi_out[e] = M.stage_hi[i];
         }
       }
       if (lane == 0) { M.out_used = used + n_st; M.stage_n = 0; }
@@ -777,7 +827,7 @@ k_tile_sums(const tile_job J)
   };
 
   const uint32_t G = 1u << g_shift, sub = tid & (G - 1u), q0 = tid >> g_shift, Q = (uint32_t)kThreads >> g_shift;
-  uint32_t n_beyond = 0, rows_local = 0;
+  [[maybe_unused]] uint32_t beyond_wave = 0, rows_wave = 0;           // candidates mode: this WAVE's rows / rows beyond the log-factorial table (scalar)
   struct batch
   {
     uint64_t k[kU], kh[kTwo ? kU : 1];
@@ -809,9 +859,10 @@ k_tile_sums(const tile_job J)
         constexpr int kRing = kSlots == kBigSlots ? KMD_TILE_RING_BIG : KMD_TILE_RING;
         constexpr int kR = KMD_TILE_RPL;                                              // records per lane and round (lane l: records l, 64 + l, ...)
         constexpr uint32_t kStep = 64u * kR;                                          // records per round
-        constexpr uint32_t kBatch = 63;                                               // runs of a wave whose description its lanes hold at a time
-        const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
+        constexpr uint32_t kBatch = kGroup;                                           // runs of a wave whose description its lanes hold at a time
+        const uint32_t* beg = s_seg + (size_t)buf * 3 * S;
         const uint32_t* len = beg + S;
+        const uint32_t* upto = beg + 2 * S;                                           // records of the group's runs up to and including this one (load_segments)
         // What the scalar unit does per round decides this kernel (PMC, round 2: 73 scalar instructions per round of
         // 64 records, most of them lane-mask algebra and the iterator's register shuffling -- one scalar unit serves
         // the CU's four SIMDs).  So:
@@ -842,16 +893,15 @@ k_tile_sums(const tile_job J)
         const uint32_t w_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
         const uint32_t share_lo = (uint32_t)(((uint64_t)n * w_u) / (uint32_t)kWaves), share_hi = (uint32_t)(((uint64_t)n * (w_u + 1u)) / (uint32_t)kWaves);
         uint32_t seq0 = 0;                                                            // records of the tile before stream `first`
-        for (uint32_t first = 0; first < S && seq0 < share_hi && !gave_up; first += kBatch)
+        for (uint32_t first = 0, grp = 0; first < S && seq0 < share_hi && !gave_up; first += kBatch, ++grp)
         {
           // lane j < 63: the piece of run `first + j` that lies in this wave's share
           const uint32_t my_s = first + lane;
           const bool mine_ok = lane < kBatch && my_s < S;
           const uint32_t my_len = mine_ok ? len[my_s] : 0u;
-          uint32_t incl = my_len;                                                     // records up to and including this run, from `first` on
-          for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, (unsigned)o, 64); incl += lane >= (uint32_t)o ? t : 0u; }
+          const uint32_t incl = mine_ok ? upto[my_s] : 0u;                            // (a lane without a run: an empty piece whatever this is)
           const uint32_t run_lo = seq0 + incl - my_len, run_hi = seq0 + incl;
-          seq0 += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          seq0 += (uint32_t)__builtin_amdgcn_readfirstlane((int)M.grp[buf][grp]);
           if (seq0 <= share_lo) continue;                                             // (none of these runs reaches the share)
           const uint32_t p_lo = run_lo > share_lo ? run_lo : share_lo, p_hi = run_hi < share_hi ? run_hi : share_hi;
           uint32_t v_rl = p_hi > p_lo ? p_hi - p_lo : 0u;                             // (< 2^29: bit 31 marks a control sample's run)
@@ -1356,7 +1406,7 @@ k_tile_sums(const tile_job J)
     // ---- inserts, general: sub-group q0 (G lanes) streams the runs q0, q0 + Q, ... of this tile
     if (!kWide && process)
     {
-      const uint32_t* beg = s_seg + (size_t)buf * 2 * S;
+      const uint32_t* beg = s_seg + (size_t)buf * 3 * S;
       const uint32_t* len = beg + S;
       uint32_t s = q0, pos = 0, end = 0;
       // the lane's next record: `pos` in run `s`; a lane that has none left parks on record 0 (s >= S)
@@ -1586,204 +1636,159 @@ k_tile_sums(const tile_job J)
         if (ballot(bad) && lane == 0) M.bad = 1;
         __syncthreads();
       }
-      const bool bad_tile = aborted || (kTwo && M.bad != 0);
+      // (wave-uniform, and said so: what comes out of LDS is a vector value to the compiler, and a loop or a counter that
+      // depends on one is kept in vector registers under lane masks)
+      const bool bad_tile = __builtin_amdgcn_readfirstlane((int)(aborted || (kTwo && M.bad != 0))) != 0;
       if constexpr (kTwo) { __syncthreads(); if (tid == 0) M.bad = 0; }     // everyone has read it
       if (bad_tile && tid == 0)
       {
-        const uint32_t at = atomicAdd(J.over_n, 1u);
-        J.over[at] = tile; J.over[J.over_stride + at] = (n < kBigBit ? n : kBigBit - 1u) | kAbortBit | (big ? kBigBit : 0u);
+        job_c* const Jo = job();
+        const uint32_t at = atomicAdd(Jo->over_n, 1u);
+        Jo->over[at] = tile; Jo->over[Jo->over_stride + at] = (n < kBigBit ? n : kBigBit - 1u) | kAbortBit | (big ? kBigBit : 0u);
       }
       if constexpr (kFilter)
       {
-        // The walk, candidates mode: ONE pass.  Every thread owns kWalk slots -- their keys and sums are read first,
-        // all of them, then looked at: a live slot goes through the chi-square pre-filter, the ~1 % that pass leave
-        // for the list, every slot is wiped.  The rows that leave are parked in LDS (kStage of them; the list's
-        // chunks take what does not fit, at once) and written to the list by wave 0 when the NEXT tile's inserts are
-        // done: nothing waits for the stores -- the barriers of the tile loop wait for LDS only -- and they have a
-        // whole walk to land before the loads of the following tile are counted again.  (Round 2 reserved a tile's
-        // entries with one returning global atomic between two barriers and wrote them in a second pass over the
-        // table: 5 500 + 2 700 of a tile's 62 000 cycles; writing them in the one pass, behind a barrier that waited
-        // for the stores as __syncthreads does, still cost 3 500.)
-        // (Measured and dropped: the workgroup's last wave fetching the next tile's segments instead of walking --
-        // the other seven cover its slots in the same five steps --: 20v20 281 -> 291 us, 3 records per row 758 -> 785.)
-        // (Measured, too: WHY the waves wait at the barrier below -- 4 000 of a 20v20 tile's 60 000 cycles, KMD_TILE_TIMING --:
-        // for wave 0, which fetches the next tile's segment table first (two loads' round trip).  Fetched at the tile's
-        // start instead, wave 0 taking that much less of the tile's records, the wait was gone -- 4 200 -> 600 cycles --
-        // and the kernel took what it took before (286 -> 287 us): with four workgroups to a CU, one's wait is the
-        // others' turn.  What bounds this kernel is what a CU gets done per cycle, not how long a workgroup stands.)
-        uint32_t late_bits = 0;
-        auto emit = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k) -> bool
+        // The walk, candidates mode.  What a tile costs here does not depend on how many records it had -- a 4096-slot
+        // table holds ~2000 rows whether they were 5 000 records or 50 000 -- so on rows of few records this half of
+        // the kernel is as long as the inserts.  Round 5's walk gave every thread five slots and ran the pre-filter,
+        // in double precision, on all of them, dead or alive (half the lanes idle), its second stage and the emission
+        // in a loop that ran two or three times a tile with a third of the lanes busy: 382 vector + 222 scalar
+        // instructions per wave and tile.  Now:
+        //  * COMPACTION FIRST.  A thread reads the keys of two adjacent slots (one ds_read_b128: the whole table in two
+        //    steps of the workgroup, the second table by its last waves); a ballot and a prefix count put the LIVE
+        //    slots' numbers into the wave's queue in LDS (kQueue x 2 bytes) -- five vector instructions per 64 slots;
+        //  * whenever 64 slots are queued (and once more at the end, for the rest) the wave evaluates them, every lane a
+        //    live row: both sums (gathered), the chi-square bound; the second stage and the emission only if a lane
+        //    needs them; the key is read only for the rows that leave;
+        //  * only live slots are wiped (an empty slot is empty: its sums are 0 -- nothing adds to a slot it did not
+        //    find its key in, but for the spare slot behind the tables), in the pass that evaluates them;
+        //  * rows and rows beyond the table are counted per WAVE, in scalar registers, from the ballots;
+        //  * the rows that leave are parked in LDS with one atomic per wave and pass (kStage of them; the workgroup's
+        //    chunk of the list takes what does not fit, at once, and should THAT run out the wave takes a chunk of its
+        //    own -- no second walk, no barriers for the rare case) and written to the list by wave 0 when the NEXT
+        //    tile's inserts are done: nothing waits for the stores -- the barriers of the tile loop wait for LDS only.
+        //  * the pre-filter's constants come from the kernel arguments here, where they are used (job()).
+        // (Measured in earlier rounds and still true: the wait at the barrier below is other workgroups' turn on the CU.)
+        job_c* const Jw = job();
+        const double w_dTc = Jw->dTc, w_dTk = Jw->dTk, w_rhs = Jw->pf_rhs;
+        const uint32_t w_lf_n = Jw->lf_n;
+        const kl_consts w_kl { Jw->kl_qc, Jw->kl_qk, Jw->kl_cut, Jw->kl_max };
+        typedef __attribute__((address_space(3))) uint16_t lds_u16;
+        typedef __attribute__((address_space(3))) uint32_t lds_u32s;
+        uint16_t* const q = M.queue[wave];
+        uint32_t qn = 0;                                                  // slots queued (wave-uniform)
+        // (row_may_pass, kmd_eval.h, on sums that are exact in one conversion; pf_rhs = pf_cut Tc Tk from the host)
+        auto may_pass = [&](unsigned long long c, unsigned long long k) -> bool
         {
-          const uint32_t at = atomicAdd(&M.stage_n, 1u);
+          const double dsc = (double)c, dsk = (double)k;
+          const double a = dsc * w_dTk - dsk * w_dTc;
+          return !(a * a < (dsc + dsk) * w_rhs);
+        };
+        // the rows of the lanes that call it (a subset of the wave, together) leave for the list
+        auto emit = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k)
+        {
+          const unsigned long long m = ballot(true);
+          const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          // (one lane adds for all of them -- written as the instruction: the compiler's own aggregation of a uniform
+          // atomic would wrap a second ballot, prefix count and broadcast around this one)
+          uint32_t first = 0;
+          if (rank == 0)
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(first) : "v"((uint32_t)(uintptr_t)(lds_u32s*)&M.stage_n), "v"((uint32_t)__popcll(m)) : "memory");
+          const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)first) + rank;
           if (at < kStage)
           {
-            M.stage_key[at] = key; M.stage_c[at] = sum_c; M.stage_k[at] = sum_k;
+            M.stage_key[at] = key; M.stage_c[at] = (typename lds_t::stage_sum_t)sum_c; M.stage_k[at] = (typename lds_t::stage_sum_t)sum_k;
             if constexpr (kTwo) M.stage_hi[at] = key_hi;
-            return true;
+            return;
           }
+          // (more rows than the tile may park: straight into the workgroup's chunk of the list)
+          job_c* const Je = job();
           const uint32_t pos = atomicAdd(&M.out_used, 1u);
-          if (pos >= M.out_cap) return false;
-          const unsigned long long e = M.out_base + pos;
-          if (e < J.row_capacity)
+          unsigned long long e = M.out_base + pos;
+          if (pos >= M.out_cap)
           {
-            J.kmer_out[e] = key; J.sum_c_out[e] = sum_c; J.sum_k_out[e] = sum_k;
-            if constexpr (kTwo) J.kmer_hi_out[e] = key_hi;
+            // ... and that is full, too: a chunk of this wave's own, the rows at its head, the rest holes
+            const unsigned long long lm = ballot(true);
+            const uint32_t lrank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+            const uint32_t ltot = (uint32_t)__popcll(lm);
+            unsigned long long fresh = 0;
+            if (lrank == 0) fresh = atomicAdd(Je->n_rows, (unsigned long long)kOutChunk);
+            fresh = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(fresh >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fresh);
+            e = fresh + lrank;
+            for (unsigned long long h = fresh + ltot + lrank; h < fresh + kOutChunk; h += ltot)
+              if (h < Je->row_capacity) Je->sum_c_out[h] = kHole;
           }
-          return true;
+          if (e < Je->row_capacity)
+          {
+            Je->kmer_out[e] = key; Je->sum_c_out[e] = sum_c; Je->sum_k_out[e] = sum_k;
+            if constexpr (kTwo) Je->kmer_hi_out[e] = key_hi;
+          }
         };
-        constexpr bool kFastWalk = kSum32 && !kTwo;
-        uint64_t w_key[kWalk];
-        unsigned long long w_c[kFastWalk ? 1 : kWalk], w_k[kFastWalk ? 1 : kWalk];       // (the fast walk's sums: c32 / k32)
-        [[maybe_unused]] uint32_t c32[kWalk], k32[kWalk];
-        auto sum_c_of = [&](int j) -> unsigned long long { if constexpr (kFastWalk) return c32[j]; else return w_c[j]; };
-        auto sum_k_of = [&](int j) -> unsigned long long { if constexpr (kFastWalk) return k32[j]; else return w_k[j]; };
-        if constexpr (kFastWalk)
+        // the last `cnt` (<= 64) slots of the queue: their rows through the pre-filter, the slots wiped
+        auto evaluate = [&](const uint32_t cnt)
         {
-          // (one-limb k-mers, 32-bit sums -- the instantiation that matters: straight-line code.  All reads, all wipes
-          // -- of every slot, empty or not: a wipe under a lane mask costs what it costs without --, the chi-square
-          // bound of all slots without a branch, and only if a slot of the wave passes it, the second stage and the
-          // emission.  As the compiler wrote the general version below for this case, the walk was 390 vector + 230
-          // scalar instructions per wave, a fifth of them lane-mask algebra and re-reads of spilled scalars: on rows of
-          // 3 records, as long as the inserts.)
-#pragma unroll
-          for (int j = 0; j < kWalk; ++j)
+          qn -= cnt;
+          if (!bad_tile) rows_wave += cnt;
+          if (lane < cnt)
           {
-            const uint32_t i = tid + (uint32_t)j * kThreads;
-            const bool in = j + 1 < kWalk || i < kAll;                    // (the last step covers the end of the second table)
-            w_key[j] = in ? M.key[i] : kEmptyKey; c32[j] = in ? M.c32[i] : 0u; k32[j] = in ? M.k32[i] : 0u;
-          }
-#pragma unroll
-          for (int j = 0; j < kWalk; ++j)
-          {
-            const uint32_t i = tid + (uint32_t)j * kThreads;
-            if (j + 1 < kWalk || i < kAll) { M.key[i] = kEmptyKey; M.c32[i] = 0u; M.k32[i] = 0u; }
-          }
-          uint32_t pass = 0;
-          const uint32_t good = bad_tile ? 0u : 1u;
-#pragma unroll
-          for (int j = 0; j < kWalk; ++j)
-          {
-            // (bit operations, not && and ||: those became a branch each)
-            const uint32_t live = (w_key[j] != kEmptyKey ? 1u : 0u) & good;
-            rows_local += live;
-            n_beyond += live & ((c32[j] >= J.lf_n ? 1u : 0u) | (k32[j] >= J.lf_n ? 1u : 0u));
-            // (row_may_pass, kmd_eval.h, on sums that are exact in one conversion; pf_rhs = pf_cut Tc Tk from the host)
-            const double dsc = (double)c32[j], dsk = (double)k32[j];
-            const double a = dsc * J.dTk - dsk * J.dTc;
-            pass |= (live & (a * a < (dsc + dsk) * J.pf_rhs ? 0u : 1u)) << j;
-          }
+            const uint32_t i = *(const lds_u16*)(uintptr_t)(q + qn + lane);
+            unsigned long long c, k;
+            read_sums(i, c, k);
+            if (!bad_tile)
+            {
+              beyond_wave += (uint32_t)__popcll(ballot((c >= w_lf_n) | (k >= w_lf_n)));
+              bool leaves = may_pass(c, k);
 #if KMD_TILE_ABLATE & 4   // dev: no pre-filter evaluation, nothing leaves (results wrong)
-          pass = 0;
+              leaves = false;
 #endif
-          // (the rows that leave -- one lane in forty has one, next to none has two: one copy of the second stage and
-          // of the emission, run for each lane's lowest pending slot until no lane has any)
-          while (ballot(pass != 0))
-          {
-            const int j = pass ? __builtin_ctz(pass) : 0;
-            uint64_t key = w_key[0]; uint32_t c = c32[0], k = k32[0];
-#pragma unroll
-            for (int t = 1; t < kWalk; ++t) if (j == t) { key = w_key[t]; c = c32[t]; k = k32[t]; }
-            if (pass && row_may_pass_kl(J, c, k) && !emit(key, 0ull, c, k)) late_bits |= 1u << j;
-            pass &= pass - 1u;
-          }
-        }
-        else
-        {
-#pragma unroll
-        for (int j = 0; j < kWalk; ++j)
-        {
-          const uint32_t i = tid + (uint32_t)j * kThreads;
-          w_key[j] = i < kAll ? M.key[i] : kEmptyKey;                   // (the last step covers the end of the second table)
-        }
-#pragma unroll
-        for (int j = 0; j < kWalk; ++j)
-        {
-          const uint32_t i = tid + (uint32_t)j * kThreads;
-          w_c[j] = 0; w_k[j] = 0;
-          if (i < kAll) read_sums(i, w_c[j], w_k[j]);                    // (an empty slot's sums are 0)
-        }
-#pragma unroll
-        for (int j = 0; j < kWalk; ++j)
-        {
-          const uint32_t i = tid + (uint32_t)j * kThreads;
-          const bool live = w_key[j] != kEmptyKey;
-          bool leaves = false;
-#if !(KMD_TILE_ABLATE & 4)   // dev: no pre-filter evaluation, nothing leaves (results wrong)
-          if (!bad_tile)
-          {
-            row_state st; st.sum_c = w_c[j]; st.sum_k = w_k[j]; st.row = 0; st.valid = live;
-            leaves = row_may_pass(J, st, n_beyond);
-            if (leaves) leaves = row_may_pass_kl(J, w_c[j], w_k[j]);
-          }
-#endif
-          rows_local += live && !bad_tile ? 1u : 0u;
-          bool late = false;
-          if (leaves) late = !emit(w_key[j], kTwo ? M.key_hi[i] : 0ull, w_c[j], w_k[j]);
-          late_bits |= late ? 1u << j : 0u;
-          if (live && !late)
-          {
+              if (ballot(leaves)) { if (leaves) leaves = row_may_pass_kl(w_kl, c, k); }
+              if (ballot(leaves)) { if (leaves) emit(M.key[i], kTwo ? M.key_hi[i] : 0ull, c, k); }
+            }
             M.key[i] = kEmptyKey; wipe_sums(i);
             if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
           }
-        }
-        }
-        bool special_late = false;
-        if (tid == 0 && M.hasmax && !bad_tile)             // the all-ones k-mer, if this tile had it
+        };
+        // (ONE copy of the evaluation in the code: the walk is a loop of half-steps -- a pair's first slot, its second --
+        // that turns to the queue whenever it holds 64 slots, and once more behind the last half-step for the rest)
+        static_assert(kSlots % (2 * kThreads) == 0 && (kSec / 2) % 64 == 0 && kSec / 2 <= (uint32_t)kThreads, "the walk's steps");
+        constexpr uint32_t kMainSteps = kSlots / (2u * kThreads);
+        // (the second table's pairs: the workgroup's last waves -- wave 0 has the next tile's segments to fetch)
+        const bool sec_mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) >= (uint32_t)kWaves - kSec / 128u;
+        const uint32_t n_half = 2u * (kMainSteps + (sec_mine ? 1u : 0u));
+        u64x2 two_keys = { kEmptyKey, kEmptyKey };
+        uint32_t pair = 0;
+#pragma nounroll
+        for (uint32_t hs = 0;;)
         {
-          row_state st; st.sum_c = M.maxsum[0]; st.sum_k = M.maxsum[1]; st.row = 0; st.valid = true;
-          ++rows_local;
-          if (row_may_pass(J, st, n_beyond) && row_may_pass_kl(J, st.sum_c, st.sum_k)) special_late = !emit(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
+          if (qn >= 64u || (hs == n_half && qn != 0u)) { evaluate(qn < 64u ? qn : 64u); continue; }
+          if (hs == n_half) break;
+          if ((hs & 1u) == 0u)
+          {
+            const uint32_t st = hs >> 1;
+            pair = st < kMainSteps ? st * (uint32_t)kThreads + tid : kSlots / 2u + (tid - ((uint32_t)kThreads - kSec / 2u));
+            two_keys = *(const lds_u64x2*)(uintptr_t)(M.key + 2u * pair);
+          }
+          const bool live = ((hs & 1u) ? two_keys.y : two_keys.x) != kEmptyKey;
+          const unsigned long long m = ballot(live);
+          const uint32_t pos = qn + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (live) *(lds_u16*)(uintptr_t)(q + pos) = (uint16_t)(2u * pair + (hs & 1u));
+          qn += (uint32_t)__popcll(m);
+          ++hs;
+        }
+        if (__builtin_amdgcn_readfirstlane((int)(wave == 0 && M.hasmax != 0)))       // the all-ones k-mer, if this tile had it
+        {
+          if (!bad_tile)
+          {
+            const unsigned long long mc = M.maxsum[0], mk = M.maxsum[1];
+            rows_wave += 1u;
+            beyond_wave += (mc >= w_lf_n || mk >= w_lf_n) ? 1u : 0u;
+            if (lane == 0 && may_pass(mc, mk) && row_may_pass_kl(w_kl, mc, mk)) emit(kEmptyKey, M.max_hi[1], mc, mk);
+          }
+          if (lane == 0) { M.hasmax = 0; M.maxsum[0] = 0; M.maxsum[1] = 0; M.max_hi[0] = ~0ull; M.max_hi[1] = 0; }
         }
 #if KMD_TILE_TIMING
         tp_walk1 = __builtin_readcyclecounter();
-        // (dev: when each wave reaches the walk's barrier -- the wait for its own LDS operations apart --, relative to wave 1)
-        if (lane == 0) M.wcnt[wave] = (uint32_t)tp_walk1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long tp_lgkm = __builtin_readcyclecounter();
 #endif
-        lds_barrier();
-#if KMD_TILE_TIMING
-        tp_resv = __builtin_readcyclecounter();
-        if (blockIdx.x == 77 && tid == 64)
-          printf("[walk barrier] tile %u: own LDS drained after %llu; waves reached it at %d %d %d %d %d %d %d %d relative to wave 1 (%llu after the walk began)\n", tile,
-                 tp_lgkm - tp_walk1, (int)(M.wcnt[0] - (uint32_t)tp_walk1), 0, (int)(M.wcnt[2] - (uint32_t)tp_walk1), (int)(M.wcnt[3] - (uint32_t)tp_walk1),
-                 (int)(M.wcnt[4] - (uint32_t)tp_walk1), (int)(M.wcnt[5] - (uint32_t)tp_walk1), (int)(M.wcnt[6] - (uint32_t)tp_walk1), (int)(M.wcnt[7] - (uint32_t)tp_walk1), tp_walk1 - tp_seg);
-#endif
-        if (M.out_used > M.out_cap)
-        {
-          // the chunk ran out: the rows left over take the first entries of a new chunk (as many chunks as they need)
-          const uint32_t extra = M.out_used - M.out_cap;
-          lds_barrier();
-          if (tid == 0)
-          {
-            const uint32_t take = (extra + kOutChunk - 1u) / kOutChunk * kOutChunk;
-            M.late_base = atomicAdd(J.n_rows, (unsigned long long)take);
-            M.late_cnt = 0; M.out_used = extra; M.out_cap = take;
-          }
-          __syncthreads();
-          auto emit_late = [&](unsigned long long key, unsigned long long key_hi, unsigned long long sum_c, unsigned long long sum_k)
-          {
-            const unsigned long long e = M.late_base + atomicAdd(&M.late_cnt, 1u);
-            if (e < J.row_capacity)
-            {
-              J.kmer_out[e] = key; J.sum_c_out[e] = sum_c; J.sum_k_out[e] = sum_k;
-              if constexpr (kTwo) J.kmer_hi_out[e] = key_hi;
-            }
-          };
-#pragma unroll
-          for (int j = 0; j < kWalk; ++j)
-            if ((late_bits >> j) & 1u)
-            {
-              const uint32_t i = tid + (uint32_t)j * kThreads;
-              emit_late(w_key[j], kTwo ? M.key_hi[i] : 0ull, sum_c_of(j), sum_k_of(j));
-              M.key[i] = kEmptyKey; wipe_sums(i);
-              if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
-            }
-          if (special_late) emit_late(kEmptyKey, M.max_hi[1], M.maxsum[0], M.maxsum[1]);
-          lds_barrier();
-          if (tid == 0) M.out_base = M.late_base;
-        }
-        if (tid == 0 && M.hasmax) { M.hasmax = 0; M.maxsum[0] = 0; M.maxsum[1] = 0; M.max_hi[0] = ~0ull; M.max_hi[1] = 0; }
       }
       else
       {
@@ -1800,30 +1805,15 @@ k_tile_sums(const tile_job J)
           const uint32_t i = tid + (uint32_t)j * kThreads;
           const bool live = i < kAll && M.key[i] != kEmptyKey;           // (the last step covers the end of the second table)
           bool leaves = live;
-#if KMD_TILE_ABLATE & 4   // dev: no pre-filter evaluation, nothing leaves (results wrong)
+#if KMD_TILE_ABLATE & 4   // dev: nothing leaves (results wrong)
           leaves = false;
-#else
-          if constexpr (kFilter)
-          {
-            unsigned long long sum_c, sum_k;
-            read_sums(i, sum_c, sum_k);
-            row_state st; st.sum_c = live ? sum_c : 0; st.sum_k = live ? sum_k : 0; st.row = 0; st.valid = live;
-            leaves = row_may_pass(J, st, n_beyond);
-          }
 #endif
-          rows_local += live ? 1u : 0u;
           out_bits |= leaves ? 1u << j : 0u;
           mine += leaves ? 1u : 0u;
         }
         if (tid == 0 && M.hasmax)                          // the all-ones k-mer, if this tile had it
         {
           special_out = true;
-          if constexpr (kFilter)
-          {
-            row_state st; st.sum_c = M.maxsum[0]; st.sum_k = M.maxsum[1]; st.row = 0; st.valid = true;
-            special_out = row_may_pass(J, st, n_beyond);
-          }
-          ++rows_local;
           mine += special_out ? 1u : 0u;
         }
       }
@@ -1903,16 +1893,18 @@ k_tile_sums(const tile_job J)
     // this launch does not have (the list was laid out for n_regions of them): holes
     flush_stage();
     __syncthreads();
+    job_c* const Jz = job();
+    const unsigned long long row_cap = Jz->row_capacity, first_base = Jz->first_base;
+    unsigned long long* const sum_c_out = Jz->sum_c_out;
     for (unsigned long long e = M.out_base + (M.out_used < M.out_cap ? M.out_used : M.out_cap) + tid; e < M.out_base + M.out_cap; e += kThreads)
-      if (e < J.row_capacity) J.sum_c_out[e] = kHole;
-    for (uint32_t r = blockIdx.x + gridDim.x; r < J.n_regions; r += gridDim.x)
-      for (unsigned long long e = J.first_base + (unsigned long long)r * kOutChunk + tid; e < J.first_base + (unsigned long long)(r + 1u) * kOutChunk; e += kThreads)
-        if (e < J.row_capacity) J.sum_c_out[e] = kHole;
+      if (e < row_cap) sum_c_out[e] = kHole;
+    for (uint32_t r = blockIdx.x + gridDim.x; r < Jz->n_regions; r += gridDim.x)
+      for (unsigned long long e = first_base + (unsigned long long)r * kOutChunk + tid; e < first_base + (unsigned long long)(r + 1u) * kOutChunk; e += kThreads)
+        if (e < row_cap) sum_c_out[e] = kHole;
     // this workgroup's rows and rows beyond the log-factorial table (merge.hpp:76; kmd_filter.hip counts
     // the same two for rows of a matrix)
-    for (int o = 32; o > 0; o >>= 1) { rows_local += __shfl_down(rows_local, o, 64); n_beyond += __shfl_down(n_beyond, o, 64); }
-    if (lane == 0 && rows_local) atomicAdd(&J.row_total[0], (unsigned long long)rows_local);
-    if (lane == 0 && n_beyond) atomicAdd(&J.row_total[1], (unsigned long long)n_beyond);
+    if (lane == 0 && rows_wave) atomicAdd(&Jz->row_total[0], (unsigned long long)rows_wave);
+    if (lane == 0 && beyond_wave) atomicAdd(&Jz->row_total[1], (unsigned long long)beyond_wave);
   }
 }
 
@@ -2020,6 +2012,8 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   KMD_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   const tile_shape sh = pick_shape();
   const float load = (float)env_u32("KMD_TILE_LOAD_PCT", 50) / 100.0f;        // distinct k-mers per slot aimed at
+  // two limbs under the 4096-slot table: 32 bytes per slot -- the segment tables of ~650 samples still fit beside it
+  const bool two_limb_big_fits = sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, true, true>) + 8 + 6 * (size_t)S * 4 <= 160 * 1024;
 
   uint32_t L = 0;
   for (int s = 1; s < S; ++s) if (offsets[s + 1] - offsets[s] > offsets[L + 1] - offsets[L]) L = (uint32_t)s;
@@ -2080,7 +2074,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
                        (uint64_t)n, d_mult, L, R0, C, static_cast<uint32_t*>(p_coarse));
     const size_t cells = ((size_t)nb_max + 1) * S;                      // (threads beyond the plan's tiles leave at once)
     hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)std::min<size_t>((cells + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_keys, d_keys_hi, d_offs, (uint32_t)S, L,
-                       d_mult, (uint64_t)n, n_l, sh.slots ? sh.slots : (two && std::getenv("KMD_TILE_SUM64") ? kSmallSlots : 0u), load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
+                       d_mult, (uint64_t)n, n_l, sh.slots ? sh.slots : (two && (std::getenv("KMD_TILE_SUM64") || !two_limb_big_fits) ? kSmallSlots : 0u), load, env_u32("KMD_TILE_FILL", 0), env_u32("KMD_TILE_G", 0),
                        grid_hint, grid_hint_big, d_plan, static_cast<uint32_t*>(p_table), d_rows, (unsigned long long)(fused ? (size_t)regions_max * kOutChunk : 0),
                        R0, C, static_cast<const uint32_t*>(p_coarse));
     KMD_HIP(hipGetLastError());
@@ -2113,7 +2107,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
 
   auto launch = [&](auto kernel, int threads, size_t lds_fixed, uint32_t tiles_at_most) -> int
   {
-    const size_t lds = (lds_fixed + 7) / 8 * 8 + 4 * (size_t)S * 4;        // + [2][begin | length] of S streams
+    const size_t lds = (lds_fixed + 7) / 8 * 8 + 6 * (size_t)S * 4;        // + [2][begin | length | prefix] of S streams
     int rc = allow_lds(kernel, lds);
     if (rc != KMD_OK) return rc;
     int per_cu = 0;
@@ -2124,14 +2118,7 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
     if (grid > tiles_at_most) grid = tiles_at_most;
     if (grid > J.n_regions) grid = J.n_regions;
     if (dbg) std::fprintf(stderr, "[tile_merge] <= %u tiles, grid %zu x %d (%d per CU), lds %zu\n", tiles_at_most, grid, threads, per_cu, lds);
-#if KMD_TILE_JOB_PTR
-    void* p_job = nullptr;
-    KMD_HIP(sc.take(&p_job, sizeof J));
-    KMD_HIP(hipMemcpyAsync(p_job, &J, sizeof J, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, static_cast<const tile_job*>(p_job));
-#else
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, st, J);
-#endif
     KMD_HIP(hipGetLastError());
     return KMD_OK;
   };
@@ -2150,12 +2137,12 @@ int tile_merge(int S, int nc, const uint64_t* d_keys, const uint64_t* d_keys_hi,
   uint32_t shape_level0 = sh.slots ? sh.slots : async ? async->shape : g_last_shape[dev & 63].load(std::memory_order_relaxed);   // 0: both
   uint32_t shape_known = sh.slots;                               // levels > 0: the plan's, read back
   bool sum32 = std::getenv("KMD_TILE_SUM64") == nullptr;     // 32-bit sums until a tile reports a count too large for them
-  // (what the instantiations that can be launched take of the 160 KB of LDS, 1024 samples' segment tables included)
+  // (what the instantiations that can be launched take of the 160 KB of LDS, 1024 samples' segment tables included; the
+  // 4096-slot table with two limbs fits up to ~650 samples: two_limb_big_fits, below)
 #if KMD_TILE_BIG_SLOTS == 4096
-  static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, true, true>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, two limbs, 32-bit sums");
-  static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, false, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, one limb, 64-bit sums");
+  static_assert(sizeof(tile_lds<kBigSlots, KMD_TILE_BIG_THREADS / 64, false, false>) + 8 + 6 * kMaxStreams * 4 <= 160 * 1024, "4096 slots, one limb, 64-bit sums");
 #endif
-  static_assert(sizeof(tile_lds<kSmallSlots, 8, true, false>) + 8 + 4 * kMaxStreams * 4 <= 160 * 1024, "2048 slots, two limbs, 64-bit sums");
+  static_assert(sizeof(tile_lds<kSmallSlots, 8, true, false>) + 8 + 6 * kMaxStreams * 4 <= 160 * 1024, "2048 slots, two limbs, 64-bit sums");
   auto run = [&](uint32_t tiles_at_most) -> int
   {
     // one instantiation per (shape, fused, two limbs, whole-wave runs, 32-bit sums)

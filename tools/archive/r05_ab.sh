@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev (GPU box): kernel-trace A/B of library variants on the fused merge, four shapes.  usage: tools/r05_ab.sh [-s "1 2 3 4"] build_sweep/a.so ...
+# dev (GPU box): kernel-trace A/B of library variants on the fused merge, four shapes.  usage: tools/archive/r05_ab.sh [-s "1 2 3 4"] build_sweep/a.so ...
 shapes="1 2 3 4"
 if [ "$1" = "-s" ]; then shapes=$2; shift 2; fi
 out=gpurun_out/r05_ab; mkdir -p $out

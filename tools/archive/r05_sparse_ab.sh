@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev (GPU box): where the fused merge's time goes on rows of few records -- kernel trace of ablated builds, phase cycles of
-# one tile (KMD_TILE_TIMING), SQ counters of the default build.   usage: tools/r05_sparse_ab.sh [variants...]
+# one tile (KMD_TILE_TIMING), SQ counters of the default build.   usage: tools/archive/r05_sparse_ab.sh [variants...]
 repo=${GRAFT_REPO_ROOT:-$PWD}
 out=gpurun_out/sparse_ab; mkdir -p $out
 A1="--sparse 0.1 --rows 40000000 --iters 3"
