@@ -394,6 +394,31 @@ def h2d_leg(K, lib, obs, mat, steps=3):
                     "serial, per step" % nbytes}
 
 
+def e2e_leg(parts=8, rows=2_000_000):
+    """The command end to end on files (never `value`): tools/cli_throughput.py fabricates a kmtricks run directory
+    (configs[2]'s sample split, `parts` partitions of `rows` rows), runs `kmdiff-hip diff -t <threads the quota gives>` on it
+    and, on the SAME files, oracle/cpu_pipeline -- liblz4 decode + the oracle's S-way merge + the oracle's test, one task
+    per partition on as many threads (global_merge::merge, merge.hpp:239-307): the like-for-like CPU baseline."""
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    threads = usable_cpus()[0]
+    with tempfile.TemporaryDirectory(prefix="kmd_e2e_") as tmp:
+        js = os.path.join(tmp, "e2e.json")
+        r = subprocess.run([sys.executable, os.path.join(here, "tools", "cli_throughput.py"), "--parts", str(parts), "--rows", str(rows), "--nc", str(NC),
+                            "--nk", str(NK), "--cpu-baseline", "--only", "-t %d" % threads, "--json", js], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        with open(js) as f:
+            got = json.load(f)
+    gpu, cpu = got["kmdiff_hip_diff"][0], got["cpu_baseline_e2e"]
+    return {"workload": "kmdiff-hip diff on %d partitions x %d rows, %dv%d, k = 31, files in the page cache" % (parts, rows, NC, NK),
+            "run_dir": got["run_dir"], "kmdiff_hip_diff": gpu,
+            "cpu_baseline_e2e": {"value": cpu["rows_per_s"], "unit": "k-mers/s", "cores": cpu["threads"], "kind": "port", "seconds": cpu["seconds"],
+                                 "sample": cpu["what"]},
+            "gpu_over_cpu": gpu["rows_per_s"] / cpu["rows_per_s"]}
+
+
 def launch_ranks(n):
     """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process and
     return its exit code (the caller has not touched the GPU runtime yet)."""
@@ -422,6 +447,12 @@ def main():
     ap.add_argument("--pipeline-partitions", type=int, default=4, help="distinct partitions' streams kept in HBM for that leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the streams -> survivors and H2D-inclusive legs (N = 1 extras)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "torch", "rccl"],
+                    help="N > 1: the wire of the job's one exchange (kmd_correct_sharded).  torch: torch.distributed's communicator on zero-copy views "
+                         "of the library's buffers (kmdiff_amd/dist.py); rccl: libkmdiff_hip_rccl.so's own communicator (ncclCommInitRank; the id "
+                         "travels through torch.distributed); auto: torch, and rccl if the warm-up exchange fails on any rank")
+    ap.add_argument("--e2e", action="store_true", help="N = 1 extra (minutes; not in the default run): `kmdiff-hip diff` on a fabricated kmtricks run "
+                    "directory -- files, LZ4 decode, PCIe and all -- with the CPU doing the same job on the same files beside it (oracle/cpu_pipeline)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as a CHILD process, before this
@@ -461,10 +492,48 @@ def main():
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         n_ranks_seen = int(one.item())
 
+    # (the N > 1 line checks itself before it times anything: every rank the launcher started is in the communicator)
+    if n_ranks_seen != world:
+        raise SystemExit("bench.py: the collective library connected %d ranks, the job has %d" % (n_ranks_seen, world))
+
     import kmdiff_amd as K
     from kmdiff_amd import dist as D
     lib = K._native.lib()
     K._native.check(lib.kmd_set_device(local_rank))
+
+    # ---- the wire of the exchange (N > 1) ----------------------------------------------------------------------
+    transport_state = {"name": "torch" if args.transport == "auto" else args.transport, "obj": None, "fallback": None}
+
+    def rccl_transport():
+        """libkmdiff_hip_rccl.so's own communicator: rank 0 draws the id, torch.distributed carries it to the others"""
+        R = K._native.rccl_lib()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            if R.kmd_rccl_unique_id(ident) != 0:
+                raise RuntimeError("kmd_rccl_unique_id: %s" % R.kmd_rccl_last_error())
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_uint8 * 128)(*box[0])
+        tr = K._native.Transport()
+        if R.kmd_transport_rccl_init(C.byref(tr), world, rank, ident) != 0:
+            raise RuntimeError("kmd_transport_rccl_init: %s" % R.kmd_rccl_last_error())
+        return tr
+
+    def all_ranks_ok(ok):
+        """True on every rank iff `ok` on every rank (plain tensors of torch.distributed, not the library's buffers)"""
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([0 if ok else 1], dtype=torch.int64, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item()) == 0
+
+    def exchange(*a):
+        return D.correct_sharded(K, *a, transport=transport_state["obj"])
+
+    if world > 1 and transport_state["name"] == "rccl":
+        if backend != "nccl":
+            raise SystemExit("bench.py: --transport rccl needs one GPU per rank (backend nccl), not a folded run")
+        transport_state["obj"] = rccl_transport()
     layout = {"tiled": K.LAYOUT_TILED, "soa": K.LAYOUT_SOA, "rows": K.LAYOUT_ROWS}[args.layout]
     thr = THRESHOLD / CUTOFF
 
@@ -487,7 +556,19 @@ def main():
     if args.warmup:
         # warm the end-of-job path too (first-use cost of the sort / correction kernels)
         n_w = acc.finish(sort=True)
-        D.correct_sharded(K, args.correction, THRESHOLD, acc.read_counters(), acc.bufs["pvalue"], acc.bufs["sign"], n_w)
+        # ... which is also the rehearsal of the wire: should the exchange fail on ANY rank (--transport auto, N > 1: the
+        # zero-copy views of torch_transport have never carried two ranks over RCCL before the first multi-GPU run), every
+        # rank switches to the library's own communicator and rehearses again -- a second failure ends the job
+        try:
+            exchange(args.correction, THRESHOLD, acc.read_counters(), acc.bufs["pvalue"], acc.bufs["sign"], n_w)
+            ok, why = True, None
+        except Exception as e:                                  # noqa: BLE001 (whatever it was, the ranks must agree on what happens next)
+            ok, why = False, repr(e)
+        if not all_ranks_ok(ok):
+            if world == 1 or args.transport != "auto" or backend != "nccl":
+                raise SystemExit("bench.py: the warm-up exchange failed on a rank (%s)" % why)
+            transport_state.update(name="rccl", obj=rccl_transport(), fallback="the torch transport failed in the warm-up exchange: %s" % (why or "on another rank"))
+            exchange(args.correction, THRESHOLD, acc.read_counters(), acc.bufs["pvalue"], acc.bufs["sign"], n_w)
     K._native.check(lib.kmd_stream_sync(None))
     acc.counters.zero()
     K._native.check(lib.kmd_stream_sync(None))
@@ -505,17 +586,23 @@ def main():
     if os.environ.get("KMD_BENCH_TEST_DIE_RANK") == str(rank) and world > 1:     # tests: a rank dies before the exchange
         os._exit(3)
     n_surv = acc.finish(sort=True)
-    keep, g_counters, (n_ctrl, n_case) = D.correct_sharded(K, args.correction, THRESHOLD, acc.read_counters(),
-                                                          acc.bufs["pvalue"], acc.bufs["sign"], n_surv)
+    keep, g_counters, (n_ctrl, n_case) = exchange(args.correction, THRESHOLD, acc.read_counters(), acc.bufs["pvalue"], acc.bufs["sign"], n_surv)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     elapsed_min = -D.max_over_ranks(-elapsed)
     elapsed = D.max_over_ranks(elapsed)
 
     my_kernel_ms = ev0.elapsed_ms(ev1) / args.steps                       # back-to-back launches
     kernel_ms_min = -D.max_over_ranks(-my_kernel_ms)
     avg_kernel_ms = D.max_over_ranks(my_kernel_ms)
+    # every rank's own numbers, in rank order (the N > 1 line shows which rank was the slow one)
+    per_rank_ms = [[my_kernel_ms, my_elapsed * 1e3 / args.steps]]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, per_rank_ms[0])
+        per_rank_ms = box
     near = int(acc.read_counters()[K._native.CNT_NEAR_THRESHOLD])    # rows decided with correctly rounded log / exp
     kept = D.allreduce_counters([int(keep.sum()), n_ctrl, n_case, near])
 
@@ -573,8 +660,13 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "backend": backend if world > 1 else None, "rccl_ranks": n_ranks_seen,
+            "transport": (transport_state["name"] if world > 1 else None), "transport_fallback": transport_state["fallback"],
             "per_rank": {"ms_per_step_min": elapsed_min * 1e3 / args.steps, "ms_per_step_max": elapsed * 1e3 / args.steps,
-                         "kernel_ms_min": kernel_ms_min, "kernel_ms_max": avg_kernel_ms},
+                         "kernel_ms_min": kernel_ms_min, "kernel_ms_max": avg_kernel_ms,
+                         "kernel_ms": [x[0] for x in per_rank_ms], "ms_per_step": [x[1] for x in per_rank_ms]},
+            # value against what the ranks' own kernels sustain (their HIP events): what the barriers, the exchange and the
+            # correction cost the job -- NOT the driver's scaling efficiency (that one compares runs at different N)
+            "scaling_efficiency": value / sum(args.rows / (x[0] * 1e-3) for x in per_rank_ms),
             "config": {"workload": "configs[2]: 256-partition synthetic matrix, 20v20, k=31, u32 counts; "
                                    "step = one partition of %d rows resident in HBM (%s layout); partition p on "
                                    "rank p %% N" % (args.rows, args.layout),
@@ -615,7 +707,11 @@ def main():
             out["pipeline"]["sparse"] = pipeline_leg(K, lib, args.pipeline_rows, iters=6, n_distinct=1, with_extras="batched", profile=K.SYNTH_MIXED)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.rows, int(totals[:NC].sum()), int(totals[NC:].sum()))
+        if args.e2e and world == 1:
+            out["e2e"] = e2e_leg()
         print(json.dumps(out), flush=True)
+    if transport_state["obj"] is not None:
+        K._native.rccl_lib().kmd_transport_rccl_destroy(C.byref(transport_state["obj"]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

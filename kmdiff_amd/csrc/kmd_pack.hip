@@ -115,82 +115,7 @@ __global__ void __launch_bounds__(256) k_unpack(const unsigned char* __restrict_
 
 } // namespace
 
-extern "C" size_t kmd_pack_block_bound(void) { return 16 + (4 * 64 + 1) * 8 + kBlock + 4 * kBlock; }
-
-extern "C" size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, uint32_t n, void* out)
-{
-  if (!kmers || !counts || !out || n == 0 || n > kBlock) return 0;
-  unsigned char* o = static_cast<unsigned char*>(out);
-  uint64_t delta[kBlock];
-  uint64_t all = 0;
-  delta[0] = 0;
-  for (uint32_t i = 1; i < n; ++i) { delta[i] = kmers[i] - kmers[i - 1]; all |= delta[i]; }
-  const uint32_t w = all ? 64u - (uint32_t)__builtin_clzll(all) : 0u;
-  const uint32_t n_words = 4 * w + 1;
-  std::memcpy(o, &kmers[0], 8);
-  o[8] = (unsigned char)w; o[9] = 0; o[12] = o[13] = o[14] = o[15] = 0;
-  uint64_t* words = reinterpret_cast<uint64_t*>(o + 16);
-  std::memset(words, 0, (size_t)n_words * 8);
-  if (w)
-  {
-    uint64_t acc = 0;
-    uint32_t fill = 0, at = 0;                               // bits of acc in use, word being written
-    for (uint32_t i = 0; i < n; ++i)
-    {
-      acc |= delta[i] << fill;
-      if (fill + w >= 64)
-      {
-        words[at++] = acc;
-        const uint32_t used = 64 - fill;                     // bits of delta[i] that went into the finished word
-        acc = used < 64 ? delta[i] >> used : 0;
-        fill = fill + w - 64;
-      }
-      else fill += w;
-    }
-    if (fill) words[at] = acc;
-  }
-  unsigned char* cb = o + 16 + (size_t)n_words * 8;
-  uint32_t* esc = reinterpret_cast<uint32_t*>(cb + kBlock);
-  uint32_t n_esc = 0;
-  for (uint32_t i = 0; i < n; ++i)
-  {
-    const uint32_t c = counts[i];
-    if (c >= kEscape) { cb[i] = (unsigned char)kEscape; esc[n_esc++] = c; }
-    else cb[i] = (unsigned char)c;
-  }
-  std::memset(cb + n, 0, kBlock - n);
-  const unsigned short ne = (unsigned short)n_esc;
-  std::memcpy(o + 10, &ne, 2);
-  size_t bytes = 16 + (size_t)n_words * 8 + kBlock + (size_t)n_esc * 4;
-  while (bytes & 7) o[bytes++] = 0;
-  return bytes;
-}
-
-// a whole stream: its blocks one behind the other (what a host does while it decodes a sample's file)
-extern "C" size_t kmd_pack_stream(const uint64_t* kmers, const uint32_t* counts, size_t n, void* out, size_t out_capacity, uint32_t* block_off8)
-{
-  if (n == 0) return 0;
-  if (!kmers || !counts || !out || !block_off8) return 0;
-  const size_t bound = kmd_pack_block_bound();
-  char* o = static_cast<char*>(out);
-  size_t at = 0, b = 0;
-  alignas(8) char tmp[16 + (4 * 64 + 1) * 8 + kBlock + 4 * kBlock];
-  for (size_t i = 0; i < n; i += kBlock, ++b)
-  {
-    const uint32_t m = (uint32_t)std::min<size_t>(kBlock, n - i);
-    if (at / 8 > 0xFFFFFFFFull) return 0;                                  // (block_off8 is 32-bit: 32 GB of one stream)
-    block_off8[b] = (uint32_t)(at / 8);
-    if (out_capacity - at >= bound) at += kmd_pack_block(kmers + i, counts + i, m, o + at);
-    else
-    {
-      const size_t got = kmd_pack_block(kmers + i, counts + i, m, tmp);    // the last blocks of a tight buffer: packed aside, copied if they fit
-      if (got == 0 || got > out_capacity - at) return 0;
-      std::memcpy(o + at, tmp, got);
-      at += got;
-    }
-  }
-  return at;
-}
+// (the host's side of the format -- kmd_pack_block_bound, kmd_pack_block, kmd_pack_stream -- is kmd_pack_host.cpp: plain C++)
 
 // The kernel's small tables (where each stream starts, in bytes, records and blocks) travel through a page-locked
 // ring kept per (device, stream): the upload is a true asynchronous copy -- a pageable source would make the call wait

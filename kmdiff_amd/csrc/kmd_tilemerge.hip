@@ -145,7 +145,7 @@ constexpr uint64_t kBigFromRecords = 200000000ull;   // partitions of this many 
 constexpr uint32_t stage_rows(uint32_t slots) { return slots >= 4096u ? 128u : 64u; }
 constexpr uint32_t kGroup = 63;                  // runs per group of a tile's segment table (one lane each; lane 63 holds none)
 constexpr uint32_t kMaxGroups = 17;              // (kMaxStreams + kGroup - 1) / kGroup
-constexpr uint32_t kQueue = 128;                 // candidates mode: live slots a wave has queued for its next full pass (< 64 + 64)
+constexpr uint32_t kQueue = 192;                 // candidates mode: live slots a wave has queued for its next passes (<= 63 + 128)
 constexpr uint32_t kOutChunk = 256;              // candidates mode: entries of the list a workgroup takes at a time
 constexpr unsigned long long kHole = ~0ull;      // sum_c of an entry that holds no row (no sum of 32-bit counts reaches it)         // 1024 samples of counts below this cannot overflow a 32-bit sum
 
@@ -637,7 +637,7 @@ struct tile_lds
   uint32_t grp[2][kMaxGroups + 1];                       // records of each group of kGroup runs of the current / the next tile
   unsigned long long stage_key[kStage], stage_hi[kTwo ? kStage : 1];     // rows parked for the list (k_tile_sums, the walk)
   stage_sum_t stage_c[kStage], stage_k[kStage];
-  uint16_t queue[kWaves][kQueue];                        // candidates mode, the walk: live slots of each wave, 64 of them evaluated at a time
+  uint8_t queue[kWaves][kQueue];                         // candidates mode, the walk: live slots of each wave (one byte each), 64 of them evaluated at a time
   alignas(16) unsigned long long key[kAll + 2];
   uint32_t c32[kSum32 ? kAll + 4 : 4];                   // kSum32: control sum of slot i (arrays of their own: a round adds to ONE
   uint32_t k32[kSum32 ? kAll + 4 : 4];                   // of them -- the run is a control's or a case's -- so its lanes spread over all banks)
@@ -788,7 +788,7 @@ k_tile_sums(const tile_job J)
   // stores to be acknowledged -- microseconds, with the whole workgroup standing by)
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // candidates mode: the rows a tile's walk parked in LDS go to the list (wave 0; the next entries of the workgroup's
-  // chunk, or -- should they not fit -- of a fresh chunk, what was left of the old one becoming holes)
+  // chunk and, should they not all fit, the first ones of a fresh chunk)
   auto flush_stage = [&]()
   {
     if constexpr (kFilter)
@@ -802,26 +802,32 @@ k_tile_sums(const tile_job J)
       const uint32_t cap = M.out_cap;
       const unsigned long long row_cap = Jf->row_capacity;
       unsigned long long* const sum_c_out = Jf->sum_c_out;
-      if (used + n_st > cap)
+      // (the rows fill what is left of the workgroup's chunk and go on at the head of a fresh one: no holes but at the
+      // kernel's end -- with up to kStage rows per tile, abandoning a chunk's tail made a fifth of the list holes, which the
+      // candidates' kernels then walk: +11 us of k_cand_eval on rows of 3 records)
+      const uint32_t room = cap - used;                             // entries left in the current chunk
+      unsigned long long fresh_base = 0;
+      if (n_st > room)
       {
-        for (unsigned long long e = base + used + lane; e < base + cap; e += 64)
-          if (e < row_cap) sum_c_out[e] = kHole;
         unsigned long long fresh = 0;
         if (lane == 0) fresh = atomicAdd(Jf->n_rows, (unsigned long long)kOutChunk);
-        base = __shfl(fresh, 0, 64);
-        used = 0;
-        if (lane == 0) { M.out_base = base; M.out_cap = kOutChunk; }
+        fresh_base = __shfl(fresh, 0, 64);
       }
       static_assert(kStage <= kOutChunk, "a tile's parked rows fit one chunk");
       for (uint32_t i = lane; i < n_st; i += 64)
       {
-        const unsigned long long e = base + used + i;
+        const unsigned long long e = i < room ? base + used + i : fresh_base + (i - room);
         if (e < row_cap)
         {
           Jf->kmer_out[e] = M.stage_key[i]; sum_c_out[e] = M.stage_c[i]; Jf->sum_k_out[e] = M.stage_k[i];
           if constexpr (kTwo) Jf->kmer_hi_out[e] = M.stage_hi[i];
         }
       }
+      if (n_st > room)
+      {
+        if (lane == 0) { M.out_base = fresh_base; M.out_cap = kOutChunk; M.out_used = n_st - room; M.stage_n = 0; }
+      }
+      else
       if (lane == 0) { M.out_used = used + n_st; M.stage_n = 0; }
     }
   };
@@ -1656,7 +1662,7 @@ k_tile_sums(const tile_job J)
         // instructions per wave and tile.  Now:
         //  * COMPACTION FIRST.  A thread reads the keys of two adjacent slots (one ds_read_b128: the whole table in two
         //    steps of the workgroup, the second table by its last waves); a ballot and a prefix count put the LIVE
-        //    slots' numbers into the wave's queue in LDS (kQueue x 2 bytes) -- five vector instructions per 64 slots;
+        //    slots into the wave's queue in LDS (kQueue bytes) -- five vector instructions per 64 slots;
         //  * whenever 64 slots are queued (and once more at the end, for the rest) the wave evaluates them, every lane a
         //    live row: both sums (gathered), the chi-square bound; the second stage and the emission only if a lane
         //    needs them; the key is read only for the rows that leave;
@@ -1673,9 +1679,9 @@ k_tile_sums(const tile_job J)
         const double w_dTc = Jw->dTc, w_dTk = Jw->dTk, w_rhs = Jw->pf_rhs;
         const uint32_t w_lf_n = Jw->lf_n;
         const kl_consts w_kl { Jw->kl_qc, Jw->kl_qk, Jw->kl_cut, Jw->kl_max };
-        typedef __attribute__((address_space(3))) uint16_t lds_u16;
+        typedef __attribute__((address_space(3))) uint8_t lds_u8;
         typedef __attribute__((address_space(3))) uint32_t lds_u32s;
-        uint16_t* const q = M.queue[wave];
+        uint8_t* const q = M.queue[wave];
         uint32_t qn = 0;                                                  // slots queued (wave-uniform)
         // (row_may_pass, kmd_eval.h, on sums that are exact in one conversion; pf_rhs = pf_cut Tc Tk from the host)
         auto may_pass = [&](unsigned long long c, unsigned long long k) -> bool
@@ -1724,14 +1730,21 @@ k_tile_sums(const tile_job J)
             if constexpr (kTwo) Je->kmer_hi_out[e] = key_hi;
           }
         };
-        // the last `cnt` (<= 64) slots of the queue: their rows through the pre-filter, the slots wiped
-        auto evaluate = [&](const uint32_t cnt)
+        // The queue holds a slot in ONE byte: a wave walks the pairs tid, tid + kThreads, ... -- its slots are
+        // step x 2 kThreads + 128 wave + (0 .. 127) -- so an entry is [step : 1][2 lane + half : 7] and the slot comes back
+        // with a shift and two adds (the second table's slots, walked by the workgroup's last waves behind their share of
+        // the main table, when the queue has been drained: step 0 again, another base).
+        // The last `cnt` (<= 64) slots of the queue: their rows through the pre-filter, the slots wiped.  kFull: 64 of them,
+        // every lane a row -- no lane mask around the pass.
+        auto evaluate = [&](const uint32_t cnt, const uint32_t slot_base, auto full_tag)
         {
+          constexpr bool kFull = decltype(full_tag)::value;
           qn -= cnt;
           if (!bad_tile) rows_wave += cnt;
-          if (lane < cnt)
+          if (kFull || lane < cnt)
           {
-            const uint32_t i = *(const lds_u16*)(uintptr_t)(q + qn + lane);
+            const uint32_t e = *(const lds_u8*)(uintptr_t)(q + qn + lane);
+            const uint32_t i = slot_base + (e >> 7) * (2u * (uint32_t)kThreads) + (e & 127u);
             unsigned long long c, k;
             read_sums(i, c, k);
             if (!bad_tile)
@@ -1748,32 +1761,42 @@ k_tile_sums(const tile_job J)
             if constexpr (kTwo) { M.key_hi[i] = 0; M.hi_min[i] = ~0ull; }
           }
         };
-        // (ONE copy of the evaluation in the code: the walk is a loop of half-steps -- a pair's first slot, its second --
-        // that turns to the queue whenever it holds 64 slots, and once more behind the last half-step for the rest)
+        // a pair's two slots into the queue (step: the entry's top bit)
+        auto enqueue_pair = [&](const u64x2 two_keys, const uint32_t step)
+        {
+          const bool live0 = two_keys.x != kEmptyKey, live1 = two_keys.y != kEmptyKey;
+          const unsigned long long m0 = ballot(live0), m1 = ballot(live1);
+          const uint32_t n0 = (uint32_t)__popcll(m0);
+          const uint32_t p0 = qn + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+          const uint32_t p1 = qn + n0 + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+          const uint32_t e0 = (step << 7) | (lane << 1);
+          if (live0) *(lds_u8*)(uintptr_t)(q + p0) = (uint8_t)e0;
+          if (live1) *(lds_u8*)(uintptr_t)(q + p1) = (uint8_t)(e0 | 1u);
+          qn += n0 + (uint32_t)__popcll(m1);
+        };
         static_assert(kSlots % (2 * kThreads) == 0 && (kSec / 2) % 64 == 0 && kSec / 2 <= (uint32_t)kThreads, "the walk's steps");
         constexpr uint32_t kMainSteps = kSlots / (2u * kThreads);
+        static_assert(kMainSteps <= 2, "one bit of a queue entry says which step");
+        static_assert(kQueue >= 63u + 128u, "a step's 128 slots behind what the last pass left");
+        const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
         // (the second table's pairs: the workgroup's last waves -- wave 0 has the next tile's segments to fetch)
-        const bool sec_mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) >= (uint32_t)kWaves - kSec / 128u;
-        const uint32_t n_half = 2u * (kMainSteps + (sec_mine ? 1u : 0u));
-        u64x2 two_keys = { kEmptyKey, kEmptyKey };
-        uint32_t pair = 0;
+        constexpr uint32_t kSecWaves = kSec / 128u;
+        const uint32_t n_phases = wave_u >= (uint32_t)kWaves - kSecWaves ? 2u : 1u;
 #pragma nounroll
-        for (uint32_t hs = 0;;)
+        for (uint32_t phase = 0; phase < n_phases; ++phase)
         {
-          if (qn >= 64u || (hs == n_half && qn != 0u)) { evaluate(qn < 64u ? qn : 64u); continue; }
-          if (hs == n_half) break;
-          if ((hs & 1u) == 0u)
+          // phase 0: this wave's share of the main table; phase 1: of the second table
+          const uint32_t slot_base = phase == 0u ? wave_u * 128u : kSlots + (wave_u - ((uint32_t)kWaves - kSecWaves)) * 128u;
+          const uint32_t n_steps = phase == 0u ? kMainSteps : 1u;
+#pragma nounroll
+          for (uint32_t st = 0; st < n_steps; ++st)
           {
-            const uint32_t st = hs >> 1;
-            pair = st < kMainSteps ? st * (uint32_t)kThreads + tid : kSlots / 2u + (tid - ((uint32_t)kThreads - kSec / 2u));
-            two_keys = *(const lds_u64x2*)(uintptr_t)(M.key + 2u * pair);
+            const uint32_t first_slot = slot_base + st * 2u * (uint32_t)kThreads + 2u * lane;
+            enqueue_pair(*(const lds_u64x2*)(uintptr_t)(M.key + first_slot), st);
+#pragma nounroll
+            while (qn >= 64u) evaluate(64u, slot_base, std::true_type());
           }
-          const bool live = ((hs & 1u) ? two_keys.y : two_keys.x) != kEmptyKey;
-          const unsigned long long m = ballot(live);
-          const uint32_t pos = qn + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (live) *(lds_u16*)(uintptr_t)(q + pos) = (uint16_t)(2u * pair + (hs & 1u));
-          qn += (uint32_t)__popcll(m);
-          ++hs;
+          if (qn) evaluate(qn, slot_base, std::false_type());
         }
         if (__builtin_amdgcn_readfirstlane((int)(wave == 0 && M.hasmax != 0)))       // the all-ones k-mer, if this tile had it
         {

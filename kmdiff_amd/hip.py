@@ -287,7 +287,11 @@ class SurvivorAccumulator:
         for survivors of merge_filter, which have no row index -- the reference's push order).
         refine = the PoissonLikelihood the survivors were tested with: their p-values are recomputed with correctly
         rounded log / exp (kmd_pvalues_refine: the bits a glibc-built reference prints).
-        Raises KmdError(KMD_E_OVERFLOW) if records were dropped."""
+        Raises KmdError(KMD_E_OVERFLOW) if records were dropped, and KmdError if the guard of `p <= threshold` could not list
+        every row within 1e-8 of the threshold (more than 4096 in one launch, KMD_CNT_NEAR_UNRESOLVED): zero the counters and
+        run the matrix again with diff_observer.process_in_pieces -- or pass allow_unresolved=True to keep the device
+        libm's decision for the rows beyond the list (a caller inside a multi-rank job should do one or the other BEFORE
+        the exchange: a rank that raises here leaves its peers to the collective's timeout)."""
         c = self.read_counters()
         n = int(c[N.CNT_SIG])
         if n > self.capacity:
@@ -341,6 +345,32 @@ class diff_observer:
         s = self.acc.struct()
         check(lib().kmd_poisson_filter(self.model.handle, C.byref(t), self.threshold, C.byref(s),
                                        self.acc.counters.ptr, stream), "kmd_poisson_filter")
+        self.acc._size = None
+
+    def process_in_pieces(self, matrix, rows_per_piece=4096, stream=None):
+        """process() over row windows of `rows_per_piece` rows (rounded up to whole blocks of the tiled layout): the way
+        to run a matrix again when finish() reports rows within 1e-8 of the threshold beyond the 4096 one launch can
+        list (KMD_CNT_NEAR_UNRESOLVED) -- a piece of 4096 rows cannot overflow the list, so every such row gets the
+        correctly rounded second look.  What `kmdiff-hip diff` does on that counter (kmdiff_amd/host/main.cpp).  The
+        caller zeroes the accumulator's counters (and forgets its records: acc.counters.zero()) before the rerun."""
+        if matrix.n_samples != self.model.nb_controls + self.model.nb_cases:
+            raise ValueError("matrix has %d samples, model expects %d" % (matrix.n_samples, self.model.nb_controls + self.model.nb_cases))
+        unit = matrix.ld if matrix.layout == N.LAYOUT_TILED else 1
+        per = max(unit, (int(rows_per_piece) + unit - 1) // unit * unit)
+        full = matrix.tile()
+        s = self.acc.struct()
+        for r0 in range(0, matrix.n_rows, per):
+            if matrix.layout == N.LAYOUT_TILED:
+                off = (r0 // matrix.ld) * matrix.n_samples * matrix.ld * matrix.count_bytes
+            elif matrix.layout == N.LAYOUT_ROWS:
+                off = r0 * matrix.ld * matrix.count_bytes
+            else:
+                off = r0 * matrix.count_bytes
+            t = N.Tile(full.d_counts + off, matrix.count_bytes, matrix.layout, matrix.ld,
+                       (full.d_kmer_lo + 8 * r0) if full.d_kmer_lo else None, (full.d_kmer_hi + 8 * r0) if full.d_kmer_hi else None,
+                       min(per, matrix.n_rows - r0), matrix.row_base + r0)
+            check(lib().kmd_poisson_filter(self.model.handle, C.byref(t), self.threshold, C.byref(s), self.acc.counters.ptr, stream),
+                  "kmd_poisson_filter")
         self.acc._size = None
 
     def process_sums(self, sums, stream=None):

@@ -662,6 +662,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     }
     else if (n_rows && pca) ck(kmd_pca_sample(pca, &tile, nullptr), "kmd_pca_sample");        // merge.hpp:150-152
     bool unresolved_redo = false;                         // the fused pass left near-threshold rows undecided: the matrix way, in pieces
+    uint64_t unresolved_rows = 0;                         // ... how many it said were beyond the list
     if (n_rows && plugin)
     {
       // diff_observer::process with the user's model (merge.hpp:68-103): the merged rows come
@@ -729,6 +730,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
                           two_limbs ? (const uint64_t*)d_kmer_col_hi.p : nullptr, (size_t)n_rows, 0 };
         sums_done = false;
         unresolved_redo = true;
+        unresolved_rows = c[KMD_CNT_NEAR_UNRESOLVED];
       }
       else
       {
@@ -776,7 +778,9 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
       // p-value with thousands of equal rows gets here.)
       uint64_t c[KMD_NCOUNTERS];
       const size_t unit = tile.layout == KMD_LAYOUT_TILED ? tile.ld : 1;                  // pieces begin on a block of the tiled layout
-      for (size_t pieces = unresolved_redo ? 2 : 1;; pieces *= 2)
+      // (the fused pass said how many rows were beyond ITS list: with them spread evenly, that many lists' worth of pieces
+      // -- plus one -- is where a retry has a chance; starting at 2 ran every doubling in between from scratch: ADVICE r5)
+      for (size_t pieces = unresolved_redo ? std::max<size_t>(2, (size_t)((unresolved_rows + 4095) / 4096) + 1) : 1;; pieces *= 2)
       {
         size_t rows_per = ((size_t)n_rows + pieces - 1) / pieces;
         rows_per = std::max<size_t>((rows_per + unit - 1) / unit * unit, unit);

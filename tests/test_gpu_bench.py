@@ -14,6 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROWS = 2_000_000
 
 
+def free_port():
+    """a TCP port nobody holds right now (the rendezvous of a torchrun started by a test: fixed numbers collide on shared boxes)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def last_json(out):
     lines = [l for l in out.strip().split("\n") if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
@@ -35,6 +43,7 @@ def test_bench_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert d["rccl_ranks"] == 1 and d["per_rank"]["ms_per_step_max"] == d["ms_per_step"]
+    assert d["transport"] is None and len(d["per_rank"]["kernel_ms"]) == 1 and 0 < d["scaling_efficiency"] <= 1.0
     pl = d["pipeline"]
     for leg in (pl, pl["overlapped"], pl["batched"]):
         rf = leg["roofline"]
@@ -57,7 +66,7 @@ def test_bench_single_gpu_line():
 @pytest.mark.parametrize("correction", ["bonferroni", "benjamini", "holm"])
 def test_bench_two_ranks_on_one_gpu(correction):
     env = dict(os.environ, KMD_BENCH_OVERSUBSCRIBE="1", KMD_BENCH_BACKEND="gloo")
-    port = {"bonferroni": 29521, "benjamini": 29522, "holm": 29523}[correction]
+    port = free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows",
                         str(ROWS), "--steps", "4", "--warmup", "1", "--correction", correction],
@@ -84,6 +93,12 @@ def test_bench_eight_ranks_folded_onto_this_gpu(correction):
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    # the N > 1 line checks itself: every rank's own kernel time and step time, the wire it used, and what the barriers and
+    # the exchange cost against the ranks' own kernels
+    pr = d["per_rank"]
+    assert len(pr["kernel_ms"]) == 8 and len(pr["ms_per_step"]) == 8 and all(x > 0 for x in pr["kernel_ms"])
+    assert max(pr["kernel_ms"]) == pr["kernel_ms_max"] and min(pr["kernel_ms"]) == pr["kernel_ms_min"]
+    assert d["transport"] == "torch" and d["transport_fallback"] is None and 0 < d["scaling_efficiency"] <= 1.0
     c = d["config"]["counters"]
     assert c["total"] == rows * 3 * 8 and c["n_sig"] == c["n_sig_control"] + c["n_sig_case"] and 0 < c["kept_after_correction"] <= c["n_sig"]
     assert abs(d["value"] - rows * 3 * 8 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
@@ -104,6 +119,33 @@ def test_bench_a_rank_that_dies_ends_the_job():
     assert not [l for l in r.stdout.split("\n") if l.startswith("{")]            # no line from a job that lost a rank
 
 
+def test_bench_rccl_transport_refuses_a_folded_run():
+    """`--transport rccl` is the library's own RCCL communicator: one GPU per rank.  Folded onto one GPU (gloo as the
+    job's backend) it says so and leaves with an error on every rank instead of timing anything."""
+    env = dict(os.environ, KMD_BENCH_OVERSUBSCRIBE="1", KMD_BENCH_BACKEND="gloo", KMD_BENCH_COLLECTIVE_TIMEOUT_S="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "500000", "--steps", "2", "--warmup", "1",
+                        "--transport", "rccl"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "--transport rccl needs one GPU per rank" in (r.stdout + r.stderr)
+    assert not [l for l in r.stdout.split("\n") if l.startswith("{")]
+
+
+def test_bench_two_gpus_over_the_librarys_own_rccl_communicator():
+    """`bench.py --gpus 2 --transport rccl` on two real GPUs (skipped on a one-GPU box): the exchange over
+    libkmdiff_hip_rccl.so's communicator instead of torch.distributed's."""
+    import kmdiff_amd as K
+    if K.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "KMD_BENCH_OVERSUBSCRIBE", "KMD_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", str(ROWS), "--steps", "4",
+                        "--warmup", "1", "--correction", "holm", "--transport", "rccl"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["transport"] == "rccl" and len(d["per_rank"]["kernel_ms"]) == 2
+
+
 def test_two_ranks_through_rccl_on_this_box():
     """tests/nccl_probe2.py: kmd_correct_sharded over RCCL with two ranks -- torch.distributed's communicator and the
     library's own (libkmdiff_hip_rccl.so).  Two GPUs: must pass.  One GPU: both ranks are put on it, which RCCL may
@@ -114,7 +156,7 @@ def test_two_ranks_through_rccl_on_this_box():
     if fold:
         env["KMD_PROBE_FOLD"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "tests", "nccl_probe2.py")], capture_output=True, text=True, timeout=600,
+                        "--master-port", str(free_port()), os.path.join(ROOT, "tests", "nccl_probe2.py")], capture_output=True, text=True, timeout=600,
                        cwd=ROOT, env=env)
     out = r.stdout + r.stderr
     note = os.path.join(ROOT, "gpurun_out", "nccl_two_ranks.txt")
@@ -164,6 +206,6 @@ def test_bench_two_gpus_over_rccl():
 def test_collectives_through_rccl():
     """tests/nccl_probe.py: the dtypes and calls of kmdiff_amd/dist.py over backend "nccl" (= RCCL)."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                        "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "tests", "nccl_probe.py")],
+                        "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "nccl_probe.py")],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "nccl probe ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -244,3 +244,45 @@ def test_threshold_on_a_p_value_of_a_row_beyond_the_table(K, oracle):
             if len(k):
                 assert got["pvalue"][k[0]] == p_rounded[i]
     assert n_oracle >= 30
+
+
+@pytest.mark.parametrize("layout", ["tiled", "rows", "soa"])
+def test_more_near_rows_than_one_launch_lists_in_pieces(K, oracle, layout):
+    """KMD_CNT_NEAR_UNRESOLVED through the Python mirror: 6 000 equal rows with the threshold ON their p-value
+    are more rows within 1e-8 of it than one launch lists (4096) -- finish() refuses the sink; diff_observer.
+    process_in_pieces runs the matrix again in windows of 4096 rows, none of which can overflow the list, and the sink
+    then holds exactly the oracle's set."""
+    nc, nk, n_bg, n_same = 4, 4, 20_000, 6_000
+    host, _, _ = oracle.synth_rows(SEED, 9, 0, n_bg, nc, nk, 4)
+    lf = oracle.lf_table(10000)
+    lib = K._native.lib()
+    chosen = None
+    for cand in [[c0, 0, 0, 0, a, b, 2, 1] for c0 in (0, 1) for a in (2, 3, 4, 5) for b in (1, 2, 3)]:
+        row = np.array(cand, dtype=np.uint32)
+        full = np.vstack([host[:n_bg // 2], np.tile(row, (n_same, 1)), host[n_bg // 2:]])
+        tot = full.sum(axis=0, dtype=np.uint64)
+        one = oracle.diff_partition(row[None, :], OL.LAYOUT_ROWS, nc, nk, int(tot[:nc].sum()), int(tot[nc:].sum()), lf, 1.0)
+        p_star = float(one["pvalue"][0])
+        model = K.PoissonLikelihood(nc, nk, tot[:nc], tot[nc:], 10000)
+        if lib.kmd_test_row_pvalue_rounded(C.c_void_p(model.handle), int(row[:nc].sum()), int(row[nc:].sum())) == p_star and 1e-12 < p_star < 1e-2:
+            chosen = (full, tot, p_star, model)
+            break
+    assert chosen is not None
+    full, tot, p_star, model = chosen
+    want = oracle.diff_partition(full, OL.LAYOUT_ROWS, nc, nk, int(tot[:nc].sum()), int(tot[nc:].sum()), lf, p_star)
+    assert (want["pvalue"] == p_star).sum() >= n_same
+    mat = K.CountMatrix.from_host(full, {"tiled": K.LAYOUT_TILED, "rows": K.LAYOUT_ROWS, "soa": K.LAYOUT_SOA}[layout])
+    acc = K.SurvivorAccumulator(len(full))
+    obs = K.diff_observer(model, acc, p_star)
+    obs.process(mat)
+    assert int(acc.read_counters()[K._native.CNT_NEAR_UNRESOLVED]) > 0
+    with pytest.raises(K._native.KmdError):
+        acc.finish()
+    acc.counters.zero()
+    obs.process_in_pieces(mat, 4096)
+    c = acc.read_counters()
+    assert int(c[K._native.CNT_NEAR_UNRESOLVED]) == 0 and int(c[K._native.CNT_NEAR_THRESHOLD]) >= n_same
+    assert int(c[K._native.CNT_TOTAL]) == len(full)
+    acc.finish()
+    got = acc.get()
+    assert got["row"].tolist() == want["row"].tolist() and got["sign"].tolist() == want["sign"].tolist()

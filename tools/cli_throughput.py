@@ -25,6 +25,9 @@ ap.add_argument("--nc", type=int, default=20)
 ap.add_argument("--nk", type=int, default=20)
 ap.add_argument("--keep", default="", help="write the run directory here, keep it, and stop")
 ap.add_argument("--matrix", action="store_true", help="also write <run>/matrices: the pre-merged feed (matrix_proxy)")
+ap.add_argument("--cpu-baseline", action="store_true", help="also: the CPU doing the same job on the same run directory (oracle/cpu_pipeline: liblz4 decode + the oracle's merge + the oracle's test, one task per partition on as many threads as the quota gives)")
+ap.add_argument("--only", default="", help="instead of the -t sweep: this one set of flags, e.g. \"-t 16\"")
+ap.add_argument("--json", default="", help="write what was measured to this file as JSON (bench.py --e2e reads it)")
 ap.add_argument("--ab", type=int, default=0, help="instead of the -t sweep: this many rounds of packed transfer against --raw-transfer at -t 16 and -t 64, alternating")
 a = ap.parse_args()
 S = a.nc + a.nk
@@ -59,9 +62,39 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/pro
         print(f, open(f).read().strip(), flush=True)
 print("cpus in affinity mask:", len(os.sched_getaffinity(0)), flush=True)
 cli = os.path.join(ROOT, "kmdiff_amd", "bin", "kmdiff-hip")
+
+
+def cpu_quota():
+    """threads the container may really run at once: the affinity mask cut by the cgroup's CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+cpu_line = None
+if a.cpu_baseline:
+    import json
+    exe = os.path.join(ROOT, "oracle", "cpu_pipeline")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_pipeline"])
+    T = cpu_quota()
+    r = subprocess.run([exe, os.path.join(root, "km"), str(a.nc), str(a.nk), str(T)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cpu_line = json.loads(r.stdout)
+    assert cpu_line["rows"] == a.parts * a.rows, cpu_line
+    print("CPU baseline (oracle/cpu_pipeline, %d threads: %s): stage 1 %.2f s = %.3e rows/s, %.3e records/s, %d survivors"
+          % (T, cpu_line["what"], cpu_line["seconds"], cpu_line["rows_per_s"], cpu_line["records_per_s"], cpu_line["survivors"]), flush=True)
 configs = (["-t", "1"], ["-t", "8"], ["-t", "16"], ["-t", "64"], ["-t", "256"], ["-t", "64", "--devices", "2"])
+if a.only:
+    configs = (a.only.split(),)
 if a.ab:
     configs = [c + m for _ in range(a.ab) for c in (["-t", "16"], ["-t", "64"]) for m in ([], ["--raw-transfer"])]
+gpu_lines = []
 for extra in configs:
     out = os.path.join(root, "out")
     shutil.rmtree(out, ignore_errors=True)
@@ -81,6 +114,14 @@ for extra in configs:
             print("    transfer: %s, %.3f bytes per record across the link" % (tr["format"], tr["bytes_per_record"]))
     except Exception:
         pass
-    print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s"
-          % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1)), flush=True)
+    print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s%s"
+          % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1),
+             "  (%.1f x the CPU baseline's stage 1)" % (cpu_line["seconds"] / float(stage1)) if cpu_line else ""), flush=True)
+    gpu_lines.append({"flags": " ".join(extra), "total_s": dt, "stage1_s": float(stage1), "rows_per_s": a.parts * a.rows / float(stage1),
+                      "records_per_s": records / float(stage1)})
+if a.json:
+    import json
+    with open(a.json, "w") as f:
+        json.dump({"run_dir": {"partitions": a.parts, "rows_per_partition": a.rows, "samples": S, "records": records, "bytes_on_disk": size},
+                   "host_threads_available": cpu_quota(), "kmdiff_hip_diff": gpu_lines, "cpu_baseline_e2e": cpu_line}, f)
 shutil.rmtree(root, ignore_errors=True)
