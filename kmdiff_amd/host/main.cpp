@@ -517,7 +517,7 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     size_t n = 0;                                        // records (k-mer feed) or rows (matrices/)
   };
   device_input dset[2];
-  dev_buf d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc, d_smk, d_sc;
+  dev_buf d_matrix, d_kmer_col, d_kmer_col_hi, d_cnt, d_srow, d_skmer, d_skmer_hi, d_sp, d_ssign, d_smc, d_smk, d_sc, d_sum_c, d_sum_k;
   // --no-matrix: the streams go straight through merge + test (kmd_merge_filter); the count rows of the
   // survivors (pop-strat, --keep-tmp, --save-sk) are looked up in the streams afterwards
   // (the default; --matrix-path keeps the k-way merge into the count matrix + K1, which a --cmodel plugin and
@@ -713,11 +713,42 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
         if (c[KMD_CNT_SIG] <= fused_cap) break;
         fused_cap = (size_t)c[KMD_CNT_SIG] + (size_t)c[KMD_CNT_SIG] / 4;
       }
-      if (c[KMD_CNT_NEAR_UNRESOLVED] != 0)
+      if (c[KMD_CNT_NEAR_UNRESOLVED] != 0 && !two_limbs)
       {
         // More rows within 1e-8 of the threshold than one launch can list (4096; include/kmdiff_hip.h): the rows beyond
-        // kept the device libm's decision.  The guard's guarantee is restored the long way: the partition is merged
-        // into a matrix and its rows are tested in pieces small enough for every near row to be listed (below).
+        // kept the device libm's decision.  The guard's guarantee is restored the long way -- and without a matrix
+        // (round 5 merged the partition into n x S x 4 bytes here: tens of GB on exactly the jobs that take the fused
+        // path because the matrix does not fit): the partition's rows as (k-mer, control sum, case sum), 24
+        // bytes each (kmd_merge_sums), tested in pieces small enough for every near row to be listed -- as many pieces
+        // as the count of unresolved rows asks for, twice as many while any is left.
+        std::fprintf(stderr, "[kmdiff-hip] partition %zu: %llu near-threshold rows beyond the list: again, as rows of sums in pieces\n", p, (unsigned long long)c[KMD_CNT_NEAR_UNRESOLVED]);
+        const size_t nr = (size_t)n_rows;
+        d_kmer_col.reserve(nr * 8); d_sum_c.reserve(nr * 8); d_sum_k.reserve(nr * 8);
+        uint64_t got = 0;
+        ck(kmd_merge_sums((int)S, (int)opt.nb_controls, (const uint64_t*)D.kmers.p, nullptr, (const uint32_t*)D.counts.p, D.offs.data(), nr,
+                          (uint64_t*)d_kmer_col.p, nullptr, (uint64_t*)d_sum_c.p, (uint64_t*)d_sum_k.p, &got, nullptr), "kmd_merge_sums");
+        if (got != nr) die("kmd_merge_sums: " + std::to_string(got) + " rows, the fused pass counted " + std::to_string(nr));
+        for (size_t pieces = std::max<size_t>(2, (size_t)((c[KMD_CNT_NEAR_UNRESOLVED] + 4095) / 4096) + 1);; pieces *= 2)
+        {
+          const size_t rows_per = (nr + pieces - 1) / pieces;
+          ck(kmd_memset(d_cnt.p, 0, KMD_NCOUNTERS * 8, nullptr), "memset");
+          for (size_t r0 = 0; r0 < nr; r0 += rows_per)
+            ck(kmd_poisson_filter_sums(model, (const uint64_t*)d_kmer_col.p + r0, (const uint64_t*)d_sum_c.p + r0, (const uint64_t*)d_sum_k.p + r0,
+                                       std::min(rows_per, nr - r0), first_threshold, &sv, (uint64_t*)d_cnt.p, nullptr), "kmd_poisson_filter_sums");
+          ck(kmd_memcpy_d2h(c, d_cnt.p, sizeof c, nullptr), "d2h");
+          if (c[KMD_CNT_SIG] > fused_cap) die("the pieces found more survivors than the fused pass");
+          if (c[KMD_CNT_NEAR_UNRESOLVED] == 0)
+          {
+            std::fprintf(stderr, "[kmdiff-hip] partition %zu: every near-threshold row decided in %zu pieces of %zu rows\n", p, pieces, rows_per);
+            break;
+          }
+          if (rows_per <= 4096) die("near-threshold rows left unresolved in a piece of 4096 rows");
+        }
+      }
+      if (c[KMD_CNT_NEAR_UNRESOLVED] != 0)
+      {
+        // (two-limb k-mers: the rows-of-sums test carries one limb -- the partition is merged into a matrix and its rows
+        // are tested in pieces, below)
         std::fprintf(stderr, "[kmdiff-hip] partition %zu: %llu near-threshold rows beyond the list: again, as a matrix in pieces\n", p, (unsigned long long)c[KMD_CNT_NEAR_UNRESOLVED]);
         const size_t n = D.n;
         d_matrix.reserve(std::max(((n + T - 1) / T) * T, n) * S * 4); d_kmer_col.reserve(n * 8);

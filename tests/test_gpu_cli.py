@@ -261,9 +261,9 @@ def test_cli_a_rank_that_fails_ends_the_run_with_its_error(synth_run, tmp_path):
 def test_cli_more_near_threshold_rows_than_one_launch_lists(tmp_path):
     """KMD_CNT_NEAR_UNRESOLVED read by the host: 6 000 rows with the same two count sums and the
     first threshold put ON their p-value -- more rows within 1e-8 of the threshold than one launch can list for the
-    correctly rounded second look (4096).  The fused pass reports the rest unresolved; the command merges the partition
-    into a matrix and tests it in pieces until none is (stderr says so), and --matrix-path gets there by halving: both
-    write what the oracle decides."""
+    correctly rounded second look (4096).  The fused pass reports the rest unresolved; the command takes the partition's
+    rows as (k-mer, control sum, case sum) -- no matrix -- and tests them in pieces until none is (stderr says so), and
+    --matrix-path gets there by halving: both write what the oracle decides."""
     import kmdiff_amd as K
     import ctypes as C
     o = OL.load()
@@ -307,7 +307,7 @@ def test_cli_more_near_threshold_rows_than_one_launch_lists(tmp_path):
         s, err = run_cli(["-d", str(tmp_path / "km"), "-1", nc, "-2", nk, "-s", repr(p_star), "-u", 1, "-c", "disabled", "--keep-tmp"] + extra,
                          tmp_path / name)
         assert "every near-threshold row decided in" in err, err[-1500:]
-        assert ("again, as a matrix in pieces" in err) == (name == "fused")
+        assert ("again, as rows of sums in pieces" in err) == (name == "fused") and "as a matrix in pieces" not in err
         assert s["near_threshold"] >= n_same and s["n_sig"] == len(want_km)
         recs = KF.read_survivor_file(str(tmp_path / name / "partitions" / "p0_uncorrected"))
         outs[name] = sorted(int(v) for v in recs["kmer"])

@@ -603,7 +603,7 @@ def test_gather_counts_of_survivors(K, oracle):
 @pytest.mark.parametrize("count_bytes", [4, 2, 1])
 def test_merge_partition_matches_oracle(K, oracle, layout_name, count_bytes, path, monkeypatch):
     """km::KmerMerger as driven at merge.hpp:265-289: device merge == oracle merge, through
-    both device implementations (bucketed LDS merge, sort-based)."""
+    both device implementations (the tile merge + matrix fill, sort-based)."""
     monkeypatch.setenv("KMD_MERGE_PATH", path)
     rng = np.random.default_rng(17)
     universe = np.unique(rng.integers(0, 1 << 62, 60000, dtype=np.uint64))

@@ -271,7 +271,8 @@ def test_more_near_rows_than_one_launch_lists_in_pieces(K, oracle, layout):
     full, tot, p_star, model = chosen
     want = oracle.diff_partition(full, OL.LAYOUT_ROWS, nc, nk, int(tot[:nc].sum()), int(tot[nc:].sum()), lf, p_star)
     assert (want["pvalue"] == p_star).sum() >= n_same
-    mat = K.CountMatrix.from_host(full, {"tiled": K.LAYOUT_TILED, "rows": K.LAYOUT_ROWS, "soa": K.LAYOUT_SOA}[layout])
+    lay = {"tiled": K.LAYOUT_TILED, "rows": K.LAYOUT_ROWS, "soa": K.LAYOUT_SOA}[layout]
+    mat = K.CountMatrix.from_host(full if layout == "rows" else np.ascontiguousarray(full.T), lay)      # ([sample][row] but for row-major)
     acc = K.SurvivorAccumulator(len(full))
     obs = K.diff_observer(model, acc, p_star)
     obs.process(mat)

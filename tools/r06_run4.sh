@@ -1,0 +1,12 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-$PWD}
+rm -rf gpurun_out/k2trace
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/k2trace -o t -- python3 tools/kbench_merge.py --keys random > gpurun_out/k2trace.log 2>&1
+python3 - <<'PY'
+import csv, glob
+for f in glob.glob('gpurun_out/k2trace/**/*kernel_stats.csv', recursive=True):
+    for r in list(csv.DictReader(open(f)))[:14]:
+        print('%-90s %4s x %9.1f us' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e3))
+PY
+tail -2 gpurun_out/k2trace.log
+python -m pytest tests/test_gpu_cli.py -x -q -m gpu -k "near_threshold or fused_path or cmodel" 2>&1 | tail -3
