@@ -29,6 +29,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <ctime>
 #include <filesystem>
 #include <functional>
 #include <future>
@@ -71,6 +72,17 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
 // Errors travel as exceptions: a GPU worker thread reports through its worker_result (run_gpu_worker), the
 // main thread prints and exits from main() -- nobody calls exit() while other workers, decoder tasks or
 // copies from page-locked memory are still alive.
+// KMD_HOST_TIMING: CPU time (CLOCK_THREAD_CPUTIME_ID -- not wall time: under a CPU quota a thread is off the core for much of
+// its wall time) the decoder threads spent in all, and of it packing records for the transfer (gather + kmd_pack_block)
+std::atomic<uint64_t> g_pack_ns { 0 }, g_decode_ns { 0 };
+const bool g_time_pack = std::getenv("KMD_HOST_TIMING") != nullptr;
+inline uint64_t thread_cpu_ns()
+{
+  timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
 [[noreturn]] void die(const std::string& msg)
 {
   throw std::runtime_error(msg);
@@ -332,6 +344,7 @@ public:
     busy_ += t.seconds();
   }
   double busy_seconds() const { std::lock_guard<std::mutex> g(mu_); return busy_; }
+  size_t decoder_threads() const { return std::min(threads_, C_.S); }
 
 private:
   void load_files(size_t p, partition_input* in) const
@@ -355,6 +368,12 @@ private:
           st.sink.raw = [self](const char* p, size_t n, uint32_t cb)
           {
             static const size_t bound = kmd_pack_block_bound();
+            struct pack_clock                                // (one reading per decoded chunk, not per block)
+            {
+              uint64_t t0 = 0;
+              pack_clock() { if (g_time_pack) t0 = thread_cpu_ns(); }
+              ~pack_clock() { if (g_time_pack) g_pack_ns += thread_cpu_ns() - t0; }
+            } clock_;
             const size_t rec = 8 + (size_t)cb;
             const bool last = p == nullptr;
             auto room = [&](size_t blocks)
@@ -442,11 +461,13 @@ private:
     std::exception_ptr err;
     auto work = [&]()
     {
+      const uint64_t t0 = g_time_pack ? thread_cpu_ns() : 0;
       for (size_t s2; (s2 = next++) < S;)
       {
         try { body(s2); }
         catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
       }
+      if (g_time_pack) g_decode_ns += thread_cpu_ns() - t0;
     };
     std::vector<std::thread> pool;
     for (size_t t = 1; t < std::min(threads_, S); ++t) pool.emplace_back(work);
@@ -881,8 +902,9 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
   {
     std::fprintf(stderr, "[kmdiff-hip] GPU %d: waited %.3f s for the file decoder (%.3f s of it for the first %zu partitions, whose staging arrays "
                          "get page-locked), %.3f s in copies + kernels\n", dev, t_loader, t_first, depth + 1, t_device);
-    std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1; of the wait, %.3f s for the copies; decoders busy %.3f s in all\n",
-                 dev, merge_time.seconds(), t_copy_wait, loader.busy_seconds());
+    std::fprintf(stderr, "[kmdiff-hip] GPU %d: last partition done %.3f s into stage 1; of the wait, %.3f s for the copies; decoders busy %.3f s in all on %zu threads = %.3f s of CPU, %.3f s of it (%.0f %%) packing for the transfer\n",
+                 dev, merge_time.seconds(), t_copy_wait, loader.busy_seconds(), loader.decoder_threads(), (double)g_decode_ns.load() * 1e-9,
+                 (double)g_pack_ns.load() * 1e-9, 100.0 * (double)g_pack_ns.load() / std::max<double>(1.0, (double)g_decode_ns.load()));
     if (turn > depth + 1)
       std::fprintf(stderr, "[kmdiff-hip] GPU %d: steady state %.2f ms per partition (%zu partitions after the first %zu)\n", dev,
                    1e3 * t_steady / (double)(turn - depth - 1), turn - depth - 1, depth + 1);

@@ -27,6 +27,8 @@ ap.add_argument("--keep", default="", help="write the run directory here, keep i
 ap.add_argument("--matrix", action="store_true", help="also write <run>/matrices: the pre-merged feed (matrix_proxy)")
 ap.add_argument("--cpu-baseline", action="store_true", help="also: the CPU doing the same job on the same run directory (oracle/cpu_pipeline: liblz4 decode + the oracle's merge + the oracle's test, one task per partition on as many threads as the quota gives)")
 ap.add_argument("--only", default="", help="instead of the -t sweep: this one set of flags, e.g. \"-t 16\"")
+ap.add_argument("--ab-preload", default="", help="with --ab N: instead of packed against --raw-transfer, the shipped library against THIS libkmdiff_hip.so "
+                "(LD_PRELOAD: an older build of the host packer, say), alternating, at -t 16")
 ap.add_argument("--json", default="", help="write what was measured to this file as JSON (bench.py --e2e reads it)")
 ap.add_argument("--ab", type=int, default=0, help="instead of the -t sweep: this many rounds of packed transfer against --raw-transfer at -t 16 and -t 64, alternating")
 a = ap.parse_args()
@@ -92,15 +94,22 @@ if a.cpu_baseline:
 configs = (["-t", "1"], ["-t", "8"], ["-t", "16"], ["-t", "64"], ["-t", "256"], ["-t", "64", "--devices", "2"])
 if a.only:
     configs = (a.only.split(),)
-if a.ab:
+preload = {}
+if a.ab and a.ab_preload:
+    configs = [["-t", "16"] + m for _ in range(a.ab) for m in ([], ["#preload"])]
+    preload = {"LD_PRELOAD": os.path.abspath(a.ab_preload)}
+elif a.ab:
     configs = [c + m for _ in range(a.ab) for c in (["-t", "16"], ["-t", "64"]) for m in ([], ["--raw-transfer"])]
 gpu_lines = []
 for extra in configs:
     out = os.path.join(root, "out")
     shutil.rmtree(out, ignore_errors=True)
     t0 = time.time()
-    r = subprocess.run([cli, "diff", "-d", os.path.join(root, "km"), "-1", str(a.nc), "-2", str(a.nk), "-o", out] + extra,
-                       capture_output=True, text=True, env=dict(os.environ, KMD_HOST_TIMING="1"))
+    env = dict(os.environ, KMD_HOST_TIMING="1")
+    if "#preload" in extra:
+        env.update(preload)
+    r = subprocess.run([cli, "diff", "-d", os.path.join(root, "km"), "-1", str(a.nc), "-2", str(a.nk), "-o", out] + [x for x in extra if x != "#preload"],
+                       capture_output=True, text=True, env=env)
     dt = time.time() - t0
     assert r.returncode == 0, r.stderr
     stage1 = [l for l in r.stderr.split("\n") if "Partitions processed" in l][0].split("(")[1].split(" s")[0]
@@ -115,7 +124,7 @@ for extra in configs:
     except Exception:
         pass
     print("kmdiff-hip diff %-24s total %.2f s, stage 1 %s s = %.3e rows/s, %.3e records/s%s"
-          % (" ".join(extra), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1),
+          % (" ".join(extra).replace("#preload", "(LD_PRELOAD " + os.path.basename(os.path.dirname(preload.get("LD_PRELOAD", "/x/y"))) + ")"), dt, stage1, a.parts * a.rows / float(stage1), records / float(stage1),
              "  (%.1f x the CPU baseline's stage 1)" % (cpu_line["seconds"] / float(stage1)) if cpu_line else ""), flush=True)
     gpu_lines.append({"flags": " ".join(extra), "total_s": dt, "stage1_s": float(stage1), "rows_per_s": a.parts * a.rows / float(stage1),
                       "records_per_s": records / float(stage1)})

@@ -71,7 +71,7 @@ def main():
     copy("pmc_popstrat.txt", "r06_pmc_popstrat.txt")
     copy("pytest_gpu.txt", "r06_pytest_gpu.txt")
     out = []
-    for name in ("cli_throughput.txt", "cli_throughput_ab.txt"):
+    for name in ("cli_throughput.txt", "cli_throughput_ab.txt", "cli_throughput_packer.txt"):
         f = os.path.join(SRC, name)
         if os.path.exists(f):
             out += ["# " + name, ""] + [l.rstrip() for l in open(f) if "amdgpu.ids" not in l] + [""]

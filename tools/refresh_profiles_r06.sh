@@ -102,6 +102,10 @@ fi
 if has cli; then
   timeout 1200 python3 tools/cli_throughput.py --rows 2000000 --parts 8 --cpu-baseline > $O/cli_throughput.txt 2>&1 < /dev/null
   timeout 900 python3 tools/cli_throughput.py --rows 2000000 --parts 8 --ab 3 > $O/cli_throughput_ab.txt 2>&1 < /dev/null
+  # the host packer of round 5 (build_sweep/r5_packer/libkmdiff_hip.so, LD_PRELOAD) against this round's, alternating, -t 16
+  if [ -f build_sweep/r5_packer/libkmdiff_hip.so ]; then
+    timeout 900 python3 tools/cli_throughput.py --rows 2000000 --parts 8 --ab 4 --ab-preload build_sweep/r5_packer/libkmdiff_hip.so > $O/cli_throughput_packer.txt 2>&1 < /dev/null
+  fi
 fi
 if has popstrat; then
   bash tools/pmc_popstrat.sh --thr 0.05 > $O/pmc_popstrat.txt 2>&1
