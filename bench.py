@@ -146,14 +146,23 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
     cap = max(1 << 16, rows // 100)
     acc = K.SurvivorAccumulator(cap)
     obs = K.diff_observer(model, acc, THRESHOLD / CUTOFF, NC, NK)
-    n_rows = K.merge_filter(ss, obs)                       # warm-up (first-use costs)
-    acc.counters.zero()
-    e0, e1 = K.Event(), K.Event()
-    e0.record()
-    for _ in range(iters):
+    # warm-up: first-use costs, and the clocks -- the first calls behind an idle moment run 5-15 % slower than the steady
+    # state a job of hundreds of partitions sees (twelve back-to-back calls on a configs[2] partition, HIP events:
+    # 2.69 2.62 2.47 2.41 2.39 2.40 2.37 2.37 2.38 2.38 2.36 2.35 ms; tools/r06_calls.py).  Round 5 timed the six calls
+    # right behind ONE warm-up call: the ramp was in the average.  Six untimed calls now; every timed call's own time is
+    # in the line (`ms_calls`), `ms` is their mean.
+    n_warm = int(os.environ.get("KMD_BENCH_PIPE_WARM", "6"))
+    for _ in range(max(1, n_warm)):
         n_rows = K.merge_filter(ss, obs)
-    e1.record()
-    ms = e0.elapsed_ms(e1) / iters
+    acc.counters.zero()
+    ev = [K.Event() for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        n_rows = K.merge_filter(ss, obs)
+        ev[i + 1].record()
+    K._native.check(lib.kmd_stream_sync(None))
+    ms_calls = [ev[i].elapsed_ms(ev[i + 1]) for i in range(iters)]
+    ms = ev[0].elapsed_ms(ev[iters]) / iters
     c = acc.read_counters()
     assert int(c[0]) == iters * n_rows == iters * rows, (int(c[0]), n_rows, rows)
     n_sig0 = int(c[1]) // iters
@@ -168,7 +177,7 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
                                      ("; MIXED presence profile: every second row in one or two samples, the others in 95 %% of the samples "
                                       "(%.1f records per row on average)" % (ss.total / float(rows))) if profile else ""),
                       "rows": rows, "records": ss.total, "samples": NC + NK},
-           "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "kmers_per_s": n_rows / (ms * 1e-3),
+           "records": ss.total, "rows": int(n_rows), "samples": NC + NK, "ms": ms, "ms_calls": ms_calls, "warmup_calls": max(1, n_warm), "kmers_per_s": n_rows / (ms * 1e-3),
            "records_per_s": ss.total / (ms * 1e-3), "bytes_algorithmic": 12 * ss.total, "roofline": roof(gbs), "n_sig": n_sig0}
     if with_extras == "batched":
         # (the sparse leg: single calls above, and the batch entry point -- no host threads, no refine timing)
@@ -702,7 +711,7 @@ def main():
             kept.clear()
             K._native.check(lib.kmd_release_cache())
             if args.pipeline_rows > 4_000_000:
-                out["pipeline"]["small"] = pipeline_leg(K, lib, 4_000_000, iters=6, n_distinct=1, with_extras=False)
+                out["pipeline"]["small"] = pipeline_leg(K, lib, 4_000_000, iters=6, n_distinct=1, with_extras="batched")
             # rows of few records beside rows of many: the MIXED profile at the same size, with a roofline block of its own
             out["pipeline"]["sparse"] = pipeline_leg(K, lib, args.pipeline_rows, iters=6, n_distinct=1, with_extras="batched", profile=K.SYNTH_MIXED)
         if not args.no_cpu_baseline and world == 1:
