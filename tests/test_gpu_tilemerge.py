@@ -572,3 +572,4 @@ def test_merge_filter_random_small_cases(K, oracle):
         if int(tcs.sum()) == 0 or int(tks.sum()) == 0:
             continue                                                 # (the model needs counts on both sides)
         run_fused(K, oracle, streams, nc, float(rng.choice([1.0, 0.2, 1e-2, 1e-6])), lf_n=int(rng.choice([10000, 200])))
+
