@@ -148,7 +148,7 @@ def pipeline_leg(K, lib, rows, iters=6, n_distinct=1, n_batch=12, with_extras=Tr
     obs = K.diff_observer(model, acc, THRESHOLD / CUTOFF, NC, NK)
     # warm-up: first-use costs, and the clocks -- the first calls behind an idle moment run 5-15 % slower than the steady
     # state a job of hundreds of partitions sees (twelve back-to-back calls on a configs[2] partition, HIP events:
-    # 2.69 2.62 2.47 2.41 2.39 2.40 2.37 2.37 2.38 2.38 2.36 2.35 ms; tools/r06_calls.py).  Round 5 timed the six calls
+    # 2.69 2.62 2.47 2.41 2.39 2.40 2.37 2.37 2.38 2.38 2.36 2.35 ms; tools/r06_calls2.py).  Round 5 timed the six calls
     # right behind ONE warm-up call: the ramp was in the average.  Six untimed calls now; every timed call's own time is
     # in the line (`ms_calls`), `ms` is their mean.
     n_warm = int(os.environ.get("KMD_BENCH_PIPE_WARM", "6"))
