@@ -470,6 +470,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before the GPU runtime loads: RCCL's IPC on these hosts is dmabuf only)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
