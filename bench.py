@@ -403,7 +403,7 @@ def h2d_leg(K, lib, obs, mat, steps=3):
                     "serial, per step" % nbytes}
 
 
-def e2e_leg(parts=8, rows=2_000_000):
+def e2e_leg(parts=int(os.environ.get("KMD_BENCH_E2E_PARTS", "8")), rows=int(os.environ.get("KMD_BENCH_E2E_ROWS", "2000000"))):
     """The command end to end on files (never `value`): tools/cli_throughput.py fabricates a kmtricks run directory
     (configs[2]'s sample split, `parts` partitions of `rows` rows), runs `kmdiff-hip diff -t <threads the quota gives>` on it
     and, on the SAME files, oracle/cpu_pipeline -- liblz4 decode + the oracle's S-way merge + the oracle's test, one task

@@ -63,6 +63,20 @@ def test_bench_single_gpu_line():
     assert 0.5 < fi["frac_of_link_ceiling"] <= 1.05 and fi["kmers_per_s"] < 0.2 * pl["kmers_per_s"] and d["value"] > 10 * fi["kmers_per_s"]
 
 
+def test_bench_e2e_leg_with_the_cpu_pipeline_beside_it():
+    """`bench.py --e2e` (never `value`): `kmdiff-hip diff` on a fabricated run directory and, on the same files, the CPU doing the
+    same job (oracle/cpu_pipeline: liblz4 decode + the oracle's merge + the oracle's test) -- here on a small directory."""
+    env = dict(os.environ, KMD_BENCH_E2E_PARTS="2", KMD_BENCH_E2E_ROWS="300000")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", str(ROWS), "--steps", "2", "--warmup", "1", "--no-pipeline", "--no-cpu-baseline", "--e2e"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    e = last_json(r.stdout)["e2e"]
+    assert "error" not in e, e
+    assert e["run_dir"]["partitions"] == 2 and e["run_dir"]["rows_per_partition"] == 300000
+    assert e["kmdiff_hip_diff"]["rows_per_s"] > 0 and e["cpu_baseline_e2e"]["value"] > 0 and e["cpu_baseline_e2e"]["kind"] == "port"
+    assert e["cpu_baseline_e2e"]["cores"] >= 1 and e["gpu_over_cpu"] > 1.0
+
+
 @pytest.mark.parametrize("correction", ["bonferroni", "benjamini", "holm"])
 def test_bench_two_ranks_on_one_gpu(correction):
     env = dict(os.environ, KMD_BENCH_OVERSUBSCRIBE="1", KMD_BENCH_BACKEND="gloo")
