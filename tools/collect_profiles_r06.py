@@ -64,7 +64,12 @@ def main():
                  "# r6_base2 = round 5's kmd_tilemerge.hip linked with this round's other objects; libkmdiff_hip = the shipped library.",
                  "# whole call (best of the iterations) | kernels of the call, average duration under rocprofv3 --kernel-trace --stats", ""]
         lines += [l.rstrip() for l in open(f) if l.strip() and "simple_timer" not in l and "amdgpu.ids" not in l]
-        open(os.path.join(DST, "r06_ab_k2t.txt"), "w").write("\n".join(lines) + "\n")
+        dst = os.path.join(DST, "r06_ab_k2t.txt")
+        if os.path.exists(dst):                      # the hand-kept blocks of experiments that were not shipped ("# (n) ...") stay
+            kept = open(dst).read().split("\n")
+            first = next((i for i, l in enumerate(kept) if l.startswith("# (")), None)
+            if first is not None: lines += [""] + [l for l in kept[first:]]
+        open(dst, "w").write("\n".join(lines).rstrip("\n") + "\n")
         print("  r06_ab_k2t.txt")
     copy("kbench.txt", "r06_kbench.txt")
     copy("kbench_k1.txt", "r06_kbench_k1.txt")
