@@ -322,6 +322,11 @@ int kmd_merge_partition(int n_samples, const uint64_t* d_kmers, const uint64_t* 
 #define KMD_PACK_BLOCK 256
 size_t kmd_pack_block_bound(void);
 size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, uint32_t n, void* out);
+/* The same block from records as a kmtricks k-mer file holds them (one-limb k-mers: [k-mer, 8 bytes][count, count_bytes = 1,
+ * 2 or 4 bytes] one behind the other -- km::KmerWriter's payload, what an LZ4 decoder leaves of cmd/diff.hpp:92-95's files):
+ * the decoder's bytes go in as they are, exactly n x (8 + count_bytes) of them are read.  Returns what kmd_pack_block
+ * returns for the same records (0: bad arguments). */
+size_t kmd_pack_records(const void* records, uint32_t count_bytes, uint32_t n, void* out);
 /* A whole stream, block by block (host, any thread): n records -> out (room for out_capacity bytes; ceil(n / 256) x
  * kmd_pack_block_bound() always suffices), block_off8[ceil(n / 256)] = where each block begins / 8.  Returns the bytes
  * written (a multiple of 8); 0 with n > 0: out too small or bad arguments. */

@@ -111,6 +111,7 @@ SIGNATURES = {
     "kmd_transport_abort": (_i, [C.POINTER(Transport)]),
     "kmd_pack_block_bound": (_sz, []),
     "kmd_pack_block": (_sz, [_vp, _vp, C.c_uint32, _vp]),
+    "kmd_pack_records": (_sz, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "kmd_pack_stream": (_sz, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "kmd_unpack_streams": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmd_merge_partition": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(_u64), _vp]),

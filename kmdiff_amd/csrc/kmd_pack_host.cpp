@@ -1,5 +1,5 @@
 // kmd_pack_host.cpp -- the host's side of the compact transfer format (kmd_pack.hip has the format and the device's
-// unpack kernel): kmd_pack_block_bound, kmd_pack_block, kmd_pack_stream.  Plain C++ (no device pass: the loops below are
+// unpack kernel): kmd_pack_block_bound, kmd_pack_block, kmd_pack_records, kmd_pack_stream.  Plain C++ (no device pass: the loops below are
 // built twice, for AVX2 and for any x86-64, and picked at load time).
 #include <algorithm>
 #include <array>
@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstring>
 #include <utility>
+
+#include <immintrin.h>
 
 #include "../../include/kmdiff_hip.h"
 
@@ -112,6 +114,73 @@ extern "C" size_t kmd_pack_block(const uint64_t* kmers, const uint32_t* counts, 
   size_t bytes = 16 + (size_t)n_words * 8 + kBlock + (size_t)n_esc * 4;
   while (bytes & 7) o[bytes++] = 0;
   return bytes;
+}
+
+// ---- records as a kmtricks k-mer file holds them: [k-mer, 8 bytes][count, 1 / 2 / 4 bytes], one behind the other -----
+// What `kmdiff-hip diff`'s decoder threads hand over: the bytes the LZ4 decoder has just written.  Taking the records
+// apart was a loop of two 8- and 4-byte copies per record in the caller -- 0.8 of the 1.55 ns a record cost to pack,
+// more than the bit-packing itself.  With 4-byte counts (the reference's default build: MAX_C = 2^32 - 1,
+// CMakeLists.txt:68-80) eight records are 96 bytes = three vectors: seven lane permutes and four blends put their
+// k-mers into two vectors and their counts into one (AVX2; picked at load time).
+namespace {
+
+template <int CB>
+void split_scalar(const unsigned char* q, uint32_t n, uint64_t* __restrict__ km, uint32_t* __restrict__ ct)
+{
+  for (uint32_t i = 0; i < n; ++i, q += 8 + CB)
+  {
+    std::memcpy(&km[i], q, 8);
+    if constexpr (CB == 4) std::memcpy(&ct[i], q + 8, 4);
+    else if constexpr (CB == 2) { uint16_t v; std::memcpy(&v, q + 8, 2); ct[i] = v; }
+    else ct[i] = q[8];
+  }
+}
+
+__attribute__((target("avx2")))
+void split12_avx2(const unsigned char* q, uint32_t n, uint64_t* __restrict__ km, uint32_t* __restrict__ ct)
+{
+  // dwords of 8 records: record j = dwords 3j, 3j + 1 (k-mer), 3j + 2 (count); A = dwords 0-7, B = 8-15, C = 16-23
+  const __m256i pk0a = _mm256_setr_epi32(0, 1, 3, 4, 6, 7, 0, 0), pk0b = _mm256_setr_epi32(0, 0, 0, 0, 0, 0, 1, 2);
+  const __m256i pk1b = _mm256_setr_epi32(4, 5, 7, 0, 0, 0, 0, 0), pk1c = _mm256_setr_epi32(0, 0, 0, 0, 2, 3, 5, 6);
+  const __m256i pca = _mm256_setr_epi32(2, 5, 0, 0, 0, 0, 0, 0), pcb = _mm256_setr_epi32(0, 0, 0, 3, 6, 0, 0, 0), pcc = _mm256_setr_epi32(0, 0, 0, 0, 0, 1, 4, 7);
+  uint32_t j = 0;
+  for (; j + 8 <= n; j += 8, q += 96)
+  {
+    const __m256i A = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(q));
+    const __m256i B = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(q + 32));
+    const __m256i C = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(q + 64));
+    const __m256i k0 = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(A, pk0a), _mm256_permutevar8x32_epi32(B, pk0b), 0xC0);
+    const __m256i k1 = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(B, pk1b), _mm256_permutevar8x32_epi32(C, pk1c), 0xF8);
+    const __m256i c = _mm256_blend_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(A, pca), _mm256_permutevar8x32_epi32(B, pcb), 0x1C),
+                                         _mm256_permutevar8x32_epi32(C, pcc), 0xE0);
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(km + j), k0);
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(km + j + 4), k1);
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(ct + j), c);
+  }
+  split_scalar<4>(q, n - j, km + j, ct + j);
+}
+
+using split_fn = void (*)(const unsigned char*, uint32_t, uint64_t*, uint32_t*);
+split_fn pick_split12()
+{
+  __builtin_cpu_init();
+  return __builtin_cpu_supports("avx2") ? &split12_avx2 : &split_scalar<4>;
+}
+const split_fn g_split12 = pick_split12();
+
+} // namespace
+
+extern "C" size_t kmd_pack_records(const void* records, uint32_t count_bytes, uint32_t n, void* out)
+{
+  if (!records || !out || n == 0 || n > kBlock) return 0;
+  const unsigned char* q = static_cast<const unsigned char*>(records);
+  uint64_t km[kBlock];
+  uint32_t ct[kBlock];
+  if (count_bytes == 4) g_split12(q, n, km, ct);
+  else if (count_bytes == 2) split_scalar<2>(q, n, km, ct);
+  else if (count_bytes == 1) split_scalar<1>(q, n, km, ct);
+  else return 0;
+  return kmd_pack_block(km, ct, n, out);
 }
 
 // a whole stream: its blocks one behind the other (what a host does while it decodes a sample's file)

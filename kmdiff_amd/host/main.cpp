@@ -73,7 +73,7 @@ struct diff_options                       // include/kmdiff/cmd/diff_opt.hpp:6-4
 // main thread prints and exits from main() -- nobody calls exit() while other workers, decoder tasks or
 // copies from page-locked memory are still alive.
 // KMD_HOST_TIMING: CPU time (CLOCK_THREAD_CPUTIME_ID -- not wall time: under a CPU quota a thread is off the core for much of
-// its wall time) the decoder threads spent in all, and of it packing records for the transfer (gather + kmd_pack_block)
+// its wall time) the decoder threads spent in all, and of it packing records for the transfer (kmd_pack_records)
 std::atomic<uint64_t> g_pack_ns { 0 }, g_decode_ns { 0 };
 const bool g_time_pack = std::getenv("KMD_HOST_TIMING") != nullptr;
 inline uint64_t thread_cpu_ns()
@@ -323,6 +323,25 @@ struct partition_input
   size_t n = 0;
 };
 
+// Page-locked staging a worker is done with is released behind the run's back: un-pinning what a 20v20 run stages (~1.5 GB:
+// three partitions' packed streams) is a quarter of a second of hipHostFree -- measured: 0.26 of the 0.63 s stage 1 took on
+// eight 2 M-row partitions -- and nothing needs it done before the process ends.  main() owns the object: its threads are
+// joined on every way out of main, before the runtime's own teardown.
+class retired_staging
+{
+public:
+  void take(std::vector<partition_input>&& slots)
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    threads_.emplace_back([held = std::move(slots)]() mutable { held.clear(); });
+  }
+  ~retired_staging() { for (auto& t : threads_) if (t.joinable()) t.join(); }
+private:
+  std::mutex mu_;
+  std::vector<std::thread> threads_;
+};
+retired_staging* g_retired = nullptr;
+
 class partition_loader
 {
 public:
@@ -361,8 +380,8 @@ private:
         sample_stream* self = &st;
         if (packed)
         {
-          // The records are packed for the transfer as they leave the LZ4 decoder (kmd_pack_block): a block's 256
-          // records are gathered from the file's [k-mer][count] layout into two small arrays on the stack and packed
+          // The records are packed for the transfer as they leave the LZ4 decoder (kmd_pack_records): a block's 256
+          // records are taken from the file's [k-mer][count] layout and packed
           // into the stream's page-locked bytes -- no pass over the data besides the decoder's own; what a chunk
           // leaves over (< 256 records) waits in `carry` for the next one.
           st.sink.raw = [self](const char* p, size_t n, uint32_t cb)
@@ -385,25 +404,23 @@ private:
             };
             auto pack = [&](const char* q, uint32_t m)
             {
-              uint64_t km[KMD_PACK_BLOCK]; uint32_t ct[KMD_PACK_BLOCK];
-              if (cb == 4) for (uint32_t i = 0; i < m; ++i) { std::memcpy(&km[i], q + i * 12, 8); std::memcpy(&ct[i], q + i * 12 + 8, 4); }
-              else if (cb == 2) for (uint32_t i = 0; i < m; ++i) { uint16_t v; std::memcpy(&km[i], q + i * 10, 8); std::memcpy(&v, q + i * 10 + 8, 2); ct[i] = v; }
-              else for (uint32_t i = 0; i < m; ++i) { std::memcpy(&km[i], q + i * 9, 8); ct[i] = (uint8_t)q[i * 9 + 8]; }
               ((uint32_t*)self->table.p)[self->n_blocks++] = (uint32_t)(self->packed_bytes / 8);
-              const size_t got = kmd_pack_block(km, ct, m, (char*)self->packed.p + self->packed_bytes);
-              if (!got) throw std::runtime_error("kmd_pack_block failed");
+              const size_t got = kmd_pack_records(q, cb, m, (char*)self->packed.p + self->packed_bytes);
+              if (!got) throw std::runtime_error("kmd_pack_records failed");
               self->packed_bytes += got;
             };
             if (self->n_blocks == 0 && self->packed_bytes == 0)
             {
-              // first records of a file: room for the whole of it in one go (page-locking is the fixed cost of a run, and
-              // growing a page-locked array copies it): LZ4 leaves sorted k-mers + small counts at 0.65-0.75 of their 12
-              // bytes, packed they take 4-6.5 -- the file's own size covers it; the arrays stay for the next partition
+              // first records of a file: room for the whole of it in one go (page-locking is the fixed cost of a run -- ~4.5 GB
+              // a second, and the first partition waits for it -- and growing a page-locked array copies it): LZ4 leaves
+              // sorted k-mers + small counts at 0.65-0.75 of their 12 bytes, packed they take 4-6.5, i.e. 0.45-0.7 of the
+              // file's size.  Five eighths of it and an eighth more (the files of a sample differ by a little from partition
+              // to partition) is asked for -- the file's whole size and a quarter, until round 6, page-locked 1.1 GB for a
+              // 20v20 run of 2 M-row partitions where 0.45 GB are used: 0.25 s, most of the 0.29 s partition 0 took --
+              // and a stream that needs more grows (room()); the arrays stay for the next partition
               const size_t guess_records = self->sink.file_size * 3 / 2 / rec + 1024;
-              // (a quarter more than asked for: the files of a sample differ by a little from partition to partition, and
-              // every growth is a page-locked allocation)
-              const size_t want_p = self->sink.file_size + (1u << 16), want_t = (guess_records / KMD_PACK_BLOCK + 2) * 4;
-              if (self->packed.cap < want_p) self->packed.reserve(want_p + want_p / 4, 0);
+              const size_t want_p = self->sink.file_size / 8 * 5 + (1u << 16), want_t = (guess_records / KMD_PACK_BLOCK + 2) * 4;
+              if (self->packed.cap < want_p) self->packed.reserve(want_p + want_p / 8, 0);
               if (self->table.cap < want_t) self->table.reserve(want_t + want_t / 4, 0);
             }
             room(n / KMD_PACK_BLOCK + 2);
@@ -886,6 +903,9 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     }
     t_device += t_dev.seconds();
     if (turn > depth) t_steady += t_wait.seconds();       // decoder wait + device work of this partition
+    if (opt.verbose_timing && std::getenv("KMD_HOST_TIMING")[0] == '2')
+      std::fprintf(stderr, "[kmdiff-hip] GPU %d: partition %zu done %.3f s into stage 1 (its turn: %.3f s waiting for decoder + copies, %.3f s copies + kernels + survivors)\n",
+                   dev, p, merge_time.seconds(), t_wait.seconds() - t_dev.seconds(), t_dev.seconds());
     R.span.emplace_back(base, ns);
     if (opt.save_sk)                                                                      // merge.hpp:83-86,272-278
     {
@@ -908,6 +928,15 @@ void gpu_worker_partitions(const run_context& C, const partition_loader& loader,
     if (turn > depth + 1)
       std::fprintf(stderr, "[kmdiff-hip] GPU %d: steady state %.2f ms per partition (%zu partitions after the first %zu)\n", dev,
                    1e3 * t_steady / (double)(turn - depth - 1), turn - depth - 1, depth + 1);
+  }
+  // (every decoder has been waited for and every copy has landed -- the last partition's kernels ran behind them -- so the
+  // ring's page-locked arrays are nobody's any more)
+  if (g_retired && !std::getenv("KMD_SYNC_RELEASE"))
+  {
+    ck(kmd_stream_sync(copy_stream), "kmd_stream_sync");
+    for (auto& f : ahead) if (f.valid()) f.wait();
+    g_retired->take(std::move(staging));
+    staging.clear();
   }
   if (pca)
   {
@@ -969,7 +998,7 @@ void do_diff(const run_context& C, survivors_of_run& O, const bool run_pca)
       gpus.emplace_back([&, wi]() { run_gpu_worker(C, loader, wi, n_units, run_pca, merge_time, results[wi]); });
     run_gpu_worker(C, loader, 0, n_units, run_pca, merge_time, results[0]);
     for (auto& t : gpus) t.join();
-    if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] workers done %.3f s into stage 1 (staging arrays released)\n", merge_time.seconds());
+    if (opt.verbose_timing) std::fprintf(stderr, "[kmdiff-hip] workers done %.3f s into stage 1 (device arrays released; the page-locked ones are released in the background)\n", merge_time.seconds());
     ck(kmd_set_device(opt.device % ndev), "kmd_set_device");
     for (auto& R : results) if (!R.error.empty()) die(R.error);
   }
@@ -1315,6 +1344,8 @@ int main(int argc, char** argv)
     return 0;
   }
   run_context C;
+  retired_staging retired;                               // (joined when main returns, whichever way)
+  g_retired = &retired;
   try
   {
     C.opt = parse(argc, argv);

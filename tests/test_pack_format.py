@@ -88,6 +88,41 @@ def test_bad_arguments_pack_nothing():
     assert L.kmd_pack_block_bound() == 16 + 257 * 8 + 256 + 1024
 
 
+@pytest.mark.parametrize("count_bytes", [1, 2, 4])
+def test_pack_records_takes_a_kmer_files_records_as_they_are(count_bytes):
+    """kmd_pack_records (what `kmdiff-hip diff`'s decoder threads call on the LZ4 decoder's output: [k-mer, 8 bytes][count,
+    1 / 2 / 4 bytes] one behind the other) writes exactly what kmd_pack_block writes for the same records taken apart --
+    every block length from 1 to 256 (the vector path's groups of eight and what is left over), records at any byte offset,
+    nothing read beyond the n records (the buffer ends with them), bad arguments pack nothing."""
+    L = K._native.lib()
+    rng = np.random.default_rng(50 + count_bytes)
+    rec = 8 + count_bytes
+    bound = int(L.kmd_pack_block_bound())
+    top = (1 << (8 * count_bytes)) - 1
+    for n in list(range(1, 41)) + [63, 64, 65, 127, 128, 200, 255, 256]:
+        km = np.cumsum(rng.integers(1, 1 << int(rng.integers(3, 50)), n, dtype=np.uint64)).astype(np.uint64)
+        ct = rng.integers(1, min(top, 300) + 1, n, dtype=np.uint64).astype(np.uint32)
+        if count_bytes == 4: ct[rng.random(n) < 0.05] = 0xFFFFFFF0
+        raw = np.zeros(n * rec, dtype=np.uint8)
+        r2 = raw.reshape(n, rec)
+        r2[:, :8] = km.view(np.uint8).reshape(n, 8)
+        r2[:, 8:] = ct.astype("<u4").view(np.uint8).reshape(n, 4)[:, :count_bytes]
+        want, got = np.zeros(bound, dtype=np.uint8), np.zeros(bound, dtype=np.uint8)
+        nw = int(L.kmd_pack_block(km.ctypes.data, ct.ctypes.data, n, want.ctypes.data))
+        for shift in (0, 1, 3):                                  # (the decoder's chunks start anywhere)
+            buf = np.zeros(shift + n * rec, dtype=np.uint8)
+            buf[shift:] = raw
+            got[:] = 0
+            ng = int(L.kmd_pack_records(buf.ctypes.data + shift, count_bytes, n, got.ctypes.data))
+            assert ng == nw and (got[:ng] == want[:nw]).all(), (n, count_bytes, shift)
+    buf = np.zeros(300 * rec, dtype=np.uint8)
+    out = np.zeros(bound, dtype=np.uint8)
+    assert L.kmd_pack_records(buf.ctypes.data, count_bytes, 0, out.ctypes.data) == 0
+    assert L.kmd_pack_records(buf.ctypes.data, count_bytes, 257, out.ctypes.data) == 0
+    assert L.kmd_pack_records(buf.ctypes.data, 3, 5, out.ctypes.data) == 0
+    assert L.kmd_pack_records(None, count_bytes, 5, out.ctypes.data) == 0
+
+
 @pytest.mark.parametrize("n", [1, 255, 256, 257, 5000])
 def test_pack_stream_is_its_blocks_one_behind_the_other(n):
     """kmd_pack_stream (a whole stream in one call: what bench.py's feed-inclusive leg and a host's decoder thread use) writes

@@ -114,7 +114,7 @@ for extra in configs:
     assert r.returncode == 0, r.stderr
     stage1 = [l for l in r.stderr.split("\n") if "Partitions processed" in l][0].split("(")[1].split(" s")[0]
     for l in r.stderr.split("\n"):
-        if "waited" in l or "steady state" in l or "last partition" in l:
+        if "waited" in l or "steady state" in l or "last partition" in l or "worker ready" in l or "workers done" in l or "Done in" in l:
             print("   ", l)
     try:
         import json

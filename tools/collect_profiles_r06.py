@@ -76,10 +76,12 @@ def main():
     copy("pmc_popstrat.txt", "r06_pmc_popstrat.txt")
     copy("pytest_gpu.txt", "r06_pytest_gpu.txt")
     out = []
-    for name in ("cli_throughput.txt", "cli_throughput_ab.txt", "cli_throughput_packer.txt"):
+    notes = {"cli_throughput_packer.txt": " (LD_PRELOAD of round 5's library: kmd_pack_records is this round's, the block packer behind it round 5's)",
+             "cli_throughput_release.txt": " (tools/archive/r06_cli_run.sh, an earlier lease of the round, before the page-locked arrays were sized to 5/8 of the file: the staging arrays released in the background against KMD_SYNC_RELEASE=1, alternating)"}
+    for name in ("cli_throughput.txt", "cli_throughput_ab.txt", "cli_throughput_packer.txt", "cli_throughput_release.txt"):
         f = os.path.join(SRC, name)
         if os.path.exists(f):
-            out += ["# " + name, ""] + [l.rstrip() for l in open(f) if "amdgpu.ids" not in l] + [""]
+            out += ["# " + name + notes.get(name, ""), ""] + [l.rstrip() for l in open(f) if "amdgpu.ids" not in l] + [""]
     if out:
         open(os.path.join(DST, "r06_cli_throughput.txt"), "w").write("\n".join(out))
         print("  r06_cli_throughput.txt")
