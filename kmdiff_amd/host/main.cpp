@@ -289,19 +289,25 @@ struct survivors_of_run
 // Its S files are LZ4-decoded by up to -t threads (the reference spends -t on whole partitions,
 // merge.hpp:239-307; here the device takes the partitions one after the other and the threads take
 // the files), and partition p + 1 is decoded while the device works on partition p.
+std::atomic<uint64_t> g_pin_ns { 0 }, g_pin_bytes { 0 };    // (KMD_HOST_TIMING) wall time inside page-locked allocations, bytes asked for
 struct pinned                                           // page-locked staging array, grown as needed, reused
 {
   void* p = nullptr; size_t cap = 0;
+  bool owned = true;                                    // false: a piece of somebody else's allocation (partition_input::slab)
   void reserve(size_t bytes, size_t keep = 0)           // the first `keep` bytes survive
   {
     if (bytes <= cap) return;
+    const auto t0 = std::chrono::steady_clock::now();
     void* q = nullptr;
     ck(kmd_malloc_host(&q, bytes), "kmd_malloc_host");
     if (keep) std::memcpy(q, p, keep);
-    if (p) kmd_free_host(p);
-    p = q; cap = bytes;
+    if (p && owned) kmd_free_host(p);
+    p = q; cap = bytes; owned = true;
+    g_pin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_pin_bytes += bytes;
   }
-  ~pinned() { if (p) kmd_free_host(p); }
+  void borrow(void* q, size_t bytes) { if (p && owned) kmd_free_host(p); p = q; cap = bytes; owned = false; }
+  ~pinned() { if (p && owned) kmd_free_host(p); }
 };
 struct sample_stream                                    // one sample's file of a partition, decoded
 {
@@ -316,6 +322,8 @@ struct sample_stream                                    // one sample's file of 
 };
 struct partition_input
 {
+  pinned slab;                                          // packed transfer: ONE page-locked allocation the streams' arrays are cut from
+                                                        // (declared before them: released after them)
   std::vector<sample_stream> st;                        // the S streams, each in its own page-locked arrays; the
                                                         // matrices/ feed: one stream of rows (counts [row][sample])
   matrix_file_info m;                                   // matrices/ feed: what the file says
@@ -358,7 +366,11 @@ public:
   void load(size_t p, partition_input* in) const
   {
     const stopwatch t;
+    const uint64_t pin0 = g_pin_ns.load(), pinb0 = g_pin_bytes.load();
     load_files(p, in);
+    if (C_.opt.verbose_timing && std::getenv("KMD_HOST_TIMING")[0] == '2')
+      std::fprintf(stderr, "[kmdiff-hip] partition %zu decoded in %.3f s (page-locked allocations meanwhile, all threads: %.3f s for %.0f MB)\n", p, t.seconds(),
+                   (double)(g_pin_ns.load() - pin0) * 1e-9, (double)(g_pin_bytes.load() - pinb0) / 1048576.0);
     std::lock_guard<std::mutex> g(mu_);
     busy_ += t.seconds();
   }
@@ -456,6 +468,35 @@ private:
       in->m = stream_matrix_file(mpaths_[p], in->st[0].sink);
       in->st[0].n = in->n = in->m.rows;
       return;
+    }
+    if (packed && !in->slab.p)
+    {
+      // The slot's page-locked arrays in ONE allocation, cut by the files' sizes (the sink's own estimate, below): eighty
+      // streams each page-locking their two arrays from the decoder threads went through the runtime one after the other
+      // (measured: 3.1 s of the 32 threads' wall time inside 160 allocations; 0.2 s in these two).  The first two
+      // partitions still take 0.15 s to decode where the others take 0.026: what is left is the allocation itself --
+      // 0.1 s per 309 MB in this process, whose memory cgroup is full of the run directory's page cache; 0.013 s in an
+      // idle one (tools/archive/r06_pin_probe.py).  A stream that outgrows its piece gets an array of its own
+      // (pinned::reserve), as before.
+      auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
+      std::vector<size_t> wp(S), wt(S);
+      size_t total = 0;
+      for (size_t s2 = 0; s2 < S; ++s2)
+      {
+        std::error_code ec;
+        const auto fsz = fs::file_size(kmer_file_path(C_.opt.kmtricks_dir, p, C_.fof[s2].id), ec);
+        const size_t sz = ec ? 0 : (size_t)fsz;
+        const size_t want_p = sz / 8 * 5 + (1u << 16), want_t = ((sz * 3 / 2 / 9 + 1024) / KMD_PACK_BLOCK + 2) * 4;     // (9: the shortest record)
+        wp[s2] = up(want_p + want_p / 8); wt[s2] = up(want_t + want_t / 4);
+        total += wp[s2] + wt[s2];
+      }
+      in->slab.reserve(total);
+      char* at = (char*)in->slab.p;
+      for (size_t s2 = 0; s2 < S; ++s2)
+      {
+        in->st[s2].packed.borrow(at, wp[s2]); at += wp[s2];
+        in->st[s2].table.borrow(at, wt[s2]); at += wt[s2];
+      }
     }
     for_samples([&](size_t s2)
     {
