@@ -542,3 +542,38 @@ def test_cli_packed_transfer_counts_beyond_one_byte_and_tiny_files(tmp_path):
     assert a == b and a["total_kmers"] == present + 1 and a["n_sig"] > 100
     for name in ("control_kmers.fasta", "case_kmers.fasta", "partitions/p0_uncorrected", "partitions/p1_uncorrected"):
         assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read(), name
+
+
+def test_cli_staging_slot_outgrown_by_a_later_partition(tmp_path):
+    """The page-locked arrays of a staging slot are cut from one allocation sized by the files of the FIRST partition that
+    uses the slot (main.cpp, partition_input::slab); a stream of a later partition that needs more moves into an array of
+    its own while it is being decoded.  Partitions 0 and 1 of a few hundred k-mers, 2 and 3 of 300 000 (a thousand times the
+    bytes, in the slots 0 and 1 were sized for), then small ones again: the packed feed and the raw one agree byte for byte
+    and every k-mer is counted."""
+    rng = np.random.default_rng(15)
+    nc, nk, k = 2, 2, 31
+    parts, present = [], 0
+    for n_keys in (300, 200, 300_000, 280_000, 500, 250_000):
+        uni = np.unique(rng.integers(0, 1 << 62, n_keys, dtype=np.uint64))
+        st = []
+        for s in range(nc + nk):
+            pick = rng.random(len(uni)) < 0.7
+            cnt = rng.integers(1, 40, int(pick.sum())).astype(np.uint32) * np.uint32(1 if s < nc else 3)
+            st.append((uni[pick], cnt))
+        present += len(np.unique(np.concatenate([t[0] for t in st])))
+        parts.append(st)
+    KF.write_run_dir(str(tmp_path / "km"), k, ["C0", "C1", "K0", "K1"], parts)
+    common = ["-d", str(tmp_path / "km"), "-1", nc, "-2", nk, "-s", 0.05, "-u", 1000, "-c", "disabled", "--keep-tmp", "-t", 4]
+    os.environ["KMD_HOST_TIMING"] = "2"                             # (a line per decoded partition: what it page-locked meanwhile)
+    try:
+        a, log = run_cli(common, tmp_path / "a")
+    finally:
+        del os.environ["KMD_HOST_TIMING"]
+    b, _ = run_cli(common + ["--raw-transfer"], tmp_path / "b")
+    assert a == b and a["total_kmers"] == present and a["n_sig"] > 1000
+    assert TRANSFER[str(tmp_path / "a")]["format"] == "packed"
+    grown = {int(l.split("partition ")[1].split(" ")[0]): float(l.split(" for ")[1].split(" MB")[0]) for l in log.split("\n") if "decoded in" in l}
+    # (the large partitions outgrew their slots' pieces -- megabytes page-locked while they were decoded; the ones behind them fit)
+    assert grown[2] > 10 and grown[3] > 10 and grown[4] < 4 and grown[5] < 4, grown
+    for name in ["control_kmers.fasta", "case_kmers.fasta"] + ["partitions/p%d_uncorrected" % p for p in range(6)]:
+        assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read(), name
