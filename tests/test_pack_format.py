@@ -1,6 +1,8 @@
 """The compact transfer format of a stream (kmd_pack_block, kmdiff_amd/csrc/kmd_pack.hip) against an independent
 decoder written from the format's description (numpy, no GPU): every block is its first k-mer, 256 bit-packed deltas of
 the block's widest delta, one-byte counts with 255 as the escape into a list of 32-bit counts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,14 @@ def test_pack_stream_is_its_blocks_one_behind_the_other(n):
     small = np.zeros(max(got - 8, 1), dtype=np.uint8)
     assert int(L.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, n, small.ctypes.data, small.nbytes, tab.ctypes.data)) == 0
     assert int(L.kmd_pack_stream(km.ctypes.data, ct.ctypes.data, 0, out.ctypes.data, out.nbytes, tab.ctypes.data)) == 0
+
+
+def test_host_packer_under_the_sanitizers():
+    """tests/pack_asan.cpp: kmd_pack_host.cpp alone, CPU build with AddressSanitizer + UBSan -- 6000 random blocks through
+    kmd_pack_records (every count width, any alignment, heap buffers that end with the last record: its AVX2 path reads 96
+    bytes at a time) == kmd_pack_block; kmd_pack_stream into a buffer of exactly the bytes it takes, refused 8 bytes short."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "kmdiff_amd", "host"), "../bin/pack_asan"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(root, "kmdiff_amd", "bin", "pack_asan"), "6000", "11"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "pack_asan ok: 6000 blocks" in r.stdout, r.stdout + r.stderr
