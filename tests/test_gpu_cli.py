@@ -577,3 +577,20 @@ def test_cli_staging_slot_outgrown_by_a_later_partition(tmp_path):
     assert grown[2] > 10 and grown[3] > 10 and grown[4] < 4 and grown[5] < 4, grown
     for name in ["control_kmers.fasta", "case_kmers.fasta"] + ["partitions/p%d_uncorrected" % p for p in range(6)]:
         assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read(), name
+
+
+def test_cli_background_release_of_the_staging_arrays_changes_nothing(synth_run, tmp_path):
+    """The page-locked staging arrays are released by a background thread while stages 2-3 run (main.cpp, retired_staging);
+    KMD_SYNC_RELEASE=1 releases them before stage 1 returns, as every round before 6 did: same outputs either way, with the
+    pop-strat stage and two workers (two threads retiring their rings) behind stage 1."""
+    run_dir, nc, nk, k, mats, kms = synth_run
+    common = ["-d", run_dir, "-1", nc, "-2", nk, "-u", 1000, "--pop-correction", "--kmer-pca", 0.05, "-c", "benjamini", "--devices", 2]
+    a, _ = run_cli(common, tmp_path / "a")
+    os.environ["KMD_SYNC_RELEASE"] = "1"
+    try:
+        b, _ = run_cli(common, tmp_path / "b")
+    finally:
+        del os.environ["KMD_SYNC_RELEASE"]
+    assert a == b and a["n_sig"] > 10
+    for name in ("control_kmers.fasta", "case_kmers.fasta", "popstrat/pcs.evec"):
+        assert open(tmp_path / "a" / name, "rb").read() == open(tmp_path / "b" / name, "rb").read(), name
